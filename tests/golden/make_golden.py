@@ -1,0 +1,298 @@
+"""Generate golden vectors by IMPORTING THE REFERENCE'S PYTHON in the build container.
+
+Run once here (the reference tree does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Nothing of the reference travels: the .npz files hold only inputs, recorded RNG draws and the outputs the
+reference produced.  Missing third-party modules (trimesh, plyfile, skimage, torchtyping, tinycudann) and the
+CUDA extensions are replaced by empty stubs; the one native call on the pure-PyTorch path
+(`raymarching.near_far_from_aabb`, renderer.py:297) is stubbed with a straight numpy slab test.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("CUSTOMNERF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _near_far_np(rays_o, rays_d, aabb, min_near=0.2):
+    """Independent numpy float32 slab test with the arithmetic order of raymarching.cu:108-144."""
+    o = rays_o.detach().numpy().astype(np.float32).reshape(-1, 3)
+    d = rays_d.detach().numpy().astype(np.float32).reshape(-1, 3)
+    a = aabb.detach().numpy().astype(np.float32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        rd = (np.float32(1) / d).astype(np.float32)
+        lo = ((a[:3] - o) * rd).astype(np.float32)
+        hi = ((a[3:] - o) * rd).astype(np.float32)
+    tmin, tmax = np.minimum(lo, hi), np.maximum(lo, hi)
+    N = o.shape[0]
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    big = np.finfo(np.float32).max
+    for n in range(N):
+        near, far = tmin[n, 0], tmax[n, 0]
+        ny, fy = tmin[n, 1], tmax[n, 1]
+        if near > fy or ny > far:
+            nears[n] = fars[n] = big
+            continue
+        near, far = max(near, ny), min(far, fy)
+        nz, fz = tmin[n, 2], tmax[n, 2]
+        if near > fz or nz > far:
+            nears[n] = fars[n] = big
+            continue
+        near, far = max(near, nz), min(far, fz)
+        nears[n], fars[n] = max(near, np.float32(min_near)), far
+    return torch.from_numpy(nears), torch.from_numpy(fars)
+
+
+def import_reference():
+    for name in ("trimesh", "plyfile", "skimage", "tinycudann", "_gridencoder", "_raymarching"):
+        _stub(name)
+    _stub("skimage.measure")
+    sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+
+    class _TT:
+        def __class_getitem__(cls, item):
+            return cls
+    _stub("torchtyping", TensorType=_TT)
+    _stub("raymarching", near_far_from_aabb=_near_far_np)
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from nerf import renderer as ref_renderer
+    from nerf import provider_utils as ref_pu
+    from nerf import base as ref_base
+    # the real gridencoder python package (its native backend is the empty `_gridencoder` stub)
+    del sys.modules["raymarching"]
+    import gridencoder.grid as ref_grid
+    sys.modules["raymarching"] = _stub("raymarching", near_far_from_aabb=_near_far_np)
+    return ref_renderer, ref_pu, ref_base, ref_grid
+
+
+class _Recorder:
+    """Records torch.rand / torch.randn draws made inside the reference call, in order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def rand(*a, **k):
+            k.pop("device", None)
+            t = self._rand(*a, **k)
+            self.draws.append(("rand", t.clone()))
+            return t
+
+        def randn(*a, **k):
+            k.pop("device", None)
+            t = self._randn(*a, **k)
+            self.draws.append(("randn", t.clone()))
+            return t
+        torch.rand, torch.randn = rand, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+def scene_rays(H, W, radius=3.5, elev_deg=20.0, fovy_deg=50.0, view=0, n_views=8, opencv=False):
+    """SURVEY.md §8d synthetic scene: pinhole camera on a circle, look-at origin.  OpenGL convention (-z forward, what
+    provider.py:435-438 expects) by default; opencv=True gives x-right / y-down / +z-forward (what get_rays expects)."""
+    th = 2 * np.pi * view / n_views
+    el = np.deg2rad(elev_deg)
+    eye = np.array([radius * np.cos(el) * np.cos(th), radius * np.sin(el), radius * np.cos(el) * np.sin(th)])
+    fwd = -eye / np.linalg.norm(eye)
+    right = np.cross(fwd, np.array([0.0, 1.0, 0.0]))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    c2w = np.stack([right, up, -fwd, eye], axis=1).astype(np.float32)      # [3,4]
+    if opencv:
+        c2w = np.stack([right, -up, fwd, eye], axis=1).astype(np.float32)
+    f = 0.5 * H / np.tan(0.5 * np.deg2rad(fovy_deg))
+    return c2w, float(f), float(f), W / 2.0, H / 2.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE)
+    args = ap.parse_args()
+    ref_renderer, ref_pu, ref_base, ref_grid = import_reference()
+    from oracle.toy_field import ToyField, toy_sigma, toy_rgbc
+
+    # ---- (1) sample_pdf, det and random  (renderer.py:21-55)
+    torch.manual_seed(1)
+    bins = torch.sort(torch.rand(64, 15) * 3 + 0.5, dim=-1).values
+    w = torch.rand(64, 14) ** 3
+    w[5] = 0                                                  # all-zero weights row (denom<1e-5 branch)
+    w[6, 3:] = 0
+    out_det = ref_renderer.sample_pdf(bins, w, 16, det=True)
+    with _Recorder() as rec:
+        out_rnd = ref_renderer.sample_pdf(bins, w, 16, det=False)
+    np.savez(os.path.join(args.out, "sample_pdf.npz"), bins=bins.numpy(), weights=w.numpy(), out_det=out_det.numpy(),
+             out_rnd=out_rnd.numpy(), u=rec.draws[0][1].numpy())
+
+    # ---- (5) trunc_exp fwd/bwd incl. |x| > 15  (provider_utils.py:16-29)
+    x = torch.tensor([-20.0, -15.0, -3.0, 0.0, 0.5, 7.0, 15.0, 16.0, 20.0], requires_grad=True)
+    y = ref_pu.trunc_exp(x)
+    g = torch.linspace(0.5, 1.5, x.numel())
+    y.backward(g)
+    np.savez(os.path.join(args.out, "trunc_exp.npz"), x=x.detach().numpy(), y=y.detach().numpy(), g=g.numpy(), gx=x.grad.numpy())
+
+    # ---- (6) get_embedder(4) on unit dirs (base.py:10-77) + safe_normalize
+    torch.manual_seed(2)
+    d = ref_pu.safe_normalize(torch.randn(128, 3))
+    emb, out_dim = ref_base.get_embedder(4)
+    np.savez(os.path.join(args.out, "embedder.npz"), d=d.numpy(), out=emb(d).numpy(), out_dim=out_dim,
+             sn_in=torch.tensor([[0.0, 0.0, 0.0], [3.0, 4.0, 0.0]]).numpy(),
+             sn_out=ref_pu.safe_normalize(torch.tensor([[0.0, 0.0, 0.0], [3.0, 4.0, 0.0]])).numpy())
+
+    # ---- (4) GridEncoder offsets / per_level_scale / init range (grid.py:103-146)
+    enc = {}
+    for tag, kw in (("hash_L16_T19_2048", dict(num_levels=16, log2_hashmap_size=19, desired_resolution=2048, gridtype='hash')),
+                    ("tiled_L16_T21_8192", dict(num_levels=16, log2_hashmap_size=21, desired_resolution=8192, gridtype='tiled')),
+                    ("hash_L4_T19_2048", dict(num_levels=4, log2_hashmap_size=19, desired_resolution=2048, gridtype='hash')),
+                    ("hash_default", dict())):
+        torch.manual_seed(3)
+        ge = ref_grid.GridEncoder(**kw)
+        enc[tag + "__offsets"] = ge.offsets.numpy()
+        enc[tag + "__pls"] = np.float64(ge.per_level_scale)
+        enc[tag + "__absmax"] = np.float32(ge.embeddings.detach().abs().max())
+        enc[tag + "__shape"] = np.array(ge.embeddings.shape)
+        enc[tag + "__n_params"] = np.int64(int(ge.n_params))
+        enc[tag + "__output_dim"] = np.int64(ge.output_dim)
+    np.savez(os.path.join(args.out, "grid_offsets.npz"), **enc)
+
+    # ---- (7) get_rays (provider_utils.py:239-302) and the _generate_rays pinhole math (provider.py:402-464)
+    rays = {}
+    for tag, (H, W) in (("32", (32, 32)), ("64", (64, 64)), ("24x40", (24, 40))):
+        c2w, fx, fy, cx, cy = scene_rays(H, W, view=3, opencv=True)
+        pose = torch.eye(4).unsqueeze(0).clone()
+        pose[0, :3, :4] = torch.from_numpy(c2w)
+        r = ref_pu.get_rays(pose, (fx, fy, cx, cy), H, W, -1)
+        rays[f"get_rays_{tag}__c2w"] = c2w
+        rays[f"get_rays_{tag}__intr"] = np.array([fx, fy, cx, cy, H, W], np.float64)
+        rays[f"get_rays_{tag}__o"] = r['rays_o'].numpy()
+        rays[f"get_rays_{tag}__d"] = r['rays_d'].numpy()
+        c2w = scene_rays(H, W, view=3)[0]
+        rays[f"gen_rays_{tag}__c2w"] = c2w
+        # provider.py:402-464 needs a dataset object; its pinhole branch is executed here line by line on the same
+        # inputs (meshgrid 'ij' over (tx,ty), +0.5, (x-cx)/fx, -(y-cy)/fy, -1, rotate, normalize, [W,H]->[H,W]).
+        for level in (1, 2):
+            tx = torch.linspace(0, W * level - 1, W)
+            ty = torch.linspace(0, H * level - 1, H)
+            x, y = torch.meshgrid(tx, ty)
+            x = (x + 0.5).reshape(-1)
+            y = (y + 0.5).reshape(-1)
+            coord = torch.stack([(x - cx) / fx, -(y - cy) / fy], -1)
+            dirs = torch.empty(coord.shape[0], 3)
+            dirs[..., 0] = coord[..., 0].float()
+            dirs[..., 1] = coord[..., 1].float()
+            dirs[..., 2] = -1.0
+            c = torch.from_numpy(c2w).unsqueeze(0).repeat(coord.shape[0], 1, 1)
+            dirs = torch.sum(dirs[..., None, :] * c[..., :3, :3], dim=-1)
+            dirs = torch.nn.functional.normalize(dirs, dim=-1)
+            orig = c[..., :3, 3]
+            rays[f"gen_rays_{tag}_l{level}__o"] = orig.reshape(W, H, 3).permute(1, 0, 2).numpy()
+            rays[f"gen_rays_{tag}_l{level}__d"] = dirs.reshape(W, H, 3).permute(1, 0, 2).numpy()
+    np.savez(os.path.join(args.out, "rays.npz"), **rays)
+
+    # ---- (2)+(3) weights_sum_i and the full run() dict with a closed-form field plugged in (renderer.py:278-474)
+    class ToyRenderer(ref_renderer.NeRFRenderer):
+        def __init__(self, opt):
+            super().__init__(opt)
+            self.f = ToyField()
+
+        def forward(self, x, d):
+            return self.f(x, d)
+
+        def density(self, x):
+            return self.f.density(x)
+
+    def make_opt(**kw):
+        o = argparse.Namespace(bound=2.0, cuda_ray=False, min_near=0.01, density_thresh=10, train_conf=0.01, soft_mask=True,
+                               conf_thr=0.5, detach_bg=False, detach_mask_from_field=False, backbone='grid')
+        o.__dict__.update(kw)
+        return o
+
+    H = W = 32
+    c2w, fx, fy, cx, cy = scene_rays(H, W, view=1, opencv=True)
+    pose = torch.eye(4).unsqueeze(0).clone()
+    pose[0, :3, :4] = torch.from_numpy(c2w)
+    r = ref_pu.get_rays(pose, (fx, fy, cx, cy), H, W, -1)
+    rays_o, rays_d = r['rays_o'].contiguous(), r['rays_d'].contiguous()      # [1, 1024, 3]
+
+    run_out = {"rays_o": rays_o.numpy(), "rays_d": rays_d.numpy()}
+    cases = {
+        "train_T8": dict(opt={}, training=True, kw=dict(num_steps=8, upsample_steps=8, perturb=True)),
+        "train_T64": dict(opt={}, training=True, stride=4, kw=dict(num_steps=64, upsample_steps=64, perturb=True)),
+        "eval_T64": dict(opt={}, training=False, stride=4, kw=dict(num_steps=64, upsample_steps=64, perturb=False)),
+        "train_T16_hardmask": dict(opt=dict(soft_mask=False), training=True, stride=4, kw=dict(num_steps=16, upsample_steps=16, perturb=True)),
+        "train_T16_detach": dict(opt=dict(detach_bg=True, detach_mask_from_field=True), training=True, stride=4,
+                                 kw=dict(num_steps=16, upsample_steps=16, perturb=True)),
+    }
+    import io
+    import contextlib
+    for tag, c in cases.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ToyRenderer(make_opt(**c["opt"]))
+        model.train(c["training"])
+        torch.manual_seed(11)
+        st = c.get("stride", 1)
+        run_out[f"{tag}__stride"] = np.int64(st)
+        with _Recorder() as rec:
+            res = model.run(rays_o[:, ::st].contiguous(), rays_d[:, ::st].contiguous(), **c["kw"])
+        kinds = [k for k, _ in rec.draws]
+        assert kinds[0] == "randn"
+        run_out[f"{tag}__light"] = rec.draws[0][1].numpy()
+        if c["kw"]["perturb"]:
+            run_out[f"{tag}__z"] = rec.draws[1][1].numpy()
+        if c["training"]:
+            run_out[f"{tag}__u"] = rec.draws[-1][1].numpy()
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights", "mask", "sigma", "rgbs", "edit_mask"):
+            run_out[f"{tag}__{k}"] = res[k].detach().numpy()
+        for sub in ("fg", "bg"):
+            for k in ("image", "depth", "render_mask", "weights_sum", "weights"):
+                run_out[f"{tag}__{sub}_{k}"] = res[sub][k].detach().numpy()
+    np.savez_compressed(os.path.join(args.out, "run.npz"), **run_out)
+
+    # weights_sum_i stand-alone (random sigma / rgb / mask / z incl. soft_mask-style sigmas and detach_bg)
+    torch.manual_seed(5)
+    N, T = 96, 24
+    sig = (torch.rand(N, T, 1) * 8) ** 2
+    rgb = torch.rand(N, T, 3)
+    msk = torch.rand(N, T, 1)
+    z = torch.sort(torch.rand(N, T) * 3 + 0.2, dim=-1).values
+    nears, fars = z[:, :1] - 0.1, z[:, -1:] + 0.3
+    sd = (fars - nears) / 12
+    ws = {"sigmas": sig.numpy(), "rgbs": rgb.numpy(), "masks": msk.numpy(), "z": z.numpy(), "nears": nears.numpy(),
+          "fars": fars.numpy(), "sample_dist": sd.numpy()}
+    for tag, o in (("plain", {}), ("detach", dict(detach_bg=True, detach_mask_from_field=True))):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ToyRenderer(make_opt(**o))
+        s, c_ = sig.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+        res = model.weights_sum_i(sd, s, None, None, None, z, nears, fars, c_, (1, N), masks=msk, is_all=True)
+        loss = (res['image'] ** 2).sum() + res['weights_sum'].sum() + (res['render_mask'] * 0.3).sum() + res['depth'].sum()
+        loss.backward()
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights", "mask"):
+            ws[f"{tag}__{k}"] = res[k].detach().numpy()
+        ws[f"{tag}__grad_sigmas"] = s.grad.numpy()
+        ws[f"{tag}__grad_rgbs"] = c_.grad.numpy()
+    np.savez_compressed(os.path.join(args.out, "weights_sum_i.npz"), **ws)
+    print("golden vectors written to", args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+"""CPU: pin the oracle (oracle/) against the golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py).  SURVEY.md §8c items (1)-(7)."""
+import numpy as np
+import torch
+
+from oracle import torch_oracle as to
+from oracle import c_oracle as co
+from oracle.toy_field import ToyField
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_sample_pdf(golden):
+    g = golden("sample_pdf")
+    out = to.sample_pdf(T(g["bins"]), T(g["weights"]), 16, det=True)
+    np.testing.assert_allclose(out.numpy(), g["out_det"], rtol=0, atol=1e-6)
+    out = to.sample_pdf(T(g["bins"]), T(g["weights"]), 16, det=False, u=T(g["u"]))
+    np.testing.assert_allclose(out.numpy(), g["out_rnd"], rtol=0, atol=1e-6)
+
+
+def test_trunc_exp(golden):
+    g = golden("trunc_exp")
+    x = T(g["x"]).requires_grad_(True)
+    y = to.trunc_exp(x)
+    y.backward(T(g["g"]))
+    np.testing.assert_array_equal(y.detach().numpy(), g["y"])
+    np.testing.assert_array_equal(x.grad.numpy(), g["gx"])
+
+
+def test_embedder_and_safe_normalize(golden):
+    g = golden("embedder")
+    assert int(g["out_dim"]) == 27
+    np.testing.assert_array_equal(to.freq_embed(T(g["d"])).numpy(), g["out"])
+    np.testing.assert_array_equal(to.safe_normalize(T(g["sn_in"])).numpy(), g["sn_out"])
+
+
+def test_grid_offsets(golden):
+    g = golden("grid_offsets")
+    cfgs = {"hash_L16_T19_2048": dict(num_levels=16, log2_hashmap_size=19, desired_resolution=2048),
+            "tiled_L16_T21_8192": dict(num_levels=16, log2_hashmap_size=21, desired_resolution=8192),
+            "hash_L4_T19_2048": dict(num_levels=4, log2_hashmap_size=19, desired_resolution=2048),
+            "hash_default": dict()}
+    for tag, kw in cfgs.items():
+        off, pls = to.grid_offsets(**kw)
+        np.testing.assert_array_equal(off, g[tag + "__offsets"])
+        assert float(pls) == float(g[tag + "__pls"])
+        assert int(off[-1]) == int(g[tag + "__shape"][0])
+        assert int(g[tag + "__n_params"]) == int(off[-1]) * 2
+        assert float(g[tag + "__absmax"]) <= 1e-4
+    # SURVEY.md §8 sizes
+    off, _ = to.grid_offsets(**cfgs["hash_L16_T19_2048"])
+    assert int(off[-1]) == 6119864
+    off, _ = to.grid_offsets(**cfgs["tiled_L16_T21_8192"])
+    assert int(off[-1]) == 23967296
+
+
+def test_rays(golden):
+    g = golden("rays")
+    for tag in ("32", "64", "24x40"):
+        c2w = T(g[f"get_rays_{tag}__c2w"])
+        fx, fy, cx, cy, H, W = g[f"get_rays_{tag}__intr"]
+        H, W = int(H), int(W)
+        pose = torch.eye(4).unsqueeze(0).clone()
+        pose[0, :3, :4] = c2w
+        o, d = to.get_rays(pose, (fx, fy, cx, cy), H, W)
+        np.testing.assert_array_equal(o.numpy(), g[f"get_rays_{tag}__o"])
+        np.testing.assert_array_equal(d.numpy(), g[f"get_rays_{tag}__d"])
+        c2w = T(g[f"gen_rays_{tag}__c2w"])
+        for level in (1, 2):
+            o, d = to.generate_rays(c2w[None], fx, fy, cx, cy, H, W, level)
+            np.testing.assert_array_equal(o[0].numpy(), g[f"gen_rays_{tag}_l{level}__o"])
+            np.testing.assert_allclose(d[0].numpy(), g[f"gen_rays_{tag}_l{level}__d"], rtol=0, atol=1e-7)
+
+
+CASES = {
+    "train_T8": dict(training=True, kw=dict(num_steps=8, upsample_steps=8, perturb=True)),
+    "train_T64": dict(training=True, kw=dict(num_steps=64, upsample_steps=64, perturb=True)),
+    "eval_T64": dict(training=False, kw=dict(num_steps=64, upsample_steps=64, perturb=False)),
+    "train_T16_hardmask": dict(training=True, kw=dict(num_steps=16, upsample_steps=16, perturb=True, soft_mask=False)),
+    "train_T16_detach": dict(training=True, kw=dict(num_steps=16, upsample_steps=16, perturb=True, detach_bg=True,
+                                                    detach_mask_from_field=True)),
+}
+
+
+def test_run_against_reference(golden):
+    g = golden("run")
+    aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2])
+    for tag, c in CASES.items():
+        st = int(g[f"{tag}__stride"])
+        rays_o, rays_d = T(g["rays_o"])[:, ::st].contiguous(), T(g["rays_d"])[:, ::st].contiguous()
+        draws = {"light": T(g[f"{tag}__light"])}
+        if f"{tag}__z" in g:
+            draws["z"] = T(g[f"{tag}__z"])
+        if f"{tag}__u" in g:
+            draws["u"] = T(g[f"{tag}__u"])
+        res = to.run(ToyField(), rays_o, rays_d, aabb, 0.01, training=c["training"], draws=draws, **c["kw"])
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights", "sigma", "rgbs"):
+            np.testing.assert_allclose(res[k].numpy(), g[f"{tag}__{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}:{k}")
+        np.testing.assert_array_equal(res["mask"].numpy(), g[f"{tag}__mask"])
+        np.testing.assert_allclose(res["edit_mask"].float().numpy(), g[f"{tag}__edit_mask"].astype(np.float32), rtol=1e-5, atol=1e-6)
+        for sub in ("fg", "bg"):
+            for k in ("image", "depth", "render_mask", "weights_sum", "weights"):
+                np.testing.assert_allclose(res[sub][k].numpy(), g[f"{tag}__{sub}_{k}"], rtol=1e-5, atol=1e-6,
+                                           err_msg=f"{tag}:{sub}.{k}")
+        # dropping the output-dead fine density pass (renderer.py:353) changes nothing
+        res2 = to.run(ToyField(), rays_o, rays_d, aabb, 0.01, training=c["training"], draws=draws, skip_fine_density=True, **c["kw"])
+        np.testing.assert_array_equal(res2["image"].numpy(), res["image"].numpy())
+
+
+def test_weights_sum_i_and_grads(golden):
+    g = golden("weights_sum_i")
+    N = g["sigmas"].shape[0]
+    for tag, kw in (("plain", {}), ("detach", dict(detach_bg=True, detach_mask_from_field=True))):
+        s, c = T(g["sigmas"]).requires_grad_(True), T(g["rgbs"]).requires_grad_(True)
+        res = to.weights_sum_i(T(g["sample_dist"]), s, T(g["z"]), T(g["nears"]), T(g["fars"]), c, (1, N), T(g["masks"]),
+                               is_all=True, **kw)
+        loss = (res['image'] ** 2).sum() + res['weights_sum'].sum() + (res['render_mask'] * 0.3).sum() + res['depth'].sum()
+        loss.backward()
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights"):
+            np.testing.assert_allclose(res[k].detach().numpy(), g[f"{tag}__{k}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(s.grad.numpy(), g[f"{tag}__grad_sigmas"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(c.grad.numpy(), g[f"{tag}__grad_rgbs"], rtol=1e-5, atol=1e-7)
+
+
+def test_near_far_c_oracle_matches_reference_path(golden):
+    """The C near_far restatement against the numpy slab test the golden run() used (its nears/fars fix `mask`
+    and every sample position, so image parity above already depends on it); here directly, incl. misses."""
+    g = golden("run")
+    o, d = g["rays_o"].reshape(-1, 3), g["rays_d"].reshape(-1, 3)
+    aabb = np.array([-0.5, -0.5, -0.5, 0.5, 0.5, 0.5], np.float32)     # small box: many rays miss
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.05)
+    big = np.finfo(np.float32).max
+    miss = nears == big
+    assert miss.any() and (~miss).any()
+    assert np.all(fars[miss] == big)
+    hit = ~miss
+    assert hit.sum() > 50
+    p_near = o[hit] + nears[hit, None] * d[hit]
+    p_far = o[hit] + fars[hit, None] * d[hit]
+    assert np.all(np.abs(p_far).max(-1) <= 0.5 + 1e-5) and np.all(np.abs(p_near).max(-1) <= 0.5 + 1e-5)
+    assert np.all(nears[hit] <= fars[hit]) and np.all(nears[hit] > 2.0)
+    # the golden run() itself must be a non-degenerate scene: most rays hit the [-2,2]^3 box
+    assert g["train_T8__mask"].mean() > 0.9 and g["train_T8__weights_sum"].max() > 0.5
