@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py — training rays/s of the CustomNeRF hot path on MI355X (contract: see the task statement / DESIGN.md §measurement).
+
+One step = one full reconstruction step of the reference's loop body (utils_init_nerf.py:194-241, 599-629) on one
+128x128 synthetic view per GPU: ray batch -> NeRFRenderer.render (the `run()` path the reference's -O2 recipe uses, 64+64
+samples; or --path march for the occupancy-march `run_cuda()` path) -> loss -> backward -> [RCCL all-reduce of the
+gradients when N>1] -> Adam.  Inputs (rays, targets, tables) are resident in HBM before the timed region.
+
+Prints ONE JSON line from rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def gather_bytes_per_point(L, C, itemsize, D=3):
+    """ALGORITHMIC bytes of the grid gather forward per point: L*2^D*C*s + 4*D + L*C*s."""
+    return L * (2 ** D) * C * itemsize + 4 * D + L * C * itemsize
+
+
+def cpu_baseline(opt, n_rays_side=40, steps=3):
+    """The oracle (CPU restatement of the reference's pure-PyTorch renderer + C grid encoder) timed on this box's host
+    cores on a BOUNDED sample of the same workload: a (side x side)-ray view of the same scene/field, same 64+64 samples,
+    forward + backward + Adam.  Reported beside the GPU number, never as the thing measured."""
+    import numpy as np
+    from oracle import torch_oracle as to
+    from customnerf_amd import scene as sc
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref = to.FieldRef(bound=opt.bound, num_levels=opt.num_levels, level_dim=opt.level_dim, base_resolution=opt.base_resolution,
+                      log2_hashmap_size=opt.log2_hashmap_size, desired_resolution=opt.desired_resolution, gridtype='hash',
+                      n_hidden_geo=opt.n_hidden_geo, seed=0)
+    params = [ref.pos_en.embeddings, ref.network, ref.density_network, ref.rgb_network]
+    optim = torch.optim.Adam([{'params': params[:1], 'lr': opt.lr * 10}, {'params': params[1:], 'lr': opt.lr}], betas=(0.9, 0.99), eps=1e-15)
+    H = W = n_rays_side
+    o, d = to.generate_rays(torch.from_numpy(sc.poses(8))[:1], *sc.intrinsics(H, W), H, W)
+    o, d = o.reshape(1, -1, 3), d.reshape(1, -1, 3)
+    rgb, mask = sc.targets(1, H, W)
+    aabb = torch.tensor([-opt.bound] * 3 + [opt.bound] * 3)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        res = to.run(ref, o, d, aabb, opt.min_near, num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, perturb=True, training=True)
+        loss = ((res['image'].reshape(-1, 3) - rgb[0]) ** 2).mean() + opt.train_conf * ((res['render_mask'].reshape(-1) - mask[0].reshape(-1)) ** 2).mean()
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": H * W / t, "unit": "rays/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"{H}x{W}-ray view of the same scene/field ({opt.num_steps}+{opt.upsample_steps} samples, L{opt.num_levels} T2^{opt.log2_hashmap_size} grid), "
+                      f"fwd+bwd+Adam, median of {steps} steps after 1 warm-up; grid encode/scatter = single-thread C oracle, MLP/renderer = torch CPU on all cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--path", choices=["run", "march"], default="run")
+    ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.gridencoder import grid as ge
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+
+    fp16 = args.dtype == "f16"
+    tcnn.set_default_dtype(torch.float16 if fp16 else torch.float32)
+    torch.manual_seed(0)
+    opt = sc.make_opt(cuda_ray=(args.path == "march"), fp16=fp16)
+    model = NeRFNetwork(opt).to(dev)
+    H = W = args.res
+    V = 8
+    c2w = torch.from_numpy(sc.poses(V)).to(dev)
+    rays_o, rays_d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')       # HIP ray-gen kernel, resident in HBM
+    rays_o, rays_d = rays_o.view(V, 1, H * W, 3), rays_d.view(V, 1, H * W, 3)
+    rgb, mask = sc.targets(V, H, W)
+    rgb, mask = rgb.to(dev), mask.to(dev)
+    if args.path == "march":
+        from customnerf_amd import raymarching
+        grid = torch.from_numpy(sc.sphere_density_grid(model.cascade, 128, opt.bound, 1.0, 100.0)).to(dev)
+        model.density_grid.copy_(grid)
+        model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
+    trainer = ReconTrainer(model, opt, fp16=fp16, world_size=world)
+    render_kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=0, max_steps=opt.max_steps)
+    n_rays = H * W
+
+    def step(i):
+        v = (i * world + rank) % V                       # each rank renders its own view (view-parallel data parallelism)
+        return trainer.train_step(rays_o[v], rays_d[v], rgb[v], mask[v], **render_kw)
+
+    for i in range(args.warmup):
+        step(i)
+    prof = [] if not args.no_roofline else None
+    ge.set_profile(prof)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ge.set_profile(None)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    result = None
+    if rank == 0:
+        value = n_rays * world * args.steps / dt
+        result = {
+            "metric": "training rays/s", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"cfg2 synthetic {H}x{W} view/GPU, hash grid L16 T2^19 (6.12M entries), "
+                                   + ("run() path 64+64 samples/ray" if args.path == "run" else "run_cuda() occupancy-march path, unit-sphere occupancy")
+                                   + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays, "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single GPU",
+                       "path": args.path, "final_loss": float(loss)},
+        }
+        if args.path == "march":
+            result["config"]["samples_per_ray"] = out.get('num_points', 0) / n_rays
+        if prof:
+            ms = [e0.elapsed_time(e1) for e0, e1, *_ in prof]
+            pts = [p[2] for p in prof]
+            L, isz = prof[0][3], prof[0][4]
+            bpp = gather_bytes_per_point(L, opt.level_dim, isz)
+            tot_ms, tot_b = sum(ms), sum(p * bpp for p in pts)
+            achieved = tot_b / (tot_ms * 1e-3) / 1e9
+            result["roofline"] = {"kernel": "k_grid_fwd (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
+                                  "algorithmic_bytes_per_point": bpp}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(opt)
+            except Exception as e:                                    # the baseline leg must never take the GPU number down
+                result["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

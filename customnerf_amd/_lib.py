@@ -1,0 +1,92 @@
+"""ctypes binding of libcustomnerf_hip.so (C-ABI in include/customnerf_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing, or an entry point is missing,
+importing this module raises.  Every call returns the library's status code through `check()`, which raises
+RuntimeError (launch failure) or ValueError (rejected arguments, where the reference raises std::runtime_error).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcustomnerf_hip.so")
+ABI_VERSION = 1
+
+vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+
+# name -> argtypes (must list every symbol include/customnerf_hip.h declares; tests/test_abi.py cross-checks)
+SIGNATURES = {
+    "cnerf_abi_version": [],
+    "cnerf_near_far_from_aabb": [vp, vp, vp, u32, f32, vp, vp, vp],
+    "cnerf_sph_from_ray": [vp, vp, f32, u32, vp, vp],
+    "cnerf_morton3D": [vp, u32, vp, vp],
+    "cnerf_morton3D_invert": [vp, u32, vp, vp],
+    "cnerf_packbits": [vp, u32, f32, vp, vp],
+    "cnerf_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cnerf_march_rays_train_count": [vp, vp, vp, f32, f32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp],
+    "cnerf_march_rays_train_write": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cnerf_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, u32, vp],
+    "cnerf_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, u32, vp],
+    "cnerf_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cnerf_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp],
+    "cnerf_compact_rays_alive": [vp, u32, vp, vp, vp],
+    "cnerf_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
+    "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
+    "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
+    "cnerf_cast_f32_to_f16": [vp, vp, u64, vp],
+    "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
+}
+
+F32, F16 = 0, 1
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is the product and has no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C customnerf_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.cnerf_target_arch.restype = C.c_char_p
+    if lib.cnerf_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI mismatch: library {lib.cnerf_abi_version()} vs binding {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError(f"customnerf_hip: {what} rejected its arguments (code {rc})")
+    raise RuntimeError(f"customnerf_hip: {what} failed with hipError {rc}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("customnerf_amd: tensors must live on the GPU (HIP device memory); there is no CPU path")
+
+
+def dtype_id(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise ValueError(f"unsupported dtype {t.dtype}")

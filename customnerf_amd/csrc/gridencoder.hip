@@ -1,0 +1,518 @@
+// Multiresolution hash / tiled grid encoder for gfx950 (CDNA4).
+//
+// Replaces the reference's `_gridencoder` extension (gridencoder/src/gridencoder.cu) behind the C-ABI of
+// include/customnerf_hip.h.  MI355X-first choices:
+//   * level geometry (table offset/size, scale, resolution) is computed once on the host and travels as kernel
+//     arguments — no per-thread exp2f/ceil, and the oracle and the kernel see bit-identical geometry;
+//   * one thread = one (point, level); the 1-D grid is swizzled so that the two levels an XCD works on stay in that
+//     XCD's private 4 MiB L2 (a 2^19-entry level is 2 MiB in fp16, 4 MiB in fp32) — XCD x owns a contiguous slice
+//     of the level-major work list, and the level list is interleaved coarse/fine so the slices cost the same;
+//   * corner features are fetched with one vector load per corner (4 B for fp16 C=2, 8 B for fp32 C=2);
+//   * the backward scatter uses hardware float atomics (global_atomic_add_f32) into a float32 gradient table
+//     for both table dtypes.
+// Arithmetic follows oracle/gridencoder_ref.c operation by operation (compiled -ffp-contract=off, explicit fma).
+#include "common.h"
+#include <math.h>
+
+#define GE_MAX_LEVELS 32
+#define GE_BLOCK 256
+
+struct GridLevels {
+    uint32_t offset[GE_MAX_LEVELS];       // first entry of the level's table
+    uint32_t size[GE_MAX_LEVELS];         // entries in the level's table (hashmap_size)
+    uint32_t resolution[GE_MAX_LEVELS];
+    float scale[GE_MAX_LEVELS];
+    uint8_t order[GE_MAX_LEVELS];         // work-list position -> level (coarse/fine interleave)
+};
+
+template <typename T, int C>
+struct alignas(sizeof(T) * C) FeatVec {
+    T v[C];
+};
+
+__device__ __forceinline__ float ge_to_float(float x) { return x; }
+__device__ __forceinline__ float ge_to_float(__half x) { return __half2float(x); }
+template <typename T> __device__ __forceinline__ T ge_from_float(float x);
+template <> __device__ __forceinline__ float ge_from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ __half ge_from_float<__half>(float x) { return __float2half_rn(x); }
+
+// acc += w * g with the accumulator type of the reference (`scalar_t results[C]`): float -> one fma;
+// half -> product rounded to half, sum rounded to half.
+__device__ __forceinline__ void ge_accum(float &acc, float w, float g) { acc = cn_fma(w, g, acc); }
+__device__ __forceinline__ void ge_accum(__half &acc, float w, __half g) {
+    acc = __float2half_rn(__half2float(acc) + __half2float(__float2half_rn(w * __half2float(g))));
+}
+
+__device__ __forceinline__ float ge_smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
+__device__ __forceinline__ float ge_smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
+
+template <int D>
+__device__ __forceinline__ uint32_t ge_fast_hash(const uint32_t (&p)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r ^= p[i] * primes[i];
+    return r;
+}
+
+// entry index (not yet multiplied by C) of a grid vertex
+template <int D>
+__device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                             const uint32_t (&p)[D]) {
+    uint32_t stride = 1, index = 0;
+    const uint32_t step = align_corners ? resolution : (resolution + 1);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += p[d] * stride;
+            stride *= step;
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = ge_fast_hash<D>(p);
+    return index % hashmap_size;
+}
+
+// blockIdx -> (level, point block).  Swizzled: XCD x (= blockIdx % 8 as dispatched) walks a contiguous slice of the
+// level-major work list, so at any moment it gathers from one or two tables that fit its own L2.
+__device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int swizzle, const GridLevels &lv, uint32_t &level, uint32_t &pb) {
+    const uint32_t total = nb * n_levels;
+    uint32_t w = blockIdx.x;
+    if (swizzle) {
+        const uint32_t cpx = (total + CN_NXCD - 1) / CN_NXCD;
+        w = (blockIdx.x % CN_NXCD) * cpx + blockIdx.x / CN_NXCD;
+    }
+    if (w >= total) return false;
+    level = lv.order[w / nb];
+    pb = w % nb;
+    return true;
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid, const GridLevels lv,
+                                                       T *__restrict__ outputs, uint32_t B, uint32_t L, uint32_t n_levels, uint32_t nb,
+                                                       T *__restrict__ dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int swizzle) {
+    uint32_t level, pb;
+    if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
+    const uint32_t b = pb * GE_BLOCK + threadIdx.x;
+    if (b >= B) return;
+
+    using Vec = FeatVec<T, C>;
+    const Vec *__restrict__ table = reinterpret_cast<const Vec *>(grid) + lv.offset[level];
+    Vec *out = reinterpret_cast<Vec *>(outputs) + ((size_t)level * B + b);
+
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        oob = oob || (in[d] < 0 || in[d] > 1);
+    }
+    if (oob) {
+        Vec z;
+#pragma unroll
+        for (int c = 0; c < C; c++) z.v[c] = ge_from_float<T>(0.0f);
+        *out = z;
+        if (dy_dx) {
+            T *dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+            for (int i = 0; i < D * C; i++) dd[i] = ge_from_float<T>(0.0f);
+        }
+        return;
+    }
+
+    const uint32_t hashmap_size = lv.size[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = cn_fma(in[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            pos_deriv[d] = ge_smoothstep_derivative(pos[d]);
+            pos[d] = ge_smoothstep(pos[d]);
+        } else {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+
+    // issue all 2^D corner gathers first (independent loads in flight), then accumulate in the reference's order
+    Vec corner[1 << D];
+    float wgt[1 << D];
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        wgt[idx] = w;
+        corner[idx] = table[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl)];
+    }
+    Vec res;
+#pragma unroll
+    for (int c = 0; c < C; c++) res.v[c] = ge_from_float<T>(0.0f);
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) ge_accum(res.v[c], wgt[idx], corner[idx].v[c]);
+    }
+    *out = res;
+
+    if (dy_dx) {
+        T *dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            T rg[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) rg[c] = ge_from_float<T>(0.0f);
+#pragma unroll
+            for (int idx = 0; idx < (1 << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t pgl[D];
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1 << nd)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                pgl[gd] = pos_grid[gd];
+                const Vec left = table[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl)];
+                pgl[gd] = pos_grid[gd] + 1;
+                const Vec right = table[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl)];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    if constexpr (sizeof(T) == 2) {
+                        const float diff = __half2float(__float2half_rn(__half2float(right.v[c]) - __half2float(left.v[c])));
+                        rg[c] = __float2half_rn(__half2float(rg[c]) + __half2float(__float2half_rn(w * diff * pos_deriv[gd])));
+                    } else {
+                        const float diff = right.v[c] - left.v[c];
+                        rg[c] = cn_fma(w * diff, pos_deriv[gd], rg[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) dd[gd * C + c] = rg[c];
+        }
+    }
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(GE_BLOCK) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+                                                       float *__restrict__ grad_grid, uint32_t B, uint32_t n_levels, uint32_t nb,
+                                                       uint32_t gridtype, int align_corners, uint32_t interp, int swizzle) {
+    uint32_t level, pb;
+    if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
+    const uint32_t b = pb * GE_BLOCK + threadIdx.x;
+    if (b >= B) return;
+
+    float in[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) return;
+    }
+    using Vec = FeatVec<T, C>;
+    const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
+    float *__restrict__ gtable = grad_grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.size[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = cn_fma(in[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) pos[d] = ge_smoothstep(pos[d]);
+    }
+    float gf[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) gf[c] = ge_to_float(g.v[c]);
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        const uint32_t index = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(&gtable[index + c], w * gf[c]);
+    }
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(GE_BLOCK) k_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx, float *__restrict__ grad_inputs,
+                                                        uint32_t B, uint32_t L) {
+    const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T *dd = dy_dx + (size_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            result = cn_fma(ge_to_float(grad[(size_t)l * B * C + (size_t)b * C + c]), ge_to_float(dd[l * D * C + d * C + c]), result);
+    }
+    grad_inputs[t] = result;
+}
+
+template <int D, int C>
+__global__ void __launch_bounds__(GE_BLOCK) k_grad_tv(const float *__restrict__ inputs, const float *__restrict__ grid, float *__restrict__ grad,
+                                                      const GridLevels lv, float weight, uint32_t B, uint32_t n_levels, uint32_t nb,
+                                                      uint32_t gridtype, int align_corners) {
+    uint32_t level, pb;
+    if (!ge_work_item(nb, n_levels, 0, lv, level, pb)) return;
+    const uint32_t b = pb * GE_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    float in[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) return;
+    }
+    const float *__restrict__ table = grid + (size_t)lv.offset[level] * C;
+    float *__restrict__ gtable = grad + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.size[level], resolution = lv.resolution[level];
+    const float scale = lv.scale[level];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(cn_fma(in[d], scale, align_corners ? 0.0f : 0.5f));
+    float results[C], idelta[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { results[c] = 0; idelta[c] = 0; }
+    const uint32_t index = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C;
+    const float w = weight / (2 * D);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t cur_d = pos_grid[d];
+        if (cur_d < resolution) {
+            pos_grid[d] = cur_d + 1;
+            const uint32_t ir = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float gv = table[index + c] - table[ir + c];
+                results[c] += gv;
+                idelta[c] = cn_fma(gv, gv, idelta[c]);
+            }
+        }
+        if (cur_d > 0) {
+            pos_grid[d] = cur_d - 1;
+            const uint32_t il = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float gv = table[index + c] - table[il + c];
+                results[c] += gv;
+                idelta[c] = cn_fma(gv, gv, idelta[c]);
+            }
+        }
+        pos_grid[d] = cur_d;
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) unsafeAtomicAdd(&gtable[index + c], w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f)));
+}
+
+__global__ void __launch_bounds__(256) k_cast_f32_f16(const float *__restrict__ src, __half *__restrict__ dst, uint64_t n) {
+    const uint64_t n8 = n / 8;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(src)[i * 2], b = reinterpret_cast<const float4 *>(src)[i * 2 + 1];
+        union { __half2 h[4]; uint4 u; } o;
+        o.h[0] = __floats2half2_rn(a.x, a.y);
+        o.h[1] = __floats2half2_rn(a.z, a.w);
+        o.h[2] = __floats2half2_rn(b.x, b.y);
+        o.h[3] = __floats2half2_rn(b.z, b.w);
+        reinterpret_cast<uint4 *>(dst)[i] = o.u;
+    }
+    for (uint64_t i = n8 * 8 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = __float2half_rn(src[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int ge_levels(const int32_t *offsets_host, uint32_t L, uint32_t n_levels, float S, uint32_t H, GridLevels &lv) {
+    if (!offsets_host) return CNERF_ENULL;
+    if (L == 0 || L > GE_MAX_LEVELS || n_levels > L) return CNERF_EINVAL;
+    for (uint32_t l = 0; l < L; l++) {
+        if (offsets_host[l + 1] <= offsets_host[l]) return CNERF_EINVAL;
+        lv.offset[l] = (uint32_t)offsets_host[l];
+        lv.size[l] = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        const float scale = exp2f(l * S) * H - 1.0f;          // gridencoder.cu:138-139 (host libm, same as the oracle)
+        lv.scale[l] = scale;
+        lv.resolution[l] = (uint32_t)ceilf(scale) + 1;
+    }
+    // coarse/fine interleave: 0, n-1, 1, n-2, ... so each XCD's slice holds one cheap and one expensive level
+    uint32_t lo = 0, hi = n_levels;
+    for (uint32_t i = 0; i < n_levels; i++) lv.order[i] = (uint8_t)((i & 1) ? --hi : lo++);
+    return CNERF_OK;
+}
+
+static int ge_swizzle_default() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CNERF_GRID_SWIZZLE");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <typename T, int D>
+static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *out, uint32_t B, uint32_t C, uint32_t L, uint32_t nl, T *dy_dx,
+                    uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+    const uint32_t nb = cn_div_up(B, GE_BLOCK);
+    const dim3 grid(nb * nl), block(GE_BLOCK);
+    const int sw = ge_swizzle_default();
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grid_fwd<T, D, 1>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
+        case 2: hipLaunchKernelGGL((k_grid_fwd<T, D, 2>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
+        case 4: hipLaunchKernelGGL((k_grid_fwd<T, D, 4>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
+        case 8: hipLaunchKernelGGL((k_grid_fwd<T, D, 8>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
+        default: return CNERF_EINVAL;
+    }
+    return cn_launch_status();
+}
+
+template <typename T>
+static int ge_fwd_D(const float *inputs, const T *emb, const GridLevels &lv, T *out, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t nl,
+                    T *dy_dx, uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+    switch (D) {
+        case 2: return ge_fwd_C<T, 2>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
+        case 3: return ge_fwd_C<T, 3>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
+        case 4: return ge_fwd_C<T, 4>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
+        case 5: return ge_fwd_C<T, 5>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
+        default: return CNERF_EINVAL;
+    }
+}
+
+template <typename T, int D>
+static int ge_bwd_C(const T *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t C, uint32_t L, uint32_t nl,
+                    const T *dy_dx, float *grad_inputs, uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+    const uint32_t nb = cn_div_up(B, GE_BLOCK);
+    const dim3 grid(nb * nl), block(GE_BLOCK);
+    const int sw = ge_swizzle_default();
+    const dim3 gin(cn_div_up(B * D, GE_BLOCK));
+    switch (C) {
+        case 1:
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 1>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 1>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+            break;
+        case 2:
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 2>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 2>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+            break;
+        case 4:
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 4>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 4>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+            break;
+        case 8:
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 8>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 8>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+            break;
+        default: return CNERF_EINVAL;
+    }
+    return cn_launch_status();
+}
+
+template <typename T>
+static int ge_bwd_D(const T *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                    uint32_t nl, const T *dy_dx, float *grad_inputs, uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+    switch (D) {
+        case 2: return ge_bwd_C<T, 2>(grad, inputs, lv, gemb, B, C, L, nl, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 3: return ge_bwd_C<T, 3>(grad, inputs, lv, gemb, B, C, L, nl, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 4: return ge_bwd_C<T, 4>(grad, inputs, lv, gemb, B, C, L, nl, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 5: return ge_bwd_C<T, 5>(grad, inputs, lv, gemb, B, C, L, nl, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        default: return CNERF_EINVAL;
+    }
+}
+
+template <int D>
+static int ge_tv_C(const float *inputs, const float *emb, float *grad, const GridLevels &lv, float weight, uint32_t B, uint32_t C, uint32_t L,
+                   uint32_t gridtype, int ac, hipStream_t st) {
+    const uint32_t nb = cn_div_up(B, GE_BLOCK);
+    const dim3 grid(nb * L), block(GE_BLOCK);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grad_tv<D, 1>), grid, block, 0, st, inputs, emb, grad, lv, weight, B, L, nb, gridtype, ac); break;
+        case 2: hipLaunchKernelGGL((k_grad_tv<D, 2>), grid, block, 0, st, inputs, emb, grad, lv, weight, B, L, nb, gridtype, ac); break;
+        case 4: hipLaunchKernelGGL((k_grad_tv<D, 4>), grid, block, 0, st, inputs, emb, grad, lv, weight, B, L, nb, gridtype, ac); break;
+        case 8: hipLaunchKernelGGL((k_grad_tv<D, 8>), grid, block, 0, st, inputs, emb, grad, lv, weight, B, L, nb, gridtype, ac); break;
+        default: return CNERF_EINVAL;
+    }
+    return cn_launch_status();
+}
+
+extern "C" {
+
+int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
+                              uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                              uint32_t interp, int dtype, void *stream) {
+    if (!inputs || !embeddings || !outputs) return CNERF_ENULL;
+    if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
+    GridLevels lv;
+    const uint32_t nl = max_level < L ? max_level : L;
+    int rc = ge_levels(offsets_host, L, nl, S, H, lv);
+    if (rc) return rc;
+    if (D < 2 || D > 5 || !(C == 1 || C == 2 || C == 4 || C == 8)) return CNERF_EINVAL;
+    if (B == 0 || nl == 0) return CNERF_OK;
+    if (dtype == CNERF_F32)
+        return ge_fwd_D<float>(inputs, (const float *)embeddings, lv, (float *)outputs, B, D, C, L, nl, (float *)dy_dx, gridtype, align_corners, interp, CN_STREAM(stream));
+    if (dtype == CNERF_F16)
+        return ge_fwd_D<__half>(inputs, (const __half *)embeddings, lv, (__half *)outputs, B, D, C, L, nl, (__half *)dy_dx, gridtype, align_corners, interp, CN_STREAM(stream));
+    return CNERF_EINVAL;
+}
+
+int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D,
+                               uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, const void *dy_dx, float *grad_inputs,
+                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream) {
+    if (!grad || !inputs || !grad_embeddings) return CNERF_ENULL;
+    if (dy_dx && !grad_inputs) return CNERF_ENULL;
+    if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
+    GridLevels lv;
+    const uint32_t nl = max_level < L ? max_level : L;
+    int rc = ge_levels(offsets_host, L, nl, S, H, lv);
+    if (rc) return rc;
+    if (D < 2 || D > 5 || !(C == 1 || C == 2 || C == 4 || C == 8)) return CNERF_EINVAL;
+    if (B == 0 || nl == 0) return CNERF_OK;
+    if (dtype == CNERF_F32)
+        return ge_bwd_D<float>((const float *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const float *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
+    if (dtype == CNERF_F16)
+        return ge_bwd_D<__half>((const __half *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const __half *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
+    return CNERF_EINVAL;
+}
+
+int cnerf_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host, float weight, uint32_t B,
+                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void *stream) {
+    if (!inputs || !embeddings || !grad) return CNERF_ENULL;
+    if (gridtype > 1) return CNERF_EINVAL;
+    GridLevels lv;
+    int rc = ge_levels(offsets_host, L, L, S, H, lv);
+    if (rc) return rc;
+    for (uint32_t l = 0; l < L; l++) lv.order[l] = (uint8_t)l;
+    if (B == 0) return CNERF_OK;
+    switch (D) {
+        case 2: return ge_tv_C<2>(inputs, embeddings, grad, lv, weight, B, C, L, gridtype, align_corners, CN_STREAM(stream));
+        case 3: return ge_tv_C<3>(inputs, embeddings, grad, lv, weight, B, C, L, gridtype, align_corners, CN_STREAM(stream));
+        case 4: return ge_tv_C<4>(inputs, embeddings, grad, lv, weight, B, C, L, gridtype, align_corners, CN_STREAM(stream));
+        case 5: return ge_tv_C<5>(inputs, embeddings, grad, lv, weight, B, C, L, gridtype, align_corners, CN_STREAM(stream));
+        default: return CNERF_EINVAL;
+    }
+}
+
+int cnerf_cast_f32_to_f16(const float *src, void *dst, uint64_t n, void *stream) {
+    if (!src || !dst) return CNERF_ENULL;
+    if (n == 0) return CNERF_OK;
+    if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 15)) return CNERF_EINVAL;
+    const uint32_t blocks = (uint32_t)(cn_div_up64(cn_div_up64(n, 8), 256) < 2048 ? cn_div_up64(cn_div_up64(n, 8), 256) : 2048);
+    hipLaunchKernelGGL(k_cast_f32_f16, dim3(blocks ? blocks : 1), dim3(256), 0, CN_STREAM(stream), src, (__half *)dst, n);
+    return cn_launch_status();
+}
+
+}  // extern "C"

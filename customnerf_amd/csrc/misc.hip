@@ -1,0 +1,117 @@
+// Ray generation, fused Adam step and library identification for gfx950.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ ray generation
+// One thread per pixel of one view.  convention 0: nerfstudio / OpenGL pinhole (reference nerf/provider.py:402-464,
+// output already in [H,W] order, i.e. the [W,H]->[H,W] permute of :460-464 is folded into the index);
+// convention 1: torch-ngp get_rays (reference nerf/provider_utils.py:239-302).
+__global__ void __launch_bounds__(256) k_generate_rays(const float *__restrict__ c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy,
+                                                       float cx, float cy, float level, int convention, float *__restrict__ origins,
+                                                       float *__restrict__ directions) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t v = blockIdx.y;
+    if (pix >= H * W) return;
+    const uint32_t iy = pix / W, ix = pix - iy * W;
+    const float *m = c2w + (size_t)v * 12;   // row-major [3,4]
+    float dx, dy, dz;
+    if (convention == 0) {
+        // torch.linspace(0, W*l-1, W)[ix]: start + ix*step for the lower half, end - (W-1-ix)*step for the upper half
+        const float endx = W * level - 1.0f, endy = H * level - 1.0f;
+        const float stepx = W > 1 ? endx / (float)(W - 1) : 0.0f, stepy = H > 1 ? endy / (float)(H - 1) : 0.0f;
+        const float x = ((ix < W / 2) ? (float)ix * stepx : endx - (float)(W - 1 - ix) * stepx) + 0.5f;
+        const float y = ((iy < H / 2) ? (float)iy * stepy : endy - (float)(H - 1 - iy) * stepy) + 0.5f;
+        const float px = (x - cx) / fx, py = -(y - cy) / fy, pz = -1.0f;
+        dx = m[0] * px + m[1] * py + m[2] * pz;
+        dy = m[4] * px + m[5] * py + m[6] * pz;
+        dz = m[8] * px + m[9] * py + m[10] * pz;
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);   // F.normalize eps
+        dx /= nrm; dy /= nrm; dz /= nrm;
+    } else {
+        const float i = (float)ix + 0.5f, j = (float)iy + 0.5f;
+        float px = (i - cx) / fx, py = (j - cy) / fy, pz = 1.0f;
+        const float nrm = sqrtf(fmaxf(px * px + py * py + pz * pz, 1e-20f));      // safe_normalize
+        px /= nrm; py /= nrm; pz /= nrm;
+        dx = px * m[0] + py * m[1] + pz * m[2];
+        dy = px * m[4] + py * m[5] + pz * m[6];
+        dz = px * m[8] + py * m[9] + pz * m[10];
+    }
+    const size_t o = ((size_t)v * H * W + pix) * 3;
+    origins[o] = m[3]; origins[o + 1] = m[7]; origins[o + 2] = m[11];
+    directions[o] = dx; directions[o + 1] = dy; directions[o + 2] = dz;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam semantics (no weight decay, no amsgrad):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  One pass: 16 B/lane vector loads, optional fp16 shadow store,
+// optional gradient zeroing (saves the separate 4 B/param memset pass of zero_grad).
+__global__ void __launch_bounds__(256) k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                              __half *__restrict__ ph, uint64_t n, float step_size, float beta1, float beta2, float eps,
+                                              float rsqrt_bc2, float gscale, int zero_grad) {
+    const uint64_t n4 = n / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float gk = ga[k] * gscale;
+            ma[k] = beta1 * ma[k] + (1.0f - beta1) * gk;
+            va[k] = beta2 * va[k] + (1.0f - beta2) * gk * gk;
+            pa[k] -= step_size * ma[k] / (sqrtf(va[k]) * rsqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = make_float4(0, 0, 0, 0);
+        if (ph) {
+            union { __half2 h[2]; uint2 u; } o;
+            o.h[0] = __floats2half2_rn(pp.x, pp.y);
+            o.h[1] = __floats2half2_rn(pp.z, pp.w);
+            reinterpret_cast<uint2 *>(ph)[i] = o.u;
+        }
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gk = g[i] * gscale;
+        const float mk = beta1 * m[i] + (1.0f - beta1) * gk;
+        const float vk = beta2 * v[i] + (1.0f - beta2) * gk * gk;
+        const float pk = p[i] - step_size * mk / (sqrtf(vk) * rsqrt_bc2 + eps);
+        m[i] = mk; v[i] = vk; p[i] = pk;
+        if (zero_grad) g[i] = 0;
+        if (ph) ph[i] = __float2half_rn(pk);
+    }
+}
+
+extern "C" {
+
+int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
+const char *cnerf_target_arch(void) { return "gfx950"; }
+
+int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy, float level,
+                        int convention, float *origins, float *directions, void *stream) {
+    if (!c2w || !origins || !directions) return CNERF_ENULL;
+    if (convention < 0 || convention > 1 || fx == 0.0f || fy == 0.0f) return CNERF_EINVAL;
+    if (V == 0 || H == 0 || W == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_generate_rays, dim3(cn_div_up(H * W, 256), V), dim3(256), 0, CN_STREAM(stream), c2w, V, H, W, fx, fy, cx, cy, level,
+                       convention, origins, directions);
+    return cn_launch_status();
+}
+
+int cnerf_adam_step(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2, float eps,
+                    uint32_t step, float grad_scale_inv, int zero_grad, void *stream) {
+    if (!p || !g || !m || !v) return CNERF_ENULL;
+    if (step == 0) return CNERF_EINVAL;
+    if (n == 0) return CNERF_OK;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CNERF_EINVAL;
+    if (p_half && (((uintptr_t)p_half) & 7)) return CNERF_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const uint64_t want = cn_div_up64(cn_div_up64(n, 4), 256);
+    const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, CN_STREAM(stream), p, g, m, v, (__half *)p_half, n, step_size, beta1, beta2, eps,
+                       rsqrt_bc2, grad_scale_inv, zero_grad);
+    return cn_launch_status();
+}
+
+}  // extern "C"

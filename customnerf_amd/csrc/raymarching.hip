@@ -1,0 +1,574 @@
+// Ray-marching kernels for gfx950 (CDNA4, wave64).
+//
+// Replaces the reference's `_raymarching` extension (raymarching/src/raymarching.cu) behind the C-ABI of
+// include/customnerf_hip.h.  Written from the kernels' documented behaviour, not translated: slot reservation
+// is a deterministic ray-ordered scan (count -> scan -> write) instead of two global atomics per ray, the alive
+// list is compacted on the device with wave ballots, and float arithmetic that decides integer outputs
+// (num_steps, voxel indices) is spelled out operation by operation so it is bit-identical to
+// oracle/raymarching_ref.c (compiled -ffp-contract=off on both sides).
+#include "common.h"
+#include <float.h>
+
+#define RM_BLOCK 256
+
+__device__ __forceinline__ float rm_signf(float x) { return copysignf(1.0f, x); }
+
+__device__ __forceinline__ int rm_mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)exponent));
+}
+
+__device__ __forceinline__ int rm_mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)exponent));
+}
+
+__host__ __device__ __forceinline__ uint32_t rm_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__host__ __device__ __forceinline__ uint32_t rm_morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return rm_expand_bits(x) | (rm_expand_bits(y) << 1) | (rm_expand_bits(z) << 2);
+}
+__host__ __device__ __forceinline__ uint32_t rm_morton3D_invert(uint32_t x) {
+    x = x & 0x49249249;
+    x = (x | (x >> 2)) & 0xc30c30c3;
+    x = (x | (x >> 4)) & 0x0f00f00f;
+    x = (x | (x >> 8)) & 0xff0000ff;
+    x = (x | (x >> 16)) & 0x0000ffff;
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------ utils
+__global__ void __launch_bounds__(RM_BLOCK) k_near_far_from_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                 const float *__restrict__ aabb, uint32_t N, float min_near,
+                                                                 float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { const float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { const float c = near_y; near_y = far_y; far_y = c; }
+    bool miss = (near > far_y || near_y > far);
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { const float c = near_z; near_z = far_z; far_z = c; }
+    miss = miss || (near > far_z || near_z > far);
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    nears[n] = miss ? FLT_MAX : near;
+    fars[n] = miss ? FLT_MAX : far;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK) k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
+                                                           uint32_t N, float *__restrict__ coords) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = cn_fma(dz, dz, cn_fma(dy, dy, dx * dx));
+    const float B = cn_fma(oz, dz, cn_fma(oy, dy, ox * dx));
+    const float C = cn_fma(-radius, radius, cn_fma(oz, oz, cn_fma(oy, oy, ox * ox)));
+    const float t = (-B + sqrtf(cn_fma(B, B, -(A * C)))) / A;
+    const float x = cn_fma(t, dx, ox), y = cn_fma(t, dy, oy), z = cn_fma(t, dz, oz);
+    const float theta = atan2f(sqrtf(cn_fma(z, z, x * x)), y);
+    const float phi = atan2f(z, x);
+    coords[n * 2] = cn_fma(2 * theta, 0.3183098861837907f, -1.0f);
+    coords[n * 2 + 1] = phi * 0.3183098861837907f;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK) k_morton3D(const int *__restrict__ coords, uint32_t N, int *__restrict__ indices) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    indices[n] = (int)rm_morton3D((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+
+__global__ void __launch_bounds__(RM_BLOCK) k_morton3D_invert(const int *__restrict__ indices, uint32_t N, int *__restrict__ coords) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const int ind = indices[n];
+    coords[n * 3] = (int)rm_morton3D_invert((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int)rm_morton3D_invert((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int)rm_morton3D_invert((uint32_t)(ind >> 2));
+}
+
+// one thread packs 8 consecutive cells = two float4 loads -> one byte
+__global__ void __launch_bounds__(RM_BLOCK) k_packbits(const float *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------------ marching core
+struct RayState {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+struct MarchConst {
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
+    uint32_t H;
+};
+struct Probe {
+    float x, y, z, dt;
+    bool occ;
+};
+
+__device__ __forceinline__ MarchConst rm_consts(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    MarchConst k;
+    k.bound = bound;
+    k.dt_gamma = dt_gamma;
+    k.dt_min = 2 * 1.7320508075688772f / max_steps;
+    k.dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
+    k.rH = 1 / (float)H;
+    k.H3 = (float)(H * H * H);
+    k.Hf = (float)H;
+    k.Cf = (float)C;
+    k.Hm1 = (float)(H - 1);
+    k.H = H;
+    return k;
+}
+
+// One probe of the occupancy bitfield at parameter t; on a miss t is advanced past the voxel (DDA-like skip).
+__device__ __forceinline__ Probe rm_probe(const RayState &r, float &t, const MarchConst &k, const uint8_t *__restrict__ grid) {
+    Probe s;
+    s.x = cn_clamp(cn_fma(t, r.dx, r.ox), -k.bound, k.bound);
+    s.y = cn_clamp(cn_fma(t, r.dy, r.oy), -k.bound, k.bound);
+    s.z = cn_clamp(cn_fma(t, r.dz, r.oz), -k.bound, k.bound);
+    s.dt = cn_clamp(t * k.dt_gamma, k.dt_min, k.dt_max);
+
+    const int lp = rm_mip_from_pos(s.x, s.y, s.z, k.Cf);
+    const int ld = rm_mip_from_dt(s.dt, k.Hf, k.Cf);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), k.bound);
+    const float mip_rbound = 1 / mip_bound;
+
+    const int nx = (int)cn_clamp((float)(0.5 * (double)cn_fma(s.x, mip_rbound, 1.0f) * (double)k.H), 0.0f, k.Hm1);
+    const int ny = (int)cn_clamp((float)(0.5 * (double)cn_fma(s.y, mip_rbound, 1.0f) * (double)k.H), 0.0f, k.Hm1);
+    const int nz = (int)cn_clamp((float)(0.5 * (double)cn_fma(s.z, mip_rbound, 1.0f) * (double)k.H), 0.0f, k.Hm1);
+
+    const uint32_t index = (uint32_t)cn_fma((float)level, k.H3, (float)rm_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    s.occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;
+
+    if (!s.occ) {
+        const float tx = cn_fma(cn_fma((nx + 0.5f + 0.5f * rm_signf(r.dx)) * k.rH, 2.0f, -1.0f), mip_bound, -s.x) * r.rdx;
+        const float ty = cn_fma(cn_fma((ny + 0.5f + 0.5f * rm_signf(r.dy)) * k.rH, 2.0f, -1.0f), mip_bound, -s.y) * r.rdy;
+        const float tz = cn_fma(cn_fma((nz + 0.5f + 0.5f * rm_signf(r.dz)) * k.rH, 2.0f, -1.0f), mip_bound, -s.z) * r.rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += cn_clamp(t * k.dt_gamma, k.dt_min, k.dt_max);
+        } while (t < tt);
+    }
+    return s;
+}
+
+__device__ __forceinline__ RayState rm_load_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, uint32_t n) {
+    RayState r;
+    r.ox = rays_o[n * 3]; r.oy = rays_o[n * 3 + 1]; r.oz = rays_o[n * 3 + 2];
+    r.dx = rays_d[n * 3]; r.dy = rays_d[n * 3 + 1]; r.dz = rays_d[n * 3 + 2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    return r;
+}
+
+// pass 1: count occupied steps per ray; rays[n] = (n, <unset>, num_steps)
+__global__ void __launch_bounds__(RM_BLOCK) k_march_train_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                                const float *__restrict__ nears, const float *__restrict__ fars,
+                                                                int *__restrict__ rays, const float *__restrict__ noises) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
+    const RayState r = rm_load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t = nears[n];
+    t = cn_fma(cn_clamp(t * dt_gamma, k.dt_min, k.dt_max), noises[n], t);
+    uint32_t num_steps = 0;
+    while (t < far && num_steps < max_steps) {
+        const Probe s = rm_probe(r, t, k, grid);
+        if (s.occ) { num_steps++; t += s.dt; }
+    }
+    rays[n * 3] = (int)n;
+    rays[n * 3 + 2] = (int)num_steps;
+}
+
+// pass 2: exclusive scan of num_steps in ray order (one workgroup; wave shuffles + one LDS hop).
+// rays[n*3+1] = base + sum_{m<n} num_steps[m];  counter[0] += total, counter[1] += N.
+#define SCAN_THREADS 1024
+__global__ void __launch_bounds__(SCAN_THREADS) k_march_train_scan(int *__restrict__ rays, int *__restrict__ counter, uint32_t N) {
+    __shared__ uint32_t wave_tot[SCAN_THREADS / CN_WAVE];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t chunk = (N + SCAN_THREADS - 1) / SCAN_THREADS;
+    const uint32_t begin = min(tid * chunk, N), end = min(begin + chunk, N);
+    uint32_t local = 0;
+    for (uint32_t n = begin; n < end; n++) local += (uint32_t)rays[n * 3 + 2];
+    const uint32_t incl = cn_wave_incl_scan(local);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SCAN_THREADS / CN_WAVE; w++) {
+        const uint32_t v = wave_tot[w];
+        if (w < wave) wave_base += v;
+        total += v;
+    }
+    const uint32_t base = (uint32_t)counter[0];
+    uint32_t run = base + wave_base + incl - local;
+    for (uint32_t n = begin; n < end; n++) {
+        rays[n * 3 + 1] = (int)run;
+        run += (uint32_t)rays[n * 3 + 2];
+    }
+    __syncthreads();   // every thread has read counter[0] before it is updated
+    if (tid == 0) {
+        counter[0] = (int)(base + total);
+        counter[1] += (int)N;
+    }
+}
+
+// pass 3: re-march and write the samples of ray n at its reserved segment
+__global__ void __launch_bounds__(RM_BLOCK) k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                                const float *__restrict__ nears, const float *__restrict__ fars,
+                                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                                const int *__restrict__ rays, const float *__restrict__ noises) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || point_index + num_steps > M) return;
+    const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
+    const RayState r = rm_load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t = nears[n];
+    t = cn_fma(cn_clamp(t * dt_gamma, k.dt_min, k.dt_max), noises[n], t);
+    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pl = deltas + (size_t)point_index * 2;
+    uint32_t step = 0;
+    float last_t = t;
+    while (t < far && step < num_steps) {
+        const Probe s = rm_probe(r, t, k, grid);
+        if (s.occ) {
+            px[0] = s.x; px[1] = s.y; px[2] = s.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += s.dt;
+            pl[0] = s.dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ compositing (training)
+template <int RS>
+__global__ void __launch_bounds__(RM_BLOCK) k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                                  const float *__restrict__ deltas, const int *__restrict__ rays, uint32_t M,
+                                                                  uint32_t N, float T_thresh, float *__restrict__ weights_sum,
+                                                                  float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    if (!(num_steps == 0 || offset + num_steps > M)) {
+        const float *ps = sigmas + offset, *pc = rgbs + (size_t)offset * RS;
+        const float2 *pl = reinterpret_cast<const float2 *>(deltas) + offset;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float2 dl = pl[step];
+            const float alpha = 1.0f - __expf(-ps[step] * dl.x);
+            const float weight = alpha * T;
+            r = cn_fma(weight, pc[0], r); g = cn_fma(weight, pc[1], g); b = cn_fma(weight, pc[2], b);
+            t += dl.y;
+            d = cn_fma(weight, t, d);
+            ws += weight;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+            pc += RS;
+        }
+    }
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+template <int RS>
+__global__ void __launch_bounds__(RM_BLOCK) k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
+                                                                  const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                                  const float *__restrict__ deltas, const int *__restrict__ rays,
+                                                                  const float *__restrict__ weights_sum, const float *__restrict__ image,
+                                                                  uint32_t M, uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
+                                                                  float *__restrict__ grad_rgbs) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
+    const float ws_final = weights_sum[index];
+    const float *ps = sigmas + offset, *pc = rgbs + (size_t)offset * RS;
+    const float2 *pl = reinterpret_cast<const float2 *>(deltas) + offset;
+    float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * RS;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float dl = pl[step].x;
+        const float alpha = 1.0f - __expf(-ps[step] * dl);
+        const float weight = alpha * T;
+        const float c0 = pc[0], c1 = pc[1], c2 = pc[2];
+        r = cn_fma(weight, c0, r); g = cn_fma(weight, c1, g); b = cn_fma(weight, c2, b);
+        T *= 1.0f - alpha;
+        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
+        gs[step] = dl * (gi0 * cn_fma(T, c0, -(r_final - r)) + gi1 * cn_fma(T, c1, -(g_final - g)) +
+                         gi2 * cn_fma(T, c2, -(b_final - b)) + gws * (1 - ws_final));
+        if (T < T_thresh) break;
+        pc += RS; gc += RS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ inference
+__global__ void __launch_bounds__(RM_BLOCK) k_march_rays(uint32_t n_alive, uint32_t n_step, const int *__restrict__ rays_alive,
+                                                         const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                         const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                                         uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
+                                                         const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                         float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
+    const RayState r = rm_load_ray(rays_o, rays_d, (uint32_t)index);
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    const float far = fars[index];
+    t = cn_fma(cn_clamp(t * dt_gamma, k.dt_min, k.dt_max), noises[n], t);
+    float last_t = t;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        const Probe s = rm_probe(r, t, k, grid);
+        if (s.occ) {
+            px[0] = s.x; px[1] = s.y; px[2] = s.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += s.dt;
+            pl[0] = s.dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+}
+
+template <int RS>
+__global__ void __launch_bounds__(RM_BLOCK) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int *__restrict__ rays_alive,
+                                                             float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                             const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                             float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float *ps = sigmas + (size_t)n * n_step, *pc = rgbs + (size_t)n * n_step * RS, *pl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (pl[0] == 0) break;
+        const float alpha = 1.0f - __expf(-ps[0] * pl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += pl[1];
+        d = cn_fma(weight, t, d);
+        r = cn_fma(weight, pc[0], r); g = cn_fma(weight, pc[1], g); b = cn_fma(weight, pc[2], b);
+        if (T < T_thresh) break;
+        ps++; pc += RS; pl += 2; step++;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = weight_sum;
+    depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// Order-preserving compaction of the alive list: ballot + popcount inside a wave, LDS for the wave bases,
+// a running base across the 1024-ray tiles.  One workgroup: the list is at most H*W entries and shrinks fast.
+__global__ void __launch_bounds__(SCAN_THREADS) k_compact_alive(const int *__restrict__ in, uint32_t n, int *__restrict__ out, int *__restrict__ count) {
+    __shared__ uint32_t wave_cnt[SCAN_THREADS / CN_WAVE];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t base = 0;
+    for (uint32_t start = 0; start < n; start += SCAN_THREADS) {
+        const uint32_t i = start + tid;
+        const int v = (i < n) ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < SCAN_THREADS / CN_WAVE; w++) {
+            const uint32_t c = wave_cnt[w];
+            if (w < wave) wbase += c;
+            tot += c;
+        }
+        if (keep) out[base + wbase + before] = v;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = (int)base;
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+#define RM_GRID(n) dim3(cn_div_up((n), RM_BLOCK)), dim3(RM_BLOCK), 0, CN_STREAM(stream)
+
+extern "C" {
+
+int cnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near, float *nears,
+                             float *fars, void *stream) {
+    if (!rays_o || !rays_d || !aabb || !nears || !fars) return CNERF_ENULL;
+    if (N == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_near_far_from_aabb, RM_GRID(N), rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return cn_launch_status();
+}
+
+int cnerf_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
+    if (!rays_o || !rays_d || !coords) return CNERF_ENULL;
+    if (N == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_sph_from_ray, RM_GRID(N), rays_o, rays_d, radius, N, coords);
+    return cn_launch_status();
+}
+
+int cnerf_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
+    if (!coords || !indices) return CNERF_ENULL;
+    if (N == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_morton3D, RM_GRID(N), coords, N, indices);
+    return cn_launch_status();
+}
+
+int cnerf_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
+    if (!coords || !indices) return CNERF_ENULL;
+    if (N == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_morton3D_invert, RM_GRID(N), indices, N, coords);
+    return cn_launch_status();
+}
+
+int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
+    if (!grid || !bitfield) return CNERF_ENULL;
+    if (N == 0) return CNERF_OK;
+    if (((uintptr_t)grid) & 15) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_packbits, RM_GRID(N), grid, N, density_thresh, bitfield);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears, const float *fars,
+                                 int32_t *rays, int32_t *counter, const float *noises, void *stream) {
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays_train_write(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                                 const float *fars, float *xyzs, float *dirs, float *deltas, const int32_t *rays, const float *noises,
+                                 void *stream) {
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !noises) return CNERF_ENULL;
+    if (M > 0 && (!xyzs || !dirs || !deltas)) return CNERF_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
+    if (N == 0 || M == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_march_train_write, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                       deltas, rays, noises);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
+                           uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
+                           float *deltas, int32_t *rays, int32_t *counter, const float *noises, void *stream) {
+    int rc = cnerf_march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, noises, stream);
+    if (rc) return rc;
+    return cnerf_march_rays_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                        noises, stream);
+}
+
+int cnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
+                                       float T_thresh, float *weights_sum, float *depth, float *image, uint32_t rgb_stride, void *stream) {
+    if (!rays || !weights_sum || !depth || !image) return CNERF_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas)) return CNERF_ENULL;
+    if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (rgb_stride == 3) hipLaunchKernelGGL(k_composite_train_fwd<3>, RM_GRID(N), sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    else hipLaunchKernelGGL(k_composite_train_fwd<4>, RM_GRID(N), sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    return cn_launch_status();
+}
+
+int cnerf_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
+                                        const float *deltas, const int32_t *rays, const float *weights_sum, const float *image, uint32_t M,
+                                        uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs, uint32_t rgb_stride, void *stream) {
+    if (!rays || !weights_sum || !image || !grad_weights_sum || !grad_image) return CNERF_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas || !grad_sigmas || !grad_rgbs)) return CNERF_ENULL;
+    if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
+    if (N == 0 || M == 0) return CNERF_OK;
+    if (rgb_stride == 3)
+        hipLaunchKernelGGL(k_composite_train_bwd<3>, RM_GRID(N), grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                           T_thresh, grad_sigmas, grad_rgbs);
+    else
+        hipLaunchKernelGGL(k_composite_train_bwd<4>, RM_GRID(N), grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                           T_thresh, grad_sigmas, grad_rgbs);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o, const float *rays_d,
+                     float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *nears,
+                     const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises, void *stream) {
+    (void)nears;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas || !noises) return CNERF_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0 || n_step == 0) return CNERF_EINVAL;
+    if (n_alive == 0) return CNERF_OK;
+    hipLaunchKernelGGL(k_march_rays, RM_GRID(n_alive), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,
+                       fars, xyzs, dirs, deltas, noises);
+    return cn_launch_status();
+}
+
+int cnerf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas,
+                         const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, uint32_t rgb_stride,
+                         void *stream) {
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return CNERF_ENULL;
+    if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
+    if (n_alive == 0) return CNERF_OK;
+    if (rgb_stride == 3)
+        hipLaunchKernelGGL(k_composite_rays<3>, RM_GRID(n_alive), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_composite_rays<4>, RM_GRID(n_alive), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return cn_launch_status();
+}
+
+int cnerf_compact_rays_alive(const int32_t *rays_alive_in, uint32_t n, int32_t *rays_alive_out, int32_t *count, void *stream) {
+    if (!count) return CNERF_ENULL;
+    if (n > 0 && (!rays_alive_in || !rays_alive_out)) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_compact_alive, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays_alive_in, n, rays_alive_out, count);
+    return cn_launch_status();
+}
+
+}  // extern "C"

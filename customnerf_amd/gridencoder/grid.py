@@ -1,0 +1,219 @@
+"""Multiresolution grid encoder module — same constructor, attributes, forward() and grad_total_variation() as
+the reference's `gridencoder/grid.py` (cited per item), backed by libcustomnerf_hip.so.
+
+Deliberate differences:
+  * the kernel-layout output [L,B,C] is also reachable (`forward(..., return_kernel_layout=True)`) so the fused field
+    kernel can consume it without the permute+reshape copy of grid.py:63;
+  * under autocast the fp16 table is a cached shadow copy refreshed only when the fp32 parameter changes (the
+    reference re-casts the whole table on every call, grid.py:45-46);
+  * gradients are accumulated in float32 for both table dtypes (the reference scatters __half2 atomics for fp16).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .._lib import lib, check, ptr, stream, dtype_id, require_cuda
+
+# Optional in-stream timing of the gather kernel (bench.py's roofline leg): when a list is installed with
+# set_profile(), every forward launch is bracketed by a pair of events recorded on the launch stream.
+_PROFILE = None
+
+
+def set_profile(sink):
+    """sink: None (off) or a list that receives (start_event, end_event, n_points, n_levels, itemsize) tuples."""
+    global _PROFILE
+    _PROFILE = sink
+
+
+_gridtype_to_id = {'hash': 0, 'tiled': 1}
+_interp_to_id = {'linear': 0, 'smoothstep': 1}
+
+
+def _offsets_host(offsets):
+    """int32 numpy copy of the level offset table (the C-ABI takes it as a host array)."""
+    if isinstance(offsets, np.ndarray):
+        return np.ascontiguousarray(offsets, dtype=np.int32)
+    cached = getattr(offsets, "_cnerf_host", None)
+    if cached is None:
+        cached = np.ascontiguousarray(offsets.detach().cpu().numpy(), dtype=np.int32)
+        try:
+            offsets._cnerf_host = cached
+        except Exception:
+            pass
+    return cached
+
+
+class _grid_encode(Function):
+    """grid.py:24-95.  `embeddings` is the float32 parameter; `table` is what the kernel reads (the parameter itself, or
+    its fp16 shadow).  Returns the encoder output in kernel layout [L,B,C]."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, table, offsets_host, per_level_scale, base_resolution, calc_grad_inputs, gridtype,
+                align_corners, interpolation, max_level):
+        require_cuda(inputs, table)
+        inputs = inputs.contiguous().float()
+        B, D = inputs.shape
+        L = offsets_host.shape[0] - 1
+        C = table.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        max_level = L if max_level is None else min(max_level, L)
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=table.dtype)
+        if max_level < L:
+            outputs.zero_()
+        if calc_grad_inputs:
+            dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=table.dtype)
+            if max_level < L:
+                dy_dx.zero_()
+        else:
+            dy_dx = None
+        prof = _PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib.cnerf_grid_encode_forward(ptr(inputs), ptr(table), offsets_host.ctypes.data, ptr(outputs), B, D, C, L, max_level, S, H,
+                                            ptr(dy_dx), gridtype, int(align_corners), interpolation, dtype_id(table), stream()),
+              "grid_encode_forward")
+        if prof is not None:
+            e1.record()
+            prof.append((e0, e1, B, max_level, table.element_size()))
+        ctx.save_for_backward(inputs, dy_dx)
+        ctx.cfg = (offsets_host, B, D, C, L, S, H, gridtype, interpolation, max_level, align_corners, tuple(embeddings.shape))
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, dy_dx = ctx.saved_tensors
+        offsets_host, B, D, C, L, S, H, gridtype, interpolation, max_level, align_corners, eshape = ctx.cfg
+        grad = grad.contiguous()                                     # already [L,B,C]: no permute copy (grid.py:81)
+        if dy_dx is not None and grad.dtype != dy_dx.dtype:
+            grad = grad.to(dy_dx.dtype)
+        grad_embeddings = torch.zeros(eshape, device=grad.device, dtype=torch.float32)
+        grad_inputs = torch.empty(B, D, device=grad.device, dtype=torch.float32) if dy_dx is not None else None
+        check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, max_level,
+                                             S, H, ptr(dy_dx), ptr(grad_inputs), gridtype, int(align_corners), interpolation,
+                                             dtype_id(grad), stream()), "grid_encode_backward")
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
+
+
+def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0, max_level=None):
+    """Functional form with the reference's signature (grid.py:27,99): returns [B, L*C]."""
+    table = embeddings
+    if torch.is_autocast_enabled() and embeddings.shape[1] % 2 == 0:          # grid.py:45-46
+        table = embeddings.detach().to(torch.half)
+    out = _grid_encode.apply(inputs, embeddings, table.detach(), _offsets_host(offsets), per_level_scale, base_resolution,
+                             calc_grad_inputs, gridtype, align_corners, interpolation, max_level)
+    L, B, C = out.shape
+    return out.permute(1, 0, 2).reshape(B, L * C)
+
+
+class GridEncoder(nn.Module):
+    """grid.py:102-192."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype='hash', align_corners=False, interpolation='linear'):
+        super().__init__()
+        if desired_resolution is not None:                                       # grid.py:107-108
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        if level_dim not in (1, 2, 4, 8):
+            raise ValueError("GridEncoding: C must be 1, 2, 4, or 8.")            # gridencoder.cu:380
+        if input_dim not in (2, 3, 4, 5):
+            raise ValueError("GridEncoding: D must be 2, 3, 4, or 5.")            # gridencoder.cu:397
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _interp_to_id[interpolation]
+        self.align_corners = align_corners
+
+        offsets, offset = [], 0                                                  # grid.py:124-135
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self._offsets_host = np.array(offsets, dtype=np.int32)
+        self.register_buffer('offsets', torch.from_numpy(self._offsets_host.copy()))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self._half_table = None
+        self._half_version = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4                                                                # grid.py:144-146
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    # ---- fp16 shadow table ------------------------------------------------------------------------------------
+    def half_table(self):
+        """fp16 copy of the table, refreshed when the parameter's version counter moved (optimizer step / load)."""
+        emb = self.embeddings
+        key = (emb._version, emb.data_ptr(), getattr(emb, '_cnerf_epoch', 0))
+        if self._half_table is None or self._half_version != key or self._half_table.device != emb.device:
+            if self._half_table is None or self._half_table.shape != emb.shape or self._half_table.device != emb.device:
+                self._half_table = torch.empty(emb.shape, dtype=torch.half, device=emb.device)
+            check(lib.cnerf_cast_f32_to_f16(ptr(emb), ptr(self._half_table), emb.numel(), stream()), "cast_f32_to_f16")
+            self._half_version = key
+        return self._half_table
+
+    def set_half_table(self, table, version_key=None):
+        """Let a fused optimiser hand over the fp16 shadow it wrote while updating the parameter."""
+        self._half_table = table
+        emb = self.embeddings
+        self._half_version = version_key if version_key is not None else (emb._version, emb.data_ptr(), getattr(emb, '_cnerf_epoch', 0))
+
+    def encode(self, inputs, bound=1, max_level=None, half=None):
+        """inputs [..., D] in [-bound, bound] -> kernel-layout features [L, B, C] (B = prod of leading dims)."""
+        inputs = (inputs + bound) / (2 * bound)                                   # grid.py:156
+        inputs = inputs.reshape(-1, self.input_dim)
+        if half is None:
+            half = torch.is_autocast_enabled() and self.level_dim % 2 == 0      # grid.py:45
+        table = self.half_table() if half else self.embeddings.detach()
+        return _grid_encode.apply(inputs, self.embeddings, table, self._offsets_host, self.per_level_scale, self.base_resolution,
+                                  inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
+
+    def forward(self, inputs, bound=1, max_level=None, return_kernel_layout=False):
+        """grid.py:151-168: [..., D] -> [..., L*C]."""
+        prefix_shape = list(inputs.shape[:-1])
+        out = self.encode(inputs, bound, max_level)
+        if return_kernel_layout:
+            return out
+        L, B, C = out.shape
+        return out.permute(1, 0, 2).reshape(prefix_shape + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """grid.py:171-192 (always float32)."""
+        D, C = self.input_dim, self.embeddings.shape[1]
+        L = self._offsets_host.shape[0] - 1
+        S = float(np.log2(self.per_level_scale))
+        H = self.base_resolution
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
+        inputs = inputs.contiguous().float()
+        require_cuda(inputs, self.embeddings)
+        check(lib.cnerf_grad_total_variation(ptr(inputs), ptr(self.embeddings), ptr(self.embeddings.grad), self._offsets_host.ctypes.data,
+                                             float(weight), B, D, C, L, S, H, self.gridtype_id, int(self.align_corners), stream()),
+              "grad_total_variation")

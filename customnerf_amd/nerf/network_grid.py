@@ -1,0 +1,103 @@
+"""NeRFNetwork — counterpart of the reference's nerf/network_grid.py:70-206 (grid backbone).
+
+Same module tree and parameter names as the reference so its state dicts line up (SURVEY.md §5 checkpoint row):
+`pos_en.embeddings`, `pos_en.offsets`, `network.params`, `density_network.params`, `rgb_network.params`.
+Grid geometry defaults to the reference's hard-coded values (tiled, log2 T = 21, finest 8192; network_grid.py:89-96)
+and can be overridden through `opt.grid_type / opt.log2_hashmap_size / opt.desired_resolution / opt.num_levels`.
+"""
+import torch
+from torch import nn
+
+from .renderer import NeRFRenderer
+from .encoding import get_encoder, get_embedder
+from .provider_utils import trunc_exp
+from .. import tcnn
+
+
+class RGB_network(nn.Module):
+    """network_grid.py:13-68: separate colour / confidence heads (used with --detach_mask_from_field / --mask_no_dir)."""
+
+    def __init__(self, input_ch_views, opt=None):
+        super().__init__()
+        self.opt = opt
+        cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64, "n_hidden_layers": 1}
+        self.rgb_network = tcnn.Network(input_ch_views + 64, 3, cfg, seed=13)
+        if getattr(opt, 'mask_no_dir', False):
+            self.conf_network = tcnn.Network(64, 1, cfg, seed=14)
+        else:
+            ndim = 1 if getattr(opt, 'keyword2', None) is None else 2
+            self.conf_network = tcnn.Network(input_ch_views + 64, ndim, cfg, seed=14)
+
+    def forward(self, x):
+        if getattr(self.opt, 'mask_no_dir', False):
+            dir_dim = x.shape[-1] - 64
+            _, fea = x.split([dir_dim, 64], dim=-1)
+            rgb = self.rgb_network(x)
+            rgb2 = self.conf_network(fea if getattr(self.opt, 'mask_no_dir_nodetach', False) else fea.detach())
+        else:
+            rgb = self.rgb_network(x)
+            rgb2 = self.conf_network(x.detach())
+        return torch.cat([rgb, rgb2], dim=-1)
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, opt, device=None, **unused):
+        super().__init__(opt)
+        grid_type = getattr(opt, 'grid_type', 'tiledgrid')
+        self.pos_en, self.pos_en_dim = get_encoder(
+            grid_type, input_dim=3,
+            num_levels=getattr(opt, 'num_levels', 16), level_dim=getattr(opt, 'level_dim', 2),
+            base_resolution=getattr(opt, 'base_resolution', 16),
+            log2_hashmap_size=getattr(opt, 'log2_hashmap_size', 21),
+            desired_resolution=getattr(opt, 'desired_resolution', 8192))
+        n_geo = getattr(opt, 'n_hidden_geo', 2)
+        self.network = tcnn.Network(self.pos_en_dim, 64, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                          "n_neurons": 64, "n_hidden_layers": n_geo}, seed=10)
+        self.density_network = tcnn.Network(64, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                    "n_neurons": 64, "n_hidden_layers": 1}, seed=11)
+        self.dir_en, input_ch_views = get_embedder(4)
+        sig = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64, "n_hidden_layers": 1}
+        if getattr(opt, 'train_conf', 0):
+            if getattr(opt, 'detach_mask_from_field', False) or getattr(opt, 'mask_no_dir', False):
+                self.rgb_network = RGB_network(input_ch_views, opt=opt)
+            else:
+                self.rgb_network = tcnn.Network(input_ch_views + 64, 3 + 1, sig, seed=12)
+        else:
+            self.rgb_network = tcnn.Network(input_ch_views + 64, 3, sig, seed=12)
+        self.bg_net = None
+
+    def background(self, d):
+        return torch.zeros(d.size(), dtype=d.dtype, device=d.device)
+
+    def gaussian(self, x):
+        """network_grid.py:150-156: density blob at the scene centre."""
+        d = (x ** 2).sum(-1)
+        return 5 * torch.exp(-d / (2 * 0.2 ** 2))
+
+    def _geo(self, x):
+        x_en = self.pos_en(x, bound=self.opt.bound)
+        fea = self.network(x_en)
+        sigma = self.density_network(fea)
+        sigma = trunc_exp(sigma.squeeze(-1) + self.gaussian(x))
+        return fea, sigma
+
+    def forward(self, x, d, l=None, ratio=1, shading='albedo'):
+        """network_grid.py:159-177 -> (sigma [P], radiances [P, 3(+1)], None)"""
+        fea, sigma = self._geo(x)
+        view_en = self.dir_en(d)
+        rgb_input = torch.cat([view_en.to(fea.dtype), fea], dim=-1)
+        radiances = self.rgb_network(rgb_input)
+        return sigma, radiances, None
+
+    def density(self, x):
+        """network_grid.py:180-193"""
+        return {'sigma': self._geo(x)[1]}
+
+    def get_params(self, lr):
+        """network_grid.py:196-206: grid lr x10."""
+        return [
+            {'params': self.pos_en.parameters(), 'lr': lr * 10},
+            {'params': self.network.parameters(), 'lr': lr},
+            {'params': self.density_network.parameters(), 'lr': lr},
+            {'params': self.rgb_network.parameters(), 'lr': lr},
+        ]

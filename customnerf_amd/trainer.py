@@ -1,0 +1,75 @@
+"""Minimal counterpart of the reference trainer's reconstruction step (nerf/utils_init_nerf.py:194-241
+`train_step_pretrain`, :599-629 the loop body) with the reference's optimiser recipe (main.py:182-189) and the
+data-parallel layer the reference lacks: ray/view sharding across ranks, one RCCL all-reduce of
+the flattened gradients per step.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .optim import FusedAdam
+
+
+class ReconTrainer:
+    def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale=128.0):
+        self.model, self.opt = model, opt
+        self.fp16 = fp16
+        self.world_size = world_size
+        self.loss_scale = loss_scale if fp16 else 1.0        # static scale (tcnn uses a fixed 128x loss scale)
+        lr = opt.lr if lr is None else lr
+        groups = model.get_params(lr)                        # grid lr x10 (network_grid.py:196-206)
+        self.base_lrs = [g['lr'] for g in groups]
+        if fused_adam:
+            self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+        self.fused_adam = fused_adam
+        self.global_step = 0
+        self._flat = None
+        for p in self.model.parameters():                    # persistent, pre-zeroed .grad buffers (zeroed by the fused step)
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+
+    def lr_factor(self):
+        return 0.1 ** min(self.global_step / self.opt.iters, 1)      # main.py:189
+
+    def loss(self, outputs, rgbs, mask):
+        """utils_init_nerf.py:220-234"""
+        pred_rgb = outputs['image']
+        loss = getattr(self.opt, 'train_rgb', 1.0) * F.mse_loss(pred_rgb.reshape(-1, 3).float(), rgbs.reshape(-1, 3))
+        if getattr(self.opt, 'train_conf', 0) and 'render_mask' in outputs:
+            loss = loss + self.opt.train_conf * F.mse_loss(outputs['render_mask'].reshape(-1).float(), mask.reshape(-1))
+        return loss
+
+    def allreduce_grads(self):
+        """One flattened RCCL all-reduce (sum) per step; the 1/world factor is folded into the Adam un-scale."""
+        if self.world_size <= 1:
+            return
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if self._flat is None or self._flat.numel() != sum(g.numel() for g in grads):
+            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
+        torch._foreach_copy_(list(self._flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self._flat.split([g.numel() for g in grads])))
+
+    def train_step(self, rays_o, rays_d, rgbs, mask, **render_kw):
+        self.model.train()
+        with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+            outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
+            loss = self.loss(outputs, rgbs, mask)
+        (loss * self.loss_scale).backward()
+        self.allreduce_grads()
+        f = self.lr_factor()
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g['lr'] = base * f
+        inv = 1.0 / (self.loss_scale * self.world_size)
+        if self.fused_adam:
+            self.optimizer.grad_scale_inv = inv
+            self.optimizer.step()
+        else:
+            if inv != 1.0:
+                torch._foreach_mul_([p.grad for p in self.model.parameters() if p.grad is not None], inv)
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=False)
+        self.global_step += 1
+        return loss.detach(), outputs

@@ -1,0 +1,157 @@
+/*
+ * customnerf_hip.h — C-ABI of libcustomnerf_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for CustomNeRF's volumetric-rendering hot path.  Each entry point replaces one function of
+ * the reference's two native torch extensions (pybind modules `_raymarching`, `_gridencoder`) or one
+ * third-party call on the path (tinycudann FullyFusedMLP).  Reference interfaces are cited per function as
+ * file:line under /root/reference.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types.  Pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - caller owns every buffer; nothing is allocated, nothing synchronises with the host; work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - returns 0 on success, a positive hipError_t if a launch failed, or a negative CNERF_E* code for rejected
+ *     arguments (the reference raises std::runtime_error / TORCH_CHECK there: gridencoder.cu:380,397,448-464).
+ *   - float32 data unless stated; `dtype` 0 = float32, 1 = float16 (IEEE binary16).
+ */
+#ifndef CUSTOMNERF_HIP_H
+#define CUSTOMNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNERF_OK 0
+#define CNERF_EINVAL (-1)      /* unsupported D / C / dtype / size */
+#define CNERF_ENULL (-2)       /* required pointer is NULL */
+
+#define CNERF_F32 0
+#define CNERF_F16 1
+
+/* ABI version of this header; cnerf_abi_version() of the loaded library must match. */
+#define CNERF_ABI_VERSION 1
+int cnerf_abi_version(void);
+/* name of the code object's target ("gfx950") */
+const char *cnerf_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * _raymarching  (reference: raymarching/src/raymarching.h:7-21, bindings.cpp:5-20)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* near_far_from_aabb — raymarching.h:7, kernel raymarching.cu:91-145.
+ * rays_o, rays_d [N,3]; aabb [6]; nears, fars [N] (miss: both = FLT_MAX). */
+int cnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                             float min_near, float *nears, float *fars, void *stream);
+
+/* sph_from_ray — raymarching.h:8, kernel raymarching.cu:162-198.  coords [N,2]. */
+int cnerf_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream);
+
+/* morton3D / morton3D_invert — raymarching.h:9-10, kernels raymarching.cu:214-226, 237-254. */
+int cnerf_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream);
+int cnerf_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream);
+
+/* packbits — raymarching.h:11, kernel raymarching.cu:267-289.  grid [N*8] floats -> bitfield [N] bytes. */
+int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream);
+
+/* march_rays_train — raymarching.h:13, kernel raymarching.cu:311-480.
+ * Same arguments as the reference binding.  Unlike the reference (atomics-ordered, nondeterministic slots) the
+ * sample segments are laid out in RAY ORDER by an exclusive scan: rays[n] = (n, offset_n, num_steps_n).
+ * counter[0] += total samples, counter[1] += N.  Rays with offset+num_steps > M are dropped (as :416).
+ * xyzs/dirs [M,3], deltas [M,2], rays [N,3] int32, counter [2] int32, noises [N]. */
+int cnerf_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                           const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                           const float *noises, void *stream);
+/* The same operation split in its two passes so a caller can size xyzs/dirs/deltas from counter[0] instead of
+ * pre-allocating N*max_steps samples (raymarching.py:197,206-208): _count fills rays[] and counter[];
+ * _write (given the rays[] produced by _count) writes the samples. */
+int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears,
+                                 const float *fars, int32_t *rays, int32_t *counter, const float *noises, void *stream);
+int cnerf_march_rays_train_write(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                                 const float *fars, float *xyzs, float *dirs, float *deltas, const int32_t *rays,
+                                 const float *noises, void *stream);
+
+/* composite_rays_train_forward / _backward — raymarching.h:14-15 (the `_sdf` twins :16-17 are byte-identical
+ * duplicates in the reference and map to the same entry points); kernels raymarching.cu:500-577, 691-772.
+ * rgbs has `rgb_stride` floats per sample (3 in the reference binding; 4 lets a caller pass the field's
+ * rgb+confidence rows without a slice/copy — renderer.py:630-635 passes such a tensor). */
+int cnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                       uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth,
+                                       float *image, uint32_t rgb_stride, void *stream);
+int cnerf_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                        const float *rgbs, const float *deltas, const int32_t *rays,
+                                        const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                        float T_thresh, float *grad_sigmas, float *grad_rgbs, uint32_t rgb_stride,
+                                        void *stream);
+
+/* march_rays / composite_rays (inference) — raymarching.h:19-20, kernels raymarching.cu:884-989, 1002-1089. */
+int cnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                     const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
+                     float *dirs, float *deltas, const float *noises, void *stream);
+int cnerf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                         const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                         float *image, uint32_t rgb_stride, void *stream);
+/* Order-preserving device-side compaction replacing `rays_alive = rays_alive[rays_alive >= 0]`
+ * (renderer.py:685): out[0..count) = the non-negative entries of in[0..n) in order, *count = their number.
+ * Wave ballot + prefix scan; `count` is a device int32. */
+int cnerf_compact_rays_alive(const int32_t *rays_alive_in, uint32_t n, int32_t *rays_alive_out, int32_t *count, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * _gridencoder  (reference: gridencoder/src/gridencoder.h:12-15, bindings.cpp:5-7)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* grid_encode_forward — gridencoder.h:12, kernel gridencoder.cu:87-244.
+ * inputs [B,D] in [0,1]; embeddings [offsets[L], C] (dtype); outputs [L,B,C] (dtype); dy_dx [B, L*D*C] (dtype) or NULL.
+ * offsets_host: HOST int32 [L+1] (the reference passes a device tensor; the level geometry — scale, resolution,
+ * table size — is derived from it on the host and travels as kernel arguments).
+ * S = log2(per_level_scale), H = base resolution.  gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.
+ * D in {2,3,4,5}, C in {1,2,4,8}, L <= 32 — else CNERF_EINVAL (gridencoder.cu:380,397). */
+int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                              void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream);
+
+/* grid_encode_backward — gridencoder.h:13, kernels gridencoder.cu:247-339 (+ :342-368 when dy_dx != NULL).
+ * grad [L,B,C] (dtype).  grad_embeddings is ALWAYS float32 [offsets[L], C], pre-zeroed by the caller
+ * (grid.py:83) and accumulated with float32 atomics (the reference uses __half2 atomics for fp16 tables).
+ * grad_inputs float32 [B,D] (written, not accumulated) when dy_dx != NULL. */
+int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                               const void *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
+                               uint32_t interp, int dtype, void *stream);
+
+/* grad_total_variation — gridencoder.h:15, kernel gridencoder.cu:505-609.  float32 only (grid.py:171). */
+int cnerf_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host,
+                               float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                               uint32_t gridtype, int align_corners, void *stream);
+
+/* float32 -> float16 shadow copy of a table (what `embeddings.to(torch.half)` does under autocast, grid.py:45-46). */
+int cnerf_cast_f32_to_f16(const float *src, void *dst, uint64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray generation (reference: nerf/provider.py:402-464 pinhole branch; nerf/provider_utils.py:239-302 get_rays)
+ * c2w [V,3,4] row-major; outputs origins, directions [V, H, W, 3].
+ * convention 0 = nerfstudio/OpenGL (provider.py: dir = normalize(R [ (x+.5-cx)/fx, -(y+.5-cy)/fy, -1 ]),
+ *                 x = linspace(0, W*level-1, W), y likewise);
+ * convention 1 = torch-ngp get_rays (dir = R normalize([ (i+.5-cx)/fx, (j+.5-cy)/fy, 1 ])), level ignored.
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy,
+                        float level, int convention, float *origins, float *directions, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step used by the reference's recipe (main.py:182: Adam betas (0.9,0.99) eps 1e-15, no weight decay),
+ * fused with gradient un-scaling, the fp16 shadow-table refresh and gradient zeroing.
+ * p, m, v float32 [n]; g float32 [n] (zeroed after use if zero_grad); p_half (may be NULL) float16 [n].
+ * step = 1-based step index (bias correction on the host); g is multiplied by grad_scale_inv first.
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_adam_step(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2,
+                    float eps, uint32_t step, float grad_scale_inv, int zero_grad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSTOMNERF_HIP_H */

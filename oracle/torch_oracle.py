@@ -369,3 +369,67 @@ def generate_rays(c2w, fx, fy, cx, cy, H, W, level=1):
         origins.append(ov.reshape(W, H, 3).permute(1, 0, 2))
         directions.append(dv.reshape(W, H, 3).permute(1, 0, 2))
     return torch.stack(origins), torch.stack(directions)
+
+
+# ------------------------------------------------------------------ run_cuda (renderer.py:597-718) and the occupancy grid
+def run_cuda_train(field, rays_o, rays_d, aabb, bound, density_bitfield, cascade, grid_size=128, noises=None, dt_gamma=0,
+                   max_steps=1024, T_thresh=1e-4, mean_count=-1, force_all_rays=True):
+    """Training branch (:617-635).  near_far uses the wrapper default min_near=0.2 as the reference does (:612-613).
+    The field's 4-channel output is sliced to rgb before compositing (what run_cuda2 does at :510; run_cuda itself
+    passes 4-channel rows to a stride-3 kernel, a reference defect — SURVEY.md §2)."""
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    nears, fars = co.near_far_from_aabb(rays_o.numpy(), rays_d.numpy(), aabb.numpy(), 0.2)
+    counter = np.zeros(2, np.int32)
+    xyzs, dirs, deltas, rays = co.march_rays_train(rays_o.numpy(), rays_d.numpy(), bound, density_bitfield, cascade, grid_size, nears,
+                                                   fars, counter, mean_count, noises, 128, force_all_rays, dt_gamma, max_steps)
+    sigmas, rgbs, _ = field(torch.from_numpy(xyzs), torch.from_numpy(dirs))
+    ws, depth, image = CompositeTrainRef.apply(sigmas, rgbs[..., :3].contiguous(), torch.from_numpy(deltas), torch.from_numpy(rays), T_thresh)
+    return dict(image=image, depth=depth, weights_sum=ws, mask=torch.from_numpy(nears < fars), rays=rays, xyzs=xyzs, dirs=dirs,
+                deltas=deltas, counter=counter, sigmas=sigmas, rgbs=rgbs)
+
+
+class CompositeTrainRef(torch.autograd.Function):
+    """raymarching.py:239-289 on the C oracle."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh):
+        ws, depth, image = co.composite_rays_train_forward(sigmas.detach().numpy(), rgbs.detach().numpy(), deltas.numpy(), rays.numpy(), T_thresh)
+        ws, depth, image = torch.from_numpy(ws), torch.from_numpy(depth), torch.from_numpy(image)
+        ctx.save_for_backward(sigmas.detach(), rgbs.detach(), deltas, rays, ws, image)
+        ctx.T = T_thresh
+        return ws, depth, image
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image):
+        sigmas, rgbs, deltas, rays, ws, image = ctx.saved_tensors
+        gs, gc = co.composite_rays_train_backward(g_ws.contiguous().numpy(), g_image.contiguous().numpy(), sigmas.numpy(), rgbs.numpy(),
+                                                  deltas.numpy(), rays.numpy(), ws.numpy(), image.numpy(), ctx.T)
+        return torch.from_numpy(gs), torch.from_numpy(gc), None, None, None
+
+
+def run_cuda_eval(field, rays_o, rays_d, aabb, bound, density_bitfield, cascade, grid_size=128, dt_gamma=0, max_steps=1024, T_thresh=1e-4):
+    """Inference branch (:651-688): march <= 8 steps at a time over the alive rays, composite, compact."""
+    rays_o = rays_o.contiguous().view(-1, 3).numpy()
+    rays_d = rays_d.contiguous().view(-1, 3).numpy()
+    N = rays_o.shape[0]
+    nears, fars = co.near_far_from_aabb(rays_o, rays_d, aabb.numpy(), 0.2)
+    weights_sum, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    rays_alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step, trace = 0, []
+    while step < max_steps:
+        n_alive = rays_alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = co.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, cascade,
+                                           grid_size, nears, fars, 128, None, dt_gamma, max_steps)
+        with torch.no_grad():
+            sigmas, rgbs, _ = field(torch.from_numpy(xyzs), torch.from_numpy(dirs))
+        co.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas.numpy(), rgbs[..., :3].contiguous().numpy(), deltas, weights_sum,
+                          depth, image, T_thresh)
+        rays_alive = np.ascontiguousarray(rays_alive[rays_alive >= 0])
+        trace.append((n_alive, n_step))
+        step += n_step
+    return dict(image=image, depth=depth, weights_sum=weights_sum, mask=nears < fars, trace=trace)

@@ -1,0 +1,174 @@
+"""GPU parity: grid encoder HIP kernels (Python surface -> ctypes -> C-ABI) against oracle/gridencoder_ref.c.
+Forward is expected bit-exact in fp32 AND fp16 (same operation order, host-computed level geometry on both sides);
+the scatter backward is compared with a tolerance because float atomics reorder the sums."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as co          # noqa: E402
+from oracle import torch_oracle as to      # noqa: E402
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_inputs(B, D, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, D)).astype(np.float32)
+    x[0] = 0.0            # exact lower corner
+    x[1] = 1.0            # exact upper corner (pos_grid = resolution-1 .. +1)
+    x[2, 0] = -0.01       # out of bounds -> zeros
+    x[3, D - 1] = 1.001   # out of bounds
+    x[4] = 0.5
+    return x
+
+
+CONFIGS = [
+    # (name, ctor kwargs)
+    ("hash_L16_T19", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048, gridtype='hash')),
+    ("tiled_L16_T19_8192", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=8192, gridtype='tiled')),
+    ("hash_L4", dict(input_dim=3, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048, gridtype='hash')),
+    ("hash_D2_C4", dict(input_dim=2, num_levels=8, level_dim=4, base_resolution=8, log2_hashmap_size=14, per_level_scale=1.5, gridtype='hash')),
+    ("hash_D3_C1_align", dict(input_dim=3, num_levels=6, level_dim=1, base_resolution=4, log2_hashmap_size=12, per_level_scale=2, gridtype='hash', align_corners=True)),
+    ("tiled_D3_C8_smooth", dict(input_dim=3, num_levels=5, level_dim=8, base_resolution=8, log2_hashmap_size=15, per_level_scale=1.7, gridtype='tiled', interpolation='smoothstep')),
+    ("hash_D4_C2", dict(input_dim=4, num_levels=4, level_dim=2, base_resolution=4, log2_hashmap_size=13, per_level_scale=2, gridtype='hash')),
+]
+
+
+def build(kw, scale=1.0, seed=0):
+    from customnerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(**kw).cuda()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        enc.embeddings.copy_(((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * scale).cuda())
+    return enc
+
+
+@pytest.mark.parametrize("name,kw", CONFIGS, ids=[c[0] for c in CONFIGS])
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+def test_forward_bit_exact(name, kw, half):
+    enc = build(kw)
+    off_ref, pls_ref = to.grid_offsets(kw.get('input_dim', 3), kw['num_levels'], kw['level_dim'], kw.get('per_level_scale', 2),
+                                       kw['base_resolution'], kw['log2_hashmap_size'], kw.get('desired_resolution'), kw.get('align_corners', False))
+    np.testing.assert_array_equal(enc.offsets.cpu().numpy(), off_ref)
+    B = 4099                                                  # ragged vs the 256-point block
+    x = make_inputs(B, enc.input_dim)
+    emb = enc.embeddings.detach().cpu().numpy()
+    gid, iid = enc.gridtype_id, enc.interp_id
+    ref, _ = co.grid_encode_forward(x, emb, off_ref, enc.per_level_scale, enc.base_resolution, False, gid, enc.align_corners, iid, None, half)
+    # call the autograd function with inputs already in [0,1] (avoids the rounding of GridEncoder.forward's affine map)
+    from customnerf_amd.gridencoder.grid import _grid_encode
+    table = enc.half_table() if half else enc.embeddings.detach()
+    out = _grid_encode.apply(cuda(x), enc.embeddings, table, enc._offsets_host, enc.per_level_scale, enc.base_resolution, False, gid,
+                             enc.align_corners, iid, None)
+    L, Bc, C = out.shape
+    got = out.permute(1, 0, 2).reshape(B, L * C).float().cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert np.all(got[2] == 0) and np.all(got[3] == 0) and np.abs(got).max() > 0.1
+
+
+def test_forward_max_level_and_empty():
+    from customnerf_amd.gridencoder.grid import _grid_encode
+    kw = CONFIGS[0][1]
+    enc = build(kw)
+    x = make_inputs(1000, 3, seed=3)
+    ref, _ = co.grid_encode_forward(x, enc.embeddings.detach().cpu().numpy(), enc._offsets_host, enc.per_level_scale, 16, False, 0, False, 0, 5)
+    out = _grid_encode.apply(cuda(x), enc.embeddings, enc.embeddings.detach(), enc._offsets_host, enc.per_level_scale, 16, False, 0, False, 0, 5)
+    got = out.permute(1, 0, 2).reshape(1000, -1).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert np.all(got[:, 10:] == 0)
+    out = enc(torch.empty(0, 3).cuda())
+    assert out.shape == (0, 32)
+
+
+@pytest.mark.parametrize("name,kw", CONFIGS[:6], ids=[c[0] for c in CONFIGS[:6]])
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+def test_dy_dx_and_input_grad(name, kw, half):
+    from customnerf_amd.gridencoder.grid import _grid_encode
+    enc = build(kw)
+    B = 777
+    x = make_inputs(B, enc.input_dim, seed=1)
+    emb = enc.embeddings.detach().cpu().numpy()
+    gid, iid = enc.gridtype_id, enc.interp_id
+    ref, dy_ref = co.grid_encode_forward(x, emb, enc._offsets_host, enc.per_level_scale, enc.base_resolution, True, gid, enc.align_corners, iid, None, half)
+    xin = cuda(x).requires_grad_(True)
+    table = enc.half_table() if half else enc.embeddings.detach()
+    out = _grid_encode.apply(xin, enc.embeddings, table, enc._offsets_host, enc.per_level_scale, enc.base_resolution, True, gid,
+                             enc.align_corners, iid, None)
+    L, _, C = out.shape
+    g = np.random.default_rng(2).standard_normal((B, L * C)).astype(np.float32)
+    if half:
+        g = co.h2f(co.f2h(g))
+    g_lbc = cuda(g).view(B, L, C).permute(1, 0, 2).contiguous().to(out.dtype)
+    out.backward(g_lbc)
+    # input gradient: sum_l,c grad * dy_dx  (gridencoder.cu:342-368)
+    ge_ref, gi_ref = co.grid_encode_backward(g, x, emb.shape, enc._offsets_host, enc.per_level_scale, enc.base_resolution, dy_ref, gid,
+                                             enc.align_corners, iid)
+    scale = max(1.0, float(np.abs(gi_ref).max()))
+    np.testing.assert_allclose(xin.grad.cpu().numpy(), gi_ref, rtol=2e-3 if half else 1e-5, atol=(2e-3 if half else 1e-5) * scale)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), ge_ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,kw", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_backward_scatter(name, kw):
+    enc = build(kw)
+    B = 20011
+    x = make_inputs(B, enc.input_dim, seed=4)
+    L, C = enc.num_levels, enc.level_dim
+    g = np.random.default_rng(5).standard_normal((B, L * C)).astype(np.float32)
+    ge_ref, _ = co.grid_encode_backward(g, x, tuple(enc.embeddings.shape), enc._offsets_host, enc.per_level_scale, enc.base_resolution, None,
+                                        enc.gridtype_id, enc.align_corners, enc.interp_id)
+    for half in (False, True):
+        enc.embeddings.grad = None
+        out = enc.encode(cuda(x) * 2 - 1, bound=1, half=half)
+        gg = co.h2f(co.f2h(g)) if half else g
+        if half:
+            ge_ref_h, _ = co.grid_encode_backward(gg, x, tuple(enc.embeddings.shape), enc._offsets_host, enc.per_level_scale,
+                                                  enc.base_resolution, None, enc.gridtype_id, enc.align_corners, enc.interp_id)
+        out.backward(cuda(gg).view(B, L, C).permute(1, 0, 2).contiguous().to(out.dtype))
+        got = enc.embeddings.grad.cpu().numpy()
+        ref = ge_ref_h if half else ge_ref
+        # the affine map (x*2-1+1)/2 may move a point by 1 ulp: compare with a tolerance scaled to the accumulated magnitude
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-3)
+        assert np.abs(got).max() > 1.0
+        assert got.dtype == np.float32
+
+
+def test_grad_total_variation():
+    kw = CONFIGS[0][1]
+    enc = build(kw, scale=0.5, seed=7)
+    B = 5000
+    x = make_inputs(B, 3, seed=8)
+    emb = enc.embeddings.detach().cpu().numpy()
+    grad = np.zeros_like(emb)
+    co.grad_total_variation(x, emb, grad, enc._offsets_host, 1e-3, enc.per_level_scale, 16, 0, False)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    enc.grad_total_variation(weight=1e-3, inputs=cuda(x) * 2 - 1, bound=1)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), grad, rtol=1e-3, atol=1e-6)
+    assert np.abs(grad).max() > 0
+
+
+def test_cast_and_half_table_refresh():
+    kw = CONFIGS[2][1]
+    enc = build(kw, scale=3.0)
+    h = enc.half_table()
+    assert torch.equal(h, enc.embeddings.detach().half())
+    ref = co.f2h(enc.embeddings.detach().cpu().numpy())
+    np.testing.assert_array_equal(h.cpu().view(torch.int16).numpy().view(np.uint16), ref)       # RNE, bit-exact vs the oracle's f2h
+    with torch.no_grad():
+        enc.embeddings.mul_(0.5)                                                                # bumps the version counter
+    assert torch.equal(enc.half_table(), enc.embeddings.detach().half())
+
+
+def test_rejects_bad_arguments():
+    from customnerf_amd.gridencoder import GridEncoder
+    with pytest.raises(ValueError):
+        GridEncoder(level_dim=3)
+    with pytest.raises(ValueError):
+        GridEncoder(input_dim=6)
+    enc = build(CONFIGS[2][1])
+    with pytest.raises(RuntimeError):
+        enc(torch.rand(8, 3))           # CPU tensor: no CPU path

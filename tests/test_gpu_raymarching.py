@@ -1,0 +1,207 @@
+"""GPU parity: raymarching.* HIP kernels (through the Python surface -> ctypes -> C-ABI) against the C oracle
+(oracle/raymarching_ref.c).  Integer / index outputs are bit-exact; float outputs exact where the arithmetic is
+spelled out identically, 1e-5-relative where a fast intrinsic (__expf) is involved (north_star tolerance 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as co          # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def rm():
+    from customnerf_amd import raymarching
+    return raymarching
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from customnerf_amd import scene as sc
+    grid = sc.sphere_density_grid(cascade=2, grid_size=128, bound=2.0, radius=1.0, value=100.0)
+    bitfield = co.packbits(grid, 10.0)
+    return sc, grid, bitfield
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rays_for(sc, H, W, view=1, opencv=True):
+    import oracle.torch_oracle as to
+    c2w = sc.camera_pose(view, opencv=opencv)
+    fx, fy, cx, cy = sc.intrinsics(H, W)
+    pose = torch.eye(4).unsqueeze(0).clone()
+    pose[0, :3, :4] = torch.from_numpy(c2w)
+    o, d = to.get_rays(pose, (fx, fy, cx, cy), H, W)
+    return o.reshape(-1, 3).contiguous().numpy(), d.reshape(-1, 3).contiguous().numpy()
+
+
+def test_near_far_bit_exact(rm, scene):
+    sc, _, _ = scene
+    o, d = rays_for(sc, 64, 64)
+    # add degenerate directions (zero components -> inf reciprocals) and rays starting inside the box
+    d2 = d.copy(); d2[::7, 1] = 0.0; d2[::11, 0] = 0.0
+    o2 = o.copy(); o2[::5] *= 0.1
+    for aabb, mn in ((np.array([-2, -2, -2, 2, 2, 2], np.float32), 0.01), (np.array([-0.5, -0.3, -0.5, 0.5, 0.7, 0.5], np.float32), 0.2)):
+        for oo, dd in ((o, d), (o2, d2)):
+            n_ref, f_ref = co.near_far_from_aabb(oo, dd, aabb, mn)
+            n, f = rm.near_far_from_aabb(cuda(oo), cuda(dd), cuda(aabb), mn)
+            np.testing.assert_array_equal(n.cpu().numpy(), n_ref)
+            np.testing.assert_array_equal(f.cpu().numpy(), f_ref)
+    # empty input
+    n, f = rm.near_far_from_aabb(torch.empty(0, 3).cuda(), torch.empty(0, 3).cuda(), cuda(aabb), 0.1)
+    assert n.numel() == 0 and f.numel() == 0
+
+
+def test_sph_from_ray(rm, scene):
+    sc, _, _ = scene
+    o, d = rays_for(sc, 32, 32)
+    ref = co.sph_from_ray(o * 0.2, d, 4.0)
+    out = rm.sph_from_ray(cuda(o * 0.2), cuda(d), 4.0).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+
+
+def test_morton_and_packbits_bit_exact(rm, scene):
+    _, grid, bitfield = scene
+    rng = np.random.default_rng(0)
+    coords = rng.integers(0, 128, size=(5000, 3)).astype(np.int32)
+    idx = rm.morton3D(cuda(coords)).cpu().numpy()
+    np.testing.assert_array_equal(idx, co.morton3D(coords))
+    back = rm.morton3D_invert(cuda(idx)).cpu().numpy()
+    np.testing.assert_array_equal(back, coords)
+    np.testing.assert_array_equal(back, co.morton3D_invert(idx))
+    bf = rm.packbits(cuda(grid), 10.0).cpu().numpy()
+    np.testing.assert_array_equal(bf, bitfield)
+    g2 = rng.random((2, 128 ** 3)).astype(np.float32)
+    np.testing.assert_array_equal(rm.packbits(cuda(g2), 0.37).cpu().numpy(), co.packbits(g2, 0.37))
+    assert bf.sum() > 0
+
+
+@pytest.mark.parametrize("H,dt_gamma,perturb", [(32, 0.0, False), (32, 0.0, True), (64, 1.0 / 128, True), (128, 0.0, True)])
+def test_march_rays_train_bit_exact(rm, scene, H, dt_gamma, perturb):
+    sc, _, bitfield = scene
+    o, d = rays_for(sc, H, H, view=2)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.2)
+    N = o.shape[0]
+    noises = np.random.default_rng(1).random(N).astype(np.float32) if perturb else np.zeros(N, np.float32)
+    xr, dr, lr, rr = co.march_rays_train(o, d, 2.0, bitfield, 2, 128, nears, fars, None, -1, noises, 128, True, dt_gamma, 1024)
+    counter = torch.zeros(2, dtype=torch.int32).cuda()
+    x, dd, l, r = rm.march_rays_train(cuda(o), cuda(d), 2.0, cuda(bitfield), 2, 128, cuda(nears), cuda(fars), counter, -1, perturb, 128,
+                                      True, dt_gamma, 1024, noises=cuda(noises))
+    np.testing.assert_array_equal(r.cpu().numpy(), rr)                     # (ray id, offset, num_steps): bit-exact, ray-ordered
+    total = int(rr[:, 2].sum())
+    assert total > N                                                       # non-trivial scene
+    assert counter.cpu().numpy().tolist() == [total, N]
+    assert x.shape == xr.shape
+    np.testing.assert_array_equal(x.cpu().numpy(), xr)
+    np.testing.assert_array_equal(dd.cpu().numpy(), dr)
+    np.testing.assert_array_equal(l.cpu().numpy(), lr)
+
+
+def test_march_rays_train_mean_count_budget(rm, scene):
+    """fixed budget M < total: overflowing rays are dropped exactly like raymarching.cu:416."""
+    sc, _, bitfield = scene
+    o, d = rays_for(sc, 32, 32, view=5)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.2)
+    mean_count = 20000
+    xr, dr, lr, rr = co.march_rays_train(o, d, 2.0, bitfield, 2, 128, nears, fars, None, mean_count, None, 128, False, 0, 1024)
+    counter = torch.zeros(2, dtype=torch.int32).cuda()
+    x, dd, l, r = rm.march_rays_train(cuda(o), cuda(d), 2.0, cuda(bitfield), 2, 128, cuda(nears), cuda(fars), counter, mean_count, False,
+                                      128, False, 0, 1024)
+    assert int(rr[:, 2].sum()) > xr.shape[0]                               # the budget really overflows
+    np.testing.assert_array_equal(r.cpu().numpy(), rr)
+    np.testing.assert_array_equal(x.cpu().numpy(), xr)
+    np.testing.assert_array_equal(l.cpu().numpy(), lr)
+    # composite must zero the dropped rays
+    sig = np.random.default_rng(2).random(xr.shape[0]).astype(np.float32) * 5
+    rgb = np.random.default_rng(3).random((xr.shape[0], 3)).astype(np.float32)
+    ws_ref, dep_ref, img_ref = co.composite_rays_train_forward(sig, rgb, lr, rr, 1e-4)
+    ws, dep, img = rm.composite_rays_train(cuda(sig), cuda(rgb), cuda(lr), cuda(rr), 1e-4)
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(img.cpu().numpy(), img_ref, rtol=1e-5, atol=1e-6)
+    dropped = (rr[:, 1] + rr[:, 2]) > xr.shape[0]
+    assert dropped.any() and np.all(ws.cpu().numpy()[rr[dropped, 0]] == 0)
+
+
+@pytest.mark.parametrize("stride", [3, 4])
+def test_composite_rays_train_fwd_bwd(rm, scene, stride):
+    sc, _, bitfield = scene
+    o, d = rays_for(sc, 64, 64, view=3)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.2)
+    xr, dr, lr, rr = co.march_rays_train(o, d, 2.0, bitfield, 2, 128, nears, fars, None, -1, None, 128, True, 0, 1024)
+    M = xr.shape[0]
+    rng = np.random.default_rng(4)
+    sig = (rng.random(M).astype(np.float32) * 3) ** 2            # includes early-terminating rays (T < 1e-4)
+    rgb4 = rng.random((M, 4)).astype(np.float32)
+    rgb = np.ascontiguousarray(rgb4[:, :3])
+    ws_ref, dep_ref, img_ref = co.composite_rays_train_forward(sig, rgb, lr, rr, 1e-4)
+    s = cuda(sig).requires_grad_(True)
+    c = cuda(rgb4 if stride == 4 else rgb).requires_grad_(True)
+    ws, dep, img = rm.composite_rays_train(s, c, cuda(lr), cuda(rr), 1e-4)
+    np.testing.assert_allclose(ws.detach().cpu().numpy(), ws_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep.detach().cpu().numpy(), dep_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), img_ref, rtol=1e-5, atol=1e-6)
+    g_ws = rng.standard_normal(ws_ref.shape).astype(np.float32)
+    g_img = rng.standard_normal(img_ref.shape).astype(np.float32)
+    gs_ref, gc_ref = co.composite_rays_train_backward(g_ws, g_img, sig, rgb, lr, rr, ws_ref, img_ref, 1e-4)
+    torch.autograd.backward([ws, img], [cuda(g_ws), cuda(g_img)])
+    np.testing.assert_allclose(s.grad.cpu().numpy(), gs_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c.grad.cpu().numpy()[:, :3], gc_ref, rtol=1e-4, atol=1e-6)
+    if stride == 4:
+        assert torch.all(c.grad[:, 3] == 0)
+
+
+def test_inference_march_composite_compact(rm, scene):
+    """One full alive-list loop (renderer.py:661-688): march_rays + composite_rays + device compaction, step by step
+    against the oracle; the alive list must match exactly at every iteration."""
+    sc, _, bitfield = scene
+    o, d = rays_for(sc, 48, 48, view=4)
+    N = o.shape[0]
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.default_rng(5)
+
+    def field(xyz):                       # closed-form sigma / rgb so both sides evaluate the same numbers
+        s = 40.0 * np.exp(-(xyz ** 2).sum(-1) / 0.15).astype(np.float32)
+        c = (0.5 + 0.5 * np.sin(xyz * 3.0)).astype(np.float32)
+        return s, c
+
+    ws_r, dep_r, img_r = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive_r, t_r = np.arange(N, dtype=np.int32), nears.copy()
+    ws, dep, img = torch.zeros(N).cuda(), torch.zeros(N).cuda(), torch.zeros(N, 3).cuda()
+    alive, t = torch.arange(N, dtype=torch.int32).cuda(), cuda(nears)
+    alive_next = torch.empty_like(alive)
+    count = torch.zeros(1, dtype=torch.int32).cuda()
+    o_g, d_g, bf_g, n_g, f_g = cuda(o), cuda(d), cuda(bitfield), cuda(nears), cuda(fars)
+    step, iters = 0, 0
+    while step < 1024:
+        n_alive = alive_r.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        noises = rng.random(n_alive).astype(np.float32) if step == 0 else np.zeros(n_alive, np.float32)
+        xr, dr, lr = co.march_rays(n_alive, n_step, alive_r, t_r, o, d, 2.0, bitfield, 2, 128, nears, fars, 128, noises, 0, 1024)
+        x, dd, l = rm.march_rays(n_alive, n_step, alive, t, o_g, d_g, 2.0, bf_g, 2, 128, n_g, f_g, 128, False, 0, 1024, noises=cuda(noises))
+        np.testing.assert_array_equal(x.cpu().numpy(), xr)
+        np.testing.assert_array_equal(l.cpu().numpy(), lr)
+        s_np, c_np = field(xr)
+        co.composite_rays(n_alive, n_step, alive_r, t_r, s_np, c_np, lr, ws_r, dep_r, img_r, 1e-2)
+        rm.composite_rays(n_alive, n_step, alive, t, cuda(s_np), cuda(c_np), l, ws, dep, img, 1e-2)
+        alive_r = np.ascontiguousarray(alive_r[alive_r >= 0])
+        rm.compact_rays_alive(alive, n_alive, alive_next, count)
+        alive, alive_next = alive_next, alive
+        k = int(count.item())
+        assert k == alive_r.shape[0]
+        np.testing.assert_array_equal(alive[:k].cpu().numpy(), alive_r)          # order-preserving, exact
+        step += n_step
+        iters += 1
+    assert iters > 5
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(t.cpu().numpy(), t_r)
