@@ -39,8 +39,16 @@ template <> __device__ __forceinline__ __half ge_from_float<__half>(float x) { r
 // acc += w * g with the accumulator type of the reference (`scalar_t results[C]`): float -> one fma;
 // half -> product rounded to half, sum rounded to half.
 __device__ __forceinline__ void ge_accum(float &acc, float w, float g) { acc = cn_fma(w, g, acc); }
+// The empty asm keeps the fp32 product a separately rounded value: without it the compiler folds
+// cvt_f16(w * g) into one v_fma_mixlo_f16 (a single rounding), which differs from the reference's
+// multiply-then-convert in rare double-rounding cases (1 fp16 ulp).
+__device__ __forceinline__ float ge_opaque(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ void ge_accum(__half &acc, float w, __half g) {
-    acc = __float2half_rn(__half2float(acc) + __half2float(__float2half_rn(w * __half2float(g))));
+    const float prod = ge_opaque(w * __half2float(g));
+    acc = __float2half_rn(ge_opaque(__half2float(acc) + __half2float(__float2half_rn(prod))));
 }
 
 __device__ __forceinline__ float ge_smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
@@ -78,8 +86,10 @@ __device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int
     const uint32_t total = nb * n_levels;
     uint32_t w = blockIdx.x;
     if (swizzle) {
-        const uint32_t cpx = (total + CN_NXCD - 1) / CN_NXCD;
-        w = (blockIdx.x % CN_NXCD) * cpx + blockIdx.x / CN_NXCD;
+        // bijective chunking for any total: XCD x gets q+1 items if x < r else q (q = total/8, r = total%8)
+        const uint32_t q = total / CN_NXCD, r = total % CN_NXCD;
+        const uint32_t xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     if (w >= total) return false;
     level = lv.order[w / nb];
@@ -189,8 +199,9 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     if constexpr (sizeof(T) == 2) {
-                        const float diff = __half2float(__float2half_rn(__half2float(right.v[c]) - __half2float(left.v[c])));
-                        rg[c] = __float2half_rn(__half2float(rg[c]) + __half2float(__float2half_rn(w * diff * pos_deriv[gd])));
+                        const float diff = __half2float(__float2half_rn(ge_opaque(__half2float(right.v[c]) - __half2float(left.v[c]))));
+                        const float prod = ge_opaque(w * diff * pos_deriv[gd]);
+                        rg[c] = __float2half_rn(ge_opaque(__half2float(rg[c]) + __half2float(__float2half_rn(prod))));
                     } else {
                         const float diff = right.v[c] - left.v[c];
                         rg[c] = cn_fma(w * diff, pos_deriv[gd], rg[c]);
@@ -454,14 +465,15 @@ extern "C" {
 int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
                               uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
                               uint32_t interp, int dtype, void *stream) {
-    if (!inputs || !embeddings || !outputs) return CNERF_ENULL;
     if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
     GridLevels lv;
     const uint32_t nl = max_level < L ? max_level : L;
     int rc = ge_levels(offsets_host, L, nl, S, H, lv);
     if (rc) return rc;
     if (D < 2 || D > 5 || !(C == 1 || C == 2 || C == 4 || C == 8)) return CNERF_EINVAL;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
     if (B == 0 || nl == 0) return CNERF_OK;
+    if (!inputs || !embeddings || !outputs) return CNERF_ENULL;
     if (dtype == CNERF_F32)
         return ge_fwd_D<float>(inputs, (const float *)embeddings, lv, (float *)outputs, B, D, C, L, nl, (float *)dy_dx, gridtype, align_corners, interp, CN_STREAM(stream));
     if (dtype == CNERF_F16)
@@ -472,15 +484,17 @@ int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const
 int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D,
                                uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, const void *dy_dx, float *grad_inputs,
                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream) {
-    if (!grad || !inputs || !grad_embeddings) return CNERF_ENULL;
-    if (dy_dx && !grad_inputs) return CNERF_ENULL;
     if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
     GridLevels lv;
     const uint32_t nl = max_level < L ? max_level : L;
     int rc = ge_levels(offsets_host, L, nl, S, H, lv);
     if (rc) return rc;
     if (D < 2 || D > 5 || !(C == 1 || C == 2 || C == 4 || C == 8)) return CNERF_EINVAL;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if (!grad_embeddings) return CNERF_ENULL;
     if (B == 0 || nl == 0) return CNERF_OK;
+    if (!grad || !inputs) return CNERF_ENULL;
+    if (dy_dx && !grad_inputs) return CNERF_ENULL;
     if (dtype == CNERF_F32)
         return ge_bwd_D<float>((const float *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const float *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
     if (dtype == CNERF_F16)

@@ -444,36 +444,36 @@ extern "C" {
 
 int cnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near, float *nears,
                              float *fars, void *stream) {
-    if (!rays_o || !rays_d || !aabb || !nears || !fars) return CNERF_ENULL;
     if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !aabb || !nears || !fars) return CNERF_ENULL;
     hipLaunchKernelGGL(k_near_far_from_aabb, RM_GRID(N), rays_o, rays_d, aabb, N, min_near, nears, fars);
     return cn_launch_status();
 }
 
 int cnerf_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
-    if (!rays_o || !rays_d || !coords) return CNERF_ENULL;
     if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !coords) return CNERF_ENULL;
     hipLaunchKernelGGL(k_sph_from_ray, RM_GRID(N), rays_o, rays_d, radius, N, coords);
     return cn_launch_status();
 }
 
 int cnerf_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
-    if (!coords || !indices) return CNERF_ENULL;
     if (N == 0) return CNERF_OK;
+    if (!coords || !indices) return CNERF_ENULL;
     hipLaunchKernelGGL(k_morton3D, RM_GRID(N), coords, N, indices);
     return cn_launch_status();
 }
 
 int cnerf_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
-    if (!coords || !indices) return CNERF_ENULL;
     if (N == 0) return CNERF_OK;
+    if (!coords || !indices) return CNERF_ENULL;
     hipLaunchKernelGGL(k_morton3D_invert, RM_GRID(N), indices, N, coords);
     return cn_launch_status();
 }
 
 int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
-    if (!grid || !bitfield) return CNERF_ENULL;
     if (N == 0) return CNERF_OK;
+    if (!grid || !bitfield) return CNERF_ENULL;
     if (((uintptr_t)grid) & 15) return CNERF_EINVAL;
     hipLaunchKernelGGL(k_packbits, RM_GRID(N), grid, N, density_thresh, bitfield);
     return cn_launch_status();
@@ -482,9 +482,9 @@ int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t 
 int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears, const float *fars,
                                  int32_t *rays, int32_t *counter, const float *noises, void *stream) {
-    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
     hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
     return cn_launch_status();
@@ -494,10 +494,10 @@ int cnerf_march_rays_train_write(const float *rays_o, const float *rays_d, const
                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                                  const float *fars, float *xyzs, float *dirs, float *deltas, const int32_t *rays, const float *noises,
                                  void *stream) {
-    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !noises) return CNERF_ENULL;
-    if (M > 0 && (!xyzs || !dirs || !deltas)) return CNERF_ENULL;
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
     if (N == 0 || M == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !noises) return CNERF_ENULL;
+    if (!xyzs || !dirs || !deltas) return CNERF_ENULL;
     hipLaunchKernelGGL(k_march_train_write, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
                        deltas, rays, noises);
     return cn_launch_status();
@@ -514,10 +514,10 @@ int cnerf_march_rays_train(const float *rays_o, const float *rays_d, const uint8
 
 int cnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
                                        float T_thresh, float *weights_sum, float *depth, float *image, uint32_t rgb_stride, void *stream) {
-    if (!rays || !weights_sum || !depth || !image) return CNERF_ENULL;
-    if (M > 0 && (!sigmas || !rgbs || !deltas)) return CNERF_ENULL;
     if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
+    if (!rays || !weights_sum || !depth || !image) return CNERF_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas)) return CNERF_ENULL;
     if (rgb_stride == 3) hipLaunchKernelGGL(k_composite_train_fwd<3>, RM_GRID(N), sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     else hipLaunchKernelGGL(k_composite_train_fwd<4>, RM_GRID(N), sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return cn_launch_status();
@@ -526,10 +526,10 @@ int cnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, c
 int cnerf_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
                                         const float *deltas, const int32_t *rays, const float *weights_sum, const float *image, uint32_t M,
                                         uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs, uint32_t rgb_stride, void *stream) {
-    if (!rays || !weights_sum || !image || !grad_weights_sum || !grad_image) return CNERF_ENULL;
-    if (M > 0 && (!sigmas || !rgbs || !deltas || !grad_sigmas || !grad_rgbs)) return CNERF_ENULL;
     if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
     if (N == 0 || M == 0) return CNERF_OK;
+    if (!rays || !weights_sum || !image || !grad_weights_sum || !grad_image) return CNERF_ENULL;
+    if (!sigmas || !rgbs || !deltas || !grad_sigmas || !grad_rgbs) return CNERF_ENULL;
     if (rgb_stride == 3)
         hipLaunchKernelGGL(k_composite_train_bwd<3>, RM_GRID(N), grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                            T_thresh, grad_sigmas, grad_rgbs);
@@ -543,9 +543,9 @@ int cnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_aliv
                      float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *nears,
                      const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises, void *stream) {
     (void)nears;
-    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas || !noises) return CNERF_ENULL;
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0 || n_step == 0) return CNERF_EINVAL;
     if (n_alive == 0) return CNERF_OK;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas || !noises) return CNERF_ENULL;
     hipLaunchKernelGGL(k_march_rays, RM_GRID(n_alive), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,
                        fars, xyzs, dirs, deltas, noises);
     return cn_launch_status();
@@ -554,9 +554,9 @@ int cnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_aliv
 int cnerf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas,
                          const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, uint32_t rgb_stride,
                          void *stream) {
-    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return CNERF_ENULL;
     if (rgb_stride != 3 && rgb_stride != 4) return CNERF_EINVAL;
     if (n_alive == 0) return CNERF_OK;
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return CNERF_ENULL;
     if (rgb_stride == 3)
         hipLaunchKernelGGL(k_composite_rays<3>, RM_GRID(n_alive), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
     else

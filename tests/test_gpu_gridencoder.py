@@ -65,7 +65,7 @@ def test_forward_bit_exact(name, kw, half):
     out = _grid_encode.apply(cuda(x), enc.embeddings, table, enc._offsets_host, enc.per_level_scale, enc.base_resolution, False, gid,
                              enc.align_corners, iid, None)
     L, Bc, C = out.shape
-    got = out.permute(1, 0, 2).reshape(B, L * C).float().cpu().numpy()
+    got = out.detach().permute(1, 0, 2).reshape(B, L * C).float().cpu().numpy()
     np.testing.assert_array_equal(got, ref)
     assert np.all(got[2] == 0) and np.all(got[3] == 0) and np.abs(got).max() > 0.1
 
@@ -77,7 +77,7 @@ def test_forward_max_level_and_empty():
     x = make_inputs(1000, 3, seed=3)
     ref, _ = co.grid_encode_forward(x, enc.embeddings.detach().cpu().numpy(), enc._offsets_host, enc.per_level_scale, 16, False, 0, False, 0, 5)
     out = _grid_encode.apply(cuda(x), enc.embeddings, enc.embeddings.detach(), enc._offsets_host, enc.per_level_scale, 16, False, 0, False, 0, 5)
-    got = out.permute(1, 0, 2).reshape(1000, -1).cpu().numpy()
+    got = out.detach().permute(1, 0, 2).reshape(1000, -1).cpu().numpy()
     np.testing.assert_array_equal(got, ref)
     assert np.all(got[:, 10:] == 0)
     out = enc(torch.empty(0, 3).cuda())

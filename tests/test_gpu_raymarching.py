@@ -201,7 +201,8 @@ def test_inference_march_composite_compact(rm, scene):
         step += n_step
         iters += 1
     assert iters > 5
-    np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=1e-5, atol=1e-5)
+    # __expf (device fast intrinsic) vs expf: ~1e-6 per sample, accumulated over the ray; budget 1e-5 (north_star: 1e-4)
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(img.cpu().numpy(), img_r, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dep.cpu().numpy(), dep_r, rtol=1e-5, atol=5e-5)
     np.testing.assert_array_equal(t.cpu().numpy(), t_r)
