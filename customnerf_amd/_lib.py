@@ -32,7 +32,8 @@ SIGNATURES = {
     "cnerf_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp],
     "cnerf_compact_rays_alive": [vp, u32, vp, vp, vp],
     "cnerf_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
-    "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
+    "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp, u64, vp],
+    "cnerf_grid_encode_backward_workspace_bytes": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
     "cnerf_cast_f32_to_f16": [vp, vp, u64, vp],
     "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],

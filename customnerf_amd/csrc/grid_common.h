@@ -1,0 +1,107 @@
+// Shared definitions of the grid-encoder kernels (gridencoder.hip, gridencoder_binned.hip).
+#pragma once
+#include "common.h"
+#include <math.h>
+
+#define GE_MAX_LEVELS 32
+#define GE_BLOCK 256
+
+struct GridLevels {
+    uint32_t offset[GE_MAX_LEVELS];       // first entry of the level's table
+    uint32_t size[GE_MAX_LEVELS];         // entries in the level's table (hashmap_size)
+    uint32_t resolution[GE_MAX_LEVELS];
+    float scale[GE_MAX_LEVELS];
+    uint8_t order[GE_MAX_LEVELS];         // work-list position -> level (coarse/fine interleave)
+};
+
+template <typename T, int C>
+struct alignas(sizeof(T) * C) FeatVec {
+    T v[C];
+};
+
+__device__ __forceinline__ float ge_to_float(float x) { return x; }
+__device__ __forceinline__ float ge_to_float(__half x) { return __half2float(x); }
+template <typename T> __device__ __forceinline__ T ge_from_float(float x);
+template <> __device__ __forceinline__ float ge_from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ __half ge_from_float<__half>(float x) { return __float2half_rn(x); }
+
+// acc += w * g with the accumulator type of the reference (`scalar_t results[C]`): float -> one fma;
+// half -> product rounded to half, sum rounded to half.
+__device__ __forceinline__ void ge_accum(float &acc, float w, float g) { acc = cn_fma(w, g, acc); }
+// The empty asm keeps the fp32 product a separately rounded value: without it the compiler folds
+// cvt_f16(w * g) into one v_fma_mixlo_f16 (a single rounding), which differs from the reference's
+// multiply-then-convert in rare double-rounding cases (1 fp16 ulp).
+__device__ __forceinline__ float ge_opaque(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ void ge_accum(__half &acc, float w, __half g) {
+    const float prod = ge_opaque(w * __half2float(g));
+    acc = __float2half_rn(ge_opaque(__half2float(acc) + __half2float(__float2half_rn(prod))));
+}
+
+__device__ __forceinline__ float ge_smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
+__device__ __forceinline__ float ge_smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
+
+template <int D>
+__device__ __forceinline__ uint32_t ge_fast_hash(const uint32_t (&p)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r ^= p[i] * primes[i];
+    return r;
+}
+
+// entry index (not yet multiplied by C) of a grid vertex
+template <int D>
+__device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                             const uint32_t (&p)[D]) {
+    uint32_t stride = 1, index = 0;
+    const uint32_t step = align_corners ? resolution : (resolution + 1);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += p[d] * stride;
+            stride *= step;
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = ge_fast_hash<D>(p);
+    return index % hashmap_size;
+}
+
+// blockIdx -> (level, point block).  Swizzled: XCD x (= blockIdx % 8 as dispatched) walks a contiguous slice of the
+// level-major work list, so at any moment it gathers from one or two tables that fit its own L2.
+__device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int swizzle, const GridLevels &lv, uint32_t &level, uint32_t &pb) {
+    const uint32_t total = nb * n_levels;
+    uint32_t w = blockIdx.x;
+    if (swizzle) {
+        // bijective chunking for any total: XCD x gets q+1 items if x < r else q (q = total/8, r = total%8)
+        const uint32_t q = total / CN_NXCD, r = total % CN_NXCD;
+        const uint32_t xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    if (w >= total) return false;
+    level = lv.order[w / nb];
+    pb = w % nb;
+    return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline int ge_levels(const int32_t *offsets_host, uint32_t L, uint32_t n_levels, float S, uint32_t H, GridLevels &lv) {
+    if (!offsets_host) return CNERF_ENULL;
+    if (L == 0 || L > GE_MAX_LEVELS || n_levels > L) return CNERF_EINVAL;
+    for (uint32_t l = 0; l < L; l++) {
+        if (offsets_host[l + 1] <= offsets_host[l]) return CNERF_EINVAL;
+        lv.offset[l] = (uint32_t)offsets_host[l];
+        lv.size[l] = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        const float scale = exp2f(l * S) * H - 1.0f;          // gridencoder.cu:138-139 (host libm, same as the oracle)
+        lv.scale[l] = scale;
+        lv.resolution[l] = (uint32_t)ceilf(scale) + 1;
+    }
+    // coarse/fine interleave: 0, n-1, 1, n-2, ... so each XCD's slice holds one cheap and one expensive level
+    uint32_t lo = 0, hi = n_levels;
+    for (uint32_t i = 0; i < n_levels; i++) lv.order[i] = (uint8_t)((i & 1) ? --hi : lo++);
+    return CNERF_OK;
+}
+

@@ -11,91 +11,7 @@
 //   * the backward scatter uses hardware float atomics (global_atomic_add_f32) into a float32 gradient table
 //     for both table dtypes.
 // Arithmetic follows oracle/gridencoder_ref.c operation by operation (compiled -ffp-contract=off, explicit fma).
-#include "common.h"
-#include <math.h>
-
-#define GE_MAX_LEVELS 32
-#define GE_BLOCK 256
-
-struct GridLevels {
-    uint32_t offset[GE_MAX_LEVELS];       // first entry of the level's table
-    uint32_t size[GE_MAX_LEVELS];         // entries in the level's table (hashmap_size)
-    uint32_t resolution[GE_MAX_LEVELS];
-    float scale[GE_MAX_LEVELS];
-    uint8_t order[GE_MAX_LEVELS];         // work-list position -> level (coarse/fine interleave)
-};
-
-template <typename T, int C>
-struct alignas(sizeof(T) * C) FeatVec {
-    T v[C];
-};
-
-__device__ __forceinline__ float ge_to_float(float x) { return x; }
-__device__ __forceinline__ float ge_to_float(__half x) { return __half2float(x); }
-template <typename T> __device__ __forceinline__ T ge_from_float(float x);
-template <> __device__ __forceinline__ float ge_from_float<float>(float x) { return x; }
-template <> __device__ __forceinline__ __half ge_from_float<__half>(float x) { return __float2half_rn(x); }
-
-// acc += w * g with the accumulator type of the reference (`scalar_t results[C]`): float -> one fma;
-// half -> product rounded to half, sum rounded to half.
-__device__ __forceinline__ void ge_accum(float &acc, float w, float g) { acc = cn_fma(w, g, acc); }
-// The empty asm keeps the fp32 product a separately rounded value: without it the compiler folds
-// cvt_f16(w * g) into one v_fma_mixlo_f16 (a single rounding), which differs from the reference's
-// multiply-then-convert in rare double-rounding cases (1 fp16 ulp).
-__device__ __forceinline__ float ge_opaque(float x) {
-    asm("" : "+v"(x));
-    return x;
-}
-__device__ __forceinline__ void ge_accum(__half &acc, float w, __half g) {
-    const float prod = ge_opaque(w * __half2float(g));
-    acc = __float2half_rn(ge_opaque(__half2float(acc) + __half2float(__float2half_rn(prod))));
-}
-
-__device__ __forceinline__ float ge_smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
-__device__ __forceinline__ float ge_smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
-
-template <int D>
-__device__ __forceinline__ uint32_t ge_fast_hash(const uint32_t (&p)[D]) {
-    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-    uint32_t r = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) r ^= p[i] * primes[i];
-    return r;
-}
-
-// entry index (not yet multiplied by C) of a grid vertex
-template <int D>
-__device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
-                                             const uint32_t (&p)[D]) {
-    uint32_t stride = 1, index = 0;
-    const uint32_t step = align_corners ? resolution : (resolution + 1);
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        if (stride <= hashmap_size) {
-            index += p[d] * stride;
-            stride *= step;
-        }
-    }
-    if (gridtype == 0 && stride > hashmap_size) index = ge_fast_hash<D>(p);
-    return index % hashmap_size;
-}
-
-// blockIdx -> (level, point block).  Swizzled: XCD x (= blockIdx % 8 as dispatched) walks a contiguous slice of the
-// level-major work list, so at any moment it gathers from one or two tables that fit its own L2.
-__device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int swizzle, const GridLevels &lv, uint32_t &level, uint32_t &pb) {
-    const uint32_t total = nb * n_levels;
-    uint32_t w = blockIdx.x;
-    if (swizzle) {
-        // bijective chunking for any total: XCD x gets q+1 items if x < r else q (q = total/8, r = total%8)
-        const uint32_t q = total / CN_NXCD, r = total % CN_NXCD;
-        const uint32_t xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
-        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    if (w >= total) return false;
-    level = lv.order[w / nb];
-    pb = w % nb;
-    return true;
-}
+#include "grid_common.h"
 
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid, const GridLevels lv,
@@ -350,23 +266,6 @@ __global__ void __launch_bounds__(256) k_cast_f32_f16(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int ge_levels(const int32_t *offsets_host, uint32_t L, uint32_t n_levels, float S, uint32_t H, GridLevels &lv) {
-    if (!offsets_host) return CNERF_ENULL;
-    if (L == 0 || L > GE_MAX_LEVELS || n_levels > L) return CNERF_EINVAL;
-    for (uint32_t l = 0; l < L; l++) {
-        if (offsets_host[l + 1] <= offsets_host[l]) return CNERF_EINVAL;
-        lv.offset[l] = (uint32_t)offsets_host[l];
-        lv.size[l] = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
-        const float scale = exp2f(l * S) * H - 1.0f;          // gridencoder.cu:138-139 (host libm, same as the oracle)
-        lv.scale[l] = scale;
-        lv.resolution[l] = (uint32_t)ceilf(scale) + 1;
-    }
-    // coarse/fine interleave: 0, n-1, 1, n-2, ... so each XCD's slice holds one cheap and one expensive level
-    uint32_t lo = 0, hi = n_levels;
-    for (uint32_t i = 0; i < n_levels; i++) lv.order[i] = (uint8_t)((i & 1) ? --hi : lo++);
-    return CNERF_OK;
-}
-
 static int ge_swizzle_default() {
     static int v = -1;
     if (v < 0) {
@@ -460,6 +359,13 @@ static int ge_tv_C(const float *inputs, const float *emb, float *grad, const Gri
     return cn_launch_status();
 }
 
+// atomic-free binned scatter (gridencoder_binned.hip)
+bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv);
+uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype);
+int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                uint32_t interp, int dtype, void *workspace, hipStream_t st);
+#define BN_MIN_UPDATES (1u << 20)        // below this many (point, level) pairs the plain atomic kernel is cheaper than five launches
+
 extern "C" {
 
 int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
@@ -481,9 +387,23 @@ int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const
     return CNERF_EINVAL;
 }
 
+int cnerf_grid_encode_backward_workspace_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                                               float S, uint32_t H, int dtype, uint64_t *bytes) {
+    if (!bytes) return CNERF_ENULL;
+    *bytes = 0;
+    GridLevels lv;
+    const uint32_t nl = max_level < L ? max_level : L;
+    int rc = ge_levels(offsets_host, L, nl, S, H, lv);
+    if (rc) return rc;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if ((uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv)) *bytes = bn_workspace_bytes(B, nl, lv, dtype);
+    return CNERF_OK;
+}
+
 int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D,
                                uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, const void *dy_dx, float *grad_inputs,
-                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream) {
+                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                               void *stream) {
     if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
     GridLevels lv;
     const uint32_t nl = max_level < L ? max_level : L;
@@ -495,6 +415,9 @@ int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int3
     if (B == 0 || nl == 0) return CNERF_OK;
     if (!grad || !inputs) return CNERF_ENULL;
     if (dy_dx && !grad_inputs) return CNERF_ENULL;
+    if (workspace && !dy_dx && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) &&
+        workspace_bytes >= bn_workspace_bytes(B, nl, lv, dtype) && !(((uintptr_t)workspace) & 255))
+        return bn_backward(grad, inputs, lv, grad_embeddings, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream));
     if (dtype == CNERF_F32)
         return ge_bwd_D<float>((const float *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const float *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
     if (dtype == CNERF_F16)

@@ -1,0 +1,372 @@
+// Grid-encoder backward WITHOUT global float atomics (gfx950).
+//
+// Why: MI355X executes every global float atomic memory-side, at a flat ~21 G atomics/s whatever the scope,
+// locality or table size (scratch/atomic_bench.hip, measured).  The straight scatter of the reference
+// (gridencoder.cu:324-337: one atomicAdd per corner per channel) needs 16 levels x 8 corners x 2 channels = 256
+// atomics per sample — 537 M for a 128x128x128-sample step, i.e. >25 ms at the hardware's ceiling.
+//
+// Instead the scatter is a two-sweep radix partition by destination, so that all additions happen in LDS:
+//   sweep 1  k_bin_hist   per (level, 1024-point block): count the corner updates per 8192-entry table chunk
+//            k_bin_scan   exclusive scans -> every (chunk, block) pair owns a contiguous record range
+//            k_bin_emit   re-derive the corners and write one 8/12-byte record {entry-in-chunk, w*g} per corner
+//   sweep 2  k_bin_accum  one workgroup per chunk (segment): zero a 64 KiB LDS image of the chunk, add its records
+//                         with LDS atomics, then add the image into the float32 gradient table with coalesced plain
+//                         read-modify-writes (one owner per chunk => no global atomics); oversized bins (the small
+//                         dense levels) are split and only those flush with atomics.
+//                         LDS float atomics (ds_add_f32) run ~8x slower than LDS integer atomics on gfx950
+//                         (scratch/lds_atomic_bench.hip: 101 vs 866 G records/s), so fp16 records are summed as 64-bit
+//                         fixed point with 24 fractional bits: every binary16 value is an exact multiple of 2^-24, so
+//                         the chunk sums are EXACT and independent of record order (deterministic), rounded once to
+//                         float32 at the flush.  float32 records keep ds_add_f32 (the parity path).
+// Traffic: 8 corners x 16 levels x 8 B = 1 KiB/sample written + read once — about the algorithmic RMW bytes of the
+// scatter itself (2048 B/sample fp32), all of it coalesced or L2-merged.
+// D = 3, C = 2 only (the configuration CustomNeRF uses); other shapes take the atomic kernel in gridencoder.hip.
+#include "grid_common.h"
+
+#define BN_CHUNK_LOG2 12
+#define BN_CHUNK (1u << BN_CHUNK_LOG2)            // table entries per bin  (x 2 ch x 8 B fixed point = 64 KiB LDS)
+#define BN_THREADS 256
+#define BN_PPT 4                                   // points per thread in the hist / emit sweeps
+#define BN_PTS (BN_THREADS * BN_PPT)               // points per block
+#define BN_MAX_CHUNKS 128                          // 2^19-entry level / 4096
+#define BN_SEG (1u << 18)                          // records per accumulate workgroup (split unit for oversized bins)
+
+struct BinPlan {
+    uint32_t bin_first[GE_MAX_LEVELS + 1];         // first bin of each level (prefix over chunks per level)
+    uint32_t nb;                                   // point blocks per level
+    uint32_t total_bins;
+};
+
+// workspace layout (all uint32 unless stated), offsets in bytes are computed by bn_layout()
+struct BinWs {
+    uint32_t *hist;        // [total_bins][nb]   counts, then (after scan) exclusive offsets inside the bin
+    uint32_t *bin_base;    // [total_bins + 1]   first record of each bin
+    uint32_t *seg_first;   // [total_bins + 1]   first accumulate-workgroup of each bin
+    void *records;
+};
+
+template <typename T> struct BinRec;
+template <> struct alignas(8) BinRec<__half> { uint32_t idx; __half2 v; };
+template <> struct BinRec<float> { uint32_t idx; float v0, v1; };
+
+__device__ __forceinline__ void bn_corners(const float (&in)[3], const GridLevels &lv, uint32_t level, uint32_t gridtype, bool align_corners,
+                                           uint32_t interp, uint32_t (&index)[8], float (&wgt)[8]) {
+    const uint32_t hashmap_size = lv.size[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    float pos[3];
+    uint32_t pos_grid[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        pos[d] = cn_fma(in[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) pos[d] = ge_smoothstep(pos[d]);
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        float w = 1;
+        uint32_t pgl[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if ((idx & (1 << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        wgt[idx] = w;
+        index[idx] = ge_index<3>(gridtype, align_corners, hashmap_size, resolution, pgl);
+    }
+}
+
+__device__ __forceinline__ bool bn_load_point(const float *__restrict__ inputs, uint32_t b, uint32_t B, float (&in)[3]) {
+    if (b >= B) return false;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        in[d] = inputs[(size_t)b * 3 + d];
+        ok = ok && !(in[d] < 0 || in[d] > 1);
+    }
+    return ok;
+}
+
+// ---- sweep 1a: histogram of corner updates per chunk, one block = BN_PTS points of one level
+__global__ void __launch_bounds__(BN_THREADS) k_bin_hist(const float *__restrict__ inputs, const GridLevels lv, const BinPlan plan,
+                                                         uint32_t *__restrict__ hist, uint32_t B, uint32_t gridtype, int align_corners,
+                                                         uint32_t interp) {
+    __shared__ uint32_t cnt[BN_MAX_CHUNKS];
+    const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
+    const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
+    if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BN_PPT; i++) {
+        const uint32_t b = pb * BN_PTS + i * BN_THREADS + threadIdx.x;
+        float in[3];
+        if (!bn_load_point(inputs, b, B, in)) continue;
+        uint32_t index[8];
+        float wgt[8];
+        bn_corners(in, lv, level, gridtype, align_corners, interp, index, wgt);
+#pragma unroll
+        for (int c = 0; c < 8; c++) atomicAdd(&cnt[index[c] >> BN_CHUNK_LOG2], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[level] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
+}
+
+// ---- sweep 1b: per bin, exclusive scan over the point blocks (in place) and the bin total
+__global__ void __launch_bounds__(1024) k_bin_scan_blocks(uint32_t *__restrict__ hist, uint32_t *__restrict__ bin_total, uint32_t nb) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    uint32_t *h = hist + (size_t)blockIdx.x * nb;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < nb; start += 1024) {
+        const uint32_t i = start + tid;
+        const uint32_t v = i < nb ? h[i] : 0;
+        const uint32_t incl = cn_wave_incl_scan(v);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint32_t t = wave_tot[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        const uint32_t base = carry;
+        if (i < nb) h[i] = base + wbase + incl - v;
+        __syncthreads();
+        if (tid == 0) carry = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) bin_total[blockIdx.x] = carry;
+}
+
+// ---- sweep 1c: scan over bins: record base per bin and accumulate-workgroup base per bin (one workgroup)
+// bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
+__global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
+                                                        uint32_t *__restrict__ seg_first, uint32_t total_bins) {
+    __shared__ uint32_t wt_r[16], wt_s[16];
+    __shared__ uint32_t carry_r, carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_r = 0; carry_s = 0; }
+    __syncthreads();
+    for (uint32_t start = 0; start < total_bins; start += 1024) {
+        const uint32_t i = start + tid;
+        const uint32_t r = i < total_bins ? bin_total[i] : 0;
+        const uint32_t s = (r + BN_SEG - 1) / BN_SEG;
+        const uint32_t ir = cn_wave_incl_scan(r), is = cn_wave_incl_scan(s);
+        if (lane == 63) { wt_r[wave] = ir; wt_s[wave] = is; }
+        __syncthreads();
+        uint32_t br = 0, bs = 0, tr = 0, ts = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) { br += wt_r[w]; bs += wt_s[w]; }
+            tr += wt_r[w]; ts += wt_s[w];
+        }
+        const uint32_t cr = carry_r, cs = carry_s;
+        if (i < total_bins) { bin_base[i] = cr + br + ir - r; seg_first[i] = cs + bs + is - s; }
+        __syncthreads();
+        if (tid == 0) { carry_r = cr + tr; carry_s = cs + ts; }
+        __syncthreads();
+    }
+    if (tid == 0) { bin_base[total_bins] = carry_r; seg_first[total_bins] = carry_s; }
+}
+
+// ---- sweep 1d: write the records
+template <typename T>
+__global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+                                                         const BinPlan plan, const uint32_t *__restrict__ hist,
+                                                         const uint32_t *__restrict__ bin_base, BinRec<T> *__restrict__ records, uint32_t B,
+                                                         uint32_t gridtype, int align_corners, uint32_t interp) {
+    __shared__ uint32_t cursor[BN_MAX_CHUNKS];
+    const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
+    const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
+    if (threadIdx.x < nch) {
+        const uint32_t bin = plan.bin_first[level] + threadIdx.x;
+        cursor[threadIdx.x] = bin_base[bin] + hist[(size_t)bin * plan.nb + pb];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BN_PPT; i++) {
+        const uint32_t b = pb * BN_PTS + i * BN_THREADS + threadIdx.x;
+        float in[3];
+        if (!bn_load_point(inputs, b, B, in)) continue;
+        uint32_t index[8];
+        float wgt[8];
+        bn_corners(in, lv, level, gridtype, align_corners, interp, index, wgt);
+        using Vec = FeatVec<T, 2>;
+        const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
+        const float g0 = ge_to_float(g.v[0]), g1 = ge_to_float(g.v[1]);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t pos = atomicAdd(&cursor[index[c] >> BN_CHUNK_LOG2], 1u);
+            BinRec<T> r;
+            r.idx = index[c] & (BN_CHUNK - 1);
+            if constexpr (sizeof(T) == 2) r.v = __floats2half2_rn(wgt[c] * g0, wgt[c] * g1);     // as gridencoder.cu:328
+            else { r.v0 = wgt[c] * g0; r.v1 = wgt[c] * g1; }
+            records[pos] = r;
+        }
+    }
+}
+
+// ---- sweep 2: accumulate one bin segment in LDS and add it to the gradient table
+#define BN_FIX_BITS 24
+template <typename T> struct BinAcc;
+template <> struct BinAcc<__half> { using type = long long; };          // exact fixed point
+template <> struct BinAcc<float> { using type = float; };
+
+template <typename T>
+__device__ __forceinline__ void bn_add_record(typename BinAcc<T>::type *acc, const BinRec<T> &r) {
+    if constexpr (sizeof(T) == 2) {
+        const float2 f = __half22float2(r.v);
+        // |f| <= 65504 and f is a multiple of 2^-24 (or 0): f * 2^24 is an exactly representable integer < 2^41
+        const long long a = (long long)(f.x * 16777216.0f), b = (long long)(f.y * 16777216.0f);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[r.idx * 2]), (unsigned long long)a);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[r.idx * 2 + 1]), (unsigned long long)b);
+    } else {
+        unsafeAtomicAdd(&acc[r.idx * 2], r.v0);
+        unsafeAtomicAdd(&acc[r.idx * 2 + 1], r.v1);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ float bn_acc_to_float(typename BinAcc<T>::type a) {
+    if constexpr (sizeof(T) == 2) return (float)((double)a * (1.0 / 16777216.0));
+    else return a;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict__ records, const uint32_t *__restrict__ bin_base,
+                                                    const uint32_t *__restrict__ seg_first, const GridLevels lv, const BinPlan plan,
+                                                    float *__restrict__ grad_grid) {
+    using A = typename BinAcc<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
+    A *acc = reinterpret_cast<A *>(bn_lds);
+    uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(A) * BN_CHUNK * 2);
+    const uint32_t nseg_total = seg_first[plan.total_bins];
+    if (blockIdx.x >= nseg_total) return;
+    if (threadIdx.x == 0) {                                            // which bin does this workgroup serve: upper_bound(seg_first, blockIdx) - 1
+        uint32_t lo = 0, hi = plan.total_bins;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_first[mid + 1] <= blockIdx.x) lo = mid + 1; else hi = mid;
+        }
+        s_bin = lo;
+    }
+    for (uint32_t i = threadIdx.x; i < sizeof(A) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t seg = blockIdx.x - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
+    const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
+    const uint32_t begin = r0 + seg * BN_SEG, end = min(begin + BN_SEG, r1);
+    constexpr int UNR = 4;
+    uint32_t i = begin + threadIdx.x;
+    for (; i + (UNR - 1) * 1024 < end; i += UNR * 1024) {
+        BinRec<T> r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) r[u] = records[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) bn_add_record<T>(acc, r[u]);
+    }
+    for (; i < end; i += 1024) bn_add_record<T>(acc, records[i]);
+    __syncthreads();
+    // locate the chunk in the table
+    uint32_t level = 0;
+    while (plan.bin_first[level + 1] <= bin) level++;
+    const uint32_t chunk = bin - plan.bin_first[level];
+    const uint32_t e0 = chunk << BN_CHUNK_LOG2;
+    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
+    float *__restrict__ dst = grad_grid + ((size_t)lv.offset[level] + e0) * 2;
+    if (nseg == 1) {
+        // sole owner of this chunk in this launch: coalesced plain read-modify-write (table sizes are multiples of 8 entries)
+        for (uint32_t j = threadIdx.x; j < n_entries * 2 / 4; j += 1024) {
+            float4 g = reinterpret_cast<float4 *>(dst)[j];
+            g.x += bn_acc_to_float<T>(acc[j * 4]); g.y += bn_acc_to_float<T>(acc[j * 4 + 1]);
+            g.z += bn_acc_to_float<T>(acc[j * 4 + 2]); g.w += bn_acc_to_float<T>(acc[j * 4 + 3]);
+            reinterpret_cast<float4 *>(dst)[j] = g;
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) {
+            const float a = bn_acc_to_float<T>(acc[j]);
+            if (a != 0.0f) unsafeAtomicAdd(&dst[j], a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline uint64_t bn_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
+
+static void bn_plan(const GridLevels &lv, uint32_t nl, uint32_t B, BinPlan &plan) {
+    plan.nb = cn_div_up(B, BN_PTS);
+    uint32_t acc = 0;
+    for (uint32_t l = 0; l < nl; l++) {
+        plan.bin_first[l] = acc;
+        acc += cn_div_up(lv.size[l], BN_CHUNK);
+    }
+    for (uint32_t l = nl; l <= GE_MAX_LEVELS; l++) plan.bin_first[l] = acc;
+    plan.total_bins = acc;
+}
+
+static uint64_t bn_layout(const BinPlan &plan, uint32_t B, uint32_t nl, int dtype, BinWs *ws, void *base) {
+    const uint64_t rec = dtype == CNERF_F16 ? 8 : 12;
+    uint64_t off = 0;
+    const uint64_t o_hist = off; off = bn_align(off + (uint64_t)plan.total_bins * plan.nb * 4);
+    const uint64_t o_base = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
+    const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
+    const uint64_t o_rec = off; off = bn_align(off + (uint64_t)B * nl * 8 * rec);
+    if (ws) {
+        char *p = (char *)base;
+        ws->hist = (uint32_t *)(p + o_hist);
+        ws->bin_base = (uint32_t *)(p + o_base);
+        ws->seg_first = (uint32_t *)(p + o_seg);
+        ws->records = p + o_rec;
+    }
+    return off;
+}
+
+// used by gridencoder.hip
+bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv) {
+    if (D != 3 || C != 2 || nl == 0) return false;
+    for (uint32_t l = 0; l < nl; l++)
+        if (cn_div_up(lv.size[l], BN_CHUNK) > BN_MAX_CHUNKS || (lv.size[l] & 7)) return false;
+    return (uint64_t)B * nl * 8 < 0xF0000000ull;          // record positions are 32-bit
+}
+
+uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
+    BinPlan plan;
+    bn_plan(lv, nl, B, plan);
+    return bn_layout(plan, B, nl, dtype, nullptr, nullptr);
+}
+
+template <typename T>
+static int bn_run(const T *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                  uint32_t interp, int dtype, void *workspace, hipStream_t st) {
+    BinPlan plan;
+    bn_plan(lv, nl, B, plan);
+    BinWs ws;
+    bn_layout(plan, B, nl, dtype, &ws, workspace);
+    const dim3 grid1(plan.nb * nl);
+    hipLaunchKernelGGL(k_bin_hist, grid1, dim3(BN_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp);
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins);
+    hipLaunchKernelGGL((k_bin_emit<T>), grid1, dim3(BN_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, (BinRec<T> *)ws.records, B,
+                       gridtype, ac, interp);
+    // upper bound of accumulate workgroups: every bin may add one partial segment
+    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64((uint64_t)B * nl * 8, BN_SEG);
+    const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(typename BinAcc<T>::type) + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accum<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bin_accum<T>), dim3((uint32_t)max_seg), dim3(1024), lds_bytes, st, (const BinRec<T> *)ws.records,
+                       ws.bin_base, ws.seg_first, lv, plan, gemb);
+    return cn_launch_status();
+}
+
+int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                uint32_t interp, int dtype, void *workspace, hipStream_t st) {
+    if (dtype == CNERF_F16) return bn_run<__half>((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
+    return bn_run<float>((const float *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
+}

@@ -44,6 +44,24 @@ def _offsets_host(offsets):
     return cached
 
 
+_WS_CACHE = {}
+
+
+def _bwd_workspace(offsets_host, B, D, C, L, max_level, S, H, dt, device):
+    """Scratch for the atomic-free binned scatter (one buffer per device, grown on demand, reused every step)."""
+    import ctypes
+    need = ctypes.c_uint64(0)
+    check(lib.cnerf_grid_encode_backward_workspace_bytes(offsets_host.ctypes.data, B, D, C, L, max_level, S, H, dt, ctypes.addressof(need)),
+          "grid_encode_backward_workspace_bytes")
+    if need.value == 0:
+        return None, 0
+    buf = _WS_CACHE.get(device)
+    if buf is None or buf.numel() < need.value:
+        buf = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS_CACHE[device] = buf
+    return buf, buf.numel()
+
+
 class _grid_encode(Function):
     """grid.py:24-95.  `embeddings` is the float32 parameter; `table` is what the kernel reads (the parameter itself, or
     its fp16 shadow).  Returns the encoder output in kernel layout [L,B,C]."""
@@ -91,9 +109,10 @@ class _grid_encode(Function):
             grad = grad.to(dy_dx.dtype)
         grad_embeddings = torch.zeros(eshape, device=grad.device, dtype=torch.float32)
         grad_inputs = torch.empty(B, D, device=grad.device, dtype=torch.float32) if dy_dx is not None else None
+        ws, ws_bytes = (None, 0) if dy_dx is not None else _bwd_workspace(offsets_host, B, D, C, L, max_level, S, H, dtype_id(grad), grad.device)
         check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, max_level,
                                              S, H, ptr(dy_dx), ptr(grad_inputs), gridtype, int(align_corners), interpolation,
-                                             dtype_id(grad), stream()), "grid_encode_backward")
+                                             dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 

@@ -118,11 +118,18 @@ int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const
 /* grid_encode_backward — gridencoder.h:13, kernels gridencoder.cu:247-339 (+ :342-368 when dy_dx != NULL).
  * grad [L,B,C] (dtype).  grad_embeddings is ALWAYS float32 [offsets[L], C], pre-zeroed by the caller
  * (grid.py:83) and accumulated with float32 atomics (the reference uses __half2 atomics for fp16 tables).
- * grad_inputs float32 [B,D] (written, not accumulated) when dy_dx != NULL. */
+ * grad_inputs float32 [B,D] (written, not accumulated) when dy_dx != NULL.
+ * workspace (optional, 256-byte aligned device scratch of at least cnerf_grid_encode_backward_workspace_bytes()):
+ * when given, large D=3/C=2 scatters run the atomic-free binned path (records partitioned by 8192-entry table
+ * chunk, summed in LDS, written back with plain coalesced stores); with NULL, or for other shapes / small B, the
+ * scatter uses global float atomics.  Both produce the same sums up to float reassociation. */
 int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                const void *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
-                               uint32_t interp, int dtype, void *stream);
+                               uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes, void *stream);
+/* *bytes = scratch size the binned scatter wants for this problem (0: the atomic path will be used). */
+int cnerf_grid_encode_backward_workspace_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                               uint32_t max_level, float S, uint32_t H, int dtype, uint64_t *bytes);
 
 /* grad_total_variation — gridencoder.h:15, kernel gridencoder.cu:505-609.  float32 only (grid.py:171). */
 int cnerf_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host,

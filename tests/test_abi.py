@@ -69,7 +69,17 @@ def test_argument_validation_without_launch():
     assert lib.cnerf_grid_encode_forward(one, one, None, one, 10, 3, 2, 2, 2, 1.0, 16, None, 0, 0, 0, 0, None) == -2
     bad = np.array([0, 8, 8], np.int32)  # empty level
     assert lib.cnerf_grid_encode_forward(one, one, bad.ctypes.data, one, 10, 3, 2, 2, 2, 1.0, 16, None, 0, 0, 0, 0, None) == -1
-    assert lib.cnerf_grid_encode_backward(one, one, off.ctypes.data, None, 10, 3, 2, 2, 2, 1.0, 16, None, None, 0, 0, 0, 0, None) == -2
+    assert lib.cnerf_grid_encode_backward(one, one, off.ctypes.data, None, 10, 3, 2, 2, 2, 1.0, 16, None, None, 0, 0, 0, 0, None, 0, None) == -2
+    # workspace query: small problems / unsupported shapes -> 0 bytes (atomic path); the 128x128x128-sample step -> ~2 GiB of records
+    need = ctypes.c_uint64(123)
+    big = np.array([0, 4920, 18744, 51512, 136696, 352696, 876984] + [876984 + 524288 * i for i in range(1, 11)], np.int32)
+    S = float(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 1000, 3, 2, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0 and need.value == 0
+    assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 4, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0 and need.value == 0
+    assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0
+    assert 2097152 * 16 * 8 * 8 <= need.value < 2097152 * 16 * 8 * 8 * 1.05
+    assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 0, ctypes.addressof(need)) == 0
+    assert 2097152 * 16 * 8 * 12 <= need.value < 2097152 * 16 * 8 * 12 * 1.05
     # empty work is accepted without a launch
     assert lib.cnerf_grid_encode_forward(one, one, off.ctypes.data, one, 0, 3, 2, 2, 2, 1.0, 16, None, 0, 0, 0, 0, None) == 0
     assert lib.cnerf_near_far_from_aabb(one, one, one, 0, 0.1, one, one, None) == 0

@@ -137,6 +137,48 @@ def test_backward_scatter(name, kw):
         assert got.dtype == np.float32
 
 
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+@pytest.mark.parametrize("name,kw", [CONFIGS[0], CONFIGS[1]], ids=[CONFIGS[0][0], CONFIGS[1][0]])
+def test_backward_binned_no_atomics(name, kw, half):
+    """Large scatters take the atomic-free binned path (partition by table chunk -> LDS sums -> plain stores); it must
+    agree with the oracle AND with the atomic kernel, accumulate into a pre-filled gradient table, and skip OOB points."""
+    from customnerf_amd.gridencoder import grid as G
+    enc = build(kw)
+    B = 70001                                  # x 16 levels > 2^20 (point, level) pairs -> binned path; ragged vs the 1024-point block
+    x = make_inputs(B, 3, seed=11)
+    x[100:200] = x[50]                         # many samples in one cell (coarse-level style duplication)
+    L, C = enc.num_levels, enc.level_dim
+    g = np.random.default_rng(12).standard_normal((B, L * C)).astype(np.float32)
+    if half:
+        g = co.h2f(co.f2h(g))
+    ge_ref, _ = co.grid_encode_backward(g, x, tuple(enc.embeddings.shape), enc._offsets_host, enc.per_level_scale, enc.base_resolution, None,
+                                        enc.gridtype_id, enc.align_corners, enc.interp_id)
+    import ctypes
+    need = ctypes.c_uint64(0)
+    S = float(np.log2(enc.per_level_scale))
+    G.lib.cnerf_grid_encode_backward_workspace_bytes(enc._offsets_host.ctypes.data, B, 3, C, L, L, S, enc.base_resolution, int(half), ctypes.addressof(need))
+    assert need.value > 0
+    table = enc.half_table() if half else enc.embeddings.detach()
+    out = G._grid_encode.apply(cuda(x), enc.embeddings, table, enc._offsets_host, enc.per_level_scale, enc.base_resolution, False,
+                               enc.gridtype_id, enc.align_corners, enc.interp_id, None)
+    glbc = cuda(g).view(B, L, C).permute(1, 0, 2).contiguous().to(out.dtype)
+    out.backward(glbc)
+    got = enc.embeddings.grad.cpu().numpy()
+    tol = 2e-3 if half else 1e-4                # fp16: each w*g product is rounded to half (as gridencoder.cu:328 does)
+    np.testing.assert_allclose(got, ge_ref, rtol=tol, atol=tol * 10)
+    # same launch through the C-ABI with workspace=NULL -> atomic kernel; and accumulation into a non-zero table
+    from customnerf_amd._lib import lib, ptr, stream, check
+    ga = torch.full(enc.embeddings.shape, 0.5, device='cuda')
+    check(lib.cnerf_grid_encode_backward(ptr(glbc), ptr(cuda(x)), enc._offsets_host.ctypes.data, ptr(ga), B, 3, C, L, L, S, enc.base_resolution,
+                                         None, None, enc.gridtype_id, 0, enc.interp_id, int(half), None, 0, stream()))
+    gb = torch.full(enc.embeddings.shape, 0.5, device='cuda')
+    ws = torch.empty(int(need.value) + 256, dtype=torch.uint8, device='cuda')
+    check(lib.cnerf_grid_encode_backward(ptr(glbc), ptr(cuda(x)), enc._offsets_host.ctypes.data, ptr(gb), B, 3, C, L, L, S, enc.base_resolution,
+                                         None, None, enc.gridtype_id, 0, enc.interp_id, int(half), ptr(ws), ws.numel(), stream()))
+    np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=tol, atol=tol * 10)
+    np.testing.assert_allclose(gb.cpu().numpy() - 0.5, ge_ref, rtol=tol, atol=tol * 10)
+
+
 def test_grad_total_variation():
     kw = CONFIGS[0][1]
     enc = build(kw, scale=0.5, seed=7)
