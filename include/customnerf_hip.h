@@ -140,6 +140,24 @@ int cnerf_grad_total_variation(const float *inputs, const float *embeddings, flo
 int cnerf_cast_f32_to_f16(const float *src, void *dst, uint64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused field evaluation: NeRFNetwork.forward / .density (nerf/network_grid.py:159-193) in one launch on the matrix
+ * cores — the tinycudann FullyFusedMLP x3 of the reference (network_grid.py:98-139) plus its glue:
+ *   fea   = MLP_net(enc)                                 enc_dim -> 64 x n_hidden_geo -> 64   (no output activation)
+ *   sigma = exp(MLP_den(fea)[0] + 5 exp(-|x|^2 / 0.08))  64 -> 64 -> 1   (trunc_exp fwd provider_utils.py:20-22; blob :150-156)
+ *   rgbc  = sigmoid(MLP_rgb([freq(d) (27), fea (64)]))   91 -> 64 -> n_rgb_out (3, or 4 = rgb + confidence; base.py:42-60)
+ * MLPs are bias-free, ReLU hidden; params_* are the float32 flat vectors of tcnn.Network (row-major [out,in] matrices,
+ * in padded to x16, out padded to x16: 64*pad16(enc_dim) + 4096*n_hidden_geo, 5120, 7168 floats).
+ * enc is the grid encoder output in ITS kernel layout [L, P, 2] (dtype), so no permute copy is needed (grid.py:49,63).
+ * xyz [P,3]; dirs [ceil(P/dir_group), 3]: one direction per dir_group consecutive samples (1 = per sample).
+ * sigma float32 [P]; rgbc float32 [P,4] 16-byte aligned (NULL => density only; channel 3 is 0 when n_rgb_out == 3).
+ * dtype CNERF_F16: fp16 weights/activations, fp32 accumulate (v_mfma_f32_32x32x16_f16), outputs rounded to fp16 values
+ * — tcnn's numerics; CNERF_F32: exact float32 (v_mfma_f32_32x32x2_f32).
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_field_forward(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                        uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                        const float *params_rgb, float *sigma, float *rgbc, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Ray generation (reference: nerf/provider.py:402-464 pinhole branch; nerf/provider_utils.py:239-302 get_rays)
  * c2w [V,3,4] row-major; outputs origins, directions [V, H, W, 3].
  * convention 0 = nerfstudio/OpenGL (provider.py: dir = normalize(R [ (x+.5-cx)/fx, -(y+.5-cy)/fy, -1 ]),
