@@ -37,6 +37,8 @@ SIGNATURES = {
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
     "cnerf_cast_f32_to_f16": [vp, vp, u64, vp],
     "cnerf_field_forward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, vp],
+    "cnerf_field_backward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp],
+    "cnerf_field_backward_workspace_bytes": [u32, u32, u32, u32, i32, vp],
     "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
 }

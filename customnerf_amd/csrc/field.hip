@@ -177,6 +177,9 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_fwd(const void *__restric
     constexpr uint32_t S64 = FLD_HID / PR::KS, SDIR = FLD_DIR / PR::KS;
     const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
     for (uint32_t tile = blockIdx.x * FLD_WAVES + wave; tile < n_tiles; tile += gridDim.x * FLD_WAVES) {
+        // keep the weight fragments in LDS: without this barrier the compiler hoists every fragment load out of the
+        // persistent loop (hundreds of VGPRs, one wave per SIMD, spills in the backward)
+        asm volatile("" ::: "memory");
         const uint32_t p = tile * FLD_TILE + (lane & 31);
         const bool valid = p < P_;
 

@@ -17,3 +17,51 @@ def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_ou
                                   int(n_rgb_out), ptr(p_net), ptr(p_den), ptr(p_rgb) if with_rgb else None, ptr(sigma), ptr(rgbc), dt, stream()),
           "field_forward")
     return sigma, rgbc
+
+
+_WS = {}
+
+
+def _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, device):
+    import ctypes
+    need = ctypes.c_uint64(0)
+    check(lib.cnerf_field_backward_workspace_bytes(P, enc_dim, n_hidden_geo, n_rgb_out, dt, ctypes.addressof(need)), "field_backward_workspace_bytes")
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < need.value:
+        buf = torch.empty(int(need.value * 1.1) + 256, dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
+
+class FieldFunction(Function):
+    """sigma [P], rgbc [P,4] = field(enc [L,P,2], xyz, dirs; params).  Differentiable in enc and the three parameter vectors
+    (positions / directions get no gradient on CustomNeRF's path).  Nothing is saved but the inputs: the backward recomputes."""
+
+    @staticmethod
+    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb):
+        xyz = xyz.contiguous().float()
+        dirs = dirs.contiguous().float()
+        sigma, rgbc = field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, True)
+        ctx.save_for_backward(enc, xyz, dirs, p_net, p_den, p_rgb)
+        ctx.cfg = (dir_group, enc_dim, n_hidden_geo, n_rgb_out)
+        return sigma, rgbc
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgbc):
+        enc, xyz, dirs, p_net, p_den, p_rgb = ctx.saved_tensors
+        dir_group, enc_dim, n_hidden_geo, n_rgb_out = ctx.cfg
+        P = xyz.shape[0]
+        dt = F16 if enc.dtype == torch.float16 else F32
+        g_sigma = g_sigma.contiguous().float()
+        g_rgbc = g_rgbc.contiguous().float()
+        g_enc = torch.empty_like(enc)
+        g_net, g_den, g_rgb = torch.zeros_like(p_net), torch.zeros_like(p_den), torch.zeros_like(p_rgb)
+        ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
+        check(lib.cnerf_field_backward(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
+                                       ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
+                                       ptr(ws), ws.numel(), dt, stream()), "field_backward")
+        return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb
+
+
+def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb):
+    return FieldFunction.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb)

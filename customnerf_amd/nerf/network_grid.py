@@ -12,6 +12,8 @@ from .renderer import NeRFRenderer
 from .encoding import get_encoder, get_embedder
 from .provider_utils import trunc_exp
 from .. import tcnn
+from ..field import field, field_forward_raw
+from ..gridencoder import GridEncoder
 
 
 class RGB_network(nn.Module):
@@ -65,6 +67,7 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.rgb_network = tcnn.Network(input_ch_views + 64, 3, sig, seed=12)
         self.bg_net = None
+        self.supports_dir_group = True
 
     def background(self, d):
         return torch.zeros(d.size(), dtype=d.dtype, device=d.device)
@@ -74,6 +77,21 @@ class NeRFNetwork(NeRFRenderer):
         d = (x ** 2).sum(-1)
         return 5 * torch.exp(-d / (2 * 0.2 ** 2))
 
+    # ---- fused MFMA path (cnerf_field_forward / _backward): the standard CustomNeRF field, one launch per evaluation
+    def _fused_cfg(self):
+        cfg = getattr(self, '_fused_cfg_cache', None)
+        if cfg is None:
+            ok = (getattr(self.opt, 'fused_field', True) and isinstance(self.pos_en, GridEncoder) and self.pos_en.level_dim == 2
+                  and self.pos_en.input_dim == 3 and self.pos_en.output_dim <= 64 and isinstance(self.rgb_network, tcnn.Network)
+                  and self.network.n_hidden_layers in (1, 2) and self.density_network.n_hidden_layers == 1
+                  and self.rgb_network.n_hidden_layers == 1 and self.rgb_network.n_output_dims in (3, 4))
+            cfg = (self.pos_en.output_dim, self.network.n_hidden_layers, self.rgb_network.n_output_dims) if ok else False
+            self._fused_cfg_cache = cfg
+        return cfg
+
+    def _half(self):
+        return self.network.compute_dtype == torch.float16
+
     def _geo(self, x):
         x_en = self.pos_en(x, bound=self.opt.bound)
         fea = self.network(x_en)
@@ -81,8 +99,19 @@ class NeRFNetwork(NeRFRenderer):
         sigma = trunc_exp(sigma.squeeze(-1) + self.gaussian(x))
         return fea, sigma
 
-    def forward(self, x, d, l=None, ratio=1, shading='albedo'):
-        """network_grid.py:159-177 -> (sigma [P], radiances [P, 3(+1)], None)"""
+    def forward(self, x, d, l=None, ratio=1, shading='albedo', dir_group=1):
+        """network_grid.py:159-177 -> (sigma [P], radiances [P, 3(+1)], None).
+        dir_group > 1: `d` holds one direction per dir_group consecutive samples (the samples of a ray share rays_d)."""
+        cfg = self._fused_cfg()
+        if cfg and x.is_cuda:
+            enc_dim, n_geo, n_rgb = cfg
+            x = x.reshape(-1, 3)
+            enc = self.pos_en.encode(x, bound=self.opt.bound, half=self._half())
+            sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
+                                self.rgb_network.params)
+            return sigma, (rgbc if n_rgb == 4 else rgbc[:, :3]), None
+        if dir_group != 1:
+            d = d.reshape(-1, 3).repeat_interleave(dir_group, dim=0)[:x.reshape(-1, 3).shape[0]]
         fea, sigma = self._geo(x)
         view_en = self.dir_en(d)
         rgb_input = torch.cat([view_en.to(fea.dtype), fea], dim=-1)
@@ -91,6 +120,14 @@ class NeRFNetwork(NeRFRenderer):
 
     def density(self, x):
         """network_grid.py:180-193"""
+        cfg = self._fused_cfg()
+        if cfg and x.is_cuda and not torch.is_grad_enabled():
+            enc_dim, n_geo, n_rgb = cfg
+            x = x.reshape(-1, 3).contiguous().float()
+            enc = self.pos_en.encode(x, bound=self.opt.bound, half=self._half())
+            sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None,
+                                         with_rgb=False)
+            return {'sigma': sigma}
         return {'sigma': self._geo(x)[1]}
 
     def get_params(self, lr):

@@ -139,7 +139,11 @@ class NeRFRenderer(nn.Module):
             xyzs = torch.gather(xyzs, dim=1, index=z_index.unsqueeze(-1).expand_as(xyzs))
 
         dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
-        sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), dirs.reshape(-1, 3))
+        if getattr(self, 'supports_dir_group', False):
+            # the fused field reads one direction per ray (samples of a ray share rays_d): no [N*S,3] expansion copy
+            sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), rays_d, dir_group=xyzs.shape[1])
+        else:
+            sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), dirs.reshape(-1, 3))
         if rgbs.shape[-1] > 3:
             n_dim = rgbs.shape[-1] - 3
             rgbs, masks = rgbs.split([3, n_dim], dim=-1)

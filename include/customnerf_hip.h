@@ -157,6 +157,19 @@ int cnerf_field_forward(const void *enc, const float *xyz, const float *dirs, ui
                         uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
                         const float *params_rgb, float *sigma, float *rgbc, int dtype, void *stream);
 
+/* Backward of cnerf_field_forward (activations are recomputed, nothing is saved by the forward).
+ * grad_sigma [P] and grad_rgbc [P,4] (16-byte aligned) in; grad_enc [L,P,2] (dtype) out = d(loss)/d(grid features) in the
+ * encoder's kernel layout (feeds cnerf_grid_encode_backward directly); grad_params_* float32, ACCUMULATED (caller
+ * pre-zeroes).  trunc_exp backward clamps the exponent to [-15,15] (provider_utils.py:26-29); positions and directions
+ * receive no gradient on this path.  workspace: 16-byte aligned scratch of cnerf_field_backward_workspace_bytes(). */
+int cnerf_field_backward(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                         uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                         const float *params_rgb, const float *grad_sigma, const float *grad_rgbc, void *grad_enc,
+                         float *grad_params_net, float *grad_params_den, float *grad_params_rgb, void *workspace,
+                         uint64_t workspace_bytes, int dtype, void *stream);
+int cnerf_field_backward_workspace_bytes(uint32_t P, uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, int dtype,
+                                         uint64_t *bytes);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray generation (reference: nerf/provider.py:402-464 pinhole branch; nerf/provider_utils.py:239-302 get_rays)
  * c2w [V,3,4] row-major; outputs origins, directions [V, H, W, 3].

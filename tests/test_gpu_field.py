@@ -68,3 +68,36 @@ def test_field_forward_dir_group_and_rgb3():
     np.testing.assert_allclose(c.cpu().numpy()[:, :3], c_ref.numpy()[:, :3], rtol=0, atol=2e-6)
     assert torch.all(c[:, 3] == 0)
     np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("L,n_geo", [(16, 2), (4, 1)])
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+def test_field_backward(L, n_geo, half):
+    """d(sigma, rgbc)/d(grid table, MLP weights) through the fused backward + the grid scatter, against autograd on the oracle."""
+    from customnerf_amd.field import field
+    P = 2077
+    ref, enc, x, d = make_case(L, n_geo, P, seed=5)
+    ref.half = half
+    ref.pos_en.half = half
+    rng = np.random.default_rng(9)
+    gs = (rng.standard_normal(P) * 0.05).astype(np.float32)
+    gc = rng.standard_normal((P, 4)).astype(np.float32)
+    s_ref, c_ref, _ = ref(torch.from_numpy(x), torch.from_numpy(d))
+    torch.autograd.backward([s_ref, c_ref], [torch.from_numpy(gs), torch.from_numpy(gc)])
+    pn, pd, pr = (t.detach().clone().cuda().requires_grad_(True) for t in (ref.network, ref.density_network, ref.rgb_network))
+    e = enc.encode(cuda(x), bound=2.0, half=half)
+    s, c = field(e, cuda(x), cuda(d), 1, 2 * L, n_geo, 4, pn, pd, pr)
+    torch.autograd.backward([s, c], [cuda(gs), cuda(gc)])
+    # fp16: activations, dz and the weight-gradient GEMM operands are halves (tcnn numerics); the oracle keeps dz in fp32
+    rt, at = (3e-2, 3e-3) if half else (1e-3, 1e-5)
+    for name, a, b in (("net", pn.grad, ref.network.grad), ("den", pd.grad, ref.density_network.grad), ("rgb", pr.grad, ref.rgb_network.grad),
+                       ("grid", enc.embeddings.grad, ref.pos_en.embeddings.grad)):
+        a, b = a.cpu().numpy(), b.numpy()
+        scale = float(np.abs(b).max())
+        assert scale > 0, name
+        err = np.abs(a - b).max() / scale
+        assert err < (rt if name != "grid" else rt * 2), f"{name}: max|diff|/max|ref| = {err:.3e}"
+        np.testing.assert_allclose(a, b, rtol=rt * 10, atol=max(at, rt * scale), err_msg=name)
+    # padded parameter rows/columns (tcnn pads 1 -> 16 outputs, 91 -> 96 inputs) must get exactly zero gradient
+    assert torch.all(pd.grad[4096 + 64:] == 0)
+    assert torch.all(pr.grad[:64 * 96].view(64, 96)[:, 91:] == 0)
