@@ -483,14 +483,23 @@ struct DwPlan {
     uint32_t n_jobs, n_tiles, k_tiles_per_split;     // K split in units of 32-sample tiles
 };
 
+// One workgroup = one 32x32 tile of one layer's dW over one K split.  Per step it stages a [32 rows x 128 samples] block of dz
+// and of the layer input into LDS with fully coalesced loads (a wave instruction reads 4 rows x 256 contiguous bytes), then
+// each wave contracts its own 32 of the 128 samples; partial tiles are reduced through LDS and added with one float atomic per
+// weight per split.  (Reading the MFMA fragments straight from HBM touches 32 rows x 32 B per instruction: 4x slower.)
+#define DW_KB 128                       // samples per staged block (4 waves x 32)
 template <bool H>
 __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_dw(const void *__restrict__ ws_, size_t ld, uint32_t n_ktiles, DwPlan plan,
                                                               float *__restrict__ g_net, float *__restrict__ g_den, float *__restrict__ g_rgb) {
     using PR = Prec<H>;
     using elem_t = typename PR::elem_t;
     using frag_t = typename PR::frag_t;
+    constexpr uint32_t ROWB = DW_KB * sizeof(elem_t);            // bytes per staged row: 256 (fp16) / 512 (fp32)
+    constexpr uint32_t PAD = 16;                                  // row padding: keeps the per-lane 16-byte fragment reads off one bank group
+    constexpr uint32_t RSTR = ROWB + PAD;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[2][32 * RSTR];      // [Z | A][row][samples]
     __shared__ float red[FLD_WAVES][32 * 32];
-    const elem_t *ws = reinterpret_cast<const elem_t *>(ws_);
+    const unsigned char *ws = reinterpret_cast<const unsigned char *>(ws_);
     const uint32_t tile = blockIdx.x, split = blockIdx.y;
     uint32_t jid = 0;
 #pragma unroll
@@ -499,31 +508,37 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_dw(const void *__rest
     const DwJob jb = plan.job[jid];
     const uint32_t lt = tile - jb.tile0, mt = lt / jb.nt_n, nt = lt % jb.nt_n;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
-    const uint32_t zr = 32 * mt + li, ar = 32 * nt + li;
-    const bool zok = zr < jb.M, aok = ar < jb.N;
-    const elem_t *zp = ws + (size_t)(jb.z_row + (zok ? zr : 0)) * ld;
-    const elem_t *ap = ws + (size_t)(jb.a_row + (aok ? ar : 0)) * ld;
 
     const uint32_t kt0 = split * plan.k_tiles_per_split, kt1 = min(kt0 + plan.k_tiles_per_split, n_ktiles);
     cn_f16v acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    // each wave walks every 4th 32-sample tile of the split; a tile is 32 / KS MFMA K-steps
-    for (uint32_t kt = kt0 + wave; kt < kt1; kt += FLD_WAVES) {
-        const size_t k = (size_t)kt * 32;
+    constexpr uint32_t CH_PER_ROW = ROWB / 16;                   // 16-byte chunks per staged row
+    constexpr uint32_t CHUNKS = 32 * CH_PER_ROW;                 // per operand
+    for (uint32_t kt = kt0; kt < kt1; kt += DW_KB / 32) {
+        const size_t k0 = (size_t)kt * 32;
+        const uint32_t k_valid = min((uint32_t)DW_KB, (kt1 - kt) * 32);
+        // ---- coalesced staging of both operands
+        for (uint32_t c = threadIdx.x; c < 2 * CHUNKS; c += FLD_THREADS) {
+            const uint32_t op = c / CHUNKS, cc = c % CHUNKS, row = cc / CH_PER_ROW, ch = cc % CH_PER_ROW;
+            const uint32_t grow = 32 * (op ? nt : mt) + row, nrows = op ? jb.N : jb.M;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (grow < nrows && ch * (16 / sizeof(elem_t)) < k_valid)
+                v = *reinterpret_cast<const uint4 *>(ws + ((size_t)((op ? jb.a_row : jb.z_row) + grow) * ld + k0) * sizeof(elem_t) + ch * 16);
+            *reinterpret_cast<uint4 *>(&stage[op][row * RSTR + ch * 16]) = v;
+        }
+        __syncthreads();
+        // ---- this wave's 32 samples: 32 / KS MFMA K-steps
+        const unsigned char *zrow = &stage[0][li * RSTR + wave * 32 * sizeof(elem_t)];
+        const unsigned char *arow = &stage[1][li * RSTR + wave * 32 * sizeof(elem_t)];
 #pragma unroll
         for (int s = 0; s < 32 / PR::KS; s++) {
-            const size_t kk = k + PR::KS * s + PR::J * hi;
-            frag_t a, b;
-            if constexpr (H) {
-                a = zok ? *reinterpret_cast<const cn_h8 *>(zp + kk) : PR::zero();
-                b = aok ? *reinterpret_cast<const cn_h8 *>(ap + kk) : PR::zero();
-            } else {
-                a = zok ? zp[kk] : 0.0f;
-                b = aok ? ap[kk] : 0.0f;
-            }
+            const uint32_t off = (PR::KS * s + PR::J * hi) * sizeof(elem_t);
+            const frag_t a = *reinterpret_cast<const frag_t *>(zrow + off);
+            const frag_t b = *reinterpret_cast<const frag_t *>(arow + off);
             acc = PR::mfma(a, b, acc);
         }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][fld_rho(r, hi) * 32 + li] = acc[r];
@@ -617,7 +632,7 @@ static int fb_launch(const void *enc, const float *xyz, const float *dirs, uint3
     fb_add_job(pl, wo.zr, 64, wo.fea, 64, 2, 0, in_r0, FLD_NDIR);                                              // r0, feature columns
     fb_add_job(pl, wo.zro, dm.n_rgb_out, wo.hr, 64, 2, FLD_HID * in_r0, 64, 0);                                // ro
     uint32_t splits = n_tiles < 64 ? 1 : (n_tiles < 4096 ? 8 : 64);
-    pl.k_tiles_per_split = cn_div_up(n_tiles, splits);
+    pl.k_tiles_per_split = cn_div_up(cn_div_up(n_tiles, splits), DW_KB / 32) * (DW_KB / 32);     // whole 128-sample blocks
     splits = cn_div_up(n_tiles, pl.k_tiles_per_split);
     hipLaunchKernelGGL((k_field_bwd_dw<H>), dim3(pl.n_tiles, splits), dim3(FLD_THREADS), 0, st, workspace, ld, n_tiles, pl, g_net, g_den, g_rgb);
     return cn_launch_status();
