@@ -1,0 +1,369 @@
+// The pure-PyTorch renderer `NeRFRenderer.run` (nerf/renderer.py:278-405) as four gfx950 kernels:
+//   k_sample_coarse        stratified samples + jitter + aabb clip                      (renderer.py:310-322)
+//   k_sample_fine_merge    coarse weights -> inverse-CDF resampling -> merge           (renderer.py:334-363 + sample_pdf :21-55)
+//   k_composite_run_fwd    the three weights_sum_i composites (all / fg / bg) at once  (renderer.py:384-402, 407-474)
+//   k_composite_run_bwd    their gradient w.r.t. sigma and rgb+confidence
+// One wavefront owns one ray: its samples sit on the 64 lanes (chunks of 64), transmittance is a multiplicative wave scan
+// (DPP shuffles), the CDF inversion a binary search in LDS, the merge a rank computation — no sort, no global scratch.
+// The reference spends ~100 elementwise/scan/sort/gather launches and three cumprod passes per step on the same work.
+#include "common.h"
+#include <float.h>
+
+#define RN_WAVES 4
+#define RN_THREADS (RN_WAVES * 64)
+#define RN_MAXS 128                  // max coarse / fine samples per ray
+
+__device__ __forceinline__ float rn_linspace01(uint32_t i, uint32_t n) {      // torch.linspace(0, 1, n)[i]
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+// torch.clamp((z - near) / (far - near), 0, 1): NaN (a ray that misses the box has far == near) propagates, as in torch
+__device__ __forceinline__ float rn_norm_depth(float z, float near, float far) {
+    const float x = (z - near) / (far - near);
+    return (x != x) ? x : fminf(fmaxf(x, 0.0f), 1.0f);
+}
+
+__device__ __forceinline__ void rn_point(const float *o, const float *d, float z, const float *aabb, float *out) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[c] = fminf(fmaxf(o[c] + d[c] * z, aabb[c]), aabb[3 + c]);
+}
+
+__global__ void __launch_bounds__(256) k_sample_coarse(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
+                                                       const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
+                                                       uint32_t N, uint32_t T, float *__restrict__ z_vals, float *__restrict__ xyzs) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * T) return;
+    const uint32_t n = idx / T, i = idx - n * T;
+    const float near = nears[n], far = fars[n];
+    float z = near + (far - near) * rn_linspace01(i, T);
+    if (noise) z = z + (noise[idx] - 0.5f) * ((far - near) / (float)T);
+    float p[3];
+    rn_point(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, z, aabb, p);
+    z_vals[idx] = z;
+    xyzs[(size_t)idx * 3] = p[0]; xyzs[(size_t)idx * 3 + 1] = p[1]; xyzs[(size_t)idx * 3 + 2] = p[2];
+}
+
+// exclusive multiplicative scan of v over the 64 lanes, times carry; returns the wave total (times carry) in `carry`
+__device__ __forceinline__ float rn_excl_prod_scan(float v, float &carry, uint32_t lane) {
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl *= o;
+    }
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float res = excl * carry;
+    carry = carry * __shfl(incl, 63, 64);
+    return res;
+}
+
+__device__ __forceinline__ float rn_incl_sum_scan(float v, float &carry, uint32_t lane) {
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += o;
+    }
+    const float res = incl + carry;
+    carry = carry + __shfl(incl, 63, 64);
+    return res;
+}
+
+__device__ __forceinline__ float rn_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                  const float *__restrict__ nears, const float *__restrict__ fars,
+                                                                  const float *__restrict__ aabb, const float *__restrict__ z_vals,
+                                                                  const float *__restrict__ sigmas, const float *__restrict__ u_rand, uint32_t N,
+                                                                  uint32_t T, uint32_t t, float *__restrict__ z_all, float *__restrict__ xyz_all) {
+    __shared__ float s_z[RN_WAVES][RN_MAXS], s_w[RN_WAVES][RN_MAXS], s_cdf[RN_WAVES][RN_MAXS], s_bin[RN_WAVES][RN_MAXS], s_nz[RN_WAVES][RN_MAXS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * RN_WAVES + wave;
+    if (n >= N) return;                                   // whole wave exits together; no workgroup barrier below
+    float *zz = s_z[wave], *ww = s_w[wave], *cdf = s_cdf[wave], *bins = s_bin[wave], *nz = s_nz[wave];
+    const float near = nears[n], far = fars[n];
+    const float sd = (far - near) / (float)T;
+    const float *zr = z_vals + (size_t)n * T, *sr = sigmas + (size_t)n * T;
+
+    for (uint32_t i = lane; i < T; i += 64) zz[i] = zr[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // weights = alpha * cumprod([1, 1 - alpha + 1e-15])[:-1]          (renderer.py:336-341)
+    float carry = 1.0f;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        float alpha = 0.0f, delta = 0.0f;
+        if (i < T) {
+            delta = (i + 1 < T) ? zz[i + 1] - zz[i] : sd;
+            alpha = 1.0f - expf(-delta * sr[i]);
+        }
+        const float tr = rn_excl_prod_scan((i < T) ? (1.0f - alpha + 1e-15f) : 1.0f, carry, lane);
+        if (i < T) {
+            ww[i] = alpha * tr;
+            bins[i] = zz[i] + 0.5f * delta;               // z_vals_mid (only i < T-1 is used)
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pdf over weights[1:-1] + 1e-5, cdf = [0, cumsum(pdf)]           (sample_pdf :28-31)
+    const uint32_t nb = T - 2;                            // number of pdf bins; cdf has nb + 1 = T - 1 entries
+    float tot = 0.0f;
+    for (uint32_t k = lane; k < nb; k += 64) tot += ww[k + 1] + 1e-5f;
+    tot = rn_wave_sum(tot);
+    float csum = 0.0f;
+    for (uint32_t base = 0; base < nb; base += 64) {
+        const uint32_t k = base + lane;
+        const float pdf = (k < nb) ? (ww[k + 1] + 1e-5f) / tot : 0.0f;
+        const float c = rn_incl_sum_scan(pdf, csum, lane);
+        if (k < nb) cdf[k + 1] = c;
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    // invert the cdf                                                   (sample_pdf :33-53)
+    const uint32_t ncdf = nb + 1;
+    for (uint32_t m = lane; m < t; m += 64) {
+        float u;
+        if (u_rand) u = u_rand[(size_t)n * t + m];
+        else {                                            // torch.linspace(0.5/t, 1 - 0.5/t, t)[m]
+            const float a = 0.0f + 0.5f / (float)t, b = 1.0f - 0.5f / (float)t;
+            const float step = (b - a) / (float)(t - 1);
+            u = (m < t / 2) ? a + step * (float)m : b - step * (float)(t - 1 - m);
+        }
+        uint32_t lo = 0, hi = ncdf;                       // searchsorted(right=True): first index with cdf > u
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t below = lo > 0 ? lo - 1 : 0, above = lo < ncdf - 1 ? lo : ncdf - 1;
+        const float cb = cdf[below], ca = cdf[above];
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float tt = (u - cb) / denom;
+        nz[m] = bins[below] + tt * (bins[above] - bins[below]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // merge by rank: position of a coarse sample = its index + #fine < it; of a fine sample = its rank among the fine ones
+    // (ties by index) + #coarse <= it.  Equal values give equal samples, so any tie order reproduces torch.sort's output.
+    const float *o = rays_o + (size_t)n * 3, *d = rays_d + (size_t)n * 3;
+    float *za = z_all + (size_t)n * (T + t), *xa = xyz_all + (size_t)n * (T + t) * 3;
+    for (uint32_t i = lane; i < T; i += 64) {
+        const float v = zz[i];
+        uint32_t pos = i;
+        for (uint32_t m = 0; m < t; m++) pos += (nz[m] < v) ? 1u : 0u;
+        float p[3];
+        rn_point(o, d, v, aabb, p);
+        za[pos] = v;
+        xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2];
+    }
+    for (uint32_t m = lane; m < t; m += 64) {
+        const float v = nz[m];
+        uint32_t pos = 0;
+        for (uint32_t k = 0; k < t; k++) {
+            const float w = nz[k];
+            pos += (w < v || (w == v && k < m)) ? 1u : 0u;
+        }
+        for (uint32_t i = 0; i < T; i++) pos += (zz[i] <= v) ? 1u : 0u;
+        float p[3];
+        rn_point(o, d, v, aabb, p);
+        za[pos] = v;
+        xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ composites
+// per-sample quantities of one variant (0 all, 1 fg, 2 bg)
+__device__ __forceinline__ float rn_edit(float conf, int soft, float thr) {
+    return soft ? 1.0f / (1.0f + expf(-(conf - thr) * 100.0f)) : (conf > 0.5f ? 1.0f : 0.0f);
+}
+__device__ __forceinline__ float rn_variant_scale(int v, float e) { return v == 0 ? 1.0f : (v == 1 ? e : 1.0f - e); }
+
+#define RN_MAXCH 4                   // up to 256 samples per ray (4 chunks of 64)
+
+__global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbc,
+                                                                  const float *__restrict__ z_vals, const float *__restrict__ nears,
+                                                                  const float *__restrict__ fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft,
+                                                                  float thr, float *__restrict__ out_ray, float *__restrict__ out_w) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * RN_WAVES + wave;
+    if (n >= N) return;
+    const float near = nears[n], far = fars[n];
+    const float sd = (far - near) / (float)num_steps;
+    const float *zr = z_vals + (size_t)n * S, *sr = sigmas + (size_t)n * S;
+    const float4 *cr = reinterpret_cast<const float4 *>(rgbc) + (size_t)n * S;
+    float carry[3] = {1.0f, 1.0f, 1.0f};
+    float acc[3][6];
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[v][k] = 0.0f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const bool ok = i < S;
+        float z = 0, delta = 0, sigma = 0;
+        float4 c = make_float4(0, 0, 0, 0);
+        if (ok) {
+            z = zr[i];
+            delta = (i + 1 < S) ? zr[i + 1] - z : sd;
+            sigma = sr[i];
+            c = cr[i];
+        }
+        const float zn = rn_norm_depth(z, near, far);
+        const float e = rn_edit(c.w, soft, thr);
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const float alpha = ok ? 1.0f - expf(-delta * (sigma * rn_variant_scale(v, e))) : 0.0f;
+            const float tr = rn_excl_prod_scan(ok ? (1.0f - alpha + 1e-15f) : 1.0f, carry[v], lane);
+            const float w = alpha * tr;
+            if (ok) {
+                acc[v][0] += w * c.x; acc[v][1] += w * c.y; acc[v][2] += w * c.z;
+                acc[v][3] += w * zn; acc[v][4] += w; acc[v][5] += w * c.w;
+                if (out_w) out_w[((size_t)v * N + n) * S + i] = w;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const float s = rn_wave_sum(acc[v][k]);
+            if (lane == 0) out_ray[((size_t)v * N + n) * 6 + k] = s;
+        }
+    }
+}
+
+// Backward.  For one variant: w_i = a_i T_i, T_i = prod_{j<i} q_j, q = 1 - a + 1e-15, a = 1 - exp(-delta * s_v).
+//   G_i = dL/dw_i = g_img . rgb_i + g_depth zn_i + g_ws + g_mask conf_i
+//   dL/da_i = G_i T_i - (sum_{k>i} G_k w_k) / q_i ;  da/ds_v = delta (1 - a)
+__global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *__restrict__ g_out, const float *__restrict__ sigmas,
+                                                                  const float *__restrict__ rgbc, const float *__restrict__ z_vals,
+                                                                  const float *__restrict__ nears, const float *__restrict__ fars, uint32_t N, uint32_t S,
+                                                                  uint32_t num_steps, int soft, float thr, int detach_bg, int detach_mask,
+                                                                  float *__restrict__ g_sigma, float *__restrict__ g_rgbc) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * RN_WAVES + wave;
+    if (n >= N) return;
+    const float near = nears[n], far = fars[n];
+    const float sd = (far - near) / (float)num_steps;
+    const float *zr = z_vals + (size_t)n * S, *sr = sigmas + (size_t)n * S;
+    const float4 *cr = reinterpret_cast<const float4 *>(rgbc) + (size_t)n * S;
+    float go[3][6];
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) go[v][k] = g_out[((size_t)v * N + n) * 6 + k];
+
+    // pass 1: totals sum_k G_k w_k per variant
+    float tot[3] = {0, 0, 0};
+    {
+        float carry[3] = {1.0f, 1.0f, 1.0f};
+        for (uint32_t base = 0; base < S; base += 64) {
+            const uint32_t i = base + lane;
+            const bool ok = i < S;
+            float z = 0, delta = 0, sigma = 0;
+            float4 c = make_float4(0, 0, 0, 0);
+            if (ok) { z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd; sigma = sr[i]; c = cr[i]; }
+            const float zn = rn_norm_depth(z, near, far);
+            const float e = rn_edit(c.w, soft, thr);
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const float alpha = ok ? 1.0f - expf(-delta * (sigma * rn_variant_scale(v, e))) : 0.0f;
+                const float tr = rn_excl_prod_scan(ok ? (1.0f - alpha + 1e-15f) : 1.0f, carry[v], lane);
+                const float G = go[v][0] * c.x + go[v][1] * c.y + go[v][2] * c.z + go[v][3] * zn + go[v][4] + (detach_mask ? 0.0f : go[v][5] * c.w);
+                if (ok) tot[v] += G * alpha * tr;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 3; v++) tot[v] = rn_wave_sum(tot[v]);
+    }
+    // pass 2: gradients
+    float carry[3] = {1.0f, 1.0f, 1.0f}, pref[3] = {0, 0, 0};
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const bool ok = i < S;
+        float z = 0, delta = 0, sigma = 0;
+        float4 c = make_float4(0, 0, 0, 0);
+        if (ok) { z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd; sigma = sr[i]; c = cr[i]; }
+        const float zn = rn_norm_depth(z, near, far);
+        const float e = rn_edit(c.w, soft, thr);
+        float gs = 0.0f, ge = 0.0f;
+        float4 gc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const float m = rn_variant_scale(v, e);
+            const float alpha = ok ? 1.0f - expf(-delta * (sigma * m)) : 0.0f;
+            const float q = 1.0f - alpha + 1e-15f;
+            const float tr = rn_excl_prod_scan(ok ? q : 1.0f, carry[v], lane);
+            const float w = alpha * tr;
+            const float G = go[v][0] * c.x + go[v][1] * c.y + go[v][2] * c.z + go[v][3] * zn + go[v][4] + (detach_mask ? 0.0f : go[v][5] * c.w);
+            const float incl = rn_incl_sum_scan(ok ? G * w : 0.0f, pref[v], lane);      // sum_{k<=i} G_k w_k
+            const float suffix = tot[v] - incl;
+            const float dalpha = G * tr - suffix / q;
+            const float dsv = dalpha * delta * (1.0f - alpha);
+            const bool detached = (v == 0) && detach_bg && !(c.w >= 0.5f);                 // renderer.py:409-418 (is_all call only)
+            if (!detached) {
+                gs += dsv * m;
+                gc.x += go[v][0] * w; gc.y += go[v][1] * w; gc.z += go[v][2] * w;
+            }
+            gc.w += go[v][5] * w;                                                          // d render_mask / d conf
+            if (v == 1) ge += dsv * sigma;
+            if (v == 2) ge -= dsv * sigma;
+        }
+        if (soft) gc.w += ge * 100.0f * e * (1.0f - e);                                    // edit = sigmoid((conf - thr) * 100), renderer.py:387
+        if (ok) {
+            g_sigma[(size_t)n * S + i] = gs;
+            reinterpret_cast<float4 *>(g_rgbc)[(size_t)n * S + i] = gc;
+        }
+    }
+}
+
+extern "C" {
+
+int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
+                        uint32_t N, uint32_t T, float *z_vals, float *xyzs, void *stream) {
+    if (T < 2 || T > RN_MAXS) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb, noise, N, T,
+                       z_vals, xyzs);
+    return cn_launch_status();
+}
+
+int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *z_vals,
+                            const float *sigmas, const float *u, uint32_t N, uint32_t T, uint32_t t, float *z_all, float *xyz_all, void *stream) {
+    if (T < 3 || T > RN_MAXS || t < 2 || t > RN_MAXS) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !sigmas || !z_all || !xyz_all) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_fine_merge, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb,
+                       z_vals, sigmas, u, N, T, t, z_all, xyz_all);
+    return cn_launch_status();
+}
+
+int cnerf_composite_run(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars, uint32_t N, uint32_t S,
+                        uint32_t num_steps, int soft_mask, float conf_thr, float *out_ray, float *out_weights, void *stream) {
+    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!sigmas || !rgbc || !z_vals || !nears || !fars || !out_ray) return CNERF_ENULL;
+    if (((uintptr_t)rgbc) & 15) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_composite_run_fwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), sigmas, rgbc, z_vals, nears, fars, N, S,
+                       num_steps, soft_mask, conf_thr, out_ray, out_weights);
+    return cn_launch_status();
+}
+
+int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
+                                 const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
+                                 int detach_mask_from_field, float *grad_sigmas, float *grad_rgbc, void *stream) {
+    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!grad_out_ray || !sigmas || !rgbc || !z_vals || !nears || !fars || !grad_sigmas || !grad_rgbc) return CNERF_ENULL;
+    if ((((uintptr_t)rgbc) | ((uintptr_t)grad_rgbc)) & 15) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_composite_run_bwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), grad_out_ray, sigmas, rgbc, z_vals, nears,
+                       fars, N, S, num_steps, soft_mask, conf_thr, detach_bg, detach_mask_from_field, grad_sigmas, grad_rgbc);
+    return cn_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+"""Python entries of the fused `run()` kernels (customnerf_amd/csrc/render.hip): stratified sampling, importance resampling +
+merge, and the three weights_sum_i composites with their backward.  Semantics: nerf/renderer.py:310-363, 384-474, 21-55."""
+import torch
+from torch.autograd import Function
+
+from .._lib import lib, check, ptr, stream, require_cuda
+
+
+def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None):
+    """-> z_vals [N,T], xyzs [N,T,3]   (renderer.py:310-322; noise [N,T] = the torch.rand draw of :317 or None)"""
+    require_cuda(rays_o, rays_d, nears, fars, aabb, noise)
+    N = rays_o.shape[0]
+    z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
+    xyz = torch.empty(N, T, 3, dtype=torch.float32, device=rays_o.device)
+    check(lib.cnerf_sample_coarse(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, int(T), ptr(z), ptr(xyz), stream()),
+          "sample_coarse")
+    return z, xyz
+
+
+def sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=None):
+    """-> z_all [N,T+t] (sorted), xyz_all [N,T+t,3]   (renderer.py:334-363; u [N,t] = the draw of sample_pdf:37, None = det)"""
+    require_cuda(z_vals, sigmas, u)
+    N, T = z_vals.shape
+    z_all = torch.empty(N, T + t, dtype=torch.float32, device=z_vals.device)
+    xyz_all = torch.empty(N, T + t, 3, dtype=torch.float32, device=z_vals.device)
+    check(lib.cnerf_sample_fine_merge(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(z_vals), ptr(sigmas), ptr(u), N, int(T), int(t),
+                                      ptr(z_all), ptr(xyz_all), stream()), "sample_fine_merge")
+    return z_all, xyz_all
+
+
+class _CompositeRun(Function):
+    """out_ray [3,N,6] (all/fg/bg x image rgb, depth, weights_sum, render_mask), weights [3,N,S]"""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbc, z_vals, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask):
+        sigmas = sigmas.contiguous().float()
+        rgbc = rgbc.contiguous().float()
+        N, S = z_vals.shape
+        out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=z_vals.device)
+        out_w = torch.empty(3, N, S, dtype=torch.float32, device=z_vals.device)
+        check(lib.cnerf_composite_run(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
+                                      ptr(out_ray), ptr(out_w), stream()), "composite_run")
+        ctx.save_for_backward(sigmas, rgbc, z_vals, nears, fars)
+        ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
+        ctx.mark_non_differentiable(out_w)
+        return out_ray, out_w
+
+    @staticmethod
+    def backward(ctx, g_ray, g_w):
+        sigmas, rgbc, z_vals, nears, fars = ctx.saved_tensors
+        num_steps, soft, thr, dbg, dmask = ctx.cfg
+        N, S = z_vals.shape
+        g_ray = g_ray.contiguous().float()
+        g_sigma = torch.empty_like(sigmas)
+        g_rgbc = torch.empty_like(rgbc)
+        check(lib.cnerf_composite_run_backward(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr, dbg,
+                                               dmask, ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward")
+        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None
+
+
+def composite_run(sigmas, rgbc, z_vals, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False):
+    return _CompositeRun.apply(sigmas, rgbc, z_vals, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask)

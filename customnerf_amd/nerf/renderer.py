@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from .. import raymarching
 from .provider_utils import custom_meshgrid, safe_normalize
+from . import render_ops
 
 
 def sample_pdf(bins, weights, n_samples, det=False, u=None):
@@ -91,6 +92,9 @@ class NeRFRenderer(nn.Module):
             bg_color=None, perturb=False, _draws=None, **kwargs):
         """renderer.py:278-405.  rays_o, rays_d [B,N,3] (B == 1) -> result dict.
         `_draws` = dict(light, z, u) replays the RNG draws of :305, :317 and sample_pdf:37 (tests)."""
+        if (getattr(self.opt, 'fused_render', True) and rays_o.is_cuda and getattr(self.opt, 'train_conf', 0) and upsample_steps >= 2
+                and 3 <= num_steps <= 128 and upsample_steps <= 128 and getattr(self, 'supports_dir_group', False)):
+            return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -168,6 +172,54 @@ class NeRFRenderer(nn.Module):
             results['edit_mask'] = edit_mask
             results['fg'] = self.weights_sum_i(sample_dist, sigmas_fg, None, dirs, None, z_vals, nears, fars, rgbs, prefix, masks=masks, if_fg=True)
             results['bg'] = self.weights_sum_i(sample_dist, sigmas_bg, None, dirs, None, z_vals, nears, fars, rgbs, prefix, masks=masks)
+        return results
+
+    def _run_fused(self, rays_o, rays_d, num_steps, upsample_steps, perturb, _draws=None):
+        """run() on the fused kernels: 2 sampling launches + 2 field launches (+1 gather each) + 1 composite launch.
+        Same result dict as run(); RNG draws keep the reference's order (rand(N,T) then rand(N,t))."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        device = rays_o.device
+        draws = _draws or {}
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        with torch.no_grad():
+            noise = None
+            if perturb:
+                noise = draws['z'].to(device).contiguous() if 'z' in draws else torch.rand(N, num_steps, device=device)
+            z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
+            sig_c = self.density(xyzs.view(-1, 3))['sigma'].float().contiguous()
+            if self.training:
+                u = draws['u'].to(device).contiguous() if 'u' in draws else torch.rand(N, upsample_steps, device=device)
+            else:
+                u = None                                                      # det=True (sample_pdf :33-35)
+            z_all, xyz_all = render_ops.sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u)
+            if getattr(self.opt, 'eval_fine_density', False):
+                self.density(xyz_all.view(-1, 3))
+        S = num_steps + upsample_steps
+        sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
+        out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps,
+                                                  bool(getattr(self.opt, 'soft_mask', False)), float(getattr(self.opt, 'conf_thr', 0.5)),
+                                                  bool(getattr(self.opt, 'detach_bg', False)), bool(getattr(self.opt, 'detach_mask_from_field', False)))
+        mask = (nears < fars).reshape(*prefix)
+
+        def pack(v):
+            r = out_ray[v]
+            return {'image': r[:, 0:3].reshape(*prefix, 3), 'depth': r[:, 3].reshape(*prefix), 'weights_sum': r[:, 4],
+                    'render_mask': r[:, 5].reshape(*prefix, 1), 'weights': out_w[v], 'mask': mask}
+        results = pack(0)
+        conf = rgbc.view(N, S, 4)[..., 3:4]
+        results['sigma'] = sigmas.view(N, S, 1)
+        results['rgbs'] = rgbc.view(N, S, 4)[..., :3]
+        if getattr(self.opt, 'soft_mask', False):
+            results['edit_mask'] = torch.sigmoid((conf.detach() - self.opt.conf_thr) * 100)
+        else:
+            results['edit_mask'] = conf.detach() > 0.5
+        results['z_vals'] = z_all
+        results['fg'] = pack(1)
+        results['bg'] = pack(2)
         return results
 
     def weights_sum_i(self, sample_dist, sigmas, normals, dirs, weights, z_vals, nears, fars, rgbs, prefix, masks=None,

@@ -181,6 +181,34 @@ int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, fl
                         float level, int convention, float *origins, float *directions, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pure-PyTorch renderer `NeRFRenderer.run` (nerf/renderer.py:278-405) as fused kernels.
+ * ---------------------------------------------------------------------------------------------- */
+/* Stratified sampling: z = near + (far-near) * linspace(0,1,T)[i] + (noise-0.5)*sample_dist (noise NULL = no
+ * perturbation), xyz = clip(o + d z, aabb)  (renderer.py:310-322).  z_vals [N,T], xyzs [N,T,3]. */
+int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb,
+                        const float *noise, uint32_t N, uint32_t T, float *z_vals, float *xyzs, void *stream);
+/* Importance resampling + merge (renderer.py:334-363 + sample_pdf :21-55): from coarse z [N,T] and sigma [N,T]
+ * computes weights, inverts the CDF at u [N,t] (u NULL = deterministic midpoints, sample_pdf:34), and writes the
+ * merged, sorted z_all [N,T+t] and xyz_all [N,T+t,3].  T, t <= 128. */
+int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                            const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
+                            uint32_t T, uint32_t t, float *z_all, float *xyz_all, void *stream);
+/* weights_sum_i x3 (renderer.py:384-402, 407-474) in one pass over [N,S] samples: all / fg (sigma*edit_mask) /
+ * bg (sigma*(1-edit_mask)) composites.  soft_mask: edit = sigmoid((conf-thr)*100) else conf>0.5.
+ * rgbc [N,S,4] (rgb + confidence), sigmas [N,S], z_vals [N,S].
+ * out_ray [3][N][6]  = per composite (all,fg,bg): image rgb, depth, weights_sum, render_mask;
+ * out_weights [3][N][S] (NULL to skip). */
+int cnerf_composite_run(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars,
+                        uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, float *out_ray,
+                        float *out_weights, void *stream);
+/* Backward of cnerf_composite_run: grad_out_ray [3][N][6] -> grad_sigmas [N,S], grad_rgbc [N,S,4]
+ * (depth and weights_sum gradients are honoured; detach_* flags follow renderer.py:409-418, 460-463). */
+int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals,
+                                 const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
+                                 int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
+                                 float *grad_sigmas, float *grad_rgbc, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step used by the reference's recipe (main.py:182: Adam betas (0.9,0.99) eps 1e-15, no weight decay),
  * fused with gradient un-scaling, the fp16 shadow-table refresh and gradient zeroing.
  * p, m, v float32 [n]; g float32 [n] (zeroed after use if zero_grad); p_half (may be NULL) float16 [n].
