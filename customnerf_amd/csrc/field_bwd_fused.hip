@@ -168,9 +168,9 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
     uint32_t hi = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // provably wave-uniform: tile descriptors live in SGPRs
     // this wave's persistent dW tiles: A0/A1, B0/B1, C0/C1, D0 (descriptors are re-derived where used, they are a few SALU ops)
-    cn_f16v wA0, wA1, wB0, wB1, wC0, wC1, wD0;
+    cn_f16v wA0, wA1, wB0, wX, wC0, wC1;      // wX: phase-B tiles 4,5 on waves 2,3 and phase-D tiles 0,1 on waves 0,1
 #pragma unroll
-    for (int r = 0; r < 16; r++) { wA0[r] = 0; wA1[r] = 0; wB0[r] = 0; wB1[r] = 0; wC0[r] = 0; wC1[r] = 0; wD0[r] = 0; }
+    for (int r = 0; r < 16; r++) { wA0[r] = 0; wA1[r] = 0; wB0[r] = 0; wX[r] = 0; wC0[r] = 0; wC1[r] = 0; }
 
     const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
     for (uint32_t tile0 = blockIdx.x * FLD_WAVES; tile0 < n_tiles; tile0 += gridDim.x * FLD_WAVES) {        // workgroup-uniform trip count
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
             ff_stage_clayout(st, 72, col, hi, zd);
             __syncthreads();
             ff_tile_mma(st, ff_tile_B(wave, dm, po), li, hi, wB0);
-            ff_tile_mma(st, ff_tile_B(4 + wave, dm, po), li, hi, wB1);
+            if (wave >= 2) ff_tile_mma(st, ff_tile_B(2 + wave, dm, po), li, hi, wX);
             fb_gemm_T<H, 2, S64>(wt + lt.off[3], d0, FLD_HID, FLD_HID, 0, FLD_HID, S64, zd, lane, dfea);
             __syncthreads();
         }
@@ -309,9 +309,13 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
         FF_PIN(col, hi);
         ff_stage_clayout(st, 0, col, hi, z1);
         FF_PIN(col, hi);
-        ff_stage_natural<SENC>(st, 64, col, hi, x0);
+        {
+            frag_t x0b[SENC];                                               // re-read (L2 hit) rather than hold 8 VGPRs across the chain
+            fb_load_enc<H, SENC>(enc, P_, dm.L, p, valid, hi, x0b);
+            ff_stage_natural<SENC>(st, 64, col, hi, x0b);
+        }
         __syncthreads();
-        ff_tile_mma(st, ff_tile_D(wave, dm, po), li, hi, wD0);
+        if (wave < 2) ff_tile_mma(st, ff_tile_D(wave, dm, po), li, hi, wX);
         {
             cn_f16v denc[TENC];
             fb_zero(denc);
@@ -338,10 +342,10 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
     ff_tile_store(part, ff_tile_A(wave, dm, po), li, hi, wA0);
     ff_tile_store(part, ff_tile_A(4 + wave, dm, po), li, hi, wA1);
     ff_tile_store(part, ff_tile_B(wave, dm, po), li, hi, wB0);
-    ff_tile_store(part, ff_tile_B(4 + wave, dm, po), li, hi, wB1);
+    if (wave >= 2) ff_tile_store(part, ff_tile_B(2 + wave, dm, po), li, hi, wX);
     ff_tile_store(part, ff_tile_C(wave, dm, po), li, hi, wC0);
     ff_tile_store(part, ff_tile_C(4 + wave, dm, po), li, hi, wC1);
-    ff_tile_store(part, ff_tile_D(wave, dm, po), li, hi, wD0);
+    if (wave < 2) ff_tile_store(part, ff_tile_D(wave, dm, po), li, hi, wX);
 }
 
 // g[i] += sum_b partials[b][i]  over the flat [net | den | rgb] parameter space
