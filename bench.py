@@ -23,6 +23,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 
+def measured_traffic(dtype, points_per_launch):
+    """HBM bytes per gather launch from the committed rocprofv3 PMC passes (profiles/*_gather_pmc.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
+    prescribes for gfx950).  The counters are per launch of a given size; scaled linearly to this run's mean launch size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gather_pmc.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))
+        e = rec.get(dtype)
+        if not e:
+            return None
+        return (2.0 * e["fetch_size_kb"] + e["write_size_kb"]) * 1024.0 * points_per_launch / e["points"]
+    except Exception:
+        return None
+
+
 def gather_bytes_per_point(L, C, itemsize, D=3):
     """ALGORITHMIC bytes of the grid gather forward per point: L*2^D*C*s + 4*D + L*C*s."""
     return L * (2 ** D) * C * itemsize + 4 * D + L * C * itemsize
@@ -160,7 +178,8 @@ def main():
             tot_ms, tot_b = sum(ms), sum(p * bpp for p in pts)
             achieved = tot_b / (tot_ms * 1e-3) / 1e9
             result["roofline"] = {"kernel": "k_grid_fwd (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "traffic": measured_traffic(args.dtype, sum(pts) / len(pts)),
                                   "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
                                   "algorithmic_bytes_per_point": bpp}
         if not args.no_cpu_baseline and world == 1:
