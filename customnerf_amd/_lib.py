@@ -39,6 +39,9 @@ SIGNATURES = {
     "cnerf_field_forward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, vp],
     "cnerf_field_backward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp],
     "cnerf_field_backward_workspace_bytes": [u32, u32, u32, u32, i32, vp],
+    "cnerf_mlp_forward": [vp, u32, vp, u32, u32, u32, u32, u32, i32, vp, u32, i32, vp],
+    "cnerf_mlp_backward": [vp, u32, vp, vp, u32, u32, u32, u32, u32, u32, i32, vp, u32, vp, vp, u64, i32, vp],
+    "cnerf_mlp_backward_workspace_bytes": [u32, u32, u32, u32, u32, i32, vp],
     "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "cnerf_sample_coarse": [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp],

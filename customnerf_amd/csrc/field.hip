@@ -134,7 +134,6 @@ __device__ __forceinline__ void fld_load_enc(const void *__restrict__ enc, uint3
 template <bool H>
 __device__ __forceinline__ void fld_dir_frags(const float *__restrict__ dirs, uint32_t dir_group, uint32_t p, bool valid, uint32_t hi,
                                               typename Prec<H>::frag_t *b) {
-    using P = Prec<H>;
     float e[FLD_DIR];
     float dx = 0, dy = 0, dz = 0;
     if (valid) {

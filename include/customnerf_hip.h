@@ -171,6 +171,25 @@ int cnerf_field_backward_workspace_bytes(uint32_t P, uint32_t enc_dim, uint32_t 
                                          uint64_t *bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * Generic fully fused MLP = tinycudann.Network(n_in, n_out, {FullyFusedMLP, ReLU, 64 neurons, 1|2 hidden layers})
+ * (reference call sites: nerf/network_grid.py:18-54 RGB_network; :98-139 when the fused field is not used).
+ * x [P, ldx] and y [P, ldy] row-major in `dtype` (leading dimensions in elements: strided views are accepted);
+ * params float32 flat: row-major [64, pad16(n_in)], ([64,64]), [pad16(n_out), 64]; bias-free; output_activation 0 none | 1 sigmoid.
+ * n_in <= 128, n_out <= 64, n_neurons == 64.  Numerics as cnerf_field_forward (CNERF_F16 = tcnn's, CNERF_F32 exact).
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_mlp_forward(const void *x, uint32_t ldx, const float *params, uint32_t P, uint32_t n_in, uint32_t n_out,
+                      uint32_t n_neurons, uint32_t n_hidden_layers, int output_activation, void *y, uint32_t ldy, int dtype,
+                      void *stream);
+/* Backward (forward recomputed): grad_y [P, ldgy] (dtype) in; grad_x [P, ldgx] (dtype) out, NULL to skip;
+ * grad_params float32, ACCUMULATED (caller pre-zeroes).  workspace: 16-byte aligned, cnerf_mlp_backward_workspace_bytes(). */
+int cnerf_mlp_backward(const void *x, uint32_t ldx, const float *params, const void *grad_y, uint32_t ldgy, uint32_t P,
+                       uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, int output_activation,
+                       void *grad_x, uint32_t ldgx, float *grad_params, void *workspace, uint64_t workspace_bytes, int dtype,
+                       void *stream);
+int cnerf_mlp_backward_workspace_bytes(uint32_t P, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
+                                       uint32_t n_hidden_layers, int dtype, uint64_t *bytes);
+
+/* ------------------------------------------------------------------------------------------------
  * Ray generation (reference: nerf/provider.py:402-464 pinhole branch; nerf/provider_utils.py:239-302 get_rays)
  * c2w [V,3,4] row-major; outputs origins, directions [V, H, W, 3].
  * convention 0 = nerfstudio/OpenGL (provider.py: dir = normalize(R [ (x+.5-cx)/fx, -(y+.5-cy)/fy, -1 ]),
