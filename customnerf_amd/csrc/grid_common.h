@@ -69,6 +69,17 @@ __device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corne
     return index % hashmap_size;
 }
 
+// does ge_index take the hash branch on this level (gridtype hash only)?
+template <int D>
+__device__ __forceinline__ bool ge_is_hashed(bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+    uint32_t stride = 1;
+    const uint32_t step = align_corners ? resolution : (resolution + 1);
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (stride <= hashmap_size) stride *= step;
+    return stride > hashmap_size;
+}
+
 // blockIdx -> (level, point block).  Swizzled: XCD x (= blockIdx % 8 as dispatched) walks a contiguous slice of the
 // level-major work list, so at any moment it gathers from one or two tables that fit its own L2.
 __device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int swizzle, const GridLevels &lv, uint32_t &level, uint32_t &pb) {

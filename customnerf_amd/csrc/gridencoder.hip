@@ -73,9 +73,17 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
     // load runs only for lanes whose pair is not adjacent.  The gather is bound by the number of cache-line requests, not by
     // bytes, so this removes a quarter (hashed) to a half (dense) of the kernel's work.  All loads are issued before the
     // accumulation, which keeps the reference's corner order (bit-exact results).
+    // Hashed levels with 4-byte entries (fp16 C=2) use an aligned FOUR-entry window instead (global_load_dwordx4): x -> x+1 flips the
+    // low bits of x only, so the partner lies in the same aligned quad unless x = 3 mod 4 (XOR distance 1 or 3): the masked second
+    // load then runs for a quarter of the lanes instead of half.
     struct alignas(sizeof(T) * C) VecPair { Vec a, b; };
+    struct alignas(sizeof(T) * C * 4) VecQuad { Vec e[4]; };
     Vec corner[1 << D];
     float wgt[1 << D];
+    bool quad = false;
+    if constexpr (sizeof(Vec) == 4) {
+        quad = gridtype == 0 && ((lv.offset[level] | hashmap_size) & 3u) == 0 && ge_is_hashed<D>(align_corners, hashmap_size, resolution);
+    }
 #pragma unroll
     for (int q = 0; q < (1 << (D - 1)); q++) {
         uint32_t pgl[D];
@@ -93,14 +101,27 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
         const uint32_t i0 = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
         pgl[0] = pos_grid[0] + 1;
         const uint32_t i1 = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-        const uint32_t lo = min(i0, i1), hi_ = max(i0, i1);
-        const uint32_t b = (lo + 1 < hashmap_size) ? lo : lo - 1;          // two-entry window stays inside the level (tables hold >= 8 entries)
-        const VecPair v = *reinterpret_cast<const VecPair *>(table + b);
-        const Vec e_lo = (b == lo) ? v.a : v.b;
-        Vec e_hi = v.b;
-        if (hi_ - lo != 1) e_hi = table[hi_];
-        corner[2 * q] = (i0 == lo) ? e_lo : e_hi;
-        corner[2 * q + 1] = (i0 == lo) ? e_hi : e_lo;
+        if (quad) {
+            if constexpr (sizeof(Vec) == 4) {
+                const VecQuad v = *reinterpret_cast<const VecQuad *>(table + (i0 & ~3u));
+                const uint32_t k0 = i0 & 3u, k1 = i1 & 3u;
+                const Vec a01 = (k0 & 1) ? v.e[1] : v.e[0], a23 = (k0 & 1) ? v.e[3] : v.e[2];
+                corner[2 * q] = (k0 & 2) ? a23 : a01;
+                const Vec b01 = (k1 & 1) ? v.e[1] : v.e[0], b23 = (k1 & 1) ? v.e[3] : v.e[2];
+                Vec e1 = (k1 & 2) ? b23 : b01;
+                if ((i0 ^ i1) > 3u) e1 = table[i1];
+                corner[2 * q + 1] = e1;
+            }
+        } else {
+            const uint32_t lo = min(i0, i1), hi_ = max(i0, i1);
+            const uint32_t b = (lo + 1 < hashmap_size) ? lo : lo - 1;          // two-entry window stays inside the level (tables hold >= 8 entries)
+            const VecPair v = *reinterpret_cast<const VecPair *>(table + b);
+            const Vec e_lo = (b == lo) ? v.a : v.b;
+            Vec e_hi = v.b;
+            if (hi_ - lo != 1) e_hi = table[hi_];
+            corner[2 * q] = (i0 == lo) ? e_lo : e_hi;
+            corner[2 * q + 1] = (i0 == lo) ? e_hi : e_lo;
+        }
     }
     Vec res;
 #pragma unroll

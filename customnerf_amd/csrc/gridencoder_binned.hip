@@ -105,8 +105,14 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_hist(const float *__restrict
         uint32_t index[8];
         float wgt[8];
         bn_corners(in, lv, level, gridtype, align_corners, interp, index, wgt);
+        // corners 2q / 2q+1 differ in x only: their entries almost always share a chunk (dense: neighbours; hashed: the x term of
+        // the hash is the identity, x -> x+1 flips low bits) -> one counter update per pair
 #pragma unroll
-        for (int c = 0; c < 8; c++) atomicAdd(&cnt[index[c] >> BN_CHUNK_LOG2], 1u);
+        for (int q = 0; q < 4; q++) {
+            const uint32_t c0 = index[2 * q] >> BN_CHUNK_LOG2, c1 = index[2 * q + 1] >> BN_CHUNK_LOG2;
+            atomicAdd(&cnt[c0], c0 == c1 ? 2u : 1u);
+            if (c0 != c1) atomicAdd(&cnt[c1], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[level] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
@@ -198,14 +204,31 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ g
         using Vec = FeatVec<T, 2>;
         const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
         const float g0 = ge_to_float(g.v[0]), g1 = ge_to_float(g.v[1]);
+        // one cursor update and one double-width store per x-pair of corners (see k_bin_hist); record order inside a bin is
+        // irrelevant: fp16 sums are exact fixed point, fp32 sums are order-dependent at rounding level only
+        struct alignas(8) RecPair { BinRec<T> a, b; };
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const uint32_t pos = atomicAdd(&cursor[index[c] >> BN_CHUNK_LOG2], 1u);
-            BinRec<T> r;
-            r.idx = index[c] & (BN_CHUNK - 1);
-            if constexpr (sizeof(T) == 2) r.v = __floats2half2_rn(wgt[c] * g0, wgt[c] * g1);     // as gridencoder.cu:328
-            else { r.v0 = wgt[c] * g0; r.v1 = wgt[c] * g1; }
-            records[pos] = r;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i0 = index[2 * q], i1 = index[2 * q + 1];
+            const uint32_t c0 = i0 >> BN_CHUNK_LOG2, c1 = i1 >> BN_CHUNK_LOG2;
+            RecPair rp;
+            rp.a.idx = i0 & (BN_CHUNK - 1);
+            rp.b.idx = i1 & (BN_CHUNK - 1);
+            if constexpr (sizeof(T) == 2) {
+                rp.a.v = __floats2half2_rn(wgt[2 * q] * g0, wgt[2 * q] * g1);     // as gridencoder.cu:328
+                rp.b.v = __floats2half2_rn(wgt[2 * q + 1] * g0, wgt[2 * q + 1] * g1);
+            } else {
+                rp.a.v0 = wgt[2 * q] * g0; rp.a.v1 = wgt[2 * q] * g1;
+                rp.b.v0 = wgt[2 * q + 1] * g0; rp.b.v1 = wgt[2 * q + 1] * g1;
+            }
+            const uint32_t pos0 = atomicAdd(&cursor[c0], c0 == c1 ? 2u : 1u);
+            if (c0 == c1) {
+                *reinterpret_cast<RecPair *>(records + pos0) = rp;
+            } else {
+                const uint32_t pos1 = atomicAdd(&cursor[c1], 1u);
+                records[pos0] = rp.a;
+                records[pos1] = rp.b;
+            }
         }
     }
 }
