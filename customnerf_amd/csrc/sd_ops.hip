@@ -1,0 +1,595 @@
+// Normalisation / softmax / element-wise kernels of the SDS path (everything around the GEMMs of sd_gemm.hip).
+// All of them are HBM-stream bound: 16-byte accesses (8 halfs) per lane, float32 arithmetic, one pass over the data wherever the
+// row fits in registers.  Layout: NHWC / [tokens, channels] half.
+#include "common.h"
+#include "../../include/customnerf_sd.h"
+
+typedef _Float16 so_h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ so_h8 so_ld8(const _Float16 *p) { return *reinterpret_cast<const so_h8 *>(p); }
+__device__ __forceinline__ void so_st8(_Float16 *p, so_h8 v) { *reinterpret_cast<so_h8 *>(p) = v; }
+__device__ __forceinline__ float so_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float so_wave_max(float v) {
+#pragma unroll
+    for (int off = CN_WAVE / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, CN_WAVE));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// Thread t of a block owns one 16-byte channel chunk (8 channels, <= 2 groups when C/G >= 4) and walks down the rows of the
+// block's slab, so its partial sums live in registers; one LDS + one global float atomic per (thread, group) at the end.
+#define GN_THREADS 256
+#define GN_MAX_G 64
+
+struct GnGeom {
+    uint32_t nchunks, cols_per_pass, rows_per_pass, cg;
+};
+__device__ __forceinline__ GnGeom gn_geom(uint32_t C, uint32_t G) {
+    GnGeom q;
+    q.nchunks = C / 8;
+    q.cols_per_pass = q.nchunks < GN_THREADS ? q.nchunks : GN_THREADS;
+    q.rows_per_pass = GN_THREADS / q.cols_per_pass;
+    q.cg = C / G;
+    return q;
+}
+
+// MODE 0: forward statistics (sum x, sum x^2).  MODE 1: backward statistics (sum g, sum g xhat), g = dy * act'(z) * gamma.
+template <int MODE>
+__global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, const float *__restrict__ fsums, uint32_t HW, uint32_t C,
+                                                         uint32_t G, float eps, int silu, uint32_t rows_per_block, float *__restrict__ out) {
+    __shared__ float acc[GN_MAX_G][2];
+    const GnGeom q = gn_geom(C, G);
+    const uint32_t b = blockIdx.y, r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) acc[i >> 1][i & 1] = 0.0f;
+    __syncthreads();
+    const uint32_t tcol = threadIdx.x % q.cols_per_pass, trow = threadIdx.x / q.cols_per_pass;
+    const float inv_n = 1.0f / ((float)HW * (float)q.cg);
+    if (trow < q.rows_per_pass) {
+        for (uint32_t col = tcol; col < q.nchunks; col += q.cols_per_pass) {
+            const uint32_t c0 = col * 8, g_lo = c0 / q.cg, g_hi = (c0 + 7) / q.cg;
+            const uint32_t split = (g_lo + 1) * q.cg - c0;              // channels [0, split) of the chunk belong to g_lo
+            float s[2][2] = {{0, 0}, {0, 0}};
+            float mean[2] = {0, 0}, rstd[2] = {0, 0}, gam[8], bet[8];
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t g = k ? g_hi : g_lo;
+                    const float m = fsums[((size_t)b * G + g) * 2] * inv_n;
+                    const float v = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - m * m;
+                    mean[k] = m;
+                    rstd[k] = rsqrtf(fmaxf(v, 0.0f) + eps);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) { gam[e] = gamma[c0 + e]; bet[e] = beta[c0 + e]; }
+            }
+            for (uint32_t r = r0 + trow; r < r1; r += q.rows_per_pass) {
+                const size_t off = ((size_t)b * HW + r) * C + c0;
+                const so_h8 xv = so_ld8(x + off);
+                so_h8 dv;
+                if (MODE == 1) dv = so_ld8(dy + off);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k = ((uint32_t)e < split) ? 0 : 1;
+                    const float xf = (float)xv[e];
+                    if (MODE == 0) {
+                        s[k][0] += xf;
+                        s[k][1] += xf * xf;
+                    } else {
+                        const float xh = (xf - mean[k]) * rstd[k];
+                        float gq = (float)dv[e];
+                        if (silu) {
+                            const float z = xh * gam[e] + bet[e], sg = so_sigmoid(z);
+                            gq *= sg * (1.0f + z * (1.0f - sg));
+                        }
+                        gq *= gam[e];
+                        s[k][0] += gq;
+                        s[k][1] += gq * xh;
+                    }
+                }
+            }
+            atomicAdd(&acc[g_lo][0], s[0][0]);
+            atomicAdd(&acc[g_lo][1], s[0][1]);
+            if (g_hi != g_lo) {
+                atomicAdd(&acc[g_hi][0], s[1][0]);
+                atomicAdd(&acc[g_hi][1], s[1][1]);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) unsafeAtomicAdd(&out[(size_t)b * G * 2 + i], acc[i >> 1][i & 1]);
+}
+
+// MODE 0: y = act(xhat gamma + beta).  MODE 1: dx = rstd (g - S1/n - xhat S2/n).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gn_apply(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, const float *__restrict__ fsums, const float *__restrict__ bsums,
+                                                  uint32_t HW, uint32_t C, uint32_t G, float eps, int silu, _Float16 *__restrict__ out, size_t total_chunks) {
+    const uint32_t nchunks = C / 8, cg = C / G;
+    const float inv_n = 1.0f / ((float)HW * (float)cg);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nchunks;
+        const uint32_t col = (uint32_t)(i - row * nchunks), b = (uint32_t)(row / HW), c0 = col * 8;
+        const uint32_t g_lo = c0 / cg, g_hi = (c0 + 7) / cg, split = (g_lo + 1) * cg - c0;
+        float mean[2], rstd[2], s1[2] = {0, 0}, s2[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t g = k ? g_hi : g_lo;
+            const float m = fsums[((size_t)b * G + g) * 2] * inv_n;
+            const float v = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - m * m;
+            mean[k] = m;
+            rstd[k] = rsqrtf(fmaxf(v, 0.0f) + eps);
+            if (MODE == 1) {
+                s1[k] = bsums[((size_t)b * G + g) * 2] * inv_n;
+                s2[k] = bsums[((size_t)b * G + g) * 2 + 1] * inv_n;
+            }
+        }
+        const so_h8 xv = so_ld8(x + i * 8);
+        so_h8 dv, o;
+        if (MODE == 1) dv = so_ld8(dy + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = ((uint32_t)e < split) ? 0 : 1;
+            const float xh = ((float)xv[e] - mean[k]) * rstd[k];
+            const float ga = gamma[c0 + e], be = beta[c0 + e];
+            const float z = xh * ga + be;
+            if (MODE == 0) {
+                o[e] = (_Float16)(silu ? z * so_sigmoid(z) : z);
+            } else {
+                float gq = (float)dv[e];
+                if (silu) {
+                    const float sg = so_sigmoid(z);
+                    gq *= sg * (1.0f + z * (1.0f - sg));
+                }
+                gq *= ga;
+                o[e] = (_Float16)(rstd[k] * (gq - s1[k] - xh * s2[k]));
+            }
+        }
+        so_st8(out + i * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+template <int CPL>
+__global__ void __launch_bounds__(256) k_layernorm(const _Float16 *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   uint32_t rows, uint32_t C, float eps, _Float16 *__restrict__ y) {
+    const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t nchunks = C / 8;
+    float v[CPL][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const uint32_t col = lane + 64 * c;
+        if (col < nchunks) {
+            const so_h8 h = so_ld8(x + (size_t)row * C + col * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v[c][e] = (float)h[e]; sum += v[c][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[c][e] = 0.0f;
+        }
+    }
+    const float mean = cn_wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        if (lane + 64 * c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = v[c][e] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(cn_wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const uint32_t col = lane + 64 * c;
+        if (col < nchunks) {
+            so_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (_Float16)((v[c][e] - mean) * rstd * gamma[col * 8 + e] + beta[col * 8 + e]);
+            so_st8(y + (size_t)row * C + col * 8, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax (one wave per row, row in registers)
+template <int CPL, bool BWD>
+__global__ void __launch_bounds__(256) k_softmax(const _Float16 *__restrict__ P, _Float16 *__restrict__ S, uint64_t rows, uint32_t cols, uint32_t ld) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t nchunks = ld / 8;
+    _Float16 *s = S + row * ld;
+    float v[CPL][8];
+    if (!BWD) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint32_t col = lane + 64 * c;
+            so_h8 h;
+            if (col < nchunks) h = so_ld8(s + col * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[c][e] = (col < nchunks && col * 8 + e < cols) ? (float)h[e] : -INFINITY;
+                mx = fmaxf(mx, v[c][e]);
+            }
+        }
+        mx = so_wave_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[c][e] = __expf(v[c][e] - mx);          // exp(-inf) = 0 for the padding
+                sum += v[c][e];
+            }
+        const float inv = 1.0f / cn_wave_sum(sum);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint32_t col = lane + 64 * c;
+            if (col < nchunks) {
+                so_h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (_Float16)(v[c][e] * inv);
+                so_st8(s + col * 8, o);
+            }
+        }
+    } else {
+        const _Float16 *p = P + row * ld;
+        float pv[CPL][8];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint32_t col = lane + 64 * c;
+            so_h8 h, hp;
+            if (col < nchunks) { h = so_ld8(s + col * 8); hp = so_ld8(p + col * 8); }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const bool ok = col < nchunks && col * 8 + e < cols;
+                v[c][e] = ok ? (float)h[e] : 0.0f;
+                pv[c][e] = ok ? (float)hp[e] : 0.0f;
+                dot += v[c][e] * pv[c][e];
+            }
+        }
+        dot = cn_wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint32_t col = lane + 64 * c;
+            if (col < nchunks) {
+                so_h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (_Float16)(pv[c][e] * (v[c][e] - dot));
+                so_st8(s + col * 8, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise
+__global__ void __launch_bounds__(256) k_geglu(const _Float16 *__restrict__ x, uint64_t rows, uint32_t C, _Float16 *__restrict__ y) {
+    const uint32_t nchunks = C / 8;
+    const size_t total = (size_t)rows * nchunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nchunks;
+        const uint32_t col = (uint32_t)(i - row * nchunks);
+        const so_h8 a = so_ld8(x + row * 2 * C + col * 8), g = so_ld8(x + row * 2 * C + C + col * 8);
+        so_h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float gf = (float)g[e];
+            o[e] = (_Float16)((float)a[e] * (0.5f * gf * (1.0f + erff(gf * 0.70710678118654752f))));
+        }
+        so_st8(y + row * C + col * 8, o);
+    }
+}
+
+template <int OP>     // 0 add, 1 silu
+__global__ void __launch_bounds__(256) k_ew(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b, uint64_t n8, uint64_t n, _Float16 *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const so_h8 av = so_ld8(a + i * 8);
+        so_h8 o;
+        if (OP == 0) {
+            const so_h8 bv = so_ld8(b + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (_Float16)((float)av[e] + (float)bv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float z = (float)av[e]; o[e] = (_Float16)(z * so_sigmoid(z)); }
+        }
+        so_st8(y + i * 8, o);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
+            const float z = (float)a[i];
+            y[i] = (_Float16)(OP == 0 ? z + (float)b[i] : z * so_sigmoid(z));
+        }
+}
+
+__global__ void __launch_bounds__(256) k_concat(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b, uint64_t rows, uint32_t C1, uint32_t C2,
+                                                _Float16 *__restrict__ y) {
+    const uint32_t n1 = C1 / 8, nc = (C1 + C2) / 8;
+    const size_t total = (size_t)rows * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nc;
+        const uint32_t col = (uint32_t)(i - row * nc);
+        const so_h8 v = col < n1 ? so_ld8(a + row * C1 + col * 8) : so_ld8(b + row * C2 + (col - n1) * 8);
+        so_st8(y + i * 8, v);
+    }
+}
+
+// 64 x 64 tiles through LDS; dst[z][c][r] = src[z][r][c]
+__global__ void __launch_bounds__(256) k_transpose(const _Float16 *__restrict__ src, _Float16 *__restrict__ dst, uint32_t rows, uint32_t cols, uint32_t lds_,
+                                                   uint32_t ldd, uint64_t ss, uint64_t sd) {
+    __shared__ _Float16 tile[64][66];
+    const _Float16 *s = src + ss * blockIdx.z;
+    _Float16 *d = dst + sd * blockIdx.z;
+    const uint32_t r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (uint32_t r = ty; r < 64; r += 4) {
+        const uint32_t rr = r0 + r, cc = c0 + tx;
+        tile[r][tx] = (rr < rows && cc < cols) ? s[(size_t)rr * lds_ + cc] : (_Float16)0;
+    }
+    __syncthreads();
+    for (uint32_t c = ty; c < 64; c += 4) {
+        const uint32_t cc = c0 + c, rr = r0 + tx;
+        if (cc < cols && rr < ldd) d[(size_t)cc * ldd + rr] = tile[tx][c];       // rr in [rows, ldd): zeros from the guarded load
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ image front-end
+__device__ __forceinline__ void so_bilin(uint32_t o, uint32_t n_in, uint32_t n_out, uint32_t &i0, uint32_t &i1, float &lam) {
+    const float scale = (float)n_in / (float)n_out;
+    float src = ((float)o + 0.5f) * scale - 0.5f;           // torch upsample_bilinear2d, align_corners = False
+    if (src < 0.0f) src = 0.0f;
+    i0 = (uint32_t)src;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    lam = src - (float)i0;
+}
+
+__global__ void __launch_bounds__(256) k_img_fwd(const float *__restrict__ img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo,
+                                                 _Float16 *__restrict__ out) {
+    const size_t total = (size_t)B * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t ox = (uint32_t)(i % Wo), oy = (uint32_t)((i / Wo) % Ho), b = (uint32_t)(i / ((size_t)Wo * Ho));
+        uint32_t y0, y1, x0, x1;
+        float ly, lx;
+        so_bilin(oy, Hi, Ho, y0, y1, ly);
+        so_bilin(ox, Wi, Wo, x0, x1, lx);
+        so_h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float *p = img + ((size_t)b * 3 + c) * Hi * Wi;
+            const float top = p[(size_t)y0 * Wi + x0] * (1.0f - lx) + p[(size_t)y0 * Wi + x1] * lx;
+            const float bot = p[(size_t)y1 * Wi + x0] * (1.0f - lx) + p[(size_t)y1 * Wi + x1] * lx;
+            o[c] = (_Float16)(2.0f * (top * (1.0f - ly) + bot * ly) - 1.0f);
+        }
+        so_st8(out + i * 8, o);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_img_bwd(const _Float16 *__restrict__ d_out, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo,
+                                                 float *__restrict__ d_img) {
+    const size_t total = (size_t)B * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t ox = (uint32_t)(i % Wo), oy = (uint32_t)((i / Wo) % Ho), b = (uint32_t)(i / ((size_t)Wo * Ho));
+        uint32_t y0, y1, x0, x1;
+        float ly, lx;
+        so_bilin(oy, Hi, Ho, y0, y1, ly);
+        so_bilin(ox, Wi, Wo, x0, x1, lx);
+        const so_h8 g = so_ld8(d_out + i * 8);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float *p = d_img + ((size_t)b * 3 + c) * Hi * Wi;
+            const float gv = 2.0f * (float)g[c];
+            unsafeAtomicAdd(&p[(size_t)y0 * Wi + x0], gv * (1.0f - ly) * (1.0f - lx));
+            unsafeAtomicAdd(&p[(size_t)y0 * Wi + x1], gv * (1.0f - ly) * lx);
+            unsafeAtomicAdd(&p[(size_t)y1 * Wi + x0], gv * ly * (1.0f - lx));
+            unsafeAtomicAdd(&p[(size_t)y1 * Wi + x1], gv * ly * lx);
+        }
+    }
+}
+
+__global__ void k_timestep_embedding(const float *__restrict__ t, uint32_t B, uint32_t dim, _Float16 *__restrict__ out) {
+    const uint32_t half = dim / 2;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
+        const uint32_t b = i / half, k = i - b * half;
+        const float w = expf(-9.210340371976184f * (float)k / (float)half);        // ln(10000)
+        const float a = t[b] * w;
+        out[(size_t)b * dim + k] = (_Float16)cosf(a);
+        out[(size_t)b * dim + half + k] = (_Float16)sinf(a);
+    }
+}
+
+__global__ void k_add_noise(const float *__restrict__ latents, const float *__restrict__ noise, float sa, float sb, uint32_t pixels, _Float16 *__restrict__ out) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += gridDim.x * blockDim.x) {
+        so_h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; c++) o[c] = (_Float16)(sa * latents[(size_t)c * pixels + p] + sb * noise[(size_t)c * pixels + p]);
+        so_st8(out + (size_t)p * 8, o);
+        so_st8(out + ((size_t)pixels + p) * 8, o);
+    }
+}
+
+__global__ void k_sds_grad(const _Float16 *__restrict__ eps, uint32_t ld, const float *__restrict__ noise, float w, float guidance, uint32_t pixels,
+                           float *__restrict__ grad) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels * 4; i += gridDim.x * blockDim.x) {
+        const uint32_t c = i / pixels, p = i - c * pixels;
+        const float eu = (float)eps[(size_t)p * ld + c], et = (float)eps[((size_t)pixels + p) * ld + c];
+        float g = w * ((et + guidance * (et - eu)) - noise[i]);
+        if (g != g) g = 0.0f;                                                  // torch.nan_to_num defaults
+        else if (g > 3.4028234663852886e38f) g = 3.4028234663852886e38f;
+        else if (g < -3.4028234663852886e38f) g = -3.4028234663852886e38f;
+        grad[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline uint32_t so_blocks(size_t work_items, uint32_t per_block = 256, uint32_t cap = 4096) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b == 0) b = 1;
+    return (uint32_t)b;
+}
+
+static int gn_check(uint32_t B, uint32_t HW, uint32_t C, uint32_t G) {
+    if (B == 0 || HW == 0 || C == 0 || G == 0 || G > GN_MAX_G || (C % G) || (C & 7) || C / G < 4) return CNERF_EINVAL;
+    return CNERF_OK;
+}
+static uint32_t gn_rows_per_block(uint32_t B, uint32_t HW) {
+    uint32_t slabs = 1024 / (B ? B : 1);
+    if (slabs < 1) slabs = 1;
+    uint32_t rpb = cn_div_up(HW, slabs);
+    if (rpb < 8) rpb = 8;
+    return rpb;
+}
+
+template <bool BWD>
+static int so_softmax(const void *P, void *S, uint64_t rows, uint32_t cols, uint32_t ld, hipStream_t st) {
+    if (cols == 0 || ld < cols || (ld & 7) || ld > 64 * 8 * 8) return CNERF_EINVAL;
+    if (rows == 0) return CNERF_OK;
+    if (!S || (BWD && !P)) return CNERF_ENULL;
+    const dim3 grid((uint32_t)((rows + 3) / 4)), block(256);
+    const uint32_t cpl = cn_div_up(ld / 8, 64);
+    if (cpl == 1) hipLaunchKernelGGL((k_softmax<1, BWD>), grid, block, 0, st, (const _Float16 *)P, (_Float16 *)S, rows, cols, ld);
+    else if (cpl == 2) hipLaunchKernelGGL((k_softmax<2, BWD>), grid, block, 0, st, (const _Float16 *)P, (_Float16 *)S, rows, cols, ld);
+    else if (cpl <= 4) hipLaunchKernelGGL((k_softmax<4, BWD>), grid, block, 0, st, (const _Float16 *)P, (_Float16 *)S, rows, cols, ld);
+    else hipLaunchKernelGGL((k_softmax<8, BWD>), grid, block, 0, st, (const _Float16 *)P, (_Float16 *)S, rows, cols, ld);
+    return cn_launch_status();
+}
+extern "C" {
+
+int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, float eps,
+                               int silu, float *sums, void *y, void *stream) {
+    int rc = gn_check(B, HW, C, G);
+    if (rc) return rc;
+    if (!x || !gamma || !beta || !sums || !y) return CNERF_ENULL;
+    hipStream_t st = CN_STREAM(stream);
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * G * 2 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t rpb = gn_rows_per_block(B, HW);
+    hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
+                       (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
+    const size_t chunks = (size_t)B * HW * (C / 8);
+    hipLaunchKernelGGL((k_gn_apply<0>), dim3(so_blocks(chunks, 256, 8192)), dim3(256), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
+                       (const float *)sums, (const float *)nullptr, HW, C, G, eps, silu, (_Float16 *)y, chunks);
+    return cn_launch_status();
+}
+
+int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                float eps, int silu, const float *sums, float *scratch, void *dx, void *stream) {
+    int rc = gn_check(B, HW, C, G);
+    if (rc) return rc;
+    if (!x || !dy || !gamma || !beta || !sums || !scratch || !dx) return CNERF_ENULL;
+    hipStream_t st = CN_STREAM(stream);
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * G * 2 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t rpb = gn_rows_per_block(B, HW);
+    hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums, HW,
+                       C, G, eps, silu, rpb, scratch);
+    const size_t chunks = (size_t)B * HW * (C / 8);
+    hipLaunchKernelGGL((k_gn_apply<1>), dim3(so_blocks(chunks, 256, 8192)), dim3(256), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums,
+                       (const float *)scratch, HW, C, G, eps, silu, (_Float16 *)dx, chunks);
+    return cn_launch_status();
+}
+
+int cnerf_sd_layernorm_forward(const void *x, const float *gamma, const float *beta, uint32_t rows, uint32_t C, float eps, void *y, void *stream) {
+    if (C == 0 || (C & 7) || C > 64 * 8 * 4) return CNERF_EINVAL;
+    if (rows == 0) return CNERF_OK;
+    if (!x || !gamma || !beta || !y) return CNERF_ENULL;
+    hipStream_t st = CN_STREAM(stream);
+    const dim3 grid(cn_div_up(rows, 4)), block(256);
+    const uint32_t cpl = cn_div_up(C / 8, 64);
+    if (cpl == 1) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, (const _Float16 *)x, gamma, beta, rows, C, eps, (_Float16 *)y);
+    else if (cpl == 2) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, (const _Float16 *)x, gamma, beta, rows, C, eps, (_Float16 *)y);
+    else hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, (const _Float16 *)x, gamma, beta, rows, C, eps, (_Float16 *)y);
+    return cn_launch_status();
+}
+
+int cnerf_sd_softmax_forward(void *S, uint64_t rows, uint32_t cols, uint32_t ld, void *stream) {
+    return so_softmax<false>(nullptr, S, rows, cols, ld, CN_STREAM(stream));
+}
+int cnerf_sd_softmax_backward(const void *P, void *dP, uint64_t rows, uint32_t cols, uint32_t ld, void *stream) {
+    return so_softmax<true>(P, dP, rows, cols, ld, CN_STREAM(stream));
+}
+
+int cnerf_sd_geglu(const void *x, uint64_t rows, uint32_t C, void *y, void *stream) {
+    if (C == 0 || (C & 7)) return CNERF_EINVAL;
+    if (rows == 0) return CNERF_OK;
+    if (!x || !y) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_geglu, dim3(so_blocks((size_t)rows * (C / 8), 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)x, rows, C, (_Float16 *)y);
+    return cn_launch_status();
+}
+
+int cnerf_sd_transpose(const void *src, void *dst, uint32_t rows, uint32_t cols, uint32_t lds_, uint32_t ldd, uint32_t batch, uint64_t ss, uint64_t sd,
+                       void *stream) {
+    if (lds_ < cols || ldd < rows) return CNERF_EINVAL;
+    if (rows == 0 || cols == 0 || batch == 0) return CNERF_OK;
+    if (!src || !dst) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_transpose, dim3(cn_div_up(cols, 64), cn_div_up(ldd, 64), batch), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)src,
+                       (_Float16 *)dst, rows, cols, lds_, ldd, ss, sd);
+    return cn_launch_status();
+}
+
+int cnerf_sd_image_to_vae_input(const float *img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo, void *out, void *stream) {
+    if (B == 0 || Hi == 0 || Wi == 0 || Ho == 0 || Wo == 0) return CNERF_EINVAL;
+    if (!img || !out) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_img_fwd, dim3(so_blocks((size_t)B * Ho * Wo)), dim3(256), 0, CN_STREAM(stream), img, B, Hi, Wi, Ho, Wo, (_Float16 *)out);
+    return cn_launch_status();
+}
+
+int cnerf_sd_image_to_vae_input_backward(const void *d_out, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo, float *d_img, void *stream) {
+    if (B == 0 || Hi == 0 || Wi == 0 || Ho == 0 || Wo == 0) return CNERF_EINVAL;
+    if (!d_out || !d_img) return CNERF_ENULL;
+    hipStream_t st = CN_STREAM(stream);
+    hipError_t e = hipMemsetAsync(d_img, 0, (size_t)B * 3 * Hi * Wi * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_img_bwd, dim3(so_blocks((size_t)B * Ho * Wo)), dim3(256), 0, st, (const _Float16 *)d_out, B, Hi, Wi, Ho, Wo, d_img);
+    return cn_launch_status();
+}
+
+int cnerf_sd_timestep_embedding(const float *t, uint32_t B, uint32_t dim, void *out, void *stream) {
+    if (B == 0 || dim == 0 || (dim & 1)) return CNERF_EINVAL;
+    if (!t || !out) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_timestep_embedding, dim3(so_blocks((size_t)B * dim / 2)), dim3(256), 0, CN_STREAM(stream), t, B, dim, (_Float16 *)out);
+    return cn_launch_status();
+}
+
+int cnerf_sd_add_noise(const float *latents, const float *noise, float alpha_bar, uint32_t pixels, void *unet_in, void *stream) {
+    if (pixels == 0 || !(alpha_bar >= 0.0f && alpha_bar <= 1.0f)) return CNERF_EINVAL;
+    if (!latents || !noise || !unet_in) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_add_noise, dim3(so_blocks(pixels)), dim3(256), 0, CN_STREAM(stream), latents, noise, sqrtf(alpha_bar), sqrtf(1.0f - alpha_bar), pixels,
+                       (_Float16 *)unet_in);
+    return cn_launch_status();
+}
+
+int cnerf_sd_sds_grad(const void *eps, uint32_t ld_eps, const float *noise, float alpha_bar, float guidance, float lambda_sd, uint32_t pixels, float *grad,
+                      void *stream) {
+    if (pixels == 0 || ld_eps < 4) return CNERF_EINVAL;
+    if (!eps || !noise || !grad) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sds_grad, dim3(so_blocks((size_t)pixels * 4)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)eps, ld_eps, noise,
+                       (1.0f - alpha_bar) * lambda_sd, guidance, pixels, grad);
+    return cn_launch_status();
+}
+
+int cnerf_sd_add(const void *a, const void *b, uint64_t n, void *y, void *stream) {
+    if (n == 0) return CNERF_OK;
+    if (!a || !b || !y) return CNERF_ENULL;
+    hipLaunchKernelGGL((k_ew<0>), dim3(so_blocks(n / 8, 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b, n / 8, n, (_Float16 *)y);
+    return cn_launch_status();
+}
+int cnerf_sd_silu(const void *x, uint64_t n, void *y, void *stream) {
+    if (n == 0) return CNERF_OK;
+    if (!x || !y) return CNERF_ENULL;
+    hipLaunchKernelGGL((k_ew<1>), dim3(so_blocks(n / 8, 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)x, (const _Float16 *)nullptr, n / 8, n, (_Float16 *)y);
+    return cn_launch_status();
+}
+int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream) {
+    if ((C1 & 7) || (C2 & 7) || C1 + C2 == 0) return CNERF_EINVAL;
+    if (rows == 0) return CNERF_OK;
+    if (!a || !b || !y) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_concat, dim3(so_blocks((size_t)rows * ((C1 + C2) / 8), 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b,
+                       rows, C1, C2, (_Float16 *)y);
+    return cn_launch_status();
+}
+
+}  // extern "C"

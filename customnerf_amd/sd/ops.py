@@ -1,0 +1,236 @@
+"""Python side of include/customnerf_sd.h: thin wrappers that allocate outputs (torch owns memory) and fill the GEMM
+descriptor.  Activations are float16, NHWC / [tokens, channels]; weights arrive packed K-major ([N, K]) in float16,
+biases and norm affine parameters in float32.  No torch arithmetic happens here and there is no fallback: every
+function ends in a libcustomnerf_hip.so call on torch's current stream (HIP-graph capturable: no host sync)."""
+import ctypes
+
+import torch
+
+from .._lib import lib, check, ptr, stream, require_cuda, SdGemmDesc
+
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
+
+def _launch(d, device):
+    need = ctypes.c_uint64(0)
+    check(lib.cnerf_sd_gemm_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "sd_gemm_workspace_bytes")
+    ws = _workspace(need.value, device) if need.value else None
+    check(lib.cnerf_sd_gemm(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0, stream()), "sd_gemm")
+
+
+def _desc(A, B, C, M, N, K, lda, ldb, ldc, bias=None, bias_rows=None, rows_per_bias_row=0, residual=None, ldr=0, act=0, alpha=1.0, C32=None):
+    d = SdGemmDesc()
+    d.A, d.B, d.C, d.C32 = ptr(A), ptr(B), ptr(C), ptr(C32)
+    d.bias, d.bias_rows, d.residual = ptr(bias), ptr(bias_rows), ptr(residual)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, lda, ldb, ldc, ldr
+    d.rows_per_bias_row, d.alpha, d.act = rows_per_bias_row, alpha, act
+    d.batch_outer = d.batch_inner = 1
+    d.ups = d.tstride = 1
+    return d
+
+
+def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, out32=False):
+    """x [..., K] half, w [N, K] half -> [..., N] half (float32 when out32)."""
+    require_cuda(x, w)
+    K = x.shape[-1]
+    N = w.shape[0]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    assert w.shape[1] == K and x2.stride(1) == 1 and x2.dtype == torch.float16 and w.dtype == torch.float16
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out32 else torch.float16, device=x.device)
+    r2 = residual.reshape(M, N) if residual is not None else None
+    d = _desc(x2, w, None if out32 else out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=r2,
+              ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
+    _launch(d, x.device)
+    return out.reshape(*x.shape[:-1], N)
+
+
+def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bias_rows=None, residual=None, act=ACT_NONE):
+    """x [B, H, W, Cin] half (NHWC), w [Cout, k*k*Cin] half packed (kh, kw, ci) -> [B, Ho, Wo, Cout] half.
+    stride/pad/ups/tstride as in customnerf_sd.h; bias_rows [B, Cout] float32 = per-image bias (time embedding)."""
+    require_cuda(x, w)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert x.is_contiguous() and x.dtype == torch.float16 and w.shape[1] == ksize * ksize * Cin
+    if out_hw is None:
+        Hu, Wu = H * ups, W * ups
+        out_hw = ((Hu + 2 * pad - ksize) // stride + 1, (Wu + 2 * pad - ksize) // stride + 1)
+    Ho, Wo = out_hw
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16, device=x.device)
+    M = B * Ho * Wo
+    d = _desc(x, w, y, M, Cout, ksize * ksize * Cin, 0, w.stride(0), Cout, bias=bias, bias_rows=bias_rows, rows_per_bias_row=Ho * Wo if bias_rows is not None else 0,
+              residual=residual, ldr=Cout, act=act)
+    d.mode, d.Cin, d.H_in, d.W_in, d.H_out, d.W_out = 1, Cin, H, W, Ho, Wo
+    d.KH = d.KW = ksize
+    d.stride, d.pad_t, d.pad_l, d.ups, d.tstride = stride, pad, pad, ups, tstride
+    _launch(d, x.device)
+    return y
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu):
+    """x [B, ..., C] half -> (y, sums [B, G, 2] float32: sum and sum of squares per group)."""
+    require_cuda(x, gamma)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    assert x.is_contiguous() and x.dtype == torch.float16
+    y = torch.empty_like(x)
+    sums = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(y), stream()), "sd_groupnorm_forward")
+    return y, sums
+
+
+def groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums):
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    scratch = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib.cnerf_sd_groupnorm_backward(ptr(x), ptr(dy), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(scratch), ptr(dx), stream()),
+          "sd_groupnorm_backward")
+    return dx
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == torch.float16
+    y = torch.empty_like(x)
+    check(lib.cnerf_sd_layernorm_forward(ptr(x), ptr(gamma), ptr(beta), x.numel() // C, C, eps, ptr(y), stream()), "sd_layernorm_forward")
+    return y
+
+
+def geglu(x):
+    C = x.shape[-1] // 2
+    assert x.is_contiguous() and x.dtype == torch.float16
+    y = torch.empty(*x.shape[:-1], C, dtype=torch.float16, device=x.device)
+    check(lib.cnerf_sd_geglu(ptr(x), x.numel() // (2 * C), C, ptr(y), stream()), "sd_geglu")
+    return y
+
+
+def add(a, b):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16
+    y = torch.empty_like(a)
+    check(lib.cnerf_sd_add(ptr(a), ptr(b), a.numel(), ptr(y), stream()), "sd_add")
+    return y
+
+
+def silu(x):
+    assert x.is_contiguous() and x.dtype == torch.float16
+    y = torch.empty_like(x)
+    check(lib.cnerf_sd_silu(ptr(x), x.numel(), ptr(y), stream()), "sd_silu")
+    return y
+
+
+def concat_channels(a, b):
+    assert a.shape[:-1] == b.shape[:-1] and a.is_contiguous() and b.is_contiguous()
+    C1, C2 = a.shape[-1], b.shape[-1]
+    y = torch.empty(*a.shape[:-1], C1 + C2, dtype=torch.float16, device=a.device)
+    check(lib.cnerf_sd_concat(ptr(a), ptr(b), a.numel() // C1, C1, C2, ptr(y), stream()), "sd_concat")
+    return y
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def transpose_batched(src, rows, cols, ld_src, ld_dst, batch, stride_src, stride_dst, dst):
+    check(lib.cnerf_sd_transpose(ptr(src), ptr(dst), rows, cols, ld_src, ld_dst, batch, stride_src, stride_dst, stream()), "sd_transpose")
+    return dst
+
+
+def attention_scores(q, k, heads, alpha):
+    """q [B, Tq, C], k [B, Tk, C] half -> P [B, heads, Tq, pad8(Tk)] = softmax(alpha q_h k_h^T) (pad columns zero)."""
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    d_ = C // heads
+    ldS = pad8(Tk)
+    S = torch.empty(B, heads, Tq, ldS, dtype=torch.float16, device=q.device)
+    d = _desc(q, k, S, Tq, Tk, d_, C, C, ldS, alpha=alpha)
+    d.batch_outer, d.batch_inner = B, heads
+    d.sa_o, d.sa_i, d.sb_o, d.sb_i, d.sc_o, d.sc_i = Tq * C, d_, Tk * C, d_, heads * Tq * ldS, Tq * ldS
+    _launch(d, q.device)
+    check(lib.cnerf_sd_softmax_forward(ptr(S), B * heads * Tq, Tk, ldS, stream()), "sd_softmax_forward")
+    return S
+
+
+def attention_apply(P, v, heads):
+    """P [B, heads, Tq, ldS], v [B, Tk, C] half -> O [B, Tq, C] = concat_h P_h v_h."""
+    B, _, Tq, ldS = P.shape
+    Tk, C = v.shape[1], v.shape[2]
+    d_ = C // heads
+    vT = torch.empty(B, C, ldS, dtype=torch.float16, device=v.device)
+    transpose_batched(v, Tk, C, C, ldS, B, Tk * C, C * ldS, vT)
+    O = torch.empty(B, Tq, C, dtype=torch.float16, device=v.device)
+    d = _desc(P, vT, O, Tq, d_, ldS, ldS, ldS, C)
+    d.batch_outer, d.batch_inner = B, heads
+    d.sa_o, d.sa_i, d.sb_o, d.sb_i, d.sc_o, d.sc_i = heads * Tq * ldS, Tq * ldS, C * ldS, d_ * ldS, Tq * C, d_
+    _launch(d, v.device)
+    return O
+
+
+def attention(q, k, v, heads):
+    """softmax(q k^T / sqrt(d)) v per head; q [B, Tq, C], k / v [B, Tk, C] half."""
+    P = attention_scores(q, k, heads, 1.0 / float(q.shape[-1] // heads) ** 0.5)
+    return attention_apply(P, v, heads)
+
+
+def gemm_nt(A, Bm, M, N, K, lda, ldb, ldc, out, alpha=1.0):
+    """out[M, N] = alpha * A[M, K] Bm[N, K]^T on raw (possibly strided) half buffers."""
+    d = _desc(A, Bm, out, M, N, K, lda, ldb, ldc, alpha=alpha)
+    _launch(d, out.device)
+    return out
+
+
+def softmax_backward_(P, dP, rows, cols, ld):
+    check(lib.cnerf_sd_softmax_backward(ptr(P), ptr(dP), rows, cols, ld, stream()), "sd_softmax_backward")
+    return dP
+
+
+def image_to_vae_input(img, Ho, Wo):
+    """img [B, 3, Hi, Wi] float32 in [0,1] -> [B, Ho, Wo, 8] half = 2 * bilinear(img) - 1, channels padded to 8."""
+    require_cuda(img)
+    B, _, Hi, Wi = img.shape
+    img = img.contiguous().float()
+    out = torch.empty(B, Ho, Wo, 8, dtype=torch.float16, device=img.device)
+    check(lib.cnerf_sd_image_to_vae_input(ptr(img), B, Hi, Wi, Ho, Wo, ptr(out), stream()), "sd_image_to_vae_input")
+    return out
+
+
+def image_to_vae_input_backward(d_out, B, Hi, Wi):
+    Ho, Wo = d_out.shape[1], d_out.shape[2]
+    d_out = d_out.contiguous()
+    d_img = torch.empty(B, 3, Hi, Wi, dtype=torch.float32, device=d_out.device)
+    check(lib.cnerf_sd_image_to_vae_input_backward(ptr(d_out), B, Hi, Wi, Ho, Wo, ptr(d_img), stream()), "sd_image_to_vae_input_backward")
+    return d_img
+
+
+def timestep_embedding(t, dim):
+    """t [B] float32 (device) -> [B, dim] half (cos | sin)."""
+    out = torch.empty(t.shape[0], dim, dtype=torch.float16, device=t.device)
+    check(lib.cnerf_sd_timestep_embedding(ptr(t), t.shape[0], dim, ptr(out), stream()), "sd_timestep_embedding")
+    return out
+
+
+def add_noise(latents, noise, alpha_bar):
+    """latents, noise [1, 4, h, w] float32 -> UNet input [2, h, w, 8] half (the CFG pair)."""
+    _, _, h, w = latents.shape
+    out = torch.empty(2, h, w, 8, dtype=torch.float16, device=latents.device)
+    check(lib.cnerf_sd_add_noise(ptr(latents), ptr(noise), float(alpha_bar), h * w, ptr(out), stream()), "sd_add_noise")
+    return out
+
+
+def sds_grad(eps, noise, alpha_bar, guidance, lambda_sd):
+    """eps [2, h, w, ld] half (uncond, text), noise [1, 4, h, w] float32 -> grad [1, 4, h, w] float32."""
+    _, h, w, ld = eps.shape
+    grad = torch.empty_like(noise)
+    check(lib.cnerf_sd_sds_grad(ptr(eps), ld, ptr(noise), float(alpha_bar), float(guidance), float(lambda_sd), h * w, ptr(grad), stream()), "sd_sds_grad")
+    return grad

@@ -1,0 +1,125 @@
+/*
+ * customnerf_sd.h — C-ABI of the score-distillation (SDS) half of the hot path in libcustomnerf_hip.so (MI355X / gfx950).
+ *
+ * The reference reaches this arithmetic through `diffusers` (third-party, un-vendored, unpinned: requirements.txt:24):
+ *   nerf/sd.py:97-105   StableDiffusion.encode_imgs   -> AutoencoderKL.encode     (VAE encoder, forward AND backward)
+ *   nerf/sd.py:115-155  StableDiffusion.train_step    -> UNet2DConditionModel     (eps-prediction, forward only)
+ * Both networks are sequences of five primitive shapes — (implicit-)GEMM, GroupNorm, LayerNorm, row softmax, element-wise —
+ * and that is the boundary drawn here: one entry point per primitive, activations in NHWC / [tokens, channels] float16,
+ * float32 accumulation on the matrix cores (v_mfma_f32_32x32x16_f16).  The network graphs (which primitive, which weights,
+ * in which order) live above the boundary in customnerf_amd/sd/ and mirror diffusers' module tree key for key.
+ *
+ * Conventions: as customnerf_hip.h (device pointers, caller-owned buffers, no allocation, no host sync, `stream`, int
+ * status).  `half` below means IEEE binary16 stored as uint16_t-sized elements.
+ */
+#ifndef CUSTOMNERF_SD_H
+#define CUSTOMNERF_SD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * cnerf_sd_gemm:  C[z][m][n] = epilogue( alpha * sum_k A(z,m,k) * B[z][n][k] )
+ * B is always "weights-like": row n holds its K values contiguously (ldb elements between rows).
+ * A is either a dense row-major matrix (mode 0: row m at A + m*lda, K contiguous) or an implicit im2col view of an NHWC
+ * activation (mode 1: m = (image, oh, ow), k = (kh, kw, c)):
+ *      num_h = oh*stride + kh - pad_t ;  num_h must be >= 0, and (tstride == 2) even, then num_h /= tstride ;
+ *      ih = num_h / ups  (ups = 2: the conv reads a nearest-neighbour 2x upsampled input without materialising it) ;
+ *      valid iff ih < H_in (same for w); invalid taps read 0.   A(m,k) = in[image][ih][iw][c], c < Cin, Cin % 8 == 0.
+ *   forward conv (torch.nn.Conv2d):            stride s, pad p, tstride 1
+ *   input-gradient of a conv (frozen weights):  stride 1, pad KH-1-p, tstride s, B = weights flipped and transposed
+ * epilogue, in this order:  (+ bias[n])  (+ bias_rows[(m / rows_per_bias_row)][n])  (activation: 0 none, 1 SiLU, 2 GELU(erf))
+ *                           (+ residual[z][m][n])  -> C (half), and/or C32 (float, optional).
+ * batching: z = zo * batch_inner + zi, operand bases advance by s?_o * zo + s?_i * zi elements (attention heads are a strided
+ * view of [batch, tokens, heads*dim]); batch = 1 and zero strides for plain GEMMs / convs.
+ * workspace: split-K partial sums (float).  cnerf_sd_gemm_workspace_bytes() gives the size the library's own split heuristic
+ * needs for this problem; a NULL / too small workspace simply disables split-K.
+ * Requirements: K % 8 == 0, lda/ldb % 8 == 0, all bases 16-byte aligned.  M, N arbitrary.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct CnerfSdGemm {
+    const void *A;            /* half */
+    const void *B;            /* half */
+    void *C;                  /* half, may be NULL when C32 is set */
+    float *C32;               /* float, optional */
+    const float *bias;        /* [N] or NULL */
+    const float *bias_rows;   /* [ceil(M / rows_per_bias_row)][N] or NULL */
+    const void *residual;     /* half [z][M][ldr] or NULL */
+    uint32_t M, N, K;
+    uint32_t lda, ldb, ldc, ldr;
+    uint32_t rows_per_bias_row;
+    float alpha;
+    int32_t act;
+    uint32_t batch_outer, batch_inner;
+    uint64_t sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;    /* residual uses the C strides */
+    int32_t mode;             /* 0 dense, 1 implicit conv */
+    uint32_t Cin, H_in, W_in, H_out, W_out, KH, KW, stride, pad_t, pad_l, ups, tstride;
+} CnerfSdGemm;
+
+int cnerf_sd_gemm(const CnerfSdGemm *desc, void *workspace, uint64_t workspace_bytes, void *stream);
+int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *desc, uint64_t *bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm over NHWC half activations x [B, HW, C] (torch.nn.GroupNorm(G, C, eps) semantics, biased variance, statistics in
+ * float32), optionally followed by SiLU (the `norm -> nonlinearity` pair of every diffusers ResnetBlock2D).
+ *   stats:   sums [B][G][2] float (sum, sum of squares) — zeroed and filled by the call
+ *   forward: y = act((x - mean) * rstd * gamma[c] + beta[c])
+ *   backward (frozen gamma/beta): dx from dy, recomputing the forward; `sums` are the forward's; scratch [B][G][2] float.
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C,
+                               uint32_t G, float eps, int silu, float *sums, void *y, void *stream);
+int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW,
+                                uint32_t C, uint32_t G, float eps, int silu, const float *sums, float *scratch, void *dx,
+                                void *stream);
+
+/* LayerNorm over the last dimension of x [rows, C] (half), float32 statistics, eps inside the sqrt. */
+int cnerf_sd_layernorm_forward(const void *x, const float *gamma, const float *beta, uint32_t rows, uint32_t C, float eps,
+                               void *y, void *stream);
+
+/* Row softmax of S [rows, ld] (half) in place over the first `cols` columns, float32 arithmetic; columns cols..ld-1 are set
+ * to zero (so the matrix can be used directly as a K-padded GEMM operand).
+ * backward: dS = P * (dP - rowsum(dP * P)), written over dP. */
+int cnerf_sd_softmax_forward(void *S, uint64_t rows, uint32_t cols, uint32_t ld, void *stream);
+int cnerf_sd_softmax_backward(const void *P, void *dP, uint64_t rows, uint32_t cols, uint32_t ld, void *stream);
+
+/* GEGLU (diffusers GEGLU): y[r][c] = x[r][c] * gelu_erf(x[r][c + C]) for x [rows, 2C] -> y [rows, C] (half). */
+int cnerf_sd_geglu(const void *x, uint64_t rows, uint32_t C, void *y, void *stream);
+
+/* Batched 2-D transpose of half matrices: dst[z][c][r] = src[z][r][c]; src row stride lds, dst row stride ldd; z advances the
+ * bases by ss / sd elements.  Pad columns of dst (r in rows..ldd-1) are zero-filled. */
+int cnerf_sd_transpose(const void *src, void *dst, uint32_t rows, uint32_t cols, uint32_t lds, uint32_t ldd, uint32_t batch,
+                       uint64_t ss, uint64_t sd, void *stream);
+
+/* Image front-end of encode_imgs (utils_init_nerf.py:303 + sd.py:100): bilinear resize (align_corners=False) of img
+ * [B,3,Hi,Wi] float32 NCHW in [0,1] to Ho x Wo, then 2x-1, written as NHWC half with channels padded to 8 (zeros).
+ * backward: d(img) float32 [B,3,Hi,Wi] from d(out) [B,Ho,Wo,8] half (overwrites d_img). */
+int cnerf_sd_image_to_vae_input(const float *img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo, void *out,
+                                void *stream);
+int cnerf_sd_image_to_vae_input_backward(const void *d_out, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo,
+                                         float *d_img, void *stream);
+
+/* Diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b][0:dim/2] = cos(t_b w_i),
+ * out[b][dim/2:] = sin(t_b w_i), w_i = exp(-ln(10000) i / (dim/2)); half output [B, dim]. */
+int cnerf_sd_timestep_embedding(const float *t, uint32_t B, uint32_t dim, void *out, void *stream);
+
+/* Score-distillation tail of train_step (sd.py:133-148) on latents [n] float32:
+ *   noisy[i]     = sqrt(ab) * latents[i] + sqrt(1 - ab) * noise[i]                      (scheduler.add_noise), half, twice (CFG pair)
+ *   grad[i]      = nan_to_num( (1 - ab) * ((e_text + g (e_text - e_uncond)) - noise[i]) * lambda_sd )
+ * cnerf_sd_add_noise writes the UNet input [2][n/4 pixels][8] (NHWC half, 4 latent channels padded to 8);
+ * cnerf_sd_sds_grad reads the UNet output eps [2][pixels][ld_eps] half and writes grad float32 [n] in the latents' NCHW order. */
+int cnerf_sd_add_noise(const float *latents, const float *noise, float alpha_bar, uint32_t pixels, void *unet_in, void *stream);
+int cnerf_sd_sds_grad(const void *eps, uint32_t ld_eps, const float *noise, float alpha_bar, float guidance, float lambda_sd,
+                      uint32_t pixels, float *grad, void *stream);
+
+/* Generic element-wise helpers on half buffers (n elements): y = a + b ; y = silu(x). */
+int cnerf_sd_add(const void *a, const void *b, uint64_t n, void *y, void *stream);
+int cnerf_sd_silu(const void *x, uint64_t n, void *y, void *stream);
+/* channel concat of NHWC half tensors: y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r] */
+int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSTOMNERF_SD_H */

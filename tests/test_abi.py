@@ -10,13 +10,15 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "customnerf_hip.h")
+HEADERS = [os.path.join(ROOT, "include", "customnerf_hip.h"), os.path.join(ROOT, "include", "customnerf_sd.h")]
+
+
+def header_source():
+    return re.sub(r"/\*.*?\*/", "", "\n".join(open(h).read() for h in HEADERS), flags=re.S)
 
 
 def declared_symbols():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(cnerf_[A-Za-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(cnerf_[A-Za-z0-9_]+)\s*\(", header_source())))
 
 
 def test_header_symbols_are_exported_and_bound():
@@ -37,7 +39,7 @@ def test_library_identity_and_arity():
     from customnerf_amd import _lib
     assert _lib.lib.cnerf_abi_version() == _lib.ABI_VERSION
     assert _lib.lib.cnerf_target_arch() == b"gfx950"
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = header_source()
     for name, argtypes in _lib.SIGNATURES.items():
         m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, src, flags=re.S)
         assert m, name

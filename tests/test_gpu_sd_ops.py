@@ -1,0 +1,217 @@
+"""GPU parity of the SDS primitives (include/customnerf_sd.h) against plain PyTorch float32 on the CPU.
+diffusers' arithmetic is third-party and unpinned: these checks pin each primitive to the torch op the
+public implementation calls (conv2d / linear / group_norm / layer_norm / softmax / gelu / interpolate)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def h(t):
+    """round to half precision, keep float32 (what the kernels see)"""
+    return t.half().float()
+
+
+def close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 320, 768), (154, 1280, 768), (8192, 320, 320), (128, 1280, 11520), (2, 1280, 320), (4096, 77, 40), (300, 8, 512)])
+def test_linear(M, N, K):
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g)
+    r = h(torch.randn(M, N, generator=g))
+    y = ops.linear(x.half().cuda(), w.half().cuda(), bias=b.cuda(), residual=r.half().cuda())
+    close(y, x @ w.t() + b + r, 2e-3, 4e-3)
+    y2 = ops.linear(x.half().cuda(), w.half().cuda(), act=ops.ACT_SILU, alpha=0.5)
+    close(y2, F.silu(0.5 * (x @ w.t())), 2e-3, 3e-3)
+    y3 = ops.linear(x.half().cuda(), w.half().cuda(), act=ops.ACT_GELU, out32=True)
+    assert y3.dtype == torch.float32
+    close(y3, F.gelu(x @ w.t()), 1e-3, 1e-3)
+
+
+CONVS = [  # B, Cin, H, W, Cout, k, stride, pad, ups
+    (2, 320, 16, 16, 320, 3, 1, 1, 1),
+    (2, 8, 16, 16, 320, 3, 1, 1, 1),          # conv_in (4 latent channels padded to 8)
+    (1, 128, 40, 24, 128, 3, 1, 1, 1),
+    (2, 640, 8, 8, 1280, 3, 1, 1, 1),         # split-K
+    (2, 320, 16, 16, 320, 3, 2, 1, 1),        # UNet downsample
+    (2, 1280, 4, 4, 1280, 3, 1, 1, 2),        # UNet upsample: nearest 2x fused into the conv
+    (2, 320, 16, 16, 640, 1, 1, 0, 1),        # 1x1 shortcut
+    (1, 64, 9, 7, 72, 3, 1, 1, 1),            # ragged everything
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,pad,ups", CONVS)
+def test_conv2d_forward(B, Cin, H, W, Cout, k, stride, pad, ups):
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = h(torch.randn(B, Cin, H, W, generator=g))
+    w = h(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    xr = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups == 2 else x
+    ref = F.conv2d(xr, w, b, stride=stride, padding=pad) + temb[:, :, None, None]
+    res = h(torch.randn_like(ref))
+    y = ops.conv2d(nhwc(x).half().cuda(), pack.pack_conv(w).cuda(), b.cuda(), k, stride=stride, pad=pad, ups=ups, bias_rows=temb.cuda(),
+                   residual=nhwc(res).half().cuda())
+    close(nchw(y), ref + res, 2e-3, 5e-3)
+
+
+def test_conv2d_vae_downsample_and_input_gradients():
+    """VAE downsample = F.pad(0,1,0,1) + conv(stride 2, pad 0); input-gradients of stride-1 and stride-2 convolutions through the
+    transposed loader (tstride) against autograd."""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, Co = 1, 128, 24, 16, 136
+    x = h(torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+    w = h(torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2)
+    y = ops.conv2d(nhwc(x.detach()).half().cuda(), pack.pack_conv(w).cuda(), None, 3, stride=2, pad=0, out_hw=(H // 2, W // 2))
+    close(nchw(y), ref, 2e-3, 4e-3)
+    dy = h(torch.randn_like(ref))
+    ref.backward(dy)
+    dx = ops.conv2d(nhwc(dy).half().cuda(), pack.pack_conv_dgrad(w).cuda(), None, 3, stride=1, pad=2, tstride=2, out_hw=(H, W))
+    close(nchw(dx), x.grad, 3e-3, 5e-3, "stride-2 dgrad")
+    # stride 1, pad 1
+    x2 = h(torch.randn(2, 64, 12, 20, generator=g)).requires_grad_(True)
+    w2 = h(torch.randn(40, 64, 3, 3, generator=g) / 24.0)
+    r2 = F.conv2d(x2, w2, None, padding=1)
+    dy2 = h(torch.randn_like(r2))
+    r2.backward(dy2)
+    dx2 = ops.conv2d(nhwc(dy2).half().cuda(), pack.pack_conv_dgrad(w2).cuda(), None, 3, stride=1, pad=1)
+    close(nchw(dx2), x2.grad, 3e-3, 5e-3, "stride-1 dgrad")
+    # UNet-style stride 2 pad 1 dgrad and a 1x1
+    x3 = h(torch.randn(1, 32, 10, 10, generator=g)).requires_grad_(True)
+    w3 = h(torch.randn(48, 32, 3, 3, generator=g) / 17.0)
+    r3 = F.conv2d(x3, w3, None, stride=2, padding=1)
+    dy3 = h(torch.randn_like(r3))
+    r3.backward(dy3)
+    dx3 = ops.conv2d(nhwc(dy3).half().cuda(), pack.pack_conv_dgrad(w3).cuda(), None, 3, stride=1, pad=1, tstride=2, out_hw=(10, 10))
+    close(nchw(dx3), x3.grad, 3e-3, 5e-3, "stride-2 pad-1 dgrad")
+
+
+@pytest.mark.parametrize("B,HW,C,G,eps,silu", [(2, 256, 320, 32, 1e-5, True), (2, 64, 2560, 32, 1e-5, True), (1, 4096, 128, 32, 1e-6, True), (2, 100, 960, 32, 1e-6, False),
+                                               (1, 777, 512, 32, 1e-6, False)])
+def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(C + HW)
+    x = h(torch.randn(B, C, HW, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5)
+    beta = torch.randn(C, generator=g) * 0.3
+    ref = F.group_norm(x, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    xg = x.detach().permute(0, 2, 1).contiguous().half().cuda()
+    y, sums = ops.groupnorm(xg, gamma.cuda(), beta.cuda(), G, eps, silu)
+    close(y.permute(0, 2, 1), ref, 2e-3, 3e-3)
+    dy = h(torch.randn_like(ref))
+    ref.backward(dy)
+    dx = ops.groupnorm_backward(xg, dy.permute(0, 2, 1).contiguous().half().cuda(), gamma.cuda(), beta.cuda(), G, eps, silu, sums)
+    close(dx.permute(0, 2, 1), x.grad, 5e-3, 4e-3)
+
+
+@pytest.mark.parametrize("rows,C", [(100, 320), (77, 640), (513, 1280), (3, 768)])
+def test_layernorm(rows, C):
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(C)
+    x = h(torch.randn(rows, C, generator=g) * 3 + 1)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    y = ops.layernorm(x.half().cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    close(y, F.layer_norm(x, (C,), gamma, beta, 1e-5), 2e-3, 4e-3)
+
+
+def test_geglu_add_silu_concat_transpose():
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(0)
+    x = h(torch.randn(37, 2 * 1280, generator=g) * 2)
+    a, gate = x.chunk(2, dim=-1)
+    close(ops.geglu(x.half().cuda()), a * F.gelu(gate), 2e-3, 2e-3)
+    p, q = h(torch.randn(1001, generator=g)), h(torch.randn(1001, generator=g))
+    close(ops.add(p.half().cuda(), q.half().cuda()), p + q, 1e-3, 1e-3)
+    close(ops.silu(p.half().cuda()), F.silu(p), 1e-3, 1e-3)
+    u, v = h(torch.randn(5, 7, 16, generator=g)), h(torch.randn(5, 7, 24, generator=g))
+    assert torch.equal(ops.concat_channels(u.half().cuda(), v.half().cuda()).cpu().float(), torch.cat([u, v], -1))
+    m = h(torch.randn(3, 77, 320, generator=g))
+    dst = torch.full((3, 320, 80), 7.0, dtype=torch.float16, device="cuda")
+    ops.transpose_batched(m.half().cuda(), 77, 320, 320, 80, 3, 77 * 320, 320 * 80, dst)
+    assert torch.equal(dst[:, :, :77].cpu().float(), m.transpose(1, 2)) and torch.all(dst[:, :, 77:] == 0)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,C,heads", [(2, 256, 256, 320, 8), (2, 64, 77, 1280, 8), (1, 300, 300, 512, 1), (2, 1024, 77, 640, 8), (1, 100, 1100, 80, 2)])
+def test_attention(B, Tq, Tk, C, heads):
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(Tq + Tk)
+    q, k, v = (h(torch.randn(B, T, C, generator=g)) for T in (Tq, Tk, Tk))
+    o = ops.attention(q.half().cuda(), k.half().cuda(), v.half().cuda(), heads)
+    d = C // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Tq, C)
+    close(o, ref, 5e-3, 5e-3)
+
+
+def test_softmax_backward():
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(5)
+    s = h(torch.randn(50, 300, generator=g) * 2).requires_grad_(True)
+    p = torch.softmax(s, -1)
+    dp = h(torch.randn(50, 300, generator=g))
+    p.backward(dp)
+    P = torch.zeros(50, 304, dtype=torch.float16, device="cuda")
+    P[:, :300] = p.detach().half().cuda()
+    dP = torch.zeros(50, 304, dtype=torch.float16, device="cuda")
+    dP[:, :300] = dp.half().cuda()
+    ops.softmax_backward_(P, dP, 50, 300, 304)
+    close(dP[:, :300], s.grad, 1e-2, 2e-4)
+    assert torch.all(dP[:, 300:] == 0)
+
+
+def test_image_front_end_and_sds_tail():
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(1, 3, 32, 32, generator=g).requires_grad_(True)
+    ref = 2 * F.interpolate(img, (128, 128), mode="bilinear", align_corners=False) - 1
+    out = ops.image_to_vae_input(img.detach().cuda(), 128, 128)
+    close(out[..., :3].permute(0, 3, 1, 2), ref, 1e-3, 1e-3)
+    assert torch.all(out[..., 3:] == 0)
+    d_out = h(torch.randn(1, 128, 128, 8, generator=g))
+    ref.backward(d_out[..., :3].permute(0, 3, 1, 2))
+    d_img = ops.image_to_vae_input_backward(d_out.half().cuda(), 1, 32, 32)
+    close(d_img, img.grad, 1e-4, 1e-4)
+    # non-integer scale (utils_init_nerf.py:303 is called with whatever H, W the view has)
+    img2 = torch.rand(2, 3, 24, 40, generator=g)
+    close(ops.image_to_vae_input(img2.cuda(), 64, 64)[..., :3].permute(0, 3, 1, 2), 2 * F.interpolate(img2, (64, 64), mode="bilinear", align_corners=False) - 1, 1e-3, 1e-3)
+    # timestep embedding (diffusers get_timestep_embedding, flip_sin_to_cos=True, freq shift 0)
+    t = torch.tensor([981.0, 20.0])
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t[:, None] * freqs[None]
+    close(ops.timestep_embedding(t.cuda(), 320), torch.cat([torch.cos(arg), torch.sin(arg)], -1), 0, 2e-3)
+    # add_noise + CFG / SDS gradient (sd.py:133-148)
+    lat, noise = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    ab = 0.37
+    xin = ops.add_noise(lat.cuda(), noise.cuda(), ab)
+    want = (math.sqrt(ab) * lat + math.sqrt(1 - ab) * noise).permute(0, 2, 3, 1)
+    close(xin[0, ..., :4], want[0], 1e-3, 1e-3)
+    assert torch.equal(xin[0], xin[1]) and torch.all(xin[..., 4:] == 0)
+    eps = h(torch.randn(2, 8, 8, 8, generator=g))
+    eps[1, 0, 0, 0] = float("nan")
+    gr = ops.sds_grad(eps.half().cuda(), noise.cuda(), ab, 7.5, 0.01)
+    eu, et = eps[0, ..., :4].permute(2, 0, 1)[None], eps[1, ..., :4].permute(2, 0, 1)[None]
+    ref_g = torch.nan_to_num((1 - ab) * ((et + 7.5 * (et - eu)) - noise) * 0.01)
+    close(gr, ref_g, 1e-5, 1e-6)
