@@ -423,12 +423,22 @@ __global__ void k_sds_grad(const _Float16 *__restrict__ eps, uint32_t ld, const 
     }
 }
 
+// zero fill as a kernel instead of a memset call: memset nodes inside captured HIP graphs were observed not to be ordered with
+// the neighbouring kernel nodes on this ROCm, which corrupts the GroupNorm statistics on replay
+__global__ void __launch_bounds__(256) k_zero_f32(float *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline uint32_t so_blocks(size_t work_items, uint32_t per_block = 256, uint32_t cap = 4096) {
     size_t b = (work_items + per_block - 1) / per_block;
     if (b > cap) b = cap;
     if (b == 0) b = 1;
     return (uint32_t)b;
+}
+
+static inline void so_zero(float *p, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_f32, dim3(so_blocks(n, 256, 2048)), dim3(256), 0, st, p, n);
 }
 
 static int gn_check(uint32_t B, uint32_t HW, uint32_t C, uint32_t G) {
@@ -464,8 +474,7 @@ int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *b
     if (rc) return rc;
     if (!x || !gamma || !beta || !sums || !y) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * G * 2 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    so_zero(sums, (size_t)B * G * 2, st);
     const uint32_t rpb = gn_rows_per_block(B, HW);
     hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
                        (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
@@ -481,8 +490,7 @@ int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamm
     if (rc) return rc;
     if (!x || !dy || !gamma || !beta || !sums || !scratch || !dx) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * G * 2 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    so_zero(scratch, (size_t)B * G * 2, st);
     const uint32_t rpb = gn_rows_per_block(B, HW);
     hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums, HW,
                        C, G, eps, silu, rpb, scratch);
@@ -541,8 +549,7 @@ int cnerf_sd_image_to_vae_input_backward(const void *d_out, uint32_t B, uint32_t
     if (B == 0 || Hi == 0 || Wi == 0 || Ho == 0 || Wo == 0) return CNERF_EINVAL;
     if (!d_out || !d_img) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    hipError_t e = hipMemsetAsync(d_img, 0, (size_t)B * 3 * Hi * Wi * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    so_zero(d_img, (size_t)B * 3 * Hi * Wi, st);
     hipLaunchKernelGGL(k_img_bwd, dim3(so_blocks((size_t)B * Ho * Wo)), dim3(256), 0, st, (const _Float16 *)d_out, B, Hi, Wi, Ho, Wo, d_img);
     return cn_launch_status();
 }

@@ -1,0 +1,121 @@
+"""LGIE editing step: counterpart of Trainer_Nerf.train_step_editing / train_step_sd / get_pt
+(nerf/utils_init_nerf.py:243-308, 353-394) on the MI355X renderer + SDS guidance.
+
+One step = render the edited field (full view, fg/bg split) -> global or local SDS term (image or fg image, resized to 512,
+VAE-encoded, UNet eps-prediction) -> background-preservation L1 against the cached render of the frozen pretrained field ->
+backward through VAE and renderer -> fused Adam.  The per-view cache of the pretrained render stays on the GPU (the
+reference parks it on the CPU and re-uploads it every step: utils_init_nerf.py:260-263)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from ..optim import FusedAdam
+
+
+class EditTrainer:
+    def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale=128.0, seed=0):
+        self.model, self.model_pretrained, self.guidance, self.opt = model, model_pretrained, guidance, opt
+        self.text_z, self.text_z_fg = text_z, text_z_fg
+        self.fp16, self.world_size = fp16, world_size
+        self.loss_scale = loss_scale if fp16 else 1.0
+        lr = opt.lr if lr is None else lr
+        groups = model.get_params(lr)
+        self.base_lrs = [g['lr'] for g in groups]
+        self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+        self.global_step = 0
+        self.pt_dict = {}
+        self._flat = None
+        self._rng = np.random.RandomState(seed)
+        for p in self.model.parameters():
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        guidance.set_system(self)
+
+    def lr_factor(self):
+        return 0.1 ** min(self.global_step / self.opt.iters, 1)
+
+    def _bg_color(self, rays_o, B, N):
+        if getattr(self.opt, 'random_bg_c', False):
+            return torch.rand((1, 3), device=rays_o.device).repeat(B * N, 1)
+        if getattr(self.opt, 'black_bg_c', False):
+            return torch.zeros((1, 3), device=rays_o.device).repeat(B * N, 1)
+        if getattr(self.opt, 'white_bg_c', False):
+            return torch.ones((1, 3), device=rays_o.device).repeat(B * N, 1)
+        return None
+
+    def get_pt(self, rays_o, rays_d, img_path, bg_color, B, H, W):
+        """utils_init_nerf.py:243-267 (clip_view matching is out of scope: SURVEY.md §8f rank 4)"""
+        if img_path not in self.pt_dict:
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+                out = self.model_pretrained.render(rays_o, rays_d, staged=False, perturb=True, bg_color=bg_color, force_all_rays=True, **vars(self.opt))
+            img = lambda t, c: t.reshape(B, H, W, c).permute(0, 3, 1, 2).contiguous().float().detach()
+            self.pt_dict[img_path] = (img(out['bg']['image'], 3), img(out['fg']['image'], 3), out['render_mask'].reshape(B, H, W, -1).float().detach(),
+                                      img(out['fg']['depth'], 1))
+        pt_rgb_bg, pt_rgb_fg, pt_mask, pt_depth_fg = self.pt_dict[img_path]
+        return pt_rgb_fg, pt_rgb_bg, pt_mask, pt_depth_fg
+
+    def train_step_sd(self, pred_rgb, pred_rgb_fg):
+        """utils_init_nerf.py:286-309: global (whole image, global prompt) or local (fg image, local prompt, scaled t) SDS term"""
+        opt = self.opt
+        t_ratio = 1
+        if getattr(opt, 'g_only', False):
+            text_emb, img_rgb = self.text_z, pred_rgb
+        elif getattr(opt, 'l_only', False):
+            text_emb, img_rgb, t_ratio = self.text_z_fg, pred_rgb_fg, opt.local_t_ratio
+        elif self._rng.random_sample() < opt.global_ratio:
+            text_emb, img_rgb = self.text_z, pred_rgb
+        else:
+            text_emb, img_rgb, t_ratio = self.text_z_fg, pred_rgb_fg, opt.local_t_ratio
+        latents = self.guidance.encode_imgs(img_rgb.float(), resize=(512, 512))            # F.interpolate(..., (512, 512)) folded into the VAE front-end
+        return self.guidance.train_step(latents, text_emb, system=self, t_ratio=t_ratio)
+
+    def train_step_editing(self, data):
+        """utils_init_nerf.py:353-394.  data = (rgbs, mask, rays_o, rays_d, H, W, img_path)"""
+        rgbs, mask, rays_o, rays_d, H, W, img_path = data
+        B, N = rays_o.shape[:2]
+        opt = self.opt
+        bg_color = self._bg_color(rays_o, B, N)
+        with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+            outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **vars(opt))
+        img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+        pred_rgb, pred_rgb_fg, pred_rgb_bg = img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
+        pred_ws = outputs['weights_sum'].reshape(B, H, W)
+        pt_rgb_fg, pt_rgb_bg, pt_mask, pt_depth_fg = self.get_pt(rays_o, rays_d, img_path, bg_color, B, H, W)
+        if getattr(opt, 'ori_bg', False):
+            non_edit = (pt_mask + outputs['render_mask'].reshape(B, H, W, -1)) < 0.5
+            non_edit = non_edit.permute(0, 3, 1, 2)
+            pt_rgb_bg = rgbs.reshape(B, H, W, 3).permute(0, 3, 1, 2) * non_edit + (~non_edit) * pt_rgb_bg
+        loss, loss_dict = 0.0, {}
+        if opt.lambda_sd:
+            loss, loss_dict = self.train_step_sd(pred_rgb, pred_rgb_fg)
+        if opt.keep_bg:
+            loss_bg = opt.keep_bg * F.l1_loss(pt_rgb_bg, pred_rgb_bg.float())
+            loss = loss + loss_bg
+            loss_dict['loss_bg'] = loss_bg.detach()
+        return pred_rgb, pred_ws, loss, loss_dict
+
+    def allreduce_grads(self):
+        if self.world_size <= 1:
+            return
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+        torch._foreach_copy_(list(self._flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self._flat.split([g.numel() for g in grads])))
+
+    def train_step(self, data):
+        """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""
+        self.model.train()
+        pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing(data)
+        (loss * self.loss_scale).backward()
+        self.allreduce_grads()
+        f = self.lr_factor()
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g['lr'] = base * f
+        self.optimizer.grad_scale_inv = 1.0 / (self.loss_scale * self.world_size)
+        self.optimizer.step()
+        self.global_step += 1
+        return loss.detach(), loss_dict

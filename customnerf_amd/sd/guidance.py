@@ -1,0 +1,109 @@
+"""`StableDiffusion` guidance with the reference's surface (nerf/sd.py:35-155) on libcustomnerf_hip.so.
+
+Same constructor arguments, `get_text_embeds`, `encode_imgs`, `train_step(latents, text_embeddings, ..., t_ratio)` and
+`set_system`; the VAE encoder and the UNet are customnerf_amd.sd.vae.VAEEncoder / unet.UNet.  Weights: pass diffusers
+state dicts (`unet_state`, `vae_state`, float16/float32 tensors keyed as in a `runwayml/stable-diffusion-v1-5` checkpoint);
+without them the networks are seeded-random of the SD-1.5 shapes (synthetic mode: benchmarks and tests — there is no
+network access to fetch the checkpoint), and `data: synthetic` is what bench.py reports.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import arch, ops
+from .unet import UNet
+from .vae import VAEEncoder
+
+
+class StableDiffusion(nn.Module):
+    def __init__(self, device, sd_version='1.5', opt=None, unet_state=None, vae_state=None, unet_cfg=None, vae_cfg=None, seed=0,
+                 text_encoder=None, tokenizer=None, use_graph=True):
+        super().__init__()
+        self.device = torch.device(device)
+        self.sd_version = sd_version
+        self.opt = opt
+        if sd_version != '1.5' and (unet_state is None or unet_cfg is None):
+            raise ValueError("only the SD-1.5 architecture is built in; other versions need unet_cfg / vae_cfg and their state dicts")
+        self.unet_cfg = unet_cfg or arch.UNET_SD15
+        self.vae_cfg = vae_cfg or arch.VAE_SD15
+        self.synthetic = unet_state is None or vae_state is None
+        if unet_state is None:
+            unet_state = arch.random_state_dict(arch.unet_params(self.unet_cfg), seed + 1)
+        if vae_state is None:
+            vae_state = arch.random_state_dict(arch.vae_encoder_params(self.vae_cfg), seed + 2)
+        self.unet = UNet(self.unet_cfg, unet_state, self.device)
+        self.vae = VAEEncoder(self.vae_cfg, vae_state, self.device)
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.num_train_timesteps = 1000
+        self.min_step = int(self.num_train_timesteps * 0.02)                                # sd.py:69
+        self.max_step = int(self.num_train_timesteps * getattr(opt, 'max_ratio', 0.98))     # sd.py:70
+        self.alphas_host = arch.alphas_cumprod(self.num_train_timesteps)                    # scheduler.alphas_cumprod (sd.py:71)
+        self.alphas = self.alphas_host.to(self.device)
+        self.system = None
+        self.use_graph = use_graph
+        self._gen = torch.Generator().manual_seed(seed)                                     # host-side timestep draws: no device sync
+
+    # ---- text (sd.py:77-94)
+    def get_text_embeds(self, prompt, negative_prompt):
+        if self.text_encoder is None or self.tokenizer is None:
+            raise NotImplementedError(
+                "the CLIP tokenizer / text encoder (transformers, runwayml/stable-diffusion-v1-5) are not available offline; pass "
+                "`text_encoder=` and `tokenizer=` or use synthetic_text_embeds()")
+        def enc(p):
+            ids = self.tokenizer(p, padding='max_length', max_length=self.tokenizer.model_max_length, truncation=True, return_tensors='pt').input_ids
+            with torch.no_grad():
+                return self.text_encoder(ids.to(self.device))[0]
+        return torch.cat([enc(negative_prompt), enc(prompt)])
+
+    def synthetic_text_embeds(self, seed=0):
+        """[2, 77, D] (uncond, text) stand-in with CLIP-like statistics (unit-variance LayerNorm output)."""
+        g = torch.Generator().manual_seed(1000 + seed)
+        return torch.randn(2, 77, self.unet_cfg["cross_attention_dim"], generator=g).to(self.device)
+
+    # ---- image -> latents (sd.py:97-105); differentiable w.r.t. imgs
+    def encode_imgs(self, imgs, sample_noise=None, resize=None):
+        B, _, H, W = imgs.shape
+        resize = resize or (H, W)
+        if sample_noise is None:
+            sample_noise = torch.randn(B, self.vae_cfg["latent_channels"], resize[0] // 8, resize[1] // 8, device=imgs.device)
+        return self.vae.encode_imgs(imgs, sample_noise, resize)
+
+    def get_params(self, lr):
+        return []
+
+    def set_system(self, system):
+        self.system = system
+
+    def draw_timestep(self, system=None, t_ratio=1):
+        """sd.py:120-131"""
+        min_step, max_step = self.min_step, self.max_step
+        if getattr(self.opt, 'stage_time', False) and system is not None and system.global_step > self.opt.iters / 2:
+            max_step = int(max_step * 0.5)
+        t = int(torch.randint(min_step, max_step + 1, [1], generator=self._gen))
+        return int(t * t_ratio)
+
+    def eps_pred(self, unet_in, t, text_embeddings):
+        tt = torch.full((unet_in.shape[0],), float(t), dtype=torch.float32, device=self.device)
+        ctx = text_embeddings.to(torch.float16).contiguous()
+        return self.unet.graphed(unet_in, tt, ctx) if self.use_graph else self.unet(unet_in, tt, ctx)
+
+    def sds_grad(self, latents, text_embeddings, t, noise):
+        """sd.py:133-148 on device: add_noise, UNet on the CFG pair, `text + g (text - uncond)`, (1 - abar_t) weighting, nan_to_num."""
+        ab = float(self.alphas_host[t])
+        unet_in = ops.add_noise(latents.contiguous(), noise, ab)
+        eps = self.eps_pred(unet_in, t, text_embeddings)
+        return ops.sds_grad(eps, noise, ab, float(self.opt.cfg), float(self.opt.lambda_sd))
+
+    def train_step(self, latents, text_embeddings, mask=None, img_path=None, tuning=False, gt_rgb=None, t_val=None, system=None, is_all=False,
+                   camera=None, tuning_cls=False, t_ratio=1, noise=None):
+        t = self.draw_timestep(system, t_ratio) if t_val is None else int(t_val)
+        with torch.no_grad():
+            lat = latents.detach().float()
+            if noise is None:
+                noise = torch.randn_like(lat)
+            grad = self.sds_grad(lat, text_embeddings, t, noise)
+        target = (latents - grad).detach()
+        loss = 0.5 * F.mse_loss(latents, target, reduction="sum")                     # d loss / d latents = grad (sd.py:150-152)
+        if getattr(self.opt, 'log_loss_item', True):
+            return loss, dict(loss_sds=loss.item())
+        return loss, dict(loss_sds=loss.detach())

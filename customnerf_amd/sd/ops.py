@@ -153,10 +153,11 @@ def attention_scores(q, k, heads, alpha):
     Tk = k.shape[1]
     d_ = C // heads
     ldS = pad8(Tk)
+    assert q.stride(2) == 1 and k.stride(2) == 1          # strided views of a fused qkv projection are fine
     S = torch.empty(B, heads, Tq, ldS, dtype=torch.float16, device=q.device)
-    d = _desc(q, k, S, Tq, Tk, d_, C, C, ldS, alpha=alpha)
+    d = _desc(q, k, S, Tq, Tk, d_, q.stride(1), k.stride(1), ldS, alpha=alpha)
     d.batch_outer, d.batch_inner = B, heads
-    d.sa_o, d.sa_i, d.sb_o, d.sb_i, d.sc_o, d.sc_i = Tq * C, d_, Tk * C, d_, heads * Tq * ldS, Tq * ldS
+    d.sa_o, d.sa_i, d.sb_o, d.sb_i, d.sc_o, d.sc_i = q.stride(0), d_, k.stride(0), d_, heads * Tq * ldS, Tq * ldS
     _launch(d, q.device)
     check(lib.cnerf_sd_softmax_forward(ptr(S), B * heads * Tq, Tk, ldS, stream()), "sd_softmax_forward")
     return S
@@ -167,8 +168,9 @@ def attention_apply(P, v, heads):
     B, _, Tq, ldS = P.shape
     Tk, C = v.shape[1], v.shape[2]
     d_ = C // heads
+    assert v.stride(2) == 1
     vT = torch.empty(B, C, ldS, dtype=torch.float16, device=v.device)
-    transpose_batched(v, Tk, C, C, ldS, B, Tk * C, C * ldS, vT)
+    transpose_batched(v, Tk, C, v.stride(1), ldS, B, v.stride(0), C * ldS, vT)
     O = torch.empty(B, Tq, C, dtype=torch.float16, device=v.device)
     d = _desc(P, vT, O, Tq, d_, ldS, ldS, ldS, C)
     d.batch_outer, d.batch_inner = B, heads

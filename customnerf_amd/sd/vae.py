@@ -1,0 +1,196 @@
+"""AutoencoderKL encoder (SD-1.5 configuration), forward and input-gradient, as a graph of libcustomnerf_hip.so primitives.
+
+Replaces `self.vae.encode(imgs).latent_dist` + `.sample() * 0.18215` of StableDiffusion.encode_imgs (nerf/sd.py:97-105),
+including the bilinear 512x512 resize in front of it (utils_init_nerf.py:303).  The SDS gradient enters the NeRF only
+through this network's input gradient (sd.py:150-152), so every op is an autograd.Function whose backward is again one of
+the library's kernels: the input-gradient of a convolution is the same implicit GEMM with flipped/transposed weights (and
+the transposed-stride loader for the three downsampling convs), GroupNorm+SiLU has a fused backward, the single-head
+mid-block attention is differentiated through explicit P = softmax(QK^T) GEMMs.  Weights are frozen (no weight gradients).
+Module tree / parameter names are diffusers' (arch.vae_encoder_params)."""
+import torch
+from torch.autograd import Function
+
+from . import ops, pack
+from .arch import VAE_ATTN_ALIASES
+
+
+class _Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, wd, bias, k, stride, pad, out_hw, residual):
+        ctx.wd, ctx.k, ctx.stride, ctx.pad, ctx.in_hw = wd, k, stride, pad, (x.shape[1], x.shape[2])
+        ctx.has_res = residual is not None
+        return ops.conv2d(x, w, bias, k, stride=stride, pad=pad, out_hw=out_hw, residual=residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.conv2d(dy, ctx.wd, None, ctx.k, stride=1, pad=ctx.k - 1 - ctx.pad, tstride=ctx.stride, out_hw=ctx.in_hw)
+        return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
+
+
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        y, sums = ops.groupnorm(x, gamma, beta, groups, eps, silu)
+        ctx.save_for_backward(x, gamma, beta, sums)
+        ctx.cfg = (groups, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, sums = ctx.saved_tensors
+        groups, eps, silu = ctx.cfg
+        return ops.groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums), None, None, None, None, None
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, wT, bias, residual):
+        ctx.wT = wT
+        ctx.has_res = residual is not None
+        return ops.linear(x, w, bias=bias, residual=residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return ops.linear(dy, ctx.wT), None, None, None, (dy if ctx.has_res else None)
+
+
+class _Attention1Head(Function):
+    """softmax(q k^T / sqrt(C)) v for q, k, v [B, T, C] (one head: the VAE mid block)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        alpha = 1.0 / float(q.shape[-1]) ** 0.5
+        P = ops.attention_scores(q, k, 1, alpha)                     # [B, 1, T, ld]
+        ctx.save_for_backward(q, k, v, P)
+        ctx.alpha = alpha
+        return ops.attention_apply(P, v, 1)
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        B, T, C = q.shape
+        ld = P.shape[-1]
+        dO = dO.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        half = dict(dtype=torch.float16, device=q.device)
+        for b in range(B):
+            Pb = P[b, 0]
+            PT = torch.empty(ld, ld, **half)                                            # P^T [Tk, Tq]
+            ops.transpose_batched(Pb, T, T, ld, ld, 1, 0, 0, PT)
+            dOT = torch.empty(C, ld, **half)
+            ops.transpose_batched(dO[b], T, C, C, ld, 1, 0, 0, dOT)
+            ops.gemm_nt(PT, dOT, T, C, ld, ld, ld, C, dv[b])                           # dV = P^T dO
+            dP = torch.empty(T, ld, **half)
+            ops.gemm_nt(dO[b], v[b], T, T, C, C, C, ld, dP)                            # dP = dO V^T
+            ops.softmax_backward_(Pb, dP, T, T, ld)                                     # dS (pad columns zero)
+            kT = torch.empty(C, ld, **half)
+            ops.transpose_batched(k[b], T, C, C, ld, 1, 0, 0, kT)
+            ops.gemm_nt(dP, kT, T, C, ld, ld, ld, C, dq[b], alpha=ctx.alpha)           # dQ = alpha dS K
+            dST = torch.empty(ld, ld, **half)
+            ops.transpose_batched(dP, T, T, ld, ld, 1, 0, 0, dST)
+            qT = torch.empty(C, ld, **half)
+            ops.transpose_batched(q[b], T, C, C, ld, 1, 0, 0, qT)
+            ops.gemm_nt(dST, qT, T, C, ld, ld, ld, C, dk[b], alpha=ctx.alpha)          # dK = alpha dS^T Q
+        return dq, dk, dv
+
+
+class _ImageInput(Function):
+    @staticmethod
+    def forward(ctx, img, Ho, Wo):
+        ctx.shape = img.shape
+        return ops.image_to_vae_input(img, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, _, Hi, Wi = ctx.shape
+        return ops.image_to_vae_input_backward(d_out, B, Hi, Wi), None, None
+
+
+class _ConvW:
+    def __init__(self, sd, p, dev):
+        w = sd[p + ".weight"].to(dev)
+        self.k = w.shape[-1]
+        self.w, self.wd, self.b = pack.pack_conv(w), pack.pack_conv_dgrad(w), pack.f32(sd[p + ".bias"].to(dev))
+
+    def __call__(self, x, stride=1, pad=None, out_hw=None, residual=None):
+        pad = (self.k // 2) if pad is None else pad
+        return _Conv.apply(x, self.w, self.wd, self.b, self.k, stride, pad, out_hw, residual)
+
+
+class _LinW:
+    def __init__(self, sd, p, dev):
+        w = sd[p + ".weight"].to(dev)
+        w = w.reshape(w.shape[0], -1)                                    # 1x1 convolutions are linears over NHWC channels
+        self.w, self.wT, self.b = pack.pack_linear(w), pack.pack_linear_T(w), pack.f32(sd[p + ".bias"].to(dev))
+
+    def __call__(self, x, residual=None):
+        return _Linear.apply(x, self.w, self.wT, self.b, residual)
+
+
+class _Resnet:
+    def __init__(self, sd, p, dev):
+        self.n1 = (pack.f32(sd[p + "norm1.weight"].to(dev)), pack.f32(sd[p + "norm1.bias"].to(dev)))
+        self.n2 = (pack.f32(sd[p + "norm2.weight"].to(dev)), pack.f32(sd[p + "norm2.bias"].to(dev)))
+        self.c1, self.c2 = _ConvW(sd, p + "conv1", dev), _ConvW(sd, p + "conv2", dev)
+        self.sc = _LinW(sd, p + "conv_shortcut", dev) if (p + "conv_shortcut.weight") in sd else None
+
+    def __call__(self, x, groups, eps):
+        h = self.c1(_GroupNorm.apply(x, *self.n1, groups, eps, True))
+        h = _GroupNorm.apply(h, *self.n2, groups, eps, True)
+        return self.c2(h, residual=self.sc(x) if self.sc is not None else x)
+
+
+class VAEEncoder:
+    def __init__(self, cfg, state_dict, device="cuda"):
+        self.cfg = cfg
+        dev = torch.device(device)
+        sd = dict(state_dict)
+        for old, new in VAE_ATTN_ALIASES.items():                       # older diffusers checkpoints
+            for suffix in (".weight", ".bias"):
+                k_old = "encoder.mid_block.attentions.0." + old + suffix
+                if k_old in sd:
+                    sd["encoder.mid_block.attentions.0." + new + suffix] = sd.pop(k_old)
+        boc = cfg["block_out_channels"]
+        self.conv_in = _ConvW(sd, "encoder.conv_in", dev)
+        self.down = []
+        for i in range(len(boc)):
+            res = [_Resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}.", dev) for j in range(cfg["layers_per_block"])]
+            ds = _ConvW(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", dev) if i < len(boc) - 1 else None
+            self.down.append((res, ds))
+        self.mid0, self.mid1 = _Resnet(sd, "encoder.mid_block.resnets.0.", dev), _Resnet(sd, "encoder.mid_block.resnets.1.", dev)
+        a = "encoder.mid_block.attentions.0."
+        self.an = (pack.f32(sd[a + "group_norm.weight"].to(dev)), pack.f32(sd[a + "group_norm.bias"].to(dev)))
+        self.aq, self.ak, self.av, self.ao = (_LinW(sd, a + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
+        self.no = (pack.f32(sd["encoder.conv_norm_out.weight"].to(dev)), pack.f32(sd["encoder.conv_norm_out.bias"].to(dev)))
+        self.conv_out = _ConvW(sd, "encoder.conv_out", dev)
+        self.quant = _LinW(sd, "quant_conv", dev)
+
+    def moments(self, x):
+        """x [B, H, W, 8] half NHWC in [-1, 1] (3 channels + zero padding) -> [B, H/8, W/8, 2*latent] half (mean | logvar)"""
+        G, eps = self.cfg["groups"], self.cfg["eps"]
+        h = self.conv_in(x)
+        for res, ds in self.down:
+            for r in res:
+                h = r(h, G, eps)
+            if ds is not None:
+                h = ds(h, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2))      # F.pad(0,1,0,1) + stride-2 conv
+        h = self.mid0(h, G, eps)
+        B, H, W, C = h.shape
+        n = _GroupNorm.apply(h, *self.an, G, eps, False).view(B, H * W, C)
+        o = _Attention1Head.apply(self.aq(n), self.ak(n), self.av(n))
+        h = self.ao(o, residual=h.view(B, H * W, C)).view(B, H, W, C)
+        h = self.mid1(h, G, eps)
+        h = self.conv_out(_GroupNorm.apply(h, *self.no, G, eps, True))
+        return self.quant(h)
+
+    def encode_imgs(self, imgs, sample_noise, resize=(512, 512)):
+        """StableDiffusion.encode_imgs (sd.py:97-105) with the caller's resize (utils_init_nerf.py:303) folded in:
+        imgs [B, 3, H, W] float32 in [0, 1] -> latents [B, latent, h, w] float32 = (mean + std * sample_noise) * 0.18215.
+        Differentiable w.r.t. imgs."""
+        x = _ImageInput.apply(imgs, resize[0], resize[1])
+        m = self.moments(x).float().permute(0, 3, 1, 2)                                # tiny [B, 8, 64, 64]: torch glue
+        mean, logvar = m.chunk(2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        return (mean + std * sample_noise) * self.cfg["scaling_factor"]
