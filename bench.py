@@ -21,6 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak of MI355X (no sparsity)
 
 
 def measured_traffic(dtype, points_per_launch):
@@ -81,8 +82,114 @@ def cpu_baseline(opt, n_rays_side=40, steps=3):
                       f"fwd+bwd+Adam, median of {steps} steps after 1 warm-up; grid encode/scatter = single-thread C oracle, MLP/renderer = torch CPU on {threads} threads"}
 
 
+def cpu_baseline_edit(steps=1):
+    """SDS half of one edit step on the host cores with the CPU oracle (oracle/sd_oracle.py): SD-1.5-shaped random weights, VAE encode
+    forward + input gradient and the UNet CFG pair, on a BOUNDED sample: a 256x256 VAE input / 32x32 latents (1/4 of the pixels of
+    the real 512x512 / 64x64 step); the reported steps/s is the measured rate divided by 4 (convolutions and projections scale
+    linearly in pixels; the self-attention share, quadratic, is undercounted — the baseline is therefore optimistic for the CPU)."""
+    from oracle import sd_oracle as so
+    from customnerf_amd.sd import arch
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    usd = arch.random_state_dict(arch.unet_params(arch.UNET_SD15), 1)
+    vsd = arch.random_state_dict(arch.vae_encoder_params(arch.VAE_SD15), 2)
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 128, 128, generator=g).requires_grad_(True)
+    text = torch.randn(2, 77, 768, generator=g)
+    alphas = arch.alphas_cumprod()
+    times = []
+    for it in range(steps):
+        t0 = time.perf_counter()
+        loss, _, _ = so.train_step_sd(vsd, arch.VAE_SD15, usd, arch.UNET_SD15, img, text, 500, torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 4, 32, 32, generator=g),
+                                      alphas, 100.0, 0.01, size=(256, 256))
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / (4.0 * t), "unit": "edit-steps/s", "cores": threads, "kind": "port",
+            "sample": f"SDS half only (VAE encode fwd+input-grad, UNet CFG pair) of one step at 256x256 / 32x32 latents = 1/4 of the pixels, {t:.1f} s measured, "
+                      f"rate divided by 4; torch CPU float32 on {threads} threads; NeRF render excluded"}
+
+
+def main_edit(args, world, rank, dev):
+    """--task edit: SDS edit-steps/s.  One step = EditTrainer.train_step: render one 128x128 view of the edited field (run() path, fg/bg split),
+    global/local SDS term (512x512 VAE encode fwd + input gradient, SD-1.5 UNet on the CFG pair), background-preservation L1 against the cached
+    pretrained render, backward through the renderer, [RCCL grad all-reduce], Adam.  View-parallel over ranks."""
+    import copy
+    import torch.distributed as dist
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.sd import StableDiffusion
+    from customnerf_amd.sd import ops as sdops
+    from customnerf_amd.sd.editing import EditTrainer
+    tcnn.set_default_dtype(torch.float16)
+    torch.manual_seed(0)
+    opt = sc.make_opt(cuda_ray=False, fp16=True, keep_bg=1000.0, lambda_sd=0.01, cfg=100.0, log_loss_item=False)
+    model = NeRFNetwork(opt).to(dev)
+    pretrained = copy.deepcopy(model).eval()
+    for p in pretrained.parameters():
+        p.requires_grad_(False)
+    guidance = StableDiffusion(dev, '1.5', opt, seed=0)                 # SD-1.5 shapes, seeded random weights (no checkpoint offline)
+    H = W = args.res
+    V = 8
+    c2w = torch.from_numpy(sc.poses(V)).to(dev)
+    rays_o, rays_d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+    rays_o, rays_d = rays_o.view(V, 1, H * W, 3), rays_d.view(V, 1, H * W, 3)
+    rgb, mask = sc.targets(V, H, W)
+    rgb, mask = rgb.to(dev), mask.to(dev)
+    trainer = EditTrainer(model, pretrained, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, world_size=world)
+
+    def step(i):
+        v = (i * world + rank) % V
+        return trainer.train_step((rgb[v], mask[v], rays_o[v], rays_d[v], H, W, f"view{v}"))
+
+    for i in range(max(args.warmup, V // world + 1)):                   # warm-up also fills the per-view cache of the pretrained render
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, ld = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return
+    result = {"metric": "SDS edit-steps/s", "value": world * args.steps / dt, "unit": "edit-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+              "config": {"workload": f"cfg3 synthetic: {H}x{W} view/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on the CFG pair "
+                                     "at 64x64 latents + VAE encoder fwd/input-grad at 512x512, lambda_sd=0.01, keep_bg=1000, LGIE global/local alternation, fwd+bwd+Adam",
+                         "parallelism": f"dp{world} (view-parallel SDS, RCCL grad all-reduce)" if world > 1 else "single GPU", "final_loss": float(loss)}}
+    if not args.no_roofline:
+        prof = []
+        guidance.use_graph = False                                       # eager launches so that each GEMM can be bracketed by events
+        sdops.set_profile(prof)
+        step(args.warmup + args.steps)
+        sdops.set_profile(None)
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        fl = sum(f for _, _, f in prof)
+        ach = fl / (ms * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "k_sd_gemm (implicit-GEMM conv / linear / attention GEMMs of the UNet + VAE)", "bound": "mfma", "achieved": ach,
+                              "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(prof),
+                              "gemm_ms_per_step": ms, "algorithmic_tflop_per_step": fl / 1e12}
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            result["cpu_baseline"] = cpu_baseline_edit()
+        except Exception as e:
+            result["cpu_baseline"] = {"value": None, "unit": "edit-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", choices=["recon", "edit"], default="recon", help="recon: training rays/s (headline); edit: SDS edit-steps/s")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -104,6 +211,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.task == "edit":
+        main_edit(args, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from customnerf_amd import scene as sc, tcnn
     from customnerf_amd.gridencoder import grid as ge

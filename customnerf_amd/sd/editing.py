@@ -31,6 +31,7 @@ class EditTrainer:
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
         guidance.set_system(self)
+        self._render_kw = {k: v for k, v in vars(opt).items() if k != 'bg_color'}       # bg_color is passed explicitly (utils_init_nerf.py:365)
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)
@@ -48,7 +49,7 @@ class EditTrainer:
         """utils_init_nerf.py:243-267 (clip_view matching is out of scope: SURVEY.md §8f rank 4)"""
         if img_path not in self.pt_dict:
             with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
-                out = self.model_pretrained.render(rays_o, rays_d, staged=False, perturb=True, bg_color=bg_color, force_all_rays=True, **vars(self.opt))
+                out = self.model_pretrained.render(rays_o, rays_d, staged=False, perturb=True, bg_color=bg_color, force_all_rays=True, **self._render_kw)
             img = lambda t, c: t.reshape(B, H, W, c).permute(0, 3, 1, 2).contiguous().float().detach()
             self.pt_dict[img_path] = (img(out['bg']['image'], 3), img(out['fg']['image'], 3), out['render_mask'].reshape(B, H, W, -1).float().detach(),
                                       img(out['fg']['depth'], 1))
@@ -77,7 +78,7 @@ class EditTrainer:
         opt = self.opt
         bg_color = self._bg_color(rays_o, B, N)
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
-            outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **vars(opt))
+            outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **self._render_kw)
         img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
         pred_rgb, pred_rgb_fg, pred_rgb_bg = img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
         pred_ws = outputs['weights_sum'].reshape(B, H, W)

@@ -10,6 +10,14 @@ from .._lib import lib, check, ptr, stream, require_cuda, SdGemmDesc
 
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 _WS = {}
+_PROFILE = None
+
+
+def set_profile(records):
+    """records: list (or None).  While set, every GEMM launch is bracketed by events on the launch stream and appended as
+    (start_event, end_event, flops) — bench.py's live MFMA roofline measurement (eager launches only, not graph replays)."""
+    global _PROFILE
+    _PROFILE = records
 
 
 def _workspace(nbytes, device):
@@ -24,7 +32,13 @@ def _launch(d, device):
     need = ctypes.c_uint64(0)
     check(lib.cnerf_sd_gemm_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "sd_gemm_workspace_bytes")
     ws = _workspace(need.value, device) if need.value else None
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.cnerf_sd_gemm(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0, stream()), "sd_gemm")
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch_outer * d.batch_inner))
 
 
 def _desc(A, B, C, M, N, K, lda, ldb, ldc, bias=None, bias_rows=None, rows_per_bias_row=0, residual=None, ldr=0, act=0, alpha=1.0, C32=None):
