@@ -1,12 +1,16 @@
 // Implicit-GEMM / GEMM kernel of the SDS path (UNet forward, VAE encoder forward + input-gradient) on the gfx950 matrix cores.
 //   C[m][n] = epilogue(alpha * sum_k A(m,k) B[n][k]),  fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16).
-// One workgroup (4 waves, 2 x 2) owns a 128 x 128 output tile; each wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs).
+// One workgroup (4 waves, 2 x 2) owns a 128 x BN output tile (BN = 128 or 64); each wave 64 x BN/2 = 2 x NT MFMA tiles.
 // K advances in steps of 64 through a double-buffered LDS stage; rows are padded to 72 halfs (144 B) which makes the
 // 16-byte fragment reads (ds_read_b128, 16-lane groups) conflict-free.  Both operands are K-contiguous in memory — NHWC
 // activations make the im2col view K-contiguous per tap, weights are packed [Cout][kh][kw][Cin] — so every global access is a
 // 16-byte load and nothing is transposed on the way to the MFMA fragments.
-// The im2col address arithmetic (tap -> input pixel, zero padding, nearest 2x upsampling, transposed stride for input
-// gradients) runs once per 16-byte chunk in the loader; there is no materialised im2col buffer.
+// im2col address arithmetic: when Cin % 64 == 0 (every conv but the first) a 64-wide K step lies inside one tap, so the tap
+// (kh, kw, channel offset) is wave-uniform and advances incrementally; per thread only one pixel offset + bounds test remains
+// (AMODE 2).  The generic path (AMODE 1) resolves the tap per 16-byte chunk.  Zero padding, nearest 2x upsampling and the
+// transposed stride of input gradients are folded into that offset; there is no materialised im2col buffer.
+// Epilogue: the fp32 tile is transposed through LDS so that bias / activation / residual / store run on 8 consecutive columns
+// per lane (16-byte residual loads and stores instead of 2-byte ones).
 // Small-M problems (the 8x8 / 16x16 UNet levels at batch 2) are split along K over blockIdx.z with fp32 partials in a
 // workspace and a separate epilogue pass, so the launch still covers the 256 CUs.
 #include "common.h"
@@ -14,15 +18,19 @@
 
 typedef _Float16 sd_h8 __attribute__((ext_vector_type(8)));
 typedef float sd_f16v __attribute__((ext_vector_type(16)));
+typedef float sd_f4 __attribute__((ext_vector_type(4)));
 
 #define SG_BM 128
-#define SG_BN 128
 #define SG_BK 64
 #define SG_LDK (SG_BK + 8)          // padded LDS row, halfs
 #define SG_THREADS 256
-#define SG_STAGE_HALFS ((SG_BM + SG_BN) * SG_LDK)
 
 __host__ __device__ __forceinline__ int sg_rho(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+__host__ __device__ constexpr uint32_t sg_stage_halfs(int bn) { return (SG_BM + bn) * SG_LDK; }
+__host__ __device__ constexpr uint32_t sg_lds_bytes(int bn) {
+    const uint32_t stages = 2 * sg_stage_halfs(bn) * 2, ctile = SG_BM * (bn + 4) * 4;
+    return stages > ctile ? stages : ctile;
+}
 
 __device__ __forceinline__ float sg_act(float v, int act) {
     if (act == 1) return v / (1.0f + __expf(-v));
@@ -30,92 +38,118 @@ __device__ __forceinline__ float sg_act(float v, int act) {
     return v;
 }
 
-// per-thread description of the A row it stages (fixed for the whole K loop)
-struct SgRowA {
-    const _Float16 *base;     // dense: row pointer; conv: image base
-    int32_t oh_s, ow_s;       // conv: oh*stride - pad_t, ow*stride - pad_l
-    bool valid;
-};
-
-__device__ __forceinline__ uint4 sg_load_a(const CnerfSdGemm &g, const SgRowA &row, uint32_t k) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (!row.valid || k >= g.K) return v;
-    if (g.mode == 0) return *reinterpret_cast<const uint4 *>(row.base + k);
-    const uint32_t tap = k / g.Cin, c = k - tap * g.Cin;
-    const uint32_t kh = tap / g.KW, kw = tap - kh * g.KW;
-    int32_t nh = row.oh_s + (int32_t)kh, nw = row.ow_s + (int32_t)kw;
-    if (nh < 0 || nw < 0) return v;
-    if (g.tstride == 2) {
-        if ((nh | nw) & 1) return v;
-        nh >>= 1; nw >>= 1;
+// map (o*stride + k - pad) to an input coordinate; false = zero tap
+__device__ __forceinline__ bool sg_coord(int32_t num, uint32_t tstride, uint32_t ups, uint32_t n_in, uint32_t &out) {
+    if (num < 0) return false;
+    if (tstride == 2) {
+        if (num & 1) return false;
+        num >>= 1;
     }
-    if (g.ups == 2) { nh >>= 1; nw >>= 1; }
-    if ((uint32_t)nh >= g.H_in || (uint32_t)nw >= g.W_in) return v;
-    return *reinterpret_cast<const uint4 *>(row.base + ((size_t)nh * g.W_in + nw) * g.Cin + c);
+    if (ups == 2) num >>= 1;
+    out = (uint32_t)num;
+    return out < n_in;
 }
 
-template <bool SPLIT>
+// AMODE 0: dense A.  1: implicit conv, tap resolved per 16-byte chunk.  2: implicit conv with Cin % 64 == 0 (tap uniform per K step).
+template <int AMODE, int NT, bool SPLIT>
 __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, float *__restrict__ partial, uint32_t k_tiles_per_split) {
+    constexpr int BN = 64 * NT;
+    constexpr int CB = BN * 8 / SG_THREADS;             // 16-byte chunks of B per thread per K step (4 | 2)
+    constexpr uint32_t STAGE = sg_stage_halfs(BN);
     extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
     _Float16 *lds = reinterpret_cast<_Float16 *>(sg_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
     const uint32_t wm = wave >> 1, wn = wave & 1;
-    // blockIdx.x walks M tiles fastest: neighbouring workgroups share the B (weight) tile through L2
-    const uint32_t m0 = blockIdx.x * SG_BM, n0 = blockIdx.y * SG_BN;
+    const uint32_t m0 = blockIdx.x * SG_BM, n0 = blockIdx.y * BN;
     uint32_t z = 0, split = 0;
     if (SPLIT) split = blockIdx.z; else z = blockIdx.z;
     const uint32_t zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
     const _Float16 *A = reinterpret_cast<const _Float16 *>(g.A) + g.sa_o * zo + g.sa_i * zi;
     const _Float16 *B = reinterpret_cast<const _Float16 *>(g.B) + g.sb_o * zo + g.sb_i * zi;
 
-    // staging role: 2 threads per row, 4 consecutive 16-byte chunks each
-    const uint32_t srow = tid >> 1, sk = (tid & 1) * 32;
-    SgRowA ra;
+    // ---- staging roles.  A: 2 threads per row, 4 consecutive chunks each.  B: 8 / CB threads per row, CB chunks each.
+    const uint32_t arow = tid >> 1, ak = (tid & 1) * 32;
+    const uint32_t brow = tid / (8 / CB), bk = (tid % (8 / CB)) * CB * 8;
+    const _Float16 *abase;
+    int32_t oh_s = 0, ow_s = 0;
+    bool a_valid;
     {
-        const uint32_t m = m0 + srow;
-        ra.valid = m < g.M;
-        ra.oh_s = ra.ow_s = 0;
-        if (g.mode == 0) ra.base = A + (size_t)m * g.lda;
+        const uint32_t m = m0 + arow;
+        a_valid = m < g.M;
+        if (AMODE == 0) abase = A + (size_t)m * g.lda;
         else {
             const uint32_t hw = g.H_out * g.W_out;
             const uint32_t img = m / hw, rem = m - img * hw, oh = rem / g.W_out, ow = rem - oh * g.W_out;
-            ra.base = A + (size_t)img * g.H_in * g.W_in * g.Cin;
-            ra.oh_s = (int32_t)(oh * g.stride) - (int32_t)g.pad_t;
-            ra.ow_s = (int32_t)(ow * g.stride) - (int32_t)g.pad_l;
+            abase = A + (size_t)img * g.H_in * g.W_in * g.Cin;
+            oh_s = (int32_t)(oh * g.stride) - (int32_t)g.pad_t;
+            ow_s = (int32_t)(ow * g.stride) - (int32_t)g.pad_l;
         }
     }
-    const uint32_t nrow = n0 + srow;
+    const uint32_t nrow = n0 + brow;
     const bool b_valid = nrow < g.N;
-    const _Float16 *brow = B + (size_t)nrow * g.ldb;
+    const _Float16 *bbase = B + (size_t)nrow * g.ldb;
 
     const uint32_t n_ktiles = (g.K + SG_BK - 1) / SG_BK;
     uint32_t kt0 = 0, kt1 = n_ktiles;
     if (SPLIT) { kt0 = split * k_tiles_per_split; kt1 = min(kt0 + k_tiles_per_split, n_ktiles); }
 
-    sd_f16v acc[2][2];
+    // uniform tap state of the fast conv path (advanced once per K step)
+    uint32_t t_kh = 0, t_kw = 0, t_c0 = 0;
+    if (AMODE == 2) {
+        const uint32_t tap = (kt0 * SG_BK) / g.Cin;
+        t_c0 = kt0 * SG_BK - tap * g.Cin;
+        t_kh = tap / g.KW;
+        t_kw = tap - t_kh * g.KW;
+    }
+
+    sd_f16v acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    uint4 sa[4], sb[4];
-    auto fetch = [&](uint32_t kt) {
-        const uint32_t k = kt * SG_BK + sk;
+    uint4 sa[4], sb[CB];
+    auto fetch = [&](uint32_t kt) __attribute__((always_inline)) {
+        const uint32_t k = kt * SG_BK;
+        if (AMODE == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            sa[c] = sg_load_a(g, ra, k + 8 * c);
-            sb[c] = (b_valid && k + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(brow + k + 8 * c) : make_uint4(0, 0, 0, 0);
+            for (int c = 0; c < 4; c++) sa[c] = (a_valid && k + ak + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(abase + k + ak + 8 * c) : make_uint4(0, 0, 0, 0);
+        } else if (AMODE == 2) {
+            uint32_t ih = 0, iw = 0;
+            const bool ok = a_valid && sg_coord(oh_s + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
+            const _Float16 *p = abase + ((size_t)ih * g.W_in + iw) * g.Cin + t_c0 + ak;
+#pragma unroll
+            for (int c = 0; c < 4; c++) sa[c] = ok ? *reinterpret_cast<const uint4 *>(p + 8 * c) : make_uint4(0, 0, 0, 0);
+            t_c0 += SG_BK;                                   // next K step (uniform)
+            if (t_c0 >= g.Cin) {
+                t_c0 = 0;
+                if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t kk = k + ak + 8 * c;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a_valid && kk < g.K) {
+                    const uint32_t tap = kk / g.Cin, ch = kk - tap * g.Cin, kh = tap / g.KW, kw = tap - kh * g.KW;
+                    uint32_t ih = 0, iw = 0;
+                    if (sg_coord(oh_s + (int32_t)kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)kw, g.tstride, g.ups, g.W_in, iw))
+                        v = *reinterpret_cast<const uint4 *>(abase + ((size_t)ih * g.W_in + iw) * g.Cin + ch);
+                }
+                sa[c] = v;
+            }
         }
+#pragma unroll
+        for (int c = 0; c < CB; c++) sb[c] = (b_valid && k + bk + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(bbase + k + bk + 8 * c) : make_uint4(0, 0, 0, 0);
     };
-    auto commit = [&](uint32_t stage) {
-        _Float16 *sA = lds + stage * SG_STAGE_HALFS, *sB = sA + SG_BM * SG_LDK;
+    auto commit = [&](uint32_t stage) __attribute__((always_inline)) {
+        _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            *reinterpret_cast<uint4 *>(sA + srow * SG_LDK + sk + 8 * c) = sa[c];
-            *reinterpret_cast<uint4 *>(sB + srow * SG_LDK + sk + 8 * c) = sb[c];
-        }
+        for (int c = 0; c < 4; c++) *reinterpret_cast<uint4 *>(sA + arow * SG_LDK + ak + 8 * c) = sa[c];
+#pragma unroll
+        for (int c = 0; c < CB; c++) *reinterpret_cast<uint4 *>(sB + brow * SG_LDK + bk + 8 * c) = sb[c];
     };
     if (kt0 < kt1) {
         fetch(kt0);
@@ -125,60 +159,89 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     for (uint32_t kt = kt0; kt < kt1; kt++) {
         const uint32_t stage = (kt - kt0) & 1;
         if (kt + 1 < kt1) fetch(kt + 1);
-        const _Float16 *sA = lds + stage * SG_STAGE_HALFS, *sB = sA + SG_BM * SG_LDK;
+        const _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
 #pragma unroll
         for (int s = 0; s < SG_BK / 16; s++) {
-            sd_h8 a[2], b[2];
+            sd_h8 a[2], b[NT];
 #pragma unroll
             for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const sd_h8 *>(sA + (wm * 64 + i * 32 + li) * SG_LDK + s * 16 + 8 * hi);
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + (wn * 64 + j * 32 + li) * SG_LDK + s * 16 + 8 * hi);
+            for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + (wn * 32 * NT + j * 32 + li) * SG_LDK + s * 16 + 8 * hi);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < kt1) commit(stage ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns column n = li (+32 j), rows rho(r, hi) (+32 i)
-    if (SPLIT) {
-        float *P = partial + (size_t)split * g.M * g.N;
+    // ---- epilogue phase 1: fp32 tile -> LDS [128][BN + 4] (lane owns column li of its MFMA tile, rows rho(r, hi))
+    constexpr uint32_t LDC = BN + 4;
+    float *ct = reinterpret_cast<float *>(sg_lds);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t n = n0 + wn * 64 + j * 32 + li;
+        for (int j = 0; j < NT; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t m = m0 + wm * 64 + i * 32 + sg_rho(r, hi);
-                    if (m < g.M && n < g.N) P[(size_t)m * g.N + n] = acc[i][j][r];
+            for (int r = 0; r < 16; r++) ct[(wm * 64 + i * 32 + sg_rho(r, hi)) * LDC + wn * 32 * NT + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    // ---- phase 2: 8 consecutive columns per lane
+    _Float16 *C = (!SPLIT && g.C) ? reinterpret_cast<_Float16 *>(g.C) + g.sc_o * zo + g.sc_i * zi : nullptr;
+    float *C32 = SPLIT ? partial + (size_t)split * g.M * g.N : (g.C32 ? g.C32 + g.sc_o * zo + g.sc_i * zi : nullptr);
+    const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
+    const uint32_t ldc32 = SPLIT ? g.N : g.ldc;
+    constexpr uint32_t CPR = BN / 8;                    // column chunks per row
+    for (uint32_t c = tid; c < SG_BM * CPR; c += SG_THREADS) {
+        const uint32_t row = c / CPR, cc = (c % CPR) * 8;
+        const uint32_t m = m0 + row, n = n0 + cc;
+        if (m >= g.M || n >= g.N) continue;
+        const sd_f4 v0 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc), v1 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bool full = n + 8 <= g.N;
+        if (!SPLIT) {
+            const float *brow_ = g.bias_rows ? g.bias_rows + (size_t)(m / g.rows_per_bias_row) * g.N : nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (n + e < g.N) {
+                    float x = v[e] * g.alpha;
+                    if (g.bias) x += g.bias[n + e];
+                    if (brow_) x += brow_[n + e];
+                    v[e] = sg_act(x, g.act);
                 }
             }
-        return;
-    }
-    _Float16 *C = g.C ? reinterpret_cast<_Float16 *>(g.C) + g.sc_o * zo + g.sc_i * zi : nullptr;
-    float *C32 = g.C32 ? g.C32 + g.sc_o * zo + g.sc_i * zi : nullptr;
-    const _Float16 *R = g.residual ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
+            if (R) {
+                const _Float16 *rp = R + (size_t)m * g.ldr + n;
+                if (full && ((g.ldr | n) & 7) == 0) {
+                    const sd_h8 rv = *reinterpret_cast<const sd_h8 *>(rp);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint32_t n = n0 + wn * 64 + j * 32 + li;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.0f;
+                    for (int e = 0; e < 8; e++) v[e] += (float)rv[e];
+                } else {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t m = m0 + wm * 64 + i * 32 + sg_rho(r, hi);
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] * g.alpha + bias;
-                if (g.bias_rows) v += g.bias_rows[(size_t)(m / g.rows_per_bias_row) * g.N + n];
-                v = sg_act(v, g.act);
-                if (R) v += (float)R[(size_t)m * g.ldr + n];
-                if (C) C[(size_t)m * g.ldc + n] = (_Float16)v;
-                if (C32) C32[(size_t)m * g.ldc + n] = v;
+                    for (int e = 0; e < 8; e++)
+                        if (n + e < g.N) v[e] += (float)rp[e];
+                }
             }
+        }
+        if (C) {
+            _Float16 *cp = C + (size_t)m * g.ldc + n;
+            if (full && ((g.ldc | n) & 7) == 0 && ((((uintptr_t)C) & 15) == 0)) {
+                sd_h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (_Float16)v[e];
+                *reinterpret_cast<sd_h8 *>(cp) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (n + e < g.N) cp[e] = (_Float16)v[e];
+            }
+        }
+        if (C32) {
+            float *cp = C32 + (size_t)m * ldc32 + n;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (n + e < g.N) cp[e] = v[e];
+        }
     }
 }
 
@@ -218,17 +281,46 @@ static int sg_check(const CnerfSdGemm *g) {
     return CNERF_OK;
 }
 
-static uint32_t sg_splits(const CnerfSdGemm *g, uint32_t &k_tiles_per_split) {
-    const uint32_t tiles = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, SG_BN);
+// output-tile width: 64 when the last 128-wide tile would be at most half full, or when 128-wide tiles cannot fill the chip
+static int sg_pick_nt(const CnerfSdGemm *g) {
+    const uint32_t rem = g->N % 128;
+    if (rem != 0 && rem <= 64) return 1;
+    const uint32_t tiles128 = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, 128) * g->batch_outer * g->batch_inner;
+    return tiles128 < 384 ? 1 : 2;
+}
+
+static uint32_t sg_splits(const CnerfSdGemm *g, int nt, uint32_t &k_tiles_per_split) {
+    const uint32_t tiles = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, 64 * nt);
     const uint32_t n_ktiles = cn_div_up(g->K, SG_BK);
     k_tiles_per_split = n_ktiles;
-    if (g->batch_outer * g->batch_inner != 1 || tiles >= 256 || n_ktiles < 8) return 1;
+    if (g->batch_outer * g->batch_inner != 1 || tiles >= 256 || n_ktiles < 16) return 1;
     uint32_t want = cn_div_up(512, tiles);
-    if (want > n_ktiles / 4) want = n_ktiles / 4;          // at least 4 K tiles (256 k) per split
+    if (want > n_ktiles / 8) want = n_ktiles / 8;          // at least 8 K steps (512 k) per split
     if (want > 32) want = 32;
     if (want <= 1) return 1;
     k_tiles_per_split = cn_div_up(n_ktiles, want);
     return cn_div_up(n_ktiles, k_tiles_per_split);
+}
+
+template <int AMODE, int NT, bool SPLIT>
+static void sg_launch(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
+    static bool attr_set = false;
+    auto kern = k_sd_gemm<AMODE, NT, SPLIT>;
+    const uint32_t lds_bytes = sg_lds_bytes(64 * NT);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(SG_THREADS), lds_bytes, st, *g, partial, kps);
+}
+
+template <int AMODE>
+static void sg_launch_nt(const CnerfSdGemm *g, int nt, bool split, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
+    if (nt == 2) {
+        if (split) sg_launch<AMODE, 2, true>(g, grid, st, partial, kps); else sg_launch<AMODE, 2, false>(g, grid, st, partial, kps);
+    } else {
+        if (split) sg_launch<AMODE, 1, true>(g, grid, st, partial, kps); else sg_launch<AMODE, 1, false>(g, grid, st, partial, kps);
+    }
 }
 
 extern "C" {
@@ -238,7 +330,7 @@ int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *g, uint64_t *bytes) {
     int rc = sg_check(g);
     if (rc) return rc;
     uint32_t kps;
-    const uint32_t splits = sg_splits(g, kps);
+    const uint32_t splits = sg_splits(g, sg_pick_nt(g), kps);
     *bytes = splits > 1 ? (uint64_t)splits * g->M * g->N * sizeof(float) : 0;
     return CNERF_OK;
 }
@@ -247,26 +339,24 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
     int rc = sg_check(g);
     if (rc) return rc;
     hipStream_t st = CN_STREAM(stream);
-    const uint32_t lds_bytes = 2 * SG_STAGE_HALFS * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sd_gemm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sd_gemm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+    const int nt = sg_pick_nt(g);
     uint32_t kps;
-    uint32_t splits = sg_splits(g, kps);
-    if (splits > 1 && (!workspace || workspace_bytes < (uint64_t)splits * g->M * g->N * sizeof(float))) { splits = 1; }
-    const dim3 block(SG_THREADS);
-    if (splits > 1) {
-        const dim3 grid(cn_div_up(g->M, SG_BM), cn_div_up(g->N, SG_BN), splits);
-        hipLaunchKernelGGL((k_sd_gemm<true>), grid, block, lds_bytes, st, *g, reinterpret_cast<float *>(workspace), kps);
+    uint32_t splits = sg_splits(g, nt, kps);
+    if (splits > 1 && (!workspace || workspace_bytes < (uint64_t)splits * g->M * g->N * sizeof(float))) {
+        splits = 1;
+        kps = cn_div_up(g->K, SG_BK);
+    }
+    const bool split = splits > 1;
+    const dim3 grid(cn_div_up(g->M, SG_BM), cn_div_up(g->N, 64 * nt), split ? splits : g->batch_outer * g->batch_inner);
+    const int amode = g->mode == 0 ? 0 : ((g->Cin % SG_BK) == 0 ? 2 : 1);
+    float *partial = reinterpret_cast<float *>(workspace);
+    if (amode == 0) sg_launch_nt<0>(g, nt, split, grid, st, partial, kps);
+    else if (amode == 1) sg_launch_nt<1>(g, nt, split, grid, st, partial, kps);
+    else sg_launch_nt<2>(g, nt, split, grid, st, partial, kps);
+    if (split) {
         const size_t total = (size_t)g->M * g->N;
         const uint32_t eb = (uint32_t)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue, dim3(eb), dim3(256), 0, st, *g, reinterpret_cast<const float *>(workspace), splits);
-    } else {
-        const dim3 grid(cn_div_up(g->M, SG_BM), cn_div_up(g->N, SG_BN), g->batch_outer * g->batch_inner);
-        hipLaunchKernelGGL((k_sd_gemm<false>), grid, block, lds_bytes, st, *g, (float *)nullptr, 0u);
     }
     return cn_launch_status();
 }
