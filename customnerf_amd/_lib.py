@@ -51,7 +51,7 @@ SIGNATURES = {
     # ---- include/customnerf_sd.h (score-distillation primitives)
     "cnerf_sd_gemm": [vp, vp, u64, vp],
     "cnerf_sd_gemm_workspace_bytes": [vp, vp],
-    "cnerf_sd_groupnorm_forward": [vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, vp],
+    "cnerf_sd_groupnorm_forward": [vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, i32, vp, vp],
     "cnerf_sd_groupnorm_backward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, vp, vp],
     "cnerf_sd_layernorm_forward": [vp, vp, vp, u32, u32, f32, vp, vp],
     "cnerf_sd_softmax_forward": [vp, u64, u32, u32, vp],
@@ -73,7 +73,7 @@ class SdGemmDesc(C.Structure):
     """struct CnerfSdGemm of include/customnerf_sd.h (field order and types must match)."""
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C32", vp), ("bias", vp), ("bias_rows", vp), ("residual", vp),
                 ("M", u32), ("N", u32), ("K", u32), ("lda", u32), ("ldb", u32), ("ldc", u32), ("ldr", u32),
-                ("rows_per_bias_row", u32), ("alpha", f32), ("act", C.c_int32), ("batch_outer", u32), ("batch_inner", u32),
+                ("rows_per_bias_row", u32), ("ld_bias_rows", u32), ("alpha", f32), ("act", C.c_int32), ("batch_outer", u32), ("batch_inner", u32),
                 ("sa_o", u64), ("sa_i", u64), ("sb_o", u64), ("sb_i", u64), ("sc_o", u64), ("sc_i", u64),
                 ("mode", C.c_int32), ("Cin", u32), ("H_in", u32), ("W_in", u32), ("H_out", u32), ("W_out", u32),
                 ("KH", u32), ("KW", u32), ("stride", u32), ("pad_t", u32), ("pad_l", u32), ("ups", u32), ("tstride", u32)]

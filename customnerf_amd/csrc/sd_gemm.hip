@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const bool full = n + 8 <= g.N;
         if (!SPLIT) {
-            const float *brow_ = g.bias_rows ? g.bias_rows + (size_t)(m / g.rows_per_bias_row) * g.N : nullptr;
+            const float *brow_ = g.bias_rows ? g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) : nullptr;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 if (n + e < g.N) {
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
         float a = 0.0f;
         for (uint32_t s = 0; s < splits; s++) a += partial[(size_t)s * total + i];
         float v = a * g.alpha + (g.bias ? g.bias[n] : 0.0f);
-        if (g.bias_rows) v += g.bias_rows[(size_t)(m / g.rows_per_bias_row) * g.N + n];
+        if (g.bias_rows) v += g.bias_rows[(size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) + n];
         v = sg_act(v, g.act);
         if (g.residual) v += (float)reinterpret_cast<const _Float16 *>(g.residual)[(size_t)m * g.ldr + n];
         if (g.C) reinterpret_cast<_Float16 *>(g.C)[(size_t)m * g.ldc + n] = (_Float16)v;

@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(256) k_gn_apply(const _Float16 *__restrict__ x
                                                   uint32_t HW, uint32_t C, uint32_t G, float eps, int silu, _Float16 *__restrict__ out, size_t total_chunks) {
     const uint32_t nchunks = C / 8, cg = C / G;
     const float inv_n = 1.0f / ((float)HW * (float)cg);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / nchunks;
-        const uint32_t col = (uint32_t)(i - row * nchunks), b = (uint32_t)(row / HW), c0 = col * 8;
+    // 32-bit index arithmetic (64-bit divisions cost more than the memory traffic at UNet sizes); total_chunks < 2^32 is checked on the host
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)total_chunks; i += gridDim.x * blockDim.x) {
+        const uint32_t row = i / nchunks;
+        const uint32_t col = i - row * nchunks, b = row / HW, c0 = col * 8;
         const uint32_t g_lo = c0 / cg, g_hi = (c0 + 7) / cg, split = (g_lo + 1) * cg - c0;
         float mean[2], rstd[2], s1[2] = {0, 0}, s2[2] = {0, 0};
 #pragma unroll
@@ -124,9 +125,9 @@ __global__ void __launch_bounds__(256) k_gn_apply(const _Float16 *__restrict__ x
                 s2[k] = bsums[((size_t)b * G + g) * 2 + 1] * inv_n;
             }
         }
-        const so_h8 xv = so_ld8(x + i * 8);
+        const so_h8 xv = so_ld8(x + (size_t)i * 8);
         so_h8 dv, o;
-        if (MODE == 1) dv = so_ld8(dy + i * 8);
+        if (MODE == 1) dv = so_ld8(dy + (size_t)i * 8);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int k = ((uint32_t)e < split) ? 0 : 1;
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const _Float16 *__restrict__ x
                 o[e] = (_Float16)(rstd[k] * (gq - s1[k] - xh * s2[k]));
             }
         }
-        so_st8(out + i * 8, o);
+        so_st8(out + (size_t)i * 8, o);
     }
 }
 
@@ -443,13 +444,18 @@ static inline void so_zero(float *p, size_t n, hipStream_t st) {
 
 static int gn_check(uint32_t B, uint32_t HW, uint32_t C, uint32_t G) {
     if (B == 0 || HW == 0 || C == 0 || G == 0 || G > GN_MAX_G || (C % G) || (C & 7) || C / G < 4) return CNERF_EINVAL;
+    if ((uint64_t)B * HW * (C / 8) >= (1ull << 32)) return CNERF_EINVAL;
     return CNERF_OK;
 }
-static uint32_t gn_rows_per_block(uint32_t B, uint32_t HW) {
-    uint32_t slabs = 1024 / (B ? B : 1);
-    if (slabs < 1) slabs = 1;
-    uint32_t rpb = cn_div_up(HW, slabs);
-    if (rpb < 8) rpb = 8;
+static uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t C) {
+    // every block ends with 2G same-address float atomics (serialised in L2): ~16 KiB of rows per block, between 16 and 1024
+    // blocks per image — enough blocks to stream a 512x512x128 tensor, few enough that the atomics stay off the critical path
+    const uint32_t row_bytes = C * 2;
+    uint32_t rpb = cn_div_up(16384, row_bytes);
+    const uint32_t lo = cn_div_up(HW, 1024), hi = cn_div_up(HW, 16);
+    if (rpb < lo) rpb = lo;
+    if (rpb > hi) rpb = hi;
+    (void)B;
     return rpb;
 }
 
@@ -469,13 +475,13 @@ static int so_softmax(const void *P, void *S, uint64_t rows, uint32_t cols, uint
 extern "C" {
 
 int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, float eps,
-                               int silu, float *sums, void *y, void *stream) {
+                               int silu, float *sums, int zero_sums, void *y, void *stream) {
     int rc = gn_check(B, HW, C, G);
     if (rc) return rc;
     if (!x || !gamma || !beta || !sums || !y) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    so_zero(sums, (size_t)B * G * 2, st);
-    const uint32_t rpb = gn_rows_per_block(B, HW);
+    if (zero_sums) so_zero(sums, (size_t)B * G * 2, st);
+    const uint32_t rpb = gn_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
                        (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
     const size_t chunks = (size_t)B * HW * (C / 8);
@@ -491,7 +497,7 @@ int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamm
     if (!x || !dy || !gamma || !beta || !sums || !scratch || !dx) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
     so_zero(scratch, (size_t)B * G * 2, st);
-    const uint32_t rpb = gn_rows_per_block(B, HW);
+    const uint32_t rpb = gn_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums, HW,
                        C, G, eps, silu, rpb, scratch);
     const size_t chunks = (size_t)B * HW * (C / 8);

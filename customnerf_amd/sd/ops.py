@@ -86,20 +86,38 @@ def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bi
               residual=residual, ldr=Cout, act=act)
     d.mode, d.Cin, d.H_in, d.W_in, d.H_out, d.W_out = 1, Cin, H, W, Ho, Wo
     d.KH = d.KW = ksize
+    if bias_rows is not None:
+        assert bias_rows.dtype == torch.float32 and bias_rows.stride(1) == 1
+        d.ld_bias_rows = bias_rows.stride(0)
     d.stride, d.pad_t, d.pad_l, d.ups, d.tstride = stride, pad, pad, ups, tstride
     _launch(d, x.device)
     return y
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu):
+class SumsPool:
+    """One pre-zeroed float32 buffer for the GroupNorm statistics of a whole network pass: a single fill launch instead of one
+    zero-fill per norm.  take() hands out consecutive [B, G, 2] slices."""
+
+    def __init__(self, n_norms, B, groups, device):
+        self.buf = torch.zeros(n_norms, B, groups, 2, dtype=torch.float32, device=device)
+        self.i = 0
+
+    def take(self):
+        s = self.buf[self.i]
+        self.i += 1
+        return s
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu, pool=None):
     """x [B, ..., C] half -> (y, sums [B, G, 2] float32: sum and sum of squares per group)."""
     require_cuda(x, gamma)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     assert x.is_contiguous() and x.dtype == torch.float16
     y = torch.empty_like(x)
-    sums = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-    check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(y), stream()), "sd_groupnorm_forward")
+    sums = pool.take() if pool is not None else torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), 0 if pool is not None else 1, ptr(y), stream()),
+          "sd_groupnorm_forward")
     return y, sums
 
 

@@ -26,11 +26,11 @@ class _Resnet:
         if self.has_sc:
             self.sw, self.sb = pack.pack_conv(g("conv_shortcut.weight")), pack.f32(g("conv_shortcut.bias"))
 
-    def __call__(self, x, temb_act, groups, eps):
-        h, _ = ops.groupnorm(x, self.n1w, self.n1b, groups, eps, True)
-        tb = ops.linear(temb_act, self.tw, bias=self.tb, out32=True) if self.has_temb else None        # [B, Cout] float32
+    def __call__(self, x, tb, groups, eps, pool=None):
+        """tb: this block's time_emb_proj(silu(temb)) [B, Cout] float32 (all blocks' projections are one batched GEMM in UNet.forward)"""
+        h, _ = ops.groupnorm(x, self.n1w, self.n1b, groups, eps, True, pool)
         h = ops.conv2d(h, self.c1w, self.c1b, 3, bias_rows=tb)
-        h, _ = ops.groupnorm(h, self.n2w, self.n2b, groups, eps, True)
+        h, _ = ops.groupnorm(h, self.n2w, self.n2b, groups, eps, True, pool)
         sc = ops.conv2d(x, self.sw, self.sb, 1, pad=0) if self.has_sc else x
         return ops.conv2d(h, self.c2w, self.c2b, 3, residual=sc)
 
@@ -53,9 +53,9 @@ class _Transformer:
         self.f1w, self.f1b = pack.pack_linear(g(t + "ff.net.0.proj.weight")), pack.f32(g(t + "ff.net.0.proj.bias"))
         self.f2w, self.f2b = pack.pack_linear(g(t + "ff.net.2.weight")), pack.f32(g(t + "ff.net.2.bias"))
 
-    def __call__(self, x, ctx, groups):
+    def __call__(self, x, ctx, groups, pool=None):
         B, H, W, C = x.shape
-        h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False)
+        h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, pool)
         h = ops.linear(h.view(B, H * W, C), self.piw, bias=self.pib)                     # 1x1 conv on NHWC = linear over channels
         n = ops.layernorm(h, *self.ln[0])
         qkv = ops.linear(n, self.qkv1)                                                   # [B, T, 3C]
@@ -102,6 +102,15 @@ class UNet:
             self.up.append((res, att, us))
         self.now, self.nob = pack.f32(g("conv_norm_out.weight")), pack.f32(g("conv_norm_out.bias"))
         self.cow, self.cob = pack.pack_conv(g("conv_out.weight")), pack.f32(g("conv_out.bias"))
+        # the 22 time_emb_proj linears all read silu(temb): stack them into one [sum Cout, 4C] GEMM (one launch instead of 22)
+        self._resnets = [r for res, _, _ in self.down for r in res] + [self.mid[0], self.mid[2]] + [r for res, _, _ in self.up for r in res]
+        self.tpw = torch.cat([r.tw for r in self._resnets], 0).contiguous()
+        self.tpb = torch.cat([r.tb for r in self._resnets], 0).contiguous()
+        off = 0
+        for r in self._resnets:
+            r.t_off, r.t_n = off, r.tw.shape[0]
+            off += r.t_n
+            del r.tw, r.tb
         self._graph = None
 
     def forward(self, x, t, ctx):
@@ -112,28 +121,31 @@ class UNet:
         temb = ops.timestep_embedding(t, cfg["block_out_channels"][0])
         temb = ops.linear(ops.linear(temb, self.t1w, bias=self.t1b, act=ops.ACT_SILU), self.t2w, bias=self.t2b)
         temb_act = ops.silu(temb)                                                      # every resnet applies SiLU before time_emb_proj
+        tp = ops.linear(temb_act, self.tpw, bias=self.tpb, out32=True)                 # [B, sum Cout] float32
+        pool = ops.SumsPool(2 * len(self._resnets) + 17, x.shape[0], G, x.device)        # one zero-fill for every GroupNorm of the pass
+        tbs = {id(r): tp[:, r.t_off:r.t_off + r.t_n] for r in self._resnets}          # per-block [B, Cout] strided views (bias_rows operand)
         h = ops.conv2d(x, self.ciw, self.cib, 3)
         skips = [h]
         for res, att, ds in self.down:
             for j, r in enumerate(res):
-                h = r(h, temb_act, G, eps)
+                h = r(h, tbs[id(r)], G, eps, pool)
                 if att is not None:
-                    h = att[j](h, ctx, G)
+                    h = att[j](h, ctx, G, pool)
                 skips.append(h)
             if ds is not None:
                 h = ops.conv2d(h, ds[0], ds[1], 3, stride=2, pad=1)
                 skips.append(h)
-        h = self.mid[0](h, temb_act, G, eps)
-        h = self.mid[1](h, ctx, G)
-        h = self.mid[2](h, temb_act, G, eps)
+        h = self.mid[0](h, tbs[id(self.mid[0])], G, eps, pool)
+        h = self.mid[1](h, ctx, G, pool)
+        h = self.mid[2](h, tbs[id(self.mid[2])], G, eps, pool)
         for res, att, us in self.up:
             for j, r in enumerate(res):
-                h = r(ops.concat_channels(h, skips.pop()), temb_act, G, eps)
+                h = r(ops.concat_channels(h, skips.pop()), tbs[id(r)], G, eps, pool)
                 if att is not None:
-                    h = att[j](h, ctx, G)
+                    h = att[j](h, ctx, G, pool)
             if us is not None:
                 h = ops.conv2d(h, us[0], us[1], 3, ups=2)
-        h, _ = ops.groupnorm(h, self.now, self.nob, G, eps, True)
+        h, _ = ops.groupnorm(h, self.now, self.nob, G, eps, True, pool)
         return ops.conv2d(h, self.cow, self.cob, 3)
 
     __call__ = forward

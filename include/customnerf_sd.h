@@ -45,11 +45,12 @@ typedef struct CnerfSdGemm {
     void *C;                  /* half, may be NULL when C32 is set */
     float *C32;               /* float, optional */
     const float *bias;        /* [N] or NULL */
-    const float *bias_rows;   /* [ceil(M / rows_per_bias_row)][N] or NULL */
+    const float *bias_rows;   /* [ceil(M / rows_per_bias_row)][ld_bias_rows] or NULL */
     const void *residual;     /* half [z][M][ldr] or NULL */
     uint32_t M, N, K;
     uint32_t lda, ldb, ldc, ldr;
     uint32_t rows_per_bias_row;
+    uint32_t ld_bias_rows;    /* floats between consecutive rows of bias_rows (0 = N) */
     float alpha;
     int32_t act;
     uint32_t batch_outer, batch_inner;
@@ -64,12 +65,13 @@ int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *desc, uint64_t *bytes);
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC half activations x [B, HW, C] (torch.nn.GroupNorm(G, C, eps) semantics, biased variance, statistics in
  * float32), optionally followed by SiLU (the `norm -> nonlinearity` pair of every diffusers ResnetBlock2D).
- *   stats:   sums [B][G][2] float (sum, sum of squares) — zeroed and filled by the call
+ *   stats:   sums [B][G][2] float (sum, sum of squares) — filled by the call; zero_sums != 0: the call zeroes them first,
+ *            zero_sums == 0: the caller passes zeros (one fill for all the norms of a network instead of one launch each)
  *   forward: y = act((x - mean) * rstd * gamma[c] + beta[c])
  *   backward (frozen gamma/beta): dx from dy, recomputing the forward; `sums` are the forward's; scratch [B][G][2] float.
  * ---------------------------------------------------------------------------------------------- */
 int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C,
-                               uint32_t G, float eps, int silu, float *sums, void *y, void *stream);
+                               uint32_t G, float eps, int silu, float *sums, int zero_sums, void *y, void *stream);
 int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW,
                                 uint32_t C, uint32_t G, float eps, int silu, const float *sums, float *scratch, void *dx,
                                 void *stream);
