@@ -1,0 +1,154 @@
+// Fused attention forward for the UNet (self-attention over 4096 / 1024 / 256 / 64 tokens, cross-attention over 77): softmax(q k^T / sqrt(d)) v per
+// head without materialising the score matrix (537 MB per layer at 64x64 latents otherwise).
+// One wave owns 32 queries, lane = query: the transposed score tile S^T = K Q^T comes out of v_mfma_f32_32x32x16_f16 with the
+// 32 keys of the tile spread over the lane's 16 accumulator registers (x 2 half-waves), so the online-softmax row statistics are
+// per-lane scalars (one cross-half exchange per key tile for the running maximum), and the probabilities — still in their C
+// registers — are directly the B fragments of the second product O^T += V^T P^T (same K-slot permutation trick as the NeRF
+// field kernels, field_common.h).  V is consumed transposed ([C][tokens], produced by cnerf_sd_transpose) so that every
+// MFMA operand is contiguous along its contraction index.  K and V^T tiles are read through L2 (they are shared by all query
+// blocks of a head); head dims 40 / 80 / 160 are padded to the 16- / 32-wide MFMA shapes with zero fragments.
+#include "common.h"
+#include "../../include/customnerf_sd.h"
+
+typedef _Float16 at_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 at_h4 __attribute__((ext_vector_type(4)));
+typedef float at_f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int at_rho(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// KS = ceil(d / 16) k-steps of the score product, DT = ceil(d / 32) output tiles
+template <int KS, int DT>
+__global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict__ Q, const _Float16 *__restrict__ K, const _Float16 *__restrict__ VT,
+                                                      _Float16 *__restrict__ O, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq, uint64_t sq,
+                                                      uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
+    const uint32_t b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const uint32_t q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= Tq) return;
+    const uint32_t qi = q0 + li;
+    const bool q_ok = qi < Tq;
+    const _Float16 *qrow = Q + sq * b + (size_t)qi * ldq + h * d;
+    const _Float16 *kbase = K + sk * b + h * d;
+    const _Float16 *vbase = VT + sv * b + (size_t)(h * d) * ldv;
+
+    // Q fragments (B operand of S^T = K Q^T): lane = query, k = 16 s + 8 hi + j
+    at_h8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const uint32_t c = 16 * s + 8 * hi;
+        at_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q_ok && c < d) v = *reinterpret_cast<const at_h8 *>(qrow + c);          // d % 8 == 0
+        qf[s] = v;
+    }
+    at_f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;                     // running max (identical in both half-waves) and this half's partial sum
+
+    const uint32_t n_kt = (Tk + 31) / 32;
+    for (uint32_t kt = 0; kt < n_kt; kt++) {
+        const uint32_t key0 = kt * 32;
+        // ---- S^T tile: rows = keys (A operand: lane = key li), cols = queries
+        at_f16v sacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+        const uint32_t krow = key0 + li;
+        const _Float16 *kp = kbase + (size_t)krow * ldk;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint32_t c = 16 * s + 8 * hi;
+            at_h8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (krow < Tk && c < d) kf = *reinterpret_cast<const at_h8 *>(kp + c);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+        }
+        // ---- online softmax over this lane's 16 keys (+ the partner half's 16)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t key = key0 + at_rho(r, hi);
+            sacc[r] = key < Tk ? sacc[r] * scale_log2e : -INFINITY;
+            tmax = fmaxf(tmax, sacc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);              // finite: every tile holds at least one valid key
+        const float corr = exp2f(m - m_new);
+        m = m_new;
+        float psum = 0.0f;
+        at_h8 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            at_h8 f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float p = exp2f(sacc[8 * s + j] - m_new);
+                const _Float16 ph = (_Float16)p;
+                f[j] = ph;
+                psum += (float)ph;                       // the denominator sums what the numerator uses
+            }
+            pf[s] = f;
+        }
+        l = l * corr + psum;
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[t][r] *= corr;
+        // ---- O^T += V^T P^T : A = V^T fragment (lane = channel row, K-slots = keys in C-register order: two runs of 4 keys)
+#pragma unroll
+        for (int t = 0; t < DT; t++) {
+            const uint32_t dd = 32 * t + li;
+            const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * hi;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                at_h8 vf = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (dd < d) {
+                    const at_h4 a = *reinterpret_cast<const at_h4 *>(vp + 16 * s), c = *reinterpret_cast<const at_h4 *>(vp + 16 * s + 8);
+                    vf = at_h8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+                }
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (!q_ok) return;
+    _Float16 *orow = O + so * b + (size_t)qi * ldo + h * d;
+#pragma unroll
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t dd = 32 * t + 8 * g + 4 * hi;            // rows rho(4g .. 4g+3, hi) are 4 consecutive channels
+            if (dd < d) {
+                at_h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (_Float16)(o[t][4 * g + e] * inv);
+                *reinterpret_cast<at_h4 *>(orow + dd) = v;          // d % 4 == 0
+            }
+        }
+}
+
+extern "C" {
+
+int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
+                       uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, void *stream) {
+    if (B == 0 || H == 0 || Tq == 0 || Tk == 0 || d == 0 || (d & 7) || d > 160) return CNERF_EINVAL;
+    if ((ldq & 7) || (ldk & 7) || (ldv & 3) || (ldo & 3) || ldv < ((Tk + 31) / 32) * 32) return CNERF_EINVAL;     // V^T rows are read in whole 32-key tiles
+    if ((sq & 7) || (sk & 7) || (sv & 3) || (so & 3)) return CNERF_EINVAL;
+    if (!q || !k || !vT || !out) return CNERF_ENULL;
+    if ((((uintptr_t)q) | ((uintptr_t)k)) & 15 || (((uintptr_t)vT) | ((uintptr_t)out)) & 7) return CNERF_EINVAL;
+    const dim3 grid(cn_div_up(Tq, 128), B * H), block(256);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+    hipStream_t st = CN_STREAM(stream);
+#define AT_LAUNCH(KS, DT)                                                                                                                           \
+    hipLaunchKernelGGL((k_sd_attention<KS, DT>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
+                       d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e)
+    const uint32_t ks = (d + 15) / 16, dt = (d + 31) / 32;
+    if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2);
+    else if (ks <= 5 && dt <= 3) AT_LAUNCH(5, 3);
+    else AT_LAUNCH(10, 5);
+#undef AT_LAUNCH
+    return cn_launch_status();
+}
+
+}  // extern "C"

@@ -212,9 +212,21 @@ def attention_apply(P, v, heads):
 
 
 def attention(q, k, v, heads):
-    """softmax(q k^T / sqrt(d)) v per head; q [B, Tq, C], k / v [B, Tk, C] half."""
-    P = attention_scores(q, k, heads, 1.0 / float(q.shape[-1] // heads) ** 0.5)
-    return attention_apply(P, v, heads)
+    """softmax(q k^T / sqrt(d)) v per head; q [B, Tq, C], k / v [B, Tk, C] half (strided views of a fused projection are fine).
+    Head dims <= 160: the fused kernel (scores never materialised); larger heads: explicit scores (attention_scores / _apply)."""
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    d_ = C // heads
+    if d_ > 160 or d_ % 8:
+        return attention_apply(attention_scores(q, k, heads, 1.0 / float(d_) ** 0.5), v, heads)
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    ldv = (Tk + 31) // 32 * 32
+    vT = torch.empty(B, C, ldv, dtype=torch.float16, device=v.device)
+    transpose_batched(v, Tk, C, v.stride(1), ldv, B, v.stride(0), C * ldv, vT)          # zero-fills the pad columns
+    out = torch.empty(B, Tq, C, dtype=torch.float16, device=q.device)
+    check(lib.cnerf_sd_attention(ptr(q), ptr(k), ptr(vT), ptr(out), B, heads, Tq, Tk, d_, q.stride(1), q.stride(0), k.stride(1), k.stride(0), ldv, C * ldv,
+                                 C, Tq * C, stream()), "sd_attention")
+    return out
 
 
 def gemm_nt(A, Bm, M, N, K, lda, ldb, ldc, out, alpha=1.0):

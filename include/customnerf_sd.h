@@ -86,6 +86,13 @@ int cnerf_sd_layernorm_forward(const void *x, const float *gamma, const float *b
 int cnerf_sd_softmax_forward(void *S, uint64_t rows, uint32_t cols, uint32_t ld, void *stream);
 int cnerf_sd_softmax_backward(const void *P, void *dP, uint64_t rows, uint32_t cols, uint32_t ld, void *stream);
 
+/* Fused attention forward (no materialised scores): out[b][q][h*d + :] = softmax(q_h k_h^T / sqrt(d)) v_h for q [B][Tq][.] (row stride
+ * ldq, batch stride sq, head h at column h*d), k likewise, vT [B][H*d][ldv] = V transposed (cnerf_sd_transpose; columns Tk..ldv-1
+ * must be finite, ldv >= Tk rounded up to 32), out row stride ldo.  d % 8 == 0, d <= 160 (the UNet's 40 / 80 / 160). */
+int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk,
+                       uint32_t d, uint32_t ldq, uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo,
+                       uint64_t so, void *stream);
+
 /* GEGLU (diffusers GEGLU): y[r][c] = x[r][c] * gelu_erf(x[r][c + C]) for x [rows, 2C] -> y [rows, C] (half). */
 int cnerf_sd_geglu(const void *x, uint64_t rows, uint32_t C, void *y, void *stream);
 
