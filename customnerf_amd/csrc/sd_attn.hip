@@ -48,21 +48,46 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
     float m = -INFINITY, l = 0.0f;                     // running max (identical in both half-waves) and this half's partial sum
 
     const uint32_t n_kt = (Tk + 31) / 32;
-    for (uint32_t kt = 0; kt < n_kt; kt++) {
-        const uint32_t key0 = kt * 32;
-        // ---- S^T tile: rows = keys (A operand: lane = key li), cols = queries
-        at_f16v sacc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
-        const uint32_t krow = key0 + li;
+    // K / V^T fragments of tile kt + 1 are fetched while tile kt is processed (register double buffer): with ~2 waves per SIMD the
+    // L2 latency of the fragment loads is otherwise exposed on every tile
+    at_h8 kf[KS], kn[KS];
+    at_h4 va[DT][2][2], vn[DT][2][2];
+    auto load_tile = [&](uint32_t kt, at_h8 (&kd)[KS], at_h4 (&vd)[DT][2][2]) __attribute__((always_inline)) {
+        const uint32_t key0 = kt * 32, krow = key0 + li;
         const _Float16 *kp = kbase + (size_t)krow * ldk;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const uint32_t c = 16 * s + 8 * hi;
-            at_h8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (krow < Tk && c < d) kf = *reinterpret_cast<const at_h8 *>(kp + c);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+            at_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kt < n_kt && krow < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(kp + c);
+            kd[s] = v;
         }
+#pragma unroll
+        for (int t = 0; t < DT; t++) {
+            const uint32_t dd = 32 * t + li;
+            const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * hi;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                at_h4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+                if (kt < n_kt && dd < d) {
+                    x = *reinterpret_cast<const at_h4 *>(vp + 16 * s);
+                    y = *reinterpret_cast<const at_h4 *>(vp + 16 * s + 8);
+                }
+                vd[t][s][0] = x;
+                vd[t][s][1] = y;
+            }
+        }
+    };
+    load_tile(0, kf, va);
+    for (uint32_t kt = 0; kt < n_kt; kt++) {
+        const uint32_t key0 = kt * 32;
+        load_tile(kt + 1, kn, vn);
+        // ---- S^T tile: rows = keys (A operand: lane = key li), cols = queries
+        at_f16v sacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; s++) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], sacc, 0, 0, 0);
         // ---- online softmax over this lane's 16 keys (+ the partner half's 16)
         float tmax = -INFINITY;
 #pragma unroll
@@ -96,19 +121,19 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
             for (int r = 0; r < 16; r++) o[t][r] *= corr;
         // ---- O^T += V^T P^T : A = V^T fragment (lane = channel row, K-slots = keys in C-register order: two runs of 4 keys)
 #pragma unroll
-        for (int t = 0; t < DT; t++) {
-            const uint32_t dd = 32 * t + li;
-            const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * hi;
+        for (int t = 0; t < DT; t++)
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                at_h8 vf = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (dd < d) {
-                    const at_h4 a = *reinterpret_cast<const at_h4 *>(vp + 16 * s), c = *reinterpret_cast<const at_h4 *>(vp + 16 * s + 8);
-                    vf = at_h8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-                }
+                const at_h4 x = va[t][s][0], y = va[t][s][1];
+                const at_h8 vf = at_h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
             }
-        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) kf[s] = kn[s];
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) { va[t][s][0] = vn[t][s][0]; va[t][s][1] = vn[t][s][1]; }
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
