@@ -348,17 +348,32 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
     if (wave < 2) ff_tile_store(part, ff_tile_D(wave, dm, po), li, hi, wX);
 }
 
-// g[i] += sum_b partials[b][i]  over the flat [net | den | rgb] parameter space
+// g[i] += sum_b partials[b][i]  over the flat [net | den | rgb] parameter space.
+// 64 columns per workgroup; the rows are split over 4 thread groups with 8 independent accumulators each (a single thread walking all
+// 256 rows is one long dependent-latency chain: 100 us for 23 MB), combined through LDS.
 __global__ void __launch_bounds__(256) k_field_reduce_partials(const float *__restrict__ partials, uint32_t n_blocks, uint32_t total, uint32_t n_net,
                                                                uint32_t n_den, float *__restrict__ g_net, float *__restrict__ g_den,
                                                                float *__restrict__ g_rgb) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float s = 0.0f;
-    for (uint32_t b = 0; b < n_blocks; b++) s += partials[(size_t)b * total + i];
-    if (i < n_net) g_net[i] += s;
-    else if (i < n_net + n_den) g_den[i - n_net] += s;
-    else g_rgb[i - n_net - n_den] += s;
+    __shared__ float red[4][64];
+    const uint32_t col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + col;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < total) {
+        uint32_t b = grp;
+        for (; b + 28 < n_blocks; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += partials[(size_t)(b + 4 * u) * total + i];
+        }
+        for (; b < n_blocks; b += 4) acc[0] += partials[(size_t)b * total + i];
+    }
+    red[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (grp == 0 && i < total) {
+        const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (i < n_net) g_net[i] += s;
+        else if (i < n_net + n_den) g_den[i - n_net] += s;
+        else g_rgb[i - n_net - n_den] += s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host entry (called from field_bwd.hip)
@@ -407,7 +422,7 @@ int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     int rc = cn_launch_status();
     if (rc) return rc;
     const uint32_t n_net = po.d0, n_den = po.r0 - po.d0;
-    hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(po.total, 256)), dim3(256), 0, st, partials, blocks, po.total, n_net, n_den, g_net,
+    hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(po.total, 64)), dim3(256), 0, st, partials, blocks, po.total, n_net, n_den, g_net,
                        g_den, g_rgb);
     return cn_launch_status();
 }

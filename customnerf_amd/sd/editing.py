@@ -7,10 +7,10 @@ backward through VAE and renderer -> fused Adam.  The per-view cache of the pret
 reference parks it on the CPU and re-uploads it every step: utils_init_nerf.py:260-263)."""
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 from ..optim import FusedAdam
+from ..trainer import allreduce_grads_flat
 
 
 class EditTrainer:
@@ -97,15 +97,7 @@ class EditTrainer:
         return pred_rgb, pred_ws, loss, loss_dict
 
     def allreduce_grads(self):
-        if self.world_size <= 1:
-            return
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n:
-            self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
-        torch._foreach_copy_(list(self._flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self._flat.split([g.numel() for g in grads])))
+        self._flat = allreduce_grads_flat(list(self.model.parameters()), self._flat, self.world_size)     # same path the gloo test exercises
 
     def train_step(self, data):
         """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""

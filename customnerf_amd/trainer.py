@@ -10,6 +10,21 @@ import torch.nn.functional as F
 from .optim import FusedAdam
 
 
+def allreduce_grads_flat(parameters, flat, world_size):
+    """One flattened all-reduce (sum) of all gradients (RCCL over xGMI on GPUs, gloo in the CPU tests); returns the flat buffer
+    for reuse.  The 1/world factor is NOT applied here (folded into the Adam un-scale).  Shared by ReconTrainer and EditTrainer."""
+    if world_size <= 1:
+        return flat
+    grads = [p.grad for p in parameters if p.grad is not None]
+    n = sum(g.numel() for g in grads)
+    if flat is None or flat.numel() != n:
+        flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+    torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    torch._foreach_copy_([g.reshape(-1) for g in grads], list(flat.split([g.numel() for g in grads])))
+    return flat
+
+
 class ReconTrainer:
     def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale=128.0):
         self.model, self.opt = model, opt
@@ -43,14 +58,7 @@ class ReconTrainer:
 
     def allreduce_grads(self):
         """One flattened RCCL all-reduce (sum) per step; the 1/world factor is folded into the Adam un-scale."""
-        if self.world_size <= 1:
-            return
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        if self._flat is None or self._flat.numel() != sum(g.numel() for g in grads):
-            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
-        torch._foreach_copy_(list(self._flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self._flat.split([g.numel() for g in grads])))
+        self._flat = allreduce_grads_flat(list(self.model.parameters()), self._flat, self.world_size)
 
     def train_step(self, rays_o, rays_d, rgbs, mask, **render_kw):
         self.model.train()
