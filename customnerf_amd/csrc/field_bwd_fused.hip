@@ -377,19 +377,36 @@ __global__ void __launch_bounds__(256) k_field_reduce_partials(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------ host entry (called from field_bwd.hip)
-#define FF_MAX_BLOCKS 256
+#define FF_MAX_BLOCKS 512              // partial-gradient rows in the workspace (the wave-specialised kernel uses two per workgroup)
 uint64_t ff_workspace_bytes(const FieldDims &dm) { return (uint64_t)FF_MAX_BLOCKS * ff_offsets(dm).total * sizeof(float) + 256; }
+
+// field_bwd_mma.hip
+bool mm_eligible(const FieldDims &dm);
+int mm_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
+              const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
+              uint32_t max_partials, hipStream_t st);
+
+void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(total, 64)), dim3(256), 0, st, partials, n_partials, total, n_net, n_den, g_net, g_den, g_rgb);
+}
 
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
               float *g_rgb, void *workspace, hipStream_t st) {
+    if (mm_eligible(dm)) {
+        const size_t rows = FF_MAX_BLOCKS;
+        hipError_t e0 = hipMemsetAsync(workspace, 0, rows * ff_offsets(dm).total * sizeof(float), st);
+        if (e0 != hipSuccess) return (int)e0;
+        return mm_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
+    }
     const FieldLds lo = fld_lds_layout<true>(dm);
     const FieldLdsT lt = fb_ldsT_layout<true>(dm);
     const uint32_t lds_bytes = (lo.off[7] + lt.off[7]) * sizeof(_Float16) + FF_STAGE_BYTES;
     if (lds_bytes > 160 * 1024) return CNERF_EINVAL;
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
     uint32_t blocks = cn_div_up(n_tiles, FLD_WAVES);
-    if (blocks > FF_MAX_BLOCKS) blocks = FF_MAX_BLOCKS;
+    if (blocks > 256) blocks = 256;
     const FfOff po = ff_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
     hipError_t e = hipMemsetAsync(partials, 0, (size_t)blocks * po.total * sizeof(float), st);
