@@ -211,19 +211,14 @@ __device__ __forceinline__ void fb_load_enc(const void *__restrict__ enc, uint32
     }
 }
 
+// direction features from an already loaded direction (padded samples must spill zeros: cos(0) = 1 otherwise)
 template <bool H>
-__device__ __forceinline__ void fb_dir_frags(const float *__restrict__ dirs, uint32_t dir_group, uint32_t p, bool valid, uint32_t hi,
-                                             typename Prec<H>::frag_t *b) {
+__device__ __forceinline__ void fb_dir_frags_from(float dx, float dy, float dz, bool valid, uint32_t hi, typename Prec<H>::frag_t *b) {
     float e[FLD_DIR];
-    float dx = 0, dy = 0, dz = 0;
-    if (valid) {
-        const float *d = dirs + (size_t)(p / dir_group) * 3;
-        dx = d[0]; dy = d[1]; dz = d[2];
-    }
     fld_dir_features<H>(dx, dy, dz, e);
     if (!valid) {
 #pragma unroll
-        for (int q = 0; q < FLD_DIR; q++) e[q] = 0.0f;       // padded samples must spill zeros (cos(0) = 1 otherwise)
+        for (int q = 0; q < FLD_DIR; q++) e[q] = 0.0f;
     }
     if constexpr (H) {
 #pragma unroll
@@ -237,6 +232,17 @@ __device__ __forceinline__ void fb_dir_frags(const float *__restrict__ dirs, uin
 #pragma unroll
         for (int s = 0; s < FLD_DIR / 2; s++) b[s] = hi ? e[2 * s + 1] : e[2 * s];
     }
+}
+
+template <bool H>
+__device__ __forceinline__ void fb_dir_frags(const float *__restrict__ dirs, uint32_t dir_group, uint32_t p, bool valid, uint32_t hi,
+                                             typename Prec<H>::frag_t *b) {
+    float dx = 0, dy = 0, dz = 0;
+    if (valid) {
+        const float *d = dirs + (size_t)(p / dir_group) * 3;
+        dx = d[0]; dy = d[1]; dz = d[2];
+    }
+    fb_dir_frags_from<H>(dx, dy, dz, valid, hi, b);
 }
 
 // LDS layout of the backward kernel: forward fragment stores (as field.hip) then the transposed stores (fp16 only)

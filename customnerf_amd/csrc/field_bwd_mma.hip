@@ -173,16 +173,27 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_mma(const void *__res
         frag_t x0p[SENC], h1p[4], h2p[4];                     // the previous tile's activations (its backward runs one barrier later)
         uint32_t p_prev = 0;
         bool valid_prev = false;
+        // grid features of the NEXT tile are requested one iteration ahead: at one wave per SIMD nothing else hides the load latency
+        frag_t x0n[SENC];
+        {
+            const uint32_t p0 = gp * FLD_TILE + li;
+            fb_load_enc<H, SENC>(enc, P_, dm.L, p0, (n_iter > 0) && p0 < P_, hi, x0n);
+        }
         for (uint32_t i = 0; i <= n_iter; i++) {
             asm volatile("" ::: "memory");
             frag_t x0c[SENC], h1c[4], h2c[4];
             uint32_t p_cur = 0;
             bool valid_cur = false;
+#pragma unroll
+            for (int s = 0; s < SENC; s++) x0c[s] = x0n[s];
+            {
+                const uint32_t pn = (gp + (i + 1) * n_pairs) * FLD_TILE + li;
+                fb_load_enc<H, SENC>(enc, P_, dm.L, pn, (i + 1 < n_iter) && pn < P_, hi, x0n);
+            }
             if (i < n_iter) {
                 const uint32_t tile = gp + i * n_pairs;
                 p_cur = tile * FLD_TILE + li;
                 valid_cur = p_cur < P_;
-                fb_load_enc<H, SENC>(enc, P_, dm.L, p_cur, valid_cur, hi, x0c);
                 cn_f16v acc[2];
                 fb_zero(acc);
                 fb_gemm<H, 2, SENC>(wl + lo.off[0], SENC, 0, x0c, lane, acc);
@@ -270,6 +281,25 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_mma(const void *__res
 #pragma unroll
                 for (int r = 0; r < 16; r++) { wrf[a][b][r] = 0.0f; wd0[a][b][r] = 0.0f; }
         }
+        // raw per-sample inputs of the NEXT tile (position, direction, incoming gradients) are requested one iteration ahead
+        struct BIn { float x, y, z, dx, dy, dz, gs; float4 gc; };
+        auto load_in = [&](uint32_t tile, bool on) __attribute__((always_inline)) {
+            BIn r;
+            r.x = r.y = r.z = r.dx = r.dy = r.dz = r.gs = 0.0f;
+            r.gc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const uint32_t p = tile * FLD_TILE + li;
+            if (on && p < P_) {
+                const float *d = dirs + (size_t)(p / dir_group) * 3;
+                r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+                if (hi == 0) {
+                    r.x = xyz[(size_t)p * 3]; r.y = xyz[(size_t)p * 3 + 1]; r.z = xyz[(size_t)p * 3 + 2];
+                    r.gs = g_sigma[p];
+                    r.gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
+                }
+            }
+            return r;
+        };
+        BIn nxt = load_in(gp, n_iter > 0);
         for (uint32_t i = 0; i <= n_iter; i++) {
             asm volatile("" ::: "memory");
             __syncthreads();
@@ -277,6 +307,8 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_mma(const void *__res
             const uint32_t tile = gp + i * n_pairs;
             const uint32_t p = tile * FLD_TILE + li;
             const bool valid = p < P_;
+            const BIn cur = nxt;
+            nxt = load_in(gp + (i + 1) * n_pairs, i + 1 < n_iter);
             frag_t fea[4];
             mm_fetch(x_fea + (i & 1) * MM_XCHG_BYTES, lane, fea);
             // ---- forward of both heads
@@ -288,7 +320,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_mma(const void *__res
             fb_zero(out);
             fb_gemm<H, 1, S64>(wl + lo.off[4], S64, 0, hd, lane, out);
             const float raw = (float)(_Float16)out[0][0];
-            fb_dir_frags<H>(dirs, dir_group, p, valid, hi, dfr);
+            fb_dir_frags_from<H>(cur.dx, cur.dy, cur.dz, valid, hi, dfr);
             fb_zero(acc);
             fb_gemm<H, 2, S64>(wl + lo.off[5], SR0, 0, fea, lane, acc);
             fb_gemm<H, 2, SDIR>(wl + lo.off[5], SR0, S64, dfr, lane, acc);
@@ -300,11 +332,10 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_mma(const void *__res
             {
                 cn_h8 f = PR::zero(), g = PR::zero();
                 if (valid && hi == 0) {
-                    const float x = xyz[(size_t)p * 3], y = xyz[(size_t)p * 3 + 1], z = xyz[(size_t)p * 3 + 2];
+                    const float x = cur.x, y = cur.y, z = cur.z;
                     const float gg = 5.0f * expf(-(x * x + y * y + z * z) / 0.08f);
-                    g[0] = (_Float16)(g_sigma[p] * expf(fminf(fmaxf(raw + gg, -15.0f), 15.0f)));
-                    const float4 gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
-                    const float gcv[4] = {gc.x, gc.y, gc.z, gc.w};
+                    g[0] = (_Float16)(cur.gs * expf(fminf(fmaxf(raw + gg, -15.0f), 15.0f)));
+                    const float gcv[4] = {cur.gc.x, cur.gc.y, cur.gc.z, cur.gc.w};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float sg = (float)(_Float16)(1.0f / (1.0f + expf(-out[0][k])));
