@@ -20,7 +20,7 @@ __device__ __forceinline__ int at_rho(int r, int hi) { return (r & 3) + 8 * (r >
 template <int KS, int DT>
 __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict__ Q, const _Float16 *__restrict__ K, const _Float16 *__restrict__ VT,
                                                       _Float16 *__restrict__ O, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq, uint64_t sq,
-                                                      uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e) {
+                                                      uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e, int causal) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
     const uint32_t b = blockIdx.y / H, h = blockIdx.y - b * H;
     const uint32_t q0 = (blockIdx.x * 4 + wave) * 32;
@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
     float m = -INFINITY, l = 0.0f;                     // running max (identical in both half-waves) and this half's partial sum
 
-    const uint32_t n_kt = (Tk + 31) / 32;
+    // causal (CLIP text encoder): query q attends to keys <= q; the wave's key range ends with its last query
+    const uint32_t n_kt = causal ? min((Tk + 31) / 32, (min(q0 + 32, Tq) + 31) / 32) : (Tk + 31) / 32;
     // K / V^T fragments of tile kt + 1 are fetched while tile kt is processed (register double buffer): with ~2 waves per SIMD the
     // L2 latency of the fragment loads is otherwise exposed on every tile
     at_h8 kf[KS], kn[KS];
@@ -93,11 +94,11 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t key = key0 + at_rho(r, hi);
-            sacc[r] = key < Tk ? sacc[r] * scale_log2e : -INFINITY;
+            sacc[r] = (key < Tk && !(causal && key > qi)) ? sacc[r] * scale_log2e : -INFINITY;
             tmax = fmaxf(tmax, sacc[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);              // finite: every tile holds at least one valid key
+        const float m_new = fmaxf(fmaxf(m, tmax), -1e30f);   // stays finite even when a causal tile holds no key for this query yet
         const float corr = exp2f(m - m_new);
         m = m_new;
         float psum = 0.0f;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
 extern "C" {
 
 int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
-                       uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, void *stream) {
+                       uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
     if (B == 0 || H == 0 || Tq == 0 || Tk == 0 || d == 0 || (d & 7) || d > 160) return CNERF_EINVAL;
     if ((ldq & 7) || (ldk & 7) || (ldv & 3) || (ldo & 3) || ldv < ((Tk + 31) / 32) * 32) return CNERF_EINVAL;     // V^T rows are read in whole 32-key tiles
     if ((sq & 7) || (sk & 7) || (sv & 3) || (so & 3)) return CNERF_EINVAL;
@@ -167,9 +168,10 @@ int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, 
     hipStream_t st = CN_STREAM(stream);
 #define AT_LAUNCH(KS, DT)                                                                                                                           \
     hipLaunchKernelGGL((k_sd_attention<KS, DT>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
-                       d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e)
+                       d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e, causal)
     const uint32_t ks = (d + 15) / 16, dt = (d + 31) / 32;
     if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2);
+    else if (ks <= 4 && dt <= 2) AT_LAUNCH(4, 2);
     else if (ks <= 5 && dt <= 3) AT_LAUNCH(5, 3);
     else AT_LAUNCH(10, 5);
 #undef AT_LAUNCH

@@ -35,6 +35,7 @@ __host__ __device__ constexpr uint32_t sg_lds_bytes(int bn) {
 __device__ __forceinline__ float sg_act(float v, int act) {
     if (act == 1) return v / (1.0f + __expf(-v));
     if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    if (act == 3) return v / (1.0f + __expf(-1.702f * v));
     return v;
 }
 
@@ -267,7 +268,7 @@ static int sg_check(const CnerfSdGemm *g) {
     if (!g->A || !g->B || (!g->C && !g->C32)) return CNERF_ENULL;
     if (g->M == 0 || g->N == 0 || g->K == 0 || (g->K & 7) || (g->ldb & 7)) return CNERF_EINVAL;
     if (g->batch_outer == 0 || g->batch_inner == 0) return CNERF_EINVAL;
-    if (g->act < 0 || g->act > 2) return CNERF_EINVAL;
+    if (g->act < 0 || g->act > 3) return CNERF_EINVAL;
     if (g->bias_rows && g->rows_per_bias_row == 0) return CNERF_EINVAL;
     if ((((uintptr_t)g->A) | ((uintptr_t)g->B)) & 15) return CNERF_EINVAL;
     if (g->mode == 0) {

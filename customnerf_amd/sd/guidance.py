@@ -45,10 +45,12 @@ class StableDiffusion(nn.Module):
 
     # ---- text (sd.py:77-94)
     def get_text_embeds(self, prompt, negative_prompt):
+        """`text_encoder` is customnerf_amd.sd.text_encoder.CLIPTextEncoder (the SD-1.5 CLIP text tower on the HIP library) built from the
+        checkpoint's `text_encoder` state dict; `tokenizer` is transformers' CLIPTokenizer (BPE vocabulary files: host-side plumbing)."""
         if self.text_encoder is None or self.tokenizer is None:
             raise NotImplementedError(
-                "the CLIP tokenizer / text encoder (transformers, runwayml/stable-diffusion-v1-5) are not available offline; pass "
-                "`text_encoder=` and `tokenizer=` or use synthetic_text_embeds()")
+                "the CLIP tokenizer vocabulary / text-encoder weights (runwayml/stable-diffusion-v1-5) are not available offline; pass "
+                "`text_encoder=CLIPTextEncoder(...)` and `tokenizer=` or use synthetic_text_embeds()")
         def enc(p):
             ids = self.tokenizer(p, padding='max_length', max_length=self.tokenizer.model_max_length, truncation=True, return_tensors='pt').input_ids
             with torch.no_grad():

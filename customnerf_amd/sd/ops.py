@@ -8,7 +8,7 @@ import torch
 
 from .._lib import lib, check, ptr, stream, require_cuda, SdGemmDesc
 
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 _WS = {}
 _PROFILE = None
 
@@ -211,13 +211,14 @@ def attention_apply(P, v, heads):
     return O
 
 
-def attention(q, k, v, heads):
+def attention(q, k, v, heads, causal=False):
     """softmax(q k^T / sqrt(d)) v per head; q [B, Tq, C], k / v [B, Tk, C] half (strided views of a fused projection are fine).
     Head dims <= 160: the fused kernel (scores never materialised); larger heads: explicit scores (attention_scores / _apply)."""
     B, Tq, C = q.shape
     Tk = k.shape[1]
     d_ = C // heads
     if d_ > 160 or d_ % 8:
+        assert not causal
         return attention_apply(attention_scores(q, k, heads, 1.0 / float(d_) ** 0.5), v, heads)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     ldv = (Tk + 31) // 32 * 32
@@ -225,7 +226,7 @@ def attention(q, k, v, heads):
     transpose_batched(v, Tk, C, v.stride(1), ldv, B, v.stride(0), C * ldv, vT)          # zero-fills the pad columns
     out = torch.empty(B, Tq, C, dtype=torch.float16, device=q.device)
     check(lib.cnerf_sd_attention(ptr(q), ptr(k), ptr(vT), ptr(out), B, heads, Tq, Tk, d_, q.stride(1), q.stride(0), k.stride(1), k.stride(0), ldv, C * ldv,
-                                 C, Tq * C, stream()), "sd_attention")
+                                 C, Tq * C, int(causal), stream()), "sd_attention")
     return out
 
 

@@ -31,7 +31,7 @@ extern "C" {
  *      valid iff ih < H_in (same for w); invalid taps read 0.   A(m,k) = in[image][ih][iw][c], c < Cin, Cin % 8 == 0.
  *   forward conv (torch.nn.Conv2d):            stride s, pad p, tstride 1
  *   input-gradient of a conv (frozen weights):  stride 1, pad KH-1-p, tstride s, B = weights flipped and transposed
- * epilogue, in this order:  (+ bias[n])  (+ bias_rows[(m / rows_per_bias_row)][n])  (activation: 0 none, 1 SiLU, 2 GELU(erf))
+ * epilogue, in this order:  (+ bias[n])  (+ bias_rows[(m / rows_per_bias_row)][n])  (activation: 0 none, 1 SiLU, 2 GELU(erf), 3 quick-GELU x*sigmoid(1.702x))
  *                           (+ residual[z][m][n])  -> C (half), and/or C32 (float, optional).
  * batching: z = zo * batch_inner + zi, operand bases advance by s?_o * zo + s?_i * zi elements (attention heads are a strided
  * view of [batch, tokens, heads*dim]); batch = 1 and zero strides for plain GEMMs / convs.
@@ -88,10 +88,11 @@ int cnerf_sd_softmax_backward(const void *P, void *dP, uint64_t rows, uint32_t c
 
 /* Fused attention forward (no materialised scores): out[b][q][h*d + :] = softmax(q_h k_h^T / sqrt(d)) v_h for q [B][Tq][.] (row stride
  * ldq, batch stride sq, head h at column h*d), k likewise, vT [B][H*d][ldv] = V transposed (cnerf_sd_transpose; columns Tk..ldv-1
- * must be finite, ldv >= Tk rounded up to 32), out row stride ldo.  d % 8 == 0, d <= 160 (the UNet's 40 / 80 / 160). */
+ * must be finite, ldv >= Tk rounded up to 32), out row stride ldo.  d % 8 == 0, d <= 160 (the UNet's 40 / 80 / 160, CLIP's 64).
+ * causal != 0: query i attends to keys <= i (CLIP text encoder). */
 int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk,
                        uint32_t d, uint32_t ldq, uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo,
-                       uint64_t so, void *stream);
+                       uint64_t so, int causal, void *stream);
 
 /* GEGLU (diffusers GEGLU): y[r][c] = x[r][c] * gelu_erf(x[r][c + C]) for x [rows, 2C] -> y [rows, C] (half). */
 int cnerf_sd_geglu(const void *x, uint64_t rows, uint32_t C, void *y, void *stream);

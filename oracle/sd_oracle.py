@@ -156,3 +156,22 @@ def train_step_sd(vae_sd, vae_cfg, unet_sd, unet_cfg, img_rgb, text_embeddings, 
     target = (latents - grad).detach()
     loss = 0.5 * F.mse_loss(latents, target, reduction="sum")
     return loss, latents, grad
+
+
+# ------------------------------------------------------------------------------------------------ CLIP text encoder (get_text_embeds, sd.py:77-94)
+def clip_text_forward(sd, cfg, input_ids):
+    """transformers CLIPTextModel (ViT-L/14 text tower of SD-1.5): pre-LN layers, causal attention, quick-GELU; returns last_hidden_state."""
+    B, T = input_ids.shape
+    W, Hh = cfg["width"], cfg["heads"]
+    h = sd["text_model.embeddings.token_embedding.weight"][input_ids] + sd["text_model.embeddings.position_embedding.weight"][:T][None]
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    for i in range(cfg["layers"]):
+        p = f"text_model.encoder.layers.{i}."
+        n = F.layer_norm(h, (W,), sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"], cfg["eps"])
+        q, k, v = (_lin(n, sd, p + f"self_attn.{x}_proj").view(B, T, Hh, W // Hh).transpose(1, 2) for x in ("q", "k", "v"))
+        w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(W // Hh) + mask, dim=-1)
+        h = h + _lin((w @ v).transpose(1, 2).reshape(B, T, W), sd, p + "self_attn.out_proj")
+        n = F.layer_norm(h, (W,), sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], cfg["eps"])
+        f = _lin(n, sd, p + "mlp.fc1")
+        h = h + _lin(f * torch.sigmoid(1.702 * f), sd, p + "mlp.fc2")
+    return F.layer_norm(h, (W,), sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"], cfg["eps"])

@@ -118,3 +118,59 @@ def test_sds_train_step_matches_oracle():
     assert all(t_ <= 980 * 0.5 + 1 for t_ in [guide.draw_timestep(None, 0.5) for _ in range(50)])
     with pytest.raises(NotImplementedError):
         guide.get_text_embeds(["a"], [""])
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "sd15"])
+def test_clip_text_encoder(cfg_name):
+    """get_text_embeds' text tower (causal attention, quick-GELU) against the oracle restatement of transformers' CLIPTextModel"""
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd import text_encoder as te
+    cfg = te.CLIP_TEXT_TINY if cfg_name == "tiny" else te.CLIP_TEXT_SD15
+    sd = half_sd(arch.random_state_dict(te.clip_text_params(cfg), seed=21))
+    if cfg_name == "sd15":
+        assert arch.count(te.clip_text_params(cfg)) == 123_060_480          # CLIP ViT-L/14 text model
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, cfg["vocab_size"], (2, 77), generator=g)
+    with torch.no_grad():
+        ref = so.clip_text_forward(sd, cfg, ids)
+        out = te.CLIPTextEncoder(cfg, sd, "cuda")(ids.cuda())[0]
+    assert out.shape == (2, 77, cfg["width"])
+    emax, el2 = rel_err(out, ref)
+    assert emax < 3e-2 and el2 < 1e-2, (emax, el2)
+    # causality: changing a late token must not change earlier positions
+    ids2 = ids.clone()
+    ids2[:, 50] = (ids2[:, 50] + 1) % cfg["vocab_size"]
+    with torch.no_grad():
+        out2 = te.CLIPTextEncoder(cfg, sd, "cuda")(ids2.cuda())[0]
+    assert torch.equal(out2[:, :50], out[:, :50]) and not torch.equal(out2[:, 50:], out[:, 50:])
+
+
+def test_get_text_embeds_with_injected_tokenizer():
+    """sd.py:77-94: [uncond ; text] order, max_length padding — with a stand-in tokenizer (the BPE vocabulary is not available offline)"""
+    import types
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd import text_encoder as te
+    from customnerf_amd.sd.guidance import StableDiffusion
+    cfg = te.CLIP_TEXT_TINY
+    sd = arch.random_state_dict(te.clip_text_params(cfg), seed=5)
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, text, padding=None, max_length=None, truncation=None, return_tensors=None):
+            ids = torch.zeros(len(text), max_length, dtype=torch.long)
+            for i, t in enumerate(text):
+                codes = [ord(c) % cfg["vocab_size"] for c in t][:max_length]
+                ids[i, :len(codes)] = torch.tensor(codes, dtype=torch.long)
+            return types.SimpleNamespace(input_ids=ids)
+
+    opt = types.SimpleNamespace(cfg=7.5, lambda_sd=0.01, max_ratio=0.98, stage_time=False, iters=10, log_loss_item=False)
+    ucfg, vcfg = arch.UNET_TINY, arch.VAE_TINY
+    guide = StableDiffusion("cuda", "1.5", opt, unet_state=arch.random_state_dict(arch.unet_params(ucfg), 1), vae_state=arch.random_state_dict(arch.vae_encoder_params(vcfg), 2),
+                            unet_cfg=ucfg, vae_cfg=vcfg, text_encoder=te.CLIPTextEncoder(cfg, sd, "cuda"), tokenizer=Tok())
+    z = guide.get_text_embeds(["a corgi in a forest"], [""])
+    assert z.shape == (2, 77, cfg["width"])
+    with torch.no_grad():
+        ref_text = so.clip_text_forward(half_sd(sd), cfg, Tok()(["a corgi in a forest"], max_length=77).input_ids)
+    assert rel_err(z[1:], ref_text)[1] < 1e-2                       # row 1 = the prompt, row 0 = the negative prompt
+    assert not torch.equal(z[0], z[1])
