@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restr
 #pragma unroll
                 for (int e = 0; e < 8; e++) { gam[e] = gamma[c0 + e]; bet[e] = beta[c0 + e]; }
             }
-            for (uint32_t r = r0 + trow; r < r1; r += q.rows_per_pass) {
+#pragma unroll 4
+            for (uint32_t r = r0 + trow; r < r1; r += q.rows_per_pass) {      // unrolled: four independent 16-byte loads in flight per thread
                 const size_t off = ((size_t)b * HW + r) * C + c0;
                 const so_h8 xv = so_ld8(x + off);
                 so_h8 dv;
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restr
                 s2[e] = bsums[((size_t)b * G + g) * 2 + 1] * inv_n;
             }
         }
+#pragma unroll 4
         for (uint32_t r = r0 + trow; r < r1; r += q.rows_per_pass) {
             const size_t off = ((size_t)b * HW + r) * C + c0;
             const so_h8 xv = so_ld8(x + off);
