@@ -24,9 +24,8 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
     const uint32_t b = blockIdx.y / H, h = blockIdx.y - b * H;
     const uint32_t q0 = (blockIdx.x * 4 + wave) * 32;
-    if (q0 >= Tq) return;
     const uint32_t qi = q0 + li;
-    const bool q_ok = qi < Tq;
+    const bool q_ok = qi < Tq;                               // waves past the last query keep running (workgroup barriers below), results unused
     const _Float16 *qrow = Q + sq * b + (size_t)qi * ldq + h * d;
     const _Float16 *kbase = K + sk * b + h * d;
     const _Float16 *vbase = VT + sv * b + (size_t)(h * d) * ldv;
@@ -47,48 +46,56 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
     float m = -INFINITY, l = 0.0f;                     // running max (identical in both half-waves) and this half's partial sum
 
-    // causal (CLIP text encoder): query q attends to keys <= q; the wave's key range ends with its last query
-    const uint32_t n_kt = causal ? min((Tk + 31) / 32, (min(q0 + 32, Tq) + 31) / 32) : (Tk + 31) / 32;
-    // K / V^T fragments of tile kt + 1 are fetched while tile kt is processed (register double buffer): with ~2 waves per SIMD the
-    // L2 latency of the fragment loads is otherwise exposed on every tile
-    at_h8 kf[KS], kn[KS];
-    at_h4 va[DT][2][2], vn[DT][2][2];
-    auto load_tile = [&](uint32_t kt, at_h8 (&kd)[KS], at_h4 (&vd)[DT][2][2]) __attribute__((always_inline)) {
-        const uint32_t key0 = kt * 32, krow = key0 + li;
-        const _Float16 *kp = kbase + (size_t)krow * ldk;
+    // The four waves of a workgroup share the K / V^T tiles of their (batch, head) through LDS, stored in MFMA fragment order
+    // ([fragment][lane] x 16 B: conflict-free ds_read_b128), double-buffered; every thread stages NF / 256 fragments-lanes per tile,
+    // fetched one tile ahead into registers.  (Each wave reading its own fragments from L2 cost 4x the L2 traffic: 1.8 GB per
+    // 4096-token layer.)
+    constexpr int NF = KS + 2 * DT;                    // fragments per key tile: KS of K, 2 per 32-channel tile of V^T
+    constexpr int PER = (NF * 64 + 255) / 256;         // staged 16-byte items per thread
+    __shared__ __attribute__((aligned(16))) at_h8 tile[2][NF * 64];
+    // causal (CLIP text encoder): query q attends to keys <= q; the workgroup's key range ends with its last query
+    const uint32_t q_end = min(blockIdx.x * 128 + 128, Tq);
+    const uint32_t n_kt = causal ? min((Tk + 31) / 32, (q_end + 31) / 32) : (Tk + 31) / 32;
+    at_h8 stage[PER];
+    auto fetch = [&](uint32_t kt) __attribute__((always_inline)) {
+        const uint32_t key0 = kt * 32;
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const uint32_t c = 16 * s + 8 * hi;
+        for (int it = 0; it < PER; it++) {
+            const uint32_t item = it * 256 + threadIdx.x, f = item >> 6, ln = item & 63, fl = ln & 31, fh = ln >> 5;
             at_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt < n_kt && krow < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(kp + c);
-            kd[s] = v;
-        }
-#pragma unroll
-        for (int t = 0; t < DT; t++) {
-            const uint32_t dd = 32 * t + li;
-            const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * hi;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                at_h4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
-                if (kt < n_kt && dd < d) {
-                    x = *reinterpret_cast<const at_h4 *>(vp + 16 * s);
-                    y = *reinterpret_cast<const at_h4 *>(vp + 16 * s + 8);
+            if (f < (uint32_t)KS) {
+                const uint32_t krow = key0 + fl, c = 16 * f + 8 * fh;
+                if (krow < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(kbase + (size_t)krow * ldk + c);
+            } else if (f < (uint32_t)NF) {
+                const uint32_t g = f - KS, t = g >> 1, s2 = g & 1, dd = 32 * t + fl;
+                if (dd < d) {
+                    const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * fh + 16 * s2;
+                    const at_h4 x = *reinterpret_cast<const at_h4 *>(vp), y = *reinterpret_cast<const at_h4 *>(vp + 8);
+                    v = at_h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
                 }
-                vd[t][s][0] = x;
-                vd[t][s][1] = y;
             }
+            stage[it] = v;
         }
     };
-    load_tile(0, kf, va);
+    auto commit = [&](uint32_t buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+            const uint32_t item = it * 256 + threadIdx.x;
+            if (item < (uint32_t)NF * 64) tile[buf][item] = stage[it];
+        }
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
     for (uint32_t kt = 0; kt < n_kt; kt++) {
-        const uint32_t key0 = kt * 32;
-        load_tile(kt + 1, kn, vn);
+        const uint32_t key0 = kt * 32, buf = kt & 1;
+        if (kt + 1 < n_kt) fetch(kt + 1);
         // ---- S^T tile: rows = keys (A operand: lane = key li), cols = queries
         at_f16v sacc;
 #pragma unroll
         for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < KS; s++) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], sacc, 0, 0, 0);
+        for (int s = 0; s < KS; s++) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][s * 64 + lane], qf[s], sacc, 0, 0, 0);
         // ---- online softmax over this lane's 16 keys (+ the partner half's 16)
         float tmax = -INFINITY;
 #pragma unroll
@@ -124,17 +131,9 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
 #pragma unroll
         for (int t = 0; t < DT; t++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const at_h4 x = va[t][s][0], y = va[t][s][1];
-                const at_h8 vf = at_h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
-            }
-#pragma unroll
-        for (int s = 0; s < KS; s++) kf[s] = kn[s];
-#pragma unroll
-        for (int t = 0; t < DT; t++)
-#pragma unroll
-            for (int s = 0; s < 2; s++) { va[t][s][0] = vn[t][s][0]; va[t][s][1] = vn[t][s][1]; }
+            for (int s = 0; s < 2; s++) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][(KS + 2 * t + s) * 64 + lane], pf[s], o[t], 0, 0, 0);
+        if (kt + 1 < n_kt) commit(buf ^ 1);
+        __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
