@@ -70,6 +70,15 @@ class StableDiffusion(nn.Module):
             sample_noise = torch.randn(B, self.vae_cfg["latent_channels"], resize[0] // 8, resize[1] // 8, device=imgs.device)
         return self.vae.encode_imgs(imgs, sample_noise, resize)
 
+    def load_custom_diffusion(self, attn_procs_state, new_token_embedding=None):
+        """sd.py:56-59 (`opt.use_cd`): Custom-Diffusion cross-attention weights into the UNet, and the `<new1>` textual-inversion
+        embedding into the text encoder.  Returns (#replaced attention layers, new token id or None)."""
+        n = self.unet.load_attn_procs(attn_procs_state)
+        tid = None
+        if new_token_embedding is not None and self.text_encoder is not None and hasattr(self.text_encoder, "add_token_embedding"):
+            tid = self.text_encoder.add_token_embedding(new_token_embedding)
+        return n, tid
+
     def get_params(self, lr):
         return []
 

@@ -43,6 +43,14 @@ class CLIPTextEncoder:
                 fc1=(pack.pack_linear(g(p + "mlp.fc1.weight")), pack.f32(g(p + "mlp.fc1.bias"))), fc2=(pack.pack_linear(g(p + "mlp.fc2.weight")), pack.f32(g(p + "mlp.fc2.bias")))))
         self.lnf = (pack.f32(g("text_model.final_layer_norm.weight")), pack.f32(g("text_model.final_layer_norm.bias")))
 
+    def add_token_embedding(self, vector):
+        """Textual inversion (`pipe.load_textual_inversion(model_id, weight_name="<new1>.bin")`, sd.py:58): appends one learned
+        embedding row and returns its token id (the tokenizer maps the placeholder string to it)."""
+        v = vector.reshape(1, -1).to(self.tok.device, torch.float16)
+        assert v.shape[1] == self.cfg["width"]
+        self.tok = torch.cat([self.tok, v], 0)
+        return self.tok.shape[0] - 1
+
     def __call__(self, input_ids):
         """input_ids [B, T<=77] int64 on device -> (last_hidden_state [B, T, width] half,)   (tuple: callers index [0], sd.py:85)"""
         cfg = self.cfg

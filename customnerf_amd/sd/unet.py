@@ -53,6 +53,21 @@ class _Transformer:
         self.f1w, self.f1b = pack.pack_linear(g(t + "ff.net.0.proj.weight")), pack.f32(g(t + "ff.net.0.proj.bias"))
         self.f2w, self.f2b = pack.pack_linear(g(t + "ff.net.2.weight")), pack.f32(g(t + "ff.net.2.bias"))
 
+    def load_custom_diffusion(self, sd, prefix, dev):
+        """Custom-Diffusion attention processor of this block (diffusers CustomDiffusionAttnProcessor, loaded by the reference through
+        `unet.load_attn_procs`, sd.py:56-58): fine-tuned cross-attention K/V projections (and optionally Q / out) replace the base ones."""
+        k, v = prefix + "to_k_custom_diffusion.weight", prefix + "to_v_custom_diffusion.weight"
+        if k in sd and v in sd:
+            self.kv2 = pack.pack_linear(torch.cat([sd[k].to(dev), sd[v].to(dev)], 0))
+        q = prefix + "to_q_custom_diffusion.weight"
+        if q in sd:
+            self.q2 = pack.pack_linear(sd[q].to(dev))
+        o = prefix + "to_out_custom_diffusion.0.weight"
+        if o in sd:
+            self.o2w = pack.pack_linear(sd[o].to(dev))
+            self.o2b = pack.f32(sd[prefix + "to_out_custom_diffusion.0.bias"].to(dev))
+        return k in sd
+
     def __call__(self, x, ctx, groups, pool=None):
         B, H, W, C = x.shape
         h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, pool)
@@ -112,6 +127,23 @@ class UNet:
             off += r.t_n
             del r.tw, r.tb
         self._graph = None
+
+    def load_attn_procs(self, state_dict):
+        """`pipe.unet.load_attn_procs(model_id, weight_name="pytorch_custom_diffusion_weights.bin")` (sd.py:57): keys
+        `<block>.attentions.<j>.transformer_blocks.0.attn2.processor.to_{k,v}_custom_diffusion.weight`.  Returns the number of
+        cross-attention layers that were replaced; invalidates a captured graph."""
+        n = 0
+        dev = self.cow.device
+        named = []
+        for i, (_, att, _) in enumerate(self.down):
+            named += [(f"down_blocks.{i}.attentions.{j}.", a) for j, a in enumerate(att or [])]
+        named.append(("mid_block.attentions.0.", self.mid[1]))
+        for i, (_, att, _) in enumerate(self.up):
+            named += [(f"up_blocks.{i}.attentions.{j}.", a) for j, a in enumerate(att or [])]
+        for name, blk in named:
+            n += int(blk.load_custom_diffusion(state_dict, name + "transformer_blocks.0.attn2.processor.", dev))
+        self._graph = None
+        return n
 
     def forward(self, x, t, ctx):
         """x [B, h, w, 8] half (4 latent channels + zero padding), t [B] float32 on device, ctx [B, 77, D] half

@@ -174,3 +174,37 @@ def test_get_text_embeds_with_injected_tokenizer():
         ref_text = so.clip_text_forward(half_sd(sd), cfg, Tok()(["a corgi in a forest"], max_length=77).input_ids)
     assert rel_err(z[1:], ref_text)[1] < 1e-2                       # row 1 = the prompt, row 0 = the negative prompt
     assert not torch.equal(z[0], z[1])
+
+
+def test_custom_diffusion_attn_procs_and_textual_inversion():
+    """sd.py:56-59: load_attn_procs replaces the cross-attention K/V projections (checked against the oracle with the same weights swapped
+    in), load_textual_inversion appends a token embedding."""
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd import text_encoder as te
+    from customnerf_amd.sd.unet import UNet
+    cfg = arch.UNET_TINY
+    sd = half_sd(arch.random_state_dict(arch.unet_params(cfg), seed=31))
+    g = torch.Generator().manual_seed(9)
+    procs, sd_cd = {}, dict(sd)
+    for k in [k for k in sd if k.endswith("attn2.to_k.weight") or k.endswith("attn2.to_v.weight")]:
+        w = (torch.randn(sd[k].shape, generator=g) / sd[k].shape[1] ** 0.5).half().float()
+        which = "to_k" if k.endswith("to_k.weight") else "to_v"
+        procs[k.replace(f"attn2.{which}.weight", f"attn2.processor.{which}_custom_diffusion.weight")] = w
+        sd_cd[k] = w
+    x = torch.randn(2, 4, 16, 16, generator=g).half().float()
+    ctx = torch.randn(2, 77, cfg["cross_attention_dim"], generator=g).half().float()
+    t = torch.tensor([300.0, 300.0])
+    net = UNet(cfg, sd, "cuda")
+    with torch.no_grad():
+        base = net(to_nhwc8(x), t.cuda(), ctx.half().cuda()).clone()
+        assert net.load_attn_procs(procs) == 16
+        out = net(to_nhwc8(x), t.cuda(), ctx.half().cuda())
+        ref = so.unet_forward(sd_cd, cfg, x, t, ctx)
+    assert rel_err(out.permute(0, 3, 1, 2), ref)[1] < 1e-2
+    assert rel_err(out, base)[1] > 1e-2                                     # the processors do change the prediction
+    enc = te.CLIPTextEncoder(te.CLIP_TEXT_TINY, arch.random_state_dict(te.clip_text_params(te.CLIP_TEXT_TINY), 1), "cuda")
+    tid = enc.add_token_embedding(torch.ones(te.CLIP_TEXT_TINY["width"]))
+    assert tid == te.CLIP_TEXT_TINY["vocab_size"]
+    ids = torch.zeros(1, 77, dtype=torch.long)
+    ids[0, 3] = tid
+    assert torch.isfinite(enc(ids.cuda())[0]).all()
