@@ -98,15 +98,24 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         for (int s = 0; s < KS; s++) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][s * 64 + lane], qf[s], sacc, 0, 0, 0);
         // ---- online softmax over this lane's 16 keys (+ the partner half's 16)
         float tmax = -INFINITY;
+        if (!causal && key0 + 32 <= Tk) {                        // interior tile (workgroup-uniform): no masking work
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t key = key0 + at_rho(r, hi);
-            sacc[r] = (key < Tk && !(causal && key > qi)) ? sacc[r] * scale_log2e : -INFINITY;
-            tmax = fmaxf(tmax, sacc[r]);
+            for (int r = 0; r < 16; r++) {
+                sacc[r] *= scale_log2e;
+                tmax = fmaxf(tmax, sacc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t key = key0 + at_rho(r, hi);
+                sacc[r] = (key < Tk && !(causal && key > qi)) ? sacc[r] * scale_log2e : -INFINITY;
+                tmax = fmaxf(tmax, sacc[r]);
+            }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(fmaxf(m, tmax), -1e30f);   // stays finite even when a causal tile holds no key for this query yet
-        const float corr = exp2f(m - m_new);
+        const bool moved = m_new != m;
+        const float corr = moved ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
         m = m_new;
         float psum = 0.0f;
         at_h8 pf[2];
@@ -115,7 +124,7 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
             at_h8 f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float p = exp2f(sacc[8 * s + j] - m_new);
+                const float p = __builtin_amdgcn_exp2f(sacc[8 * s + j] - m_new);       // v_exp_f32: exp2(-inf) = 0 for masked keys
                 const _Float16 ph = (_Float16)p;
                 f[j] = ph;
                 psum += (float)ph;                       // the denominator sums what the numerator uses
@@ -123,10 +132,12 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
             pf[s] = f;
         }
         l = l * corr + psum;
+        if (__any(moved)) {                                      // the running maxima settle after a few tiles: skip the rescale when no lane moved
 #pragma unroll
-        for (int t = 0; t < DT; t++)
+            for (int t = 0; t < DT; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) o[t][r] *= corr;
+                for (int r = 0; r < 16; r++) o[t][r] *= corr;
+        }
         // ---- O^T += V^T P^T : A = V^T fragment (lane = channel row, K-slots = keys in C-register order: two runs of 4 keys)
 #pragma unroll
         for (int t = 0; t < DT; t++)
