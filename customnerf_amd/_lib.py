@@ -77,7 +77,8 @@ class SdGemmDesc(C.Structure):
                 ("rows_per_bias_row", u32), ("ld_bias_rows", u32), ("alpha", f32), ("act", C.c_int32), ("batch_outer", u32), ("batch_inner", u32),
                 ("sa_o", u64), ("sa_i", u64), ("sb_o", u64), ("sb_i", u64), ("sc_o", u64), ("sc_i", u64),
                 ("mode", C.c_int32), ("Cin", u32), ("H_in", u32), ("W_in", u32), ("H_out", u32), ("W_out", u32),
-                ("KH", u32), ("KW", u32), ("stride", u32), ("pad_t", u32), ("pad_l", u32), ("ups", u32), ("tstride", u32)]
+                ("KH", u32), ("KW", u32), ("stride", u32), ("pad_t", u32), ("pad_l", u32), ("ups", u32), ("tstride", u32),
+                ("gn_sums", vp), ("gn_groups", u32), ("gn_rows", u32)]
 
 F32, F16 = 0, 1
 

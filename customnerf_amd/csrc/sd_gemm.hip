@@ -188,6 +188,18 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             for (int r = 0; r < 16; r++) ct[(wm * 64 + i * 32 + sg_rho(r, hi)) * LDC + wn * 32 * NT + j * 32 + li] = acc[i][j][r];
     __syncthreads();
     // ---- phase 2: 8 consecutive columns per lane
+    // optional: GroupNorm statistics of the output for the norm that reads it next.  A thread's column chunk is fixed over its rows, so
+    // the (<= 2) groups' sums live in registers; flushed per image into a small LDS table, then one global atomic per (image, group) and tile.
+    const bool do_gn = !SPLIT && g.gn_sums != nullptr;
+    __shared__ float gn_lds[4][36][2];
+    const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u;
+    const uint32_t gn_g0 = n0 / gn_cg, gn_i0 = do_gn ? m0 / g.gn_rows : 0u;
+    if (do_gn) {
+        for (uint32_t i = tid; i < 4 * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0.0f;
+        __syncthreads();
+    }
+    float gs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    uint32_t gn_img = 0xFFFFFFFFu;
     _Float16 *C = (!SPLIT && g.C) ? reinterpret_cast<_Float16 *>(g.C) + g.sc_o * zo + g.sc_i * zi : nullptr;
     float *C32 = SPLIT ? partial + (size_t)split * g.M * g.N : (g.C32 ? g.C32 + g.sc_o * zo + g.sc_i * zi : nullptr);
     const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
@@ -224,6 +236,30 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                 }
             }
         }
+        if (do_gn) {
+            const uint32_t img = m / g.gn_rows;
+            const uint32_t g_lo = n / gn_cg, split_c = (g_lo + 1) * gn_cg - n;      // columns [0, split_c) of the chunk belong to g_lo
+            if (img != gn_img) {
+                if (gn_img != 0xFFFFFFFFu) {
+                    const uint32_t gl = n / gn_cg - gn_g0;
+                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+                    gs[0][0] = gs[0][1] = gs[1][0] = gs[1][1] = 0.0f;
+                }
+                gn_img = img;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (n + e < g.N) {
+                    const float xf = (float)(_Float16)v[e];                         // what the consumer will read
+                    const int k = ((uint32_t)e < split_c) ? 0 : 1;
+                    gs[k][0] += xf;
+                    gs[k][1] += xf * xf;
+                }
+            }
+        }
         if (C) {
             _Float16 *cp = C + (size_t)m * g.ldc + n;
             if (full && ((g.ldc | n) & 7) == 0 && ((((uintptr_t)C) & 15) == 0)) {
@@ -242,6 +278,25 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
 #pragma unroll
             for (int e = 0; e < 8; e++)
                 if (n + e < g.N) cp[e] = v[e];
+        }
+    }
+    if (do_gn) {
+        if (gn_img != 0xFFFFFFFFu) {
+            const uint32_t gl = (n0 + (tid % CPR) * 8) / gn_cg - gn_g0;
+            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+        }
+        __syncthreads();
+        const uint32_t n_img = g.M / g.gn_rows;
+        for (uint32_t i = tid; i < 4 * 36; i += SG_THREADS) {
+            const uint32_t im = i / 36, gl = i % 36, img = gn_i0 + im, grp = gn_g0 + gl;
+            const float a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
+            if (img < n_img && grp < g.gn_groups && (a != 0.0f || b2 != 0.0f)) {
+                unsafeAtomicAdd(&g.gn_sums[((size_t)img * g.gn_groups + grp) * 2], a);
+                unsafeAtomicAdd(&g.gn_sums[((size_t)img * g.gn_groups + grp) * 2 + 1], b2);
+            }
         }
     }
 }
@@ -270,6 +325,9 @@ static int sg_check(const CnerfSdGemm *g) {
     if (g->batch_outer == 0 || g->batch_inner == 0) return CNERF_EINVAL;
     if (g->act < 0 || g->act > 3) return CNERF_EINVAL;
     if (g->bias_rows && g->rows_per_bias_row == 0) return CNERF_EINVAL;
+    if (g->gn_sums && (g->gn_groups == 0 || g->N % g->gn_groups || g->N / g->gn_groups < 4 || g->gn_rows < 64 || g->M % g->gn_rows ||
+                       g->batch_outer * g->batch_inner != 1))
+        return CNERF_EINVAL;
     if ((((uintptr_t)g->A) | ((uintptr_t)g->B)) & 15) return CNERF_EINVAL;
     if (g->mode == 0) {
         if (g->lda & 7) return CNERF_EINVAL;

@@ -502,10 +502,11 @@ int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *b
     if (rc) return rc;
     if (!x || !gamma || !beta || !sums || !y) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    if (zero_sums) so_zero(sums, (size_t)B * G * 2, st);
+    if (zero_sums == 1) so_zero(sums, (size_t)B * G * 2, st);
     const uint32_t rpb = gn_rows_per_block(B, HW, C);
-    hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
-                       (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
+    if (zero_sums != 2)
+        hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
+                           (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
     const uint32_t rpa = gn_apply_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_apply<0>), dim3(cn_div_up(HW, rpa), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
                        (const float *)sums, (const float *)nullptr, HW, C, G, eps, silu, rpa, (_Float16 *)y);

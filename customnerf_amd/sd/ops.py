@@ -29,6 +29,7 @@ def _workspace(nbytes, device):
 
 
 def _launch(d, device):
+    """-> True when the library ran the problem split-K (then desc.gn_sums was NOT filled)"""
     need = ctypes.c_uint64(0)
     check(lib.cnerf_sd_gemm_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "sd_gemm_workspace_bytes")
     ws = _workspace(need.value, device) if need.value else None
@@ -39,6 +40,18 @@ def _launch(d, device):
     if _PROFILE is not None:
         e1.record()
         _PROFILE.append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch_outer * d.batch_inner))
+    return need.value > 0
+
+
+def _attach_gn(d, gn, M, N):
+    """gn = (sums [B, G, 2] float32 pre-zeroed, groups, rows_per_image) or None -> whether the request is admissible"""
+    if gn is None:
+        return False
+    sums, groups, rows = gn
+    if rows < 64 or M % rows or N % groups or N // groups < 4:
+        return False
+    d.gn_sums, d.gn_groups, d.gn_rows = ptr(sums), groups, rows
+    return True
 
 
 def _desc(A, B, C, M, N, K, lda, ldb, ldc, bias=None, bias_rows=None, rows_per_bias_row=0, residual=None, ldr=0, act=0, alpha=1.0, C32=None):
@@ -52,8 +65,9 @@ def _desc(A, B, C, M, N, K, lda, ldb, ldc, bias=None, bias_rows=None, rows_per_b
     return d
 
 
-def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, out32=False):
-    """x [..., K] half, w [N, K] half -> [..., N] half (float32 when out32)."""
+def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, out32=False, gn=None):
+    """x [..., K] half, w [N, K] half -> [..., N] half (float32 when out32).
+    gn = (sums, groups, rows_per_image): also accumulate the GroupNorm statistics of the output into `sums`; returns (y, ok) then."""
     require_cuda(x, w)
     K = x.shape[-1]
     N = w.shape[0]
@@ -65,11 +79,13 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
     r2 = residual.reshape(M, N) if residual is not None else None
     d = _desc(x2, w, None if out32 else out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=r2,
               ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
-    _launch(d, x.device)
-    return out.reshape(*x.shape[:-1], N)
+    want = _attach_gn(d, gn, M, N)
+    split = _launch(d, x.device)
+    y = out.reshape(*x.shape[:-1], N)
+    return (y, want and not split) if gn is not None else y
 
 
-def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bias_rows=None, residual=None, act=ACT_NONE):
+def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bias_rows=None, residual=None, act=ACT_NONE, gn=None):
     """x [B, H, W, Cin] half (NHWC), w [Cout, k*k*Cin] half packed (kh, kw, ci) -> [B, Ho, Wo, Cout] half.
     stride/pad/ups/tstride as in customnerf_sd.h; bias_rows [B, Cout] float32 = per-image bias (time embedding)."""
     require_cuda(x, w)
@@ -90,8 +106,9 @@ def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bi
         assert bias_rows.dtype == torch.float32 and bias_rows.stride(1) == 1
         d.ld_bias_rows = bias_rows.stride(0)
     d.stride, d.pad_t, d.pad_l, d.ups, d.tstride = stride, pad, pad, ups, tstride
-    _launch(d, x.device)
-    return y
+    want = _attach_gn(d, gn, M, Cout)
+    split = _launch(d, x.device)
+    return (y, want and not split) if gn is not None else y
 
 
 class SumsPool:
@@ -108,15 +125,19 @@ class SumsPool:
         return s
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu, pool=None):
-    """x [B, ..., C] half -> (y, sums [B, G, 2] float32: sum and sum of squares per group)."""
+def groupnorm(x, gamma, beta, groups, eps, silu, pool=None, sums=None, sums_ready=True):
+    """x [B, ..., C] half -> (y, sums [B, G, 2] float32: sum and sum of squares per group).
+    sums given and sums_ready: the statistics were already accumulated by the GEMM that produced x (its gn= request) — only the apply
+    pass runs; sums given, not ready: a pre-zeroed buffer to fill (the producer ran split-K and left it untouched)."""
     require_cuda(x, gamma)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     assert x.is_contiguous() and x.dtype == torch.float16
     y = torch.empty_like(x)
-    sums = pool.take() if pool is not None else torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-    check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), 0 if pool is not None else 1, ptr(y), stream()),
+    mode = (2 if sums_ready else 0) if sums is not None else (0 if pool is not None else 1)
+    if sums is None:
+        sums = pool.take() if pool is not None else torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), mode, ptr(y), stream()),
           "sd_groupnorm_forward")
     return y, sums
 

@@ -26,13 +26,24 @@ class _Resnet:
         if self.has_sc:
             self.sw, self.sb = pack.pack_conv(g("conv_shortcut.weight")), pack.f32(g("conv_shortcut.bias"))
 
-    def __call__(self, x, tb, groups, eps, pool=None):
-        """tb: this block's time_emb_proj(silu(temb)) [B, Cout] float32 (all blocks' projections are one batched GEMM in UNet.forward)"""
-        h, _ = ops.groupnorm(x, self.n1w, self.n1b, groups, eps, True, pool)
-        h = ops.conv2d(h, self.c1w, self.c1b, 3, bias_rows=tb)
-        h, _ = ops.groupnorm(h, self.n2w, self.n2b, groups, eps, True, pool)
+    def __call__(self, x, tb, groups, eps, pool, x_sums=None, out_gn=False):
+        """tb: this block's time_emb_proj(silu(temb)) [B, Cout] float32 (all blocks' projections are one batched GEMM in UNet.forward).
+        GroupNorm statistics ride on the producing GEMM's epilogue where there is one: x_sums = (sums, ready) for norm1's input, and with
+        out_gn the block returns the same for its own output (for the norm that consumes it next).  -> (y, y_sums | None)"""
+        hw = x.shape[1] * x.shape[2]
+        if x_sums is not None:
+            h, _ = ops.groupnorm(x, self.n1w, self.n1b, groups, eps, True, sums=x_sums[0], sums_ready=x_sums[1])
+        else:
+            h, _ = ops.groupnorm(x, self.n1w, self.n1b, groups, eps, True, pool)
+        s2 = pool.take()
+        h, ok = ops.conv2d(h, self.c1w, self.c1b, 3, bias_rows=tb, gn=(s2, groups, hw))
+        h, _ = ops.groupnorm(h, self.n2w, self.n2b, groups, eps, True, sums=s2, sums_ready=ok)
         sc = ops.conv2d(x, self.sw, self.sb, 1, pad=0) if self.has_sc else x
-        return ops.conv2d(h, self.c2w, self.c2b, 3, residual=sc)
+        if not out_gn:
+            return ops.conv2d(h, self.c2w, self.c2b, 3, residual=sc), None
+        so = pool.take()
+        y, ok = ops.conv2d(h, self.c2w, self.c2b, 3, residual=sc, gn=(so, groups, hw))
+        return y, (so, ok)
 
 
 class _Transformer:
@@ -68,9 +79,13 @@ class _Transformer:
             self.o2b = pack.f32(sd[prefix + "to_out_custom_diffusion.0.bias"].to(dev))
         return k in sd
 
-    def __call__(self, x, ctx, groups, pool=None):
+    def __call__(self, x, ctx, groups, pool, x_sums=None, out_gn=False):
+        """-> (y, y_sums | None), see _Resnet.__call__"""
         B, H, W, C = x.shape
-        h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, pool)
+        if x_sums is not None:
+            h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, sums=x_sums[0], sums_ready=x_sums[1])
+        else:
+            h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, pool)
         h = ops.linear(h.view(B, H * W, C), self.piw, bias=self.pib)                     # 1x1 conv on NHWC = linear over channels
         n = ops.layernorm(h, *self.ln[0])
         qkv = ops.linear(n, self.qkv1)                                                   # [B, T, 3C]
@@ -84,7 +99,11 @@ class _Transformer:
         n = ops.layernorm(h, *self.ln[2])
         f = ops.geglu(ops.linear(n, self.f1w, bias=self.f1b))
         h = ops.linear(f, self.f2w, bias=self.f2b, residual=h)
-        return ops.linear(h, self.pow, bias=self.pob, residual=x.view(B, H * W, C)).view(B, H, W, C)
+        if not out_gn:
+            return ops.linear(h, self.pow, bias=self.pob, residual=x.view(B, H * W, C)).view(B, H, W, C), None
+        so = pool.take()
+        y, ok = ops.linear(h, self.pow, bias=self.pob, residual=x.view(B, H * W, C), gn=(so, groups, H * W))
+        return y.view(B, H, W, C), (so, ok)
 
 
 class UNet:
@@ -154,30 +173,40 @@ class UNet:
         temb = ops.linear(ops.linear(temb, self.t1w, bias=self.t1b, act=ops.ACT_SILU), self.t2w, bias=self.t2b)
         temb_act = ops.silu(temb)                                                      # every resnet applies SiLU before time_emb_proj
         tp = ops.linear(temb_act, self.tpw, bias=self.tpb, out32=True)                 # [B, sum Cout] float32
-        pool = ops.SumsPool(2 * len(self._resnets) + 17, x.shape[0], G, x.device)        # one zero-fill for every GroupNorm of the pass
+        pool = ops.SumsPool(3 * len(self._resnets) + 34, x.shape[0], G, x.device)        # one zero-fill for every GroupNorm of the pass (a few slices go unused)
         tbs = {id(r): tp[:, r.t_off:r.t_off + r.t_n] for r in self._resnets}          # per-block [B, Cout] strided views (bias_rows operand)
-        h = ops.conv2d(x, self.ciw, self.cib, 3)
+        hs0 = pool.take()
+        h, ok = ops.conv2d(x, self.ciw, self.cib, 3, gn=(hs0, G, x.shape[1] * x.shape[2]))
+        hs = (hs0, ok)                                                             # statistics of h for the norm that reads it next
         skips = [h]
         for res, att, ds in self.down:
             for j, r in enumerate(res):
-                h = r(h, tbs[id(r)], G, eps, pool)
+                h, hs = r(h, tbs[id(r)], G, eps, pool, x_sums=hs, out_gn=True)
                 if att is not None:
-                    h = att[j](h, ctx, G, pool)
+                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=True)
                 skips.append(h)
             if ds is not None:
-                h = ops.conv2d(h, ds[0], ds[1], 3, stride=2, pad=1)
+                so = pool.take()
+                h, ok = ops.conv2d(h, ds[0], ds[1], 3, stride=2, pad=1, gn=(so, G, (h.shape[1] // 2) * (h.shape[2] // 2)))
+                hs = (so, ok)
                 skips.append(h)
-        h = self.mid[0](h, tbs[id(self.mid[0])], G, eps, pool)
-        h = self.mid[1](h, ctx, G, pool)
-        h = self.mid[2](h, tbs[id(self.mid[2])], G, eps, pool)
-        for res, att, us in self.up:
+        h, hs = self.mid[0](h, tbs[id(self.mid[0])], G, eps, pool, x_sums=hs, out_gn=True)
+        h, hs = self.mid[1](h, ctx, G, pool, x_sums=hs, out_gn=True)
+        h, hs = self.mid[2](h, tbs[id(self.mid[2])], G, eps, pool, x_sums=hs, out_gn=False)
+        n_up = len(self.up)
+        for bi, (res, att, us) in enumerate(self.up):
             for j, r in enumerate(res):
-                h = r(ops.concat_channels(h, skips.pop()), tbs[id(r)], G, eps, pool)
+                # the block input is a channel concat: its norm computes its own statistics; the output feeds a norm only through attention
+                h, hs = r(ops.concat_channels(h, skips.pop()), tbs[id(r)], G, eps, pool, out_gn=att is not None)
                 if att is not None:
-                    h = att[j](h, ctx, G, pool)
+                    last = bi == n_up - 1 and j == len(res) - 1                     # -> conv_norm_out
+                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=last)
             if us is not None:
                 h = ops.conv2d(h, us[0], us[1], 3, ups=2)
-        h, _ = ops.groupnorm(h, self.now, self.nob, G, eps, True, pool)
+        if hs is not None:
+            h, _ = ops.groupnorm(h, self.now, self.nob, G, eps, True, sums=hs[0], sums_ready=hs[1])
+        else:
+            h, _ = ops.groupnorm(h, self.now, self.nob, G, eps, True, pool)
         return ops.conv2d(h, self.cow, self.cob, 3)
 
     __call__ = forward

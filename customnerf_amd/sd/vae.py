@@ -15,23 +15,35 @@ from .arch import VAE_ATTN_ALIASES
 
 
 class _Conv(Function):
-    @staticmethod
-    def forward(ctx, x, w, wd, bias, k, stride, pad, out_hw, residual):
-        ctx.wd, ctx.k, ctx.stride, ctx.pad, ctx.in_hw = wd, k, stride, pad, (x.shape[1], x.shape[2])
-        ctx.has_res = residual is not None
-        return ops.conv2d(x, w, bias, k, stride=stride, pad=pad, out_hw=out_hw, residual=residual)
+    """conv (+ residual).  gn_sums: a pre-zeroed [B, G, 2] buffer — the GEMM epilogue accumulates the statistics of the output for the
+    GroupNorm that consumes it next (second, non-differentiable output = 1 when it did, 0 when the schedule was split-K)."""
 
     @staticmethod
-    def backward(ctx, dy):
+    def forward(ctx, x, w, wd, bias, k, stride, pad, out_hw, residual, gn_sums, groups):
+        ctx.wd, ctx.k, ctx.stride, ctx.pad, ctx.in_hw = wd, k, stride, pad, (x.shape[1], x.shape[2])
+        ctx.has_res = residual is not None
+        if gn_sums is None:
+            return ops.conv2d(x, w, bias, k, stride=stride, pad=pad, out_hw=out_hw, residual=residual), None
+        oh, ow = out_hw if out_hw is not None else ((x.shape[1] + 2 * pad - k) // stride + 1, (x.shape[2] + 2 * pad - k) // stride + 1)
+        y, ok = ops.conv2d(x, w, bias, k, stride=stride, pad=pad, out_hw=out_hw, residual=residual, gn=(gn_sums, groups, oh * ow))
+        flag = torch.tensor(1 if ok else 0)
+        ctx.mark_non_differentiable(flag)
+        return y, flag
+
+    @staticmethod
+    def backward(ctx, dy, _flag=None):
         dy = dy.contiguous()
         dx = ops.conv2d(dy, ctx.wd, None, ctx.k, stride=1, pad=ctx.k - 1 - ctx.pad, tstride=ctx.stride, out_hw=ctx.in_hw)
-        return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
+        return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None), None, None
 
 
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
-        y, sums = ops.groupnorm(x, gamma, beta, groups, eps, silu)
+    def forward(ctx, x, gamma, beta, groups, eps, silu, sums_in=None, sums_ready=False):
+        if sums_in is not None:
+            y, sums = ops.groupnorm(x, gamma, beta, groups, eps, silu, sums=sums_in, sums_ready=sums_ready)
+        else:
+            y, sums = ops.groupnorm(x, gamma, beta, groups, eps, silu)
         ctx.save_for_backward(x, gamma, beta, sums)
         ctx.cfg = (groups, eps, silu)
         return y
@@ -40,7 +52,7 @@ class _GroupNorm(Function):
     def backward(ctx, dy):
         x, gamma, beta, sums = ctx.saved_tensors
         groups, eps, silu = ctx.cfg
-        return ops.groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums), None, None, None, None, None
+        return ops.groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums), None, None, None, None, None, None, None
 
 
 class _Linear(Function):
@@ -114,9 +126,14 @@ class _ConvW:
         self.k = w.shape[-1]
         self.w, self.wd, self.b = pack.pack_conv(w), pack.pack_conv_dgrad(w), pack.f32(sd[p + ".bias"].to(dev))
 
-    def __call__(self, x, stride=1, pad=None, out_hw=None, residual=None):
+    def __call__(self, x, stride=1, pad=None, out_hw=None, residual=None, gn=None):
+        """gn = (pool, groups): also return the GroupNorm statistics of the output -> (y, (sums, ready)); else -> y"""
         pad = (self.k // 2) if pad is None else pad
-        return _Conv.apply(x, self.w, self.wd, self.b, self.k, stride, pad, out_hw, residual)
+        if gn is None:
+            return _Conv.apply(x, self.w, self.wd, self.b, self.k, stride, pad, out_hw, residual, None, 0)[0]
+        sums = gn[0].take()
+        y, flag = _Conv.apply(x, self.w, self.wd, self.b, self.k, stride, pad, out_hw, residual, sums, gn[1])
+        return y, (sums, bool(flag))
 
 
 class _LinW:
@@ -136,10 +153,15 @@ class _Resnet:
         self.c1, self.c2 = _ConvW(sd, p + "conv1", dev), _ConvW(sd, p + "conv2", dev)
         self.sc = _LinW(sd, p + "conv_shortcut", dev) if (p + "conv_shortcut.weight") in sd else None
 
-    def __call__(self, x, groups, eps):
-        h = self.c1(_GroupNorm.apply(x, *self.n1, groups, eps, True))
-        h = _GroupNorm.apply(h, *self.n2, groups, eps, True)
-        return self.c2(h, residual=self.sc(x) if self.sc is not None else x)
+    def __call__(self, x, groups, eps, pool, x_sums=None, out_gn=False):
+        """x_sums = (sums, ready) of x from its producer (or None); out_gn: also return the statistics of the output"""
+        h = _GroupNorm.apply(x, *self.n1, groups, eps, True, *(x_sums if x_sums is not None else (None, False)))
+        h, hs = self.c1(h, gn=(pool, groups))
+        h = _GroupNorm.apply(h, *self.n2, groups, eps, True, *hs)
+        res = self.sc(x) if self.sc is not None else x
+        if out_gn:
+            return self.c2(h, residual=res, gn=(pool, groups))
+        return self.c2(h, residual=res), None
 
 
 class VAEEncoder:
@@ -170,19 +192,22 @@ class VAEEncoder:
     def moments(self, x):
         """x [B, H, W, 8] half NHWC in [-1, 1] (3 channels + zero padding) -> [B, H/8, W/8, 2*latent] half (mean | logvar)"""
         G, eps = self.cfg["groups"], self.cfg["eps"]
-        h = self.conv_in(x)
-        for res, ds in self.down:
-            for r in res:
-                h = r(h, G, eps)
+        n_res = sum(len(res) for res, _ in self.down) + 2
+        pool = ops.SumsPool(2 * n_res + 8, x.shape[0], G, x.device)          # one zero-fill; the producing GEMMs fill the statistics
+        h, hs = self.conv_in(x, gn=(pool, G))
+        for bi, (res, ds) in enumerate(self.down):
+            for j, r in enumerate(res):
+                feeds_norm = not (ds is not None and j == len(res) - 1)       # the last resnet of a block feeds the downsample conv
+                h, hs = r(h, G, eps, pool, x_sums=hs, out_gn=feeds_norm)
             if ds is not None:
-                h = ds(h, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2))      # F.pad(0,1,0,1) + stride-2 conv
-        h = self.mid0(h, G, eps)
+                h, hs = ds(h, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2), gn=(pool, G))      # F.pad(0,1,0,1) + stride-2 conv
+        h, hs = self.mid0(h, G, eps, pool, x_sums=hs, out_gn=True)
         B, H, W, C = h.shape
-        n = _GroupNorm.apply(h, *self.an, G, eps, False).view(B, H * W, C)
+        n = _GroupNorm.apply(h, *self.an, G, eps, False, *hs).view(B, H * W, C)
         o = _Attention1Head.apply(self.aq(n), self.ak(n), self.av(n))
         h = self.ao(o, residual=h.view(B, H * W, C)).view(B, H, W, C)
-        h = self.mid1(h, G, eps)
-        h = self.conv_out(_GroupNorm.apply(h, *self.no, G, eps, True))
+        h, hs = self.mid1(h, G, eps, pool, out_gn=True)
+        h = self.conv_out(_GroupNorm.apply(h, *self.no, G, eps, True, *hs))
         return self.quant(h)
 
     def encode_imgs(self, imgs, sample_noise, resize=(512, 512)):

@@ -57,6 +57,11 @@ typedef struct CnerfSdGemm {
     uint64_t sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;    /* residual uses the C strides */
     int32_t mode;             /* 0 dense, 1 implicit conv */
     uint32_t Cin, H_in, W_in, H_out, W_out, KH, KW, stride, pad_t, pad_l, ups, tstride;
+    /* optional GroupNorm statistics of the OUTPUT (the norm that consumes C next): gn_sums [M / gn_rows][gn_groups][2] float, pre-zeroed,
+     * receives sum and sum of squares of the half-rounded outputs per (image, channel group); N % gn_groups == 0, gn_rows >= 64.
+     * Ignored (left untouched) when the library runs this problem split-K: cnerf_sd_gemm_workspace_bytes() != 0 tells. */
+    float *gn_sums;
+    uint32_t gn_groups, gn_rows;
 } CnerfSdGemm;
 
 int cnerf_sd_gemm(const CnerfSdGemm *desc, void *workspace, uint64_t workspace_bytes, void *stream);
@@ -66,7 +71,8 @@ int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *desc, uint64_t *bytes);
  * GroupNorm over NHWC half activations x [B, HW, C] (torch.nn.GroupNorm(G, C, eps) semantics, biased variance, statistics in
  * float32), optionally followed by SiLU (the `norm -> nonlinearity` pair of every diffusers ResnetBlock2D).
  *   stats:   sums [B][G][2] float (sum, sum of squares) — filled by the call; zero_sums != 0: the call zeroes them first,
- *            zero_sums == 0: the caller passes zeros (one fill for all the norms of a network instead of one launch each)
+ *            zero_sums == 0: the caller passes zeros (one fill for all the norms of a network instead of one launch each);
+ *            zero_sums == 2: `sums` already hold the statistics (filled by the producing cnerf_sd_gemm's gn_sums): no statistics pass
  *   forward: y = act((x - mean) * rstd * gamma[c] + beta[c])
  *   backward (frozen gamma/beta): dx from dy, recomputing the forward; `sums` are the forward's; scratch [B][G][2] float.
  * ---------------------------------------------------------------------------------------------- */

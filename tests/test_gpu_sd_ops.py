@@ -215,3 +215,25 @@ def test_image_front_end_and_sds_tail():
     eu, et = eps[0, ..., :4].permute(2, 0, 1)[None], eps[1, ..., :4].permute(2, 0, 1)[None]
     ref_g = torch.nan_to_num((1 - ab) * ((et + 7.5 * (et - eu)) - noise) * 0.01)
     close(gr, ref_g, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("B,C,H,Co", [(2, 320, 64, 320), (1, 128, 96, 128), (2, 64, 8, 128), (2, 320, 16, 640)])
+def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
+    """the producing conv accumulates the next GroupNorm's statistics in its epilogue (gn=): same normalised output as the two-pass norm"""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, H, C, generator=g).half().cuda()
+    w = pack.pack_conv(torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C)).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    sums = torch.zeros(B, 32, 2, device="cuda")
+    y, ok = ops.conv2d(x, w, b, 3, gn=(sums, 32, H * H))
+    y_ref = ops.conv2d(x, w, b, 3)
+    assert torch.equal(y, y_ref)
+    n_ref, s_ref = ops.groupnorm(y_ref, gamma, beta, 32, 1e-5, True)
+    if not ok:                                           # split-K schedule: the library leaves the statistics to the norm
+        assert torch.all(sums == 0)
+        return
+    close(sums, s_ref, 2e-4, 1e-2)
+    n_fused, _ = ops.groupnorm(y, gamma, beta, 32, 1e-5, True, sums=sums)
+    close(n_fused, n_ref, 2e-3, 2e-3)
