@@ -395,9 +395,6 @@ int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
               float *g_rgb, void *workspace, hipStream_t st) {
     if (mm_eligible(dm)) {
-        const size_t rows = FF_MAX_BLOCKS;
-        hipError_t e0 = hipMemsetAsync(workspace, 0, rows * ff_offsets(dm).total * sizeof(float), st);
-        if (e0 != hipSuccess) return (int)e0;
         return mm_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
     }
     const FieldLds lo = fld_lds_layout<true>(dm);

@@ -419,6 +419,9 @@ int mm_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     if (blocks > 256) blocks = 256;
     const MmOff po = mm_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
+    // the partial rows are only written where a layer has rows / columns: zero the 2 * blocks rows in use (padding entries stay 0)
+    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)2 * blocks * po.total * sizeof(float), st);
+    if (e0 != hipSuccess) return (int)e0;
     if (dm.n_hidden_geo == 2) {
         auto kern = k_field_bwd_mma<2>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
