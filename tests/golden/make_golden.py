@@ -291,6 +291,24 @@ def main():
         ws[f"{tag}__grad_sigmas"] = s.grad.numpy()
         ws[f"{tag}__grad_rgbs"] = c_.grad.numpy()
     np.savez_compressed(os.path.join(args.out, "weights_sum_i.npz"), **ws)
+
+    # ---- dataset front-end: pose normalisation of NerfstudioData._load_renderings (provider.py:226-236; provider_utils.py:35-115)
+    g = torch.Generator().manual_seed(11)
+    V = 23
+    ang = torch.rand(V, generator=g) * 6.28
+    eye = torch.stack([3.0 * torch.cos(ang), 0.8 + 0.3 * torch.rand(V, generator=g), 3.0 * torch.sin(ang)], -1) + torch.tensor([0.7, -0.4, 1.1])
+    fwd = torch.nn.functional.normalize(-eye + 0.2 * torch.randn(V, 3, generator=g), dim=-1)
+    right = torch.nn.functional.normalize(torch.cross(fwd, torch.tensor([0.05, 1.0, 0.1]).expand(V, 3), dim=-1), dim=-1)
+    up = torch.cross(right, fwd, dim=-1)
+    poses = torch.eye(4).repeat(V, 1, 1)
+    poses[:, :3, 0], poses[:, :3, 1], poses[:, :3, 2], poses[:, :3, 3] = right, up, -fwd, eye
+    orient = {"poses": poses.numpy()}
+    for method in ("up", "none"):
+        for center in (True, False):
+            out, tr = ref_pu.auto_orient_and_center_poses(poses.clone(), method=method, center_poses=center)
+            orient[f"{method}_{int(center)}__poses"] = out.numpy()
+            orient[f"{method}_{int(center)}__transform"] = tr.numpy()
+    np.savez(os.path.join(args.out, "orient.npz"), **orient)
     print("golden vectors written to", args.out)
 
 
