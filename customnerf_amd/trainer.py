@@ -81,3 +81,31 @@ class ReconTrainer:
             self.optimizer.zero_grad(set_to_none=False)
         self.global_step += 1
         return loss.detach(), outputs
+
+
+def train_one_epoch(trainer, views, shard=None, log=None):
+    """Loop body of Trainer_Nerf.train_one_epoch (nerf/utils_init_nerf.py:577-671) over an indexable of view tuples
+    (rgbs, mask, rays_o, rays_d, H, W, img_path) — e.g. customnerf_amd.nerf.provider.NerfstudioScene — for ReconTrainer or EditTrainer:
+    occupancy refresh every `opt.update_extra_interval` steps on the march path (:601-606), one optimiser step per view, mean loss.
+    shard = (rank, world): view-parallel data parallelism, rank r takes views r, r + world, ... (the reference uses a DistributedSampler)."""
+    model, opt = trainer.model, trainer.opt
+    rank, world = shard if shard is not None else (0, 1)
+    model.train()
+    total, n = 0.0, 0
+    for i in range(rank, len(views), world):
+        if getattr(model, 'cuda_ray', False) and trainer.global_step % getattr(opt, 'update_extra_interval', 16) == 0:
+            with torch.autocast('cuda', dtype=torch.float16, enabled=trainer.fp16):
+                model.update_extra_state()
+        data = views[i]
+        if hasattr(trainer, 'train_step_editing'):                     # EditTrainer
+            loss, loss_dict = trainer.train_step(data)
+        else:
+            rgbs, mask, rays_o, rays_d, H, W, _ = data
+            loss, _ = trainer.train_step(rays_o, rays_d, rgbs, mask, num_steps=opt.num_steps, upsample_steps=opt.upsample_steps,
+                                         dt_gamma=getattr(opt, 'dt_gamma', 0), max_steps=opt.max_steps)
+        total = total + loss                                           # stays on the device: no per-step host sync
+        n += 1
+    avg = float(total) / max(n, 1)
+    if log is not None:
+        log(f"==> Finished epoch: average_loss {avg:.6f} over {n} views, lr x{trainer.lr_factor():.4f}")
+    return avg

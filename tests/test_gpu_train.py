@@ -73,3 +73,29 @@ def test_march_path_step_runs_and_refreshes_occupancy():
         assert np.array_equal(rays[1:, 1], np.cumsum(rays[:-1, 2]))               # exclusive scan of the counts
     model.update_extra_state()
     assert model.mean_count > 0
+
+
+def test_train_one_epoch_on_a_disk_scene(tmp_path):
+    """dataset front-end -> ReconTrainer via train_one_epoch (utils_init_nerf.py:577-671): loss goes down over epochs on a tiny scene"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_provider import _write_scene
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider import NerfstudioScene
+    from customnerf_amd.trainer import ReconTrainer, train_one_epoch
+    _write_scene(str(tmp_path))
+    views = NerfstudioScene(str(tmp_path), resolution_level=2, device="cuda")
+    tcnn.set_default_dtype(torch.float16)
+    torch.manual_seed(0)
+    opt = sc.make_opt(fp16=True, num_levels=8, num_steps=16, upsample_steps=16, iters=200)
+    model = NeRFNetwork(opt).cuda()
+    tr = ReconTrainer(model, opt, fp16=True)
+    logs = []
+    losses = [train_one_epoch(tr, views, log=logs.append) for _ in range(4)]
+    assert tr.global_step == 4 * len(views) and len(logs) == 4
+    assert losses[-1] < losses[0] and all(np.isfinite(losses)), losses
+    # view-parallel shard: rank 1 of 2 sees every second view
+    before = tr.global_step
+    train_one_epoch(tr, views, shard=(1, 2))
+    assert tr.global_step - before == len(range(1, len(views), 2))
