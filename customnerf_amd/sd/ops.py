@@ -242,9 +242,24 @@ def attention(q, k, v, heads, causal=False):
         assert not causal
         return attention_apply(attention_scores(q, k, heads, 1.0 / float(d_) ** 0.5), v, heads)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    return attention_vt(q, k, transpose_v(v), heads, causal)
+
+
+def transpose_v(v):
+    """v [B, Tk, C] -> V^T [B, C, round32(Tk)] (pad columns zero): the operand layout of the fused attention kernel"""
+    B, Tk, C = v.shape
     ldv = (Tk + 31) // 32 * 32
     vT = torch.empty(B, C, ldv, dtype=torch.float16, device=v.device)
     transpose_batched(v, Tk, C, v.stride(1), ldv, B, v.stride(0), C * ldv, vT)          # zero-fills the pad columns
+    return vT
+
+
+def attention_vt(q, k, vT, heads, causal=False):
+    """fused attention with V already transposed (transpose_v): q [B, Tq, C], k [B, Tk, C] (strided views fine), vT [B, C, ldv]"""
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    d_ = C // heads
+    ldv = vT.shape[2]
     out = torch.empty(B, Tq, C, dtype=torch.float16, device=q.device)
     check(lib.cnerf_sd_attention(ptr(q), ptr(k), ptr(vT), ptr(out), B, heads, Tq, Tk, d_, q.stride(1), q.stride(0), k.stride(1), k.stride(0), ldv, C * ldv,
                                  C, Tq * C, int(causal), stream()), "sd_attention")

@@ -79,8 +79,14 @@ class _Transformer:
             self.o2b = pack.f32(sd[prefix + "to_out_custom_diffusion.0.bias"].to(dev))
         return k in sd
 
-    def __call__(self, x, ctx, groups, pool, x_sums=None, out_gn=False):
-        """-> (y, y_sums | None), see _Resnet.__call__"""
+    def context_kv(self, ctx):
+        """cross-attention keys / transposed values of a text embedding: they depend on the prompt only, not on the latents or t"""
+        C = self.q2.shape[0]
+        kv = ops.linear(ctx, self.kv2)                                                   # [B, 77, 2C]
+        return kv[..., :C], ops.transpose_v(kv[..., C:])
+
+    def __call__(self, x, ctx, groups, pool, x_sums=None, out_gn=False, kv=None):
+        """-> (y, y_sums | None), see _Resnet.__call__.  kv: this block's context_kv(ctx) when the caller caches it per prompt."""
         B, H, W, C = x.shape
         if x_sums is not None:
             h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, sums=x_sums[0], sums_ready=x_sums[1])
@@ -93,8 +99,9 @@ class _Transformer:
         h = ops.linear(a, self.o1w, bias=self.o1b, residual=h)
         n = ops.layernorm(h, *self.ln[1])
         q = ops.linear(n, self.q2)
-        kv = ops.linear(ctx, self.kv2)                                                   # [B, 77, 2C]
-        a = ops.attention(q, kv[..., :C], kv[..., C:], self.heads)
+        if kv is None:
+            kv = self.context_kv(ctx)
+        a = ops.attention_vt(q, kv[0], kv[1], self.heads)
         h = ops.linear(a, self.o2w, bias=self.o2b, residual=h)
         n = ops.layernorm(h, *self.ln[2])
         f = ops.geglu(ops.linear(n, self.f1w, bias=self.f1b))
@@ -164,9 +171,20 @@ class UNet:
         self._graph = None
         return n
 
-    def forward(self, x, t, ctx):
+    def transformers(self):
+        out = [a for _, att, _ in self.down for a in (att or [])] + [self.mid[1]] + [a for _, att, _ in self.up for a in (att or [])]
+        return out
+
+    def context_kv(self, ctx):
+        """Cross-attention K / V^T of all 16 transformer blocks for one text embedding [B, 77, D] (32 launches that depend on the prompt
+        only): computed once per prompt and passed to forward(..., ctx_kv=...) / cached by graphed()."""
+        ctx = ctx.to(torch.float16).contiguous()
+        return {id(a): a.context_kv(ctx) for a in self.transformers()}
+
+    def forward(self, x, t, ctx, ctx_kv=None):
         """x [B, h, w, 8] half (4 latent channels + zero padding), t [B] float32 on device, ctx [B, 77, D] half
-        -> eps [B, h, w, 4] half."""
+        -> eps [B, h, w, 4] half.  ctx_kv: context_kv(ctx) (then ctx itself is not read)."""
+        kvs = ctx_kv if ctx_kv is not None else {}
         cfg = self.cfg
         G, eps = cfg["groups"], cfg["eps"]
         temb = ops.timestep_embedding(t, cfg["block_out_channels"][0])
@@ -183,7 +201,7 @@ class UNet:
             for j, r in enumerate(res):
                 h, hs = r(h, tbs[id(r)], G, eps, pool, x_sums=hs, out_gn=True)
                 if att is not None:
-                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=True)
+                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=True, kv=kvs.get(id(att[j])))
                 skips.append(h)
             if ds is not None:
                 so = pool.take()
@@ -191,7 +209,7 @@ class UNet:
                 hs = (so, ok)
                 skips.append(h)
         h, hs = self.mid[0](h, tbs[id(self.mid[0])], G, eps, pool, x_sums=hs, out_gn=True)
-        h, hs = self.mid[1](h, ctx, G, pool, x_sums=hs, out_gn=True)
+        h, hs = self.mid[1](h, ctx, G, pool, x_sums=hs, out_gn=True, kv=kvs.get(id(self.mid[1])))
         h, hs = self.mid[2](h, tbs[id(self.mid[2])], G, eps, pool, x_sums=hs, out_gn=False)
         n_up = len(self.up)
         for bi, (res, att, us) in enumerate(self.up):
@@ -200,7 +218,7 @@ class UNet:
                 h, hs = r(ops.concat_channels(h, skips.pop()), tbs[id(r)], G, eps, pool, out_gn=att is not None)
                 if att is not None:
                     last = bi == n_up - 1 and j == len(res) - 1                     # -> conv_norm_out
-                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=last)
+                    h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=last, kv=kvs.get(id(att[j])))
             if us is not None:
                 h = ops.conv2d(h, us[0], us[1], 3, ups=2)
         if hs is not None:
@@ -212,22 +230,31 @@ class UNet:
     __call__ = forward
 
     def graphed(self, x, t, ctx):
-        """Same as forward() but replayed from a HIP graph captured on first use (static shapes; inputs are copied into the
-        graph's buffers; the returned tensor is the graph's static output buffer, overwritten by the next call).
-        ~700 launches per forward would otherwise be host-bound."""
-        key = (tuple(x.shape), tuple(ctx.shape))
-        if self._graph is None or self._graph[0] != key:
-            sx, st, sc = x.clone(), t.clone(), ctx.clone()
+        """Same as forward() but replayed from a HIP graph captured on first use (static shapes; x and t are copied into the graph's
+        buffers; the returned tensor is the graph's static output buffer, overwritten by the next call).  One graph per text embedding
+        (keyed by the tensor's storage and version; the editing loop alternates between two prompts): its cross-attention K / V^T are
+        computed once, outside the graph.  ~550 launches per forward would otherwise be host-bound."""
+        if self._graph is None:
+            self._graph = {}
+        key = (tuple(x.shape), ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        ent = self._graph.get(key)
+        if ent is None:
+            if len(self._graph) >= 4:                                                  # small LRU: drop the oldest context
+                self._graph.pop(next(iter(self._graph)))
+            sx, st = x.clone(), t.clone()
+            with torch.no_grad():
+                kv = self.context_kv(ctx)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.forward(sx, st, sc)                                               # warm-up: workspace growth, function attributes
+                self.forward(sx, st, None, ctx_kv=kv)                                  # warm-up: workspace growth, function attributes
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.forward(sx, st, sc)
-            self._graph = (key, graph, sx, st, sc, out)
-        _, graph, sx, st, sc, out = self._graph
-        sx.copy_(x); st.copy_(t); sc.copy_(ctx)
+                out = self.forward(sx, st, None, ctx_kv=kv)
+            ent = (graph, sx, st, (kv, ctx), out)                                   # holding ctx keeps its storage (the cache key) from being recycled
+            self._graph[key] = ent
+        graph, sx, st, _, out = ent
+        sx.copy_(x); st.copy_(t)
         graph.replay()
         return out
