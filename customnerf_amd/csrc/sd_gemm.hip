@@ -36,7 +36,7 @@ __device__ __forceinline__ float sg_act(float v, int act) {
     if (act == 1) return v / (1.0f + __expf(-v));
     if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     if (act == 3) return v / (1.0f + __expf(-1.702f * v));
-    return v;
+    return v;                                            // 0, and 4 (GEGLU pairs are combined by the caller)
 }
 
 // map (o*stride + k - pad) to an input coordinate; false = zero tap
@@ -236,6 +236,18 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                 }
             }
         }
+        if (!SPLIT && g.act == 4) {
+            // GEGLU on interleaved (value, gate) column pairs: out[m][n / 2 + e] = v[2e] * gelu(v[2e + 1]); the output is N / 2 wide
+            _Float16 *cp = C + (size_t)m * g.ldc + n / 2;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (n + 2 * e + 1 < g.N) {
+                    const float gt = v[2 * e + 1];
+                    cp[e] = (_Float16)(v[2 * e] * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752f))));
+                }
+            }
+            continue;
+        }
         if (do_gn) {
             const uint32_t img = m / g.gn_rows;
             const uint32_t g_lo = n / gn_cg, split_c = (g_lo + 1) * gn_cg - n;      // columns [0, split_c) of the chunk belong to g_lo
@@ -304,6 +316,21 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
 // split-K tail: sum the partials, apply the epilogue
 __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGemm g, const float *__restrict__ partial, uint32_t splits) {
     const size_t total = (size_t)g.M * g.N;
+    if (g.act == 4) {                                       // GEGLU pairs: one thread per output element
+        const size_t half = total / 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+            const uint32_t m = (uint32_t)(i / (g.N / 2)), c = (uint32_t)(i - (size_t)m * (g.N / 2)), n = 2 * c;
+            float a = 0.0f, b = 0.0f;
+            for (uint32_t s = 0; s < splits; s++) {
+                const float2 p = *reinterpret_cast<const float2 *>(partial + (size_t)s * total + (size_t)m * g.N + n);
+                a += p.x; b += p.y;
+            }
+            a = a * g.alpha + (g.bias ? g.bias[n] : 0.0f);
+            b = b * g.alpha + (g.bias ? g.bias[n + 1] : 0.0f);
+            reinterpret_cast<_Float16 *>(g.C)[(size_t)m * g.ldc + c] = (_Float16)(a * (0.5f * b * (1.0f + erff(b * 0.70710678118654752f))));
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t m = (uint32_t)(i / g.N), n = (uint32_t)(i - (size_t)m * g.N);
         float a = 0.0f;
@@ -323,7 +350,8 @@ static int sg_check(const CnerfSdGemm *g) {
     if (!g->A || !g->B || (!g->C && !g->C32)) return CNERF_ENULL;
     if (g->M == 0 || g->N == 0 || g->K == 0 || (g->K & 7) || (g->ldb & 7)) return CNERF_EINVAL;
     if (g->batch_outer == 0 || g->batch_inner == 0) return CNERF_EINVAL;
-    if (g->act < 0 || g->act > 3) return CNERF_EINVAL;
+    if (g->act < 0 || g->act > 4) return CNERF_EINVAL;
+    if (g->act == 4 && ((g->N & 7) || g->residual || g->C32 || !g->C || g->gn_sums)) return CNERF_EINVAL;
     if (g->bias_rows && g->rows_per_bias_row == 0) return CNERF_EINVAL;
     if (g->gn_sums && (g->gn_groups == 0 || g->N % g->gn_groups || g->N / g->gn_groups < 4 || g->gn_rows < 64 || g->M % g->gn_rows ||
                        g->batch_outer * g->batch_inner != 1))

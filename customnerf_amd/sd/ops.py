@@ -8,7 +8,7 @@ import torch
 
 from .._lib import lib, check, ptr, stream, require_cuda, SdGemmDesc
 
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 _WS = {}
 _PROFILE = None
 
@@ -74,14 +74,15 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
     x2 = x.reshape(-1, K)
     M = x2.shape[0]
     assert w.shape[1] == K and x2.stride(1) == 1 and x2.dtype == torch.float16 and w.dtype == torch.float16
+    No = N // 2 if act == ACT_GEGLU else N            # GEGLU pairs (value, gate) -> N / 2 outputs (weights interleaved: pack.interleave_geglu)
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32 if out32 else torch.float16, device=x.device)
+        out = torch.empty(M, No, dtype=torch.float32 if out32 else torch.float16, device=x.device)
     r2 = residual.reshape(M, N) if residual is not None else None
     d = _desc(x2, w, None if out32 else out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=r2,
               ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
     want = _attach_gn(d, gn, M, N)
     split = _launch(d, x.device)
-    y = out.reshape(*x.shape[:-1], N)
+    y = out.reshape(*x.shape[:-1], No)
     return (y, want and not split) if gn is not None else y
 
 

@@ -44,3 +44,12 @@ def f32(t):
 def pad_vec8(v):
     n = v.shape[0]
     return torch.nn.functional.pad(v, (0, pad8(n) - n)) if n % 8 else v
+
+
+def interleave_geglu(w, b):
+    """diffusers GEGLU: proj [2*inner, C] = [value rows ; gate rows].  Interleave to (value_0, gate_0, value_1, gate_1, ...) so that the
+    GEMM epilogue sees each pair in adjacent columns (ACT_GEGLU) and the 2*inner-wide intermediate is never written."""
+    inner = w.shape[0] // 2
+    wi = torch.stack([w[:inner], w[inner:]], 1).reshape(2 * inner, -1)
+    bi = torch.stack([b[:inner], b[inner:]], 1).reshape(2 * inner)
+    return wi, bi

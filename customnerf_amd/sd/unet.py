@@ -61,7 +61,8 @@ class _Transformer:
         self.q2 = pack.pack_linear(g(t + "attn2.to_q.weight"))
         self.kv2 = pack.pack_linear(torch.cat([g(t + "attn2.to_k.weight"), g(t + "attn2.to_v.weight")], 0))
         self.o2w, self.o2b = pack.pack_linear(g(t + "attn2.to_out.0.weight")), pack.f32(g(t + "attn2.to_out.0.bias"))
-        self.f1w, self.f1b = pack.pack_linear(g(t + "ff.net.0.proj.weight")), pack.f32(g(t + "ff.net.0.proj.bias"))
+        f1w, f1b = pack.interleave_geglu(g(t + "ff.net.0.proj.weight"), g(t + "ff.net.0.proj.bias"))       # GEGLU fused into the GEMM epilogue
+        self.f1w, self.f1b = pack.pack_linear(f1w), pack.f32(f1b)
         self.f2w, self.f2b = pack.pack_linear(g(t + "ff.net.2.weight")), pack.f32(g(t + "ff.net.2.bias"))
 
     def load_custom_diffusion(self, sd, prefix, dev):
@@ -104,7 +105,7 @@ class _Transformer:
         a = ops.attention_vt(q, kv[0], kv[1], self.heads)
         h = ops.linear(a, self.o2w, bias=self.o2b, residual=h)
         n = ops.layernorm(h, *self.ln[2])
-        f = ops.geglu(ops.linear(n, self.f1w, bias=self.f1b))
+        f = ops.linear(n, self.f1w, bias=self.f1b, act=ops.ACT_GEGLU)                     # [B, T, 4C]
         h = ops.linear(f, self.f2w, bias=self.f2b, residual=h)
         if not out_gn:
             return ops.linear(h, self.pow, bias=self.pob, residual=x.view(B, H * W, C)).view(B, H, W, C), None

@@ -31,7 +31,8 @@ extern "C" {
  *      valid iff ih < H_in (same for w); invalid taps read 0.   A(m,k) = in[image][ih][iw][c], c < Cin, Cin % 8 == 0.
  *   forward conv (torch.nn.Conv2d):            stride s, pad p, tstride 1
  *   input-gradient of a conv (frozen weights):  stride 1, pad KH-1-p, tstride s, B = weights flipped and transposed
- * epilogue, in this order:  (+ bias[n])  (+ bias_rows[(m / rows_per_bias_row)][n])  (activation: 0 none, 1 SiLU, 2 GELU(erf), 3 quick-GELU x*sigmoid(1.702x))
+ * epilogue, in this order:  (+ bias[n])  (+ bias_rows[(m / rows_per_bias_row)][n])  (activation: 0 none, 1 SiLU, 2 GELU(erf), 3 quick-GELU x*sigmoid(1.702x),
+ *                           4 GEGLU on interleaved column pairs: C[m][j] = y[2j] * gelu(y[2j+1]), C is N/2 wide, no residual)
  *                           (+ residual[z][m][n])  -> C (half), and/or C32 (float, optional).
  * batching: z = zo * batch_inner + zi, operand bases advance by s?_o * zo + s?_i * zi elements (attention heads are a strided
  * view of [batch, tokens, heads*dim]); batch = 1 and zero strides for plain GEMMs / convs.

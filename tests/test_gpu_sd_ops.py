@@ -237,3 +237,18 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     close(sums, s_ref, 2e-4, 1e-2)
     n_fused, _ = ops.groupnorm(y, gamma, beta, 32, 1e-5, True, sums=sums)
     close(n_fused, n_ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("M,C", [(8192, 320), (128, 1280), (77, 64)])
+def test_linear_fused_geglu(M, C):
+    """GEGLU folded into the projection's epilogue (interleaved value/gate rows) == proj followed by the GEGLU kernel"""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(M)
+    x = h(torch.randn(M, C, generator=g))
+    w = h(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b = torch.randn(8 * C, generator=g)
+    a, gate = (x @ w.t() + b).chunk(2, dim=-1)
+    wi, bi = pack.interleave_geglu(w, b)
+    y = ops.linear(x.half().cuda(), wi.half().cuda(), bias=bi.cuda(), act=ops.ACT_GEGLU)
+    assert y.shape == (M, 4 * C)
+    close(y, a * F.gelu(gate), 3e-3, 3e-3)
