@@ -41,6 +41,7 @@ class StableDiffusion(nn.Module):
         self.alphas = self.alphas_host.to(self.device)
         self.system = None
         self.use_graph = use_graph
+        self._ctx_cache = {}
         self._gen = torch.Generator().manual_seed(seed)                                     # host-side timestep draws: no device sync
 
     # ---- text (sd.py:77-94)
@@ -93,9 +94,21 @@ class StableDiffusion(nn.Module):
         t = int(torch.randint(min_step, max_step + 1, [1], generator=self._gen))
         return int(t * t_ratio)
 
+    def _ctx_half(self, text_embeddings):
+        """float16 copy of a text embedding, cached per source tensor (storage + version): the UNet keeps one captured graph and one
+        set of cross-attention K / V^T per context tensor, so the same prompt must arrive as the same tensor every step."""
+        key = (text_embeddings.data_ptr(), text_embeddings._version, tuple(text_embeddings.shape), text_embeddings.dtype)
+        ent = self._ctx_cache.get(key)
+        if ent is None:
+            if len(self._ctx_cache) >= 8:
+                self._ctx_cache.pop(next(iter(self._ctx_cache)))
+            ent = (text_embeddings, text_embeddings.to(self.device, torch.float16).contiguous())      # the source reference pins the key
+            self._ctx_cache[key] = ent
+        return ent[1]
+
     def eps_pred(self, unet_in, t, text_embeddings):
         tt = torch.full((unet_in.shape[0],), float(t), dtype=torch.float32, device=self.device)
-        ctx = text_embeddings.to(torch.float16).contiguous()
+        ctx = self._ctx_half(text_embeddings)
         return self.unet.graphed(unet_in, tt, ctx) if self.use_graph else self.unet(unet_in, tt, ctx)
 
     def sds_grad(self, latents, text_embeddings, t, noise):
