@@ -61,6 +61,8 @@ SIGNATURES = {
     "cnerf_sd_transpose": [vp, vp, u32, u32, u32, u32, u32, u64, u64, vp],
     "cnerf_sd_image_to_vae_input": [vp, u32, u32, u32, u32, u32, vp, vp],
     "cnerf_sd_image_to_vae_input_backward": [vp, u32, u32, u32, u32, u32, vp, vp],
+    "cnerf_sd_clip_preprocess": [vp, u32, u32, u32, u32, vp, vp, vp, vp],
+    "cnerf_sd_patchify": [vp, u32, u32, u32, vp, vp],
     "cnerf_sd_timestep_embedding": [vp, u32, u32, vp, vp],
     "cnerf_sd_add_noise": [vp, vp, f32, u32, vp, vp],
     "cnerf_sd_sds_grad": [vp, u32, vp, f32, f32, f32, u32, vp, vp],

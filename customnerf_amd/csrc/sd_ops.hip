@@ -378,6 +378,64 @@ __global__ void __launch_bounds__(256) k_img_fwd(const float *__restrict__ img, 
     }
 }
 
+// ---- CLIP image front-end (nerf/clip.py:13-17: T.Resize(224, BICUBIC, antialias=None) -> T.CenterCrop(224) -> T.Normalize) -------------------
+// Cubic convolution coefficients of torch's upsample_bicubic2d (A = -0.75), taps x0-1 .. x0+2, border indices clamped.
+__device__ __forceinline__ void so_cubic(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ void __launch_bounds__(256) k_clip_preprocess(const float *__restrict__ img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Hr, uint32_t Wr,
+                                                         uint32_t S, uint32_t top, uint32_t left, float3 mean, float3 inv_std, float *__restrict__ out) {
+    const size_t total = (size_t)B * 3 * S * S;
+    const float sy = (float)Hi / (float)Hr, sx = (float)Wi / (float)Wr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t ox = (uint32_t)(i % S), oy = (uint32_t)((i / S) % S), c = (uint32_t)((i / ((size_t)S * S)) % 3), b = (uint32_t)(i / ((size_t)3 * S * S));
+        const float fy = sy * ((float)(oy + top) + 0.5f) - 0.5f, fx = sx * ((float)(ox + left) + 0.5f) - 0.5f;
+        const float yf = floorf(fy), xf = floorf(fx);
+        float wy[4], wx[4];
+        so_cubic(fy - yf, wy);
+        so_cubic(fx - xf, wx);
+        const int y0 = (int)yf, x0 = (int)xf;
+        const float *p = img + ((size_t)b * 3 + c) * Hi * Wi;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int yy = min(max(y0 - 1 + j, 0), (int)Hi - 1);
+            float row = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = min(max(x0 - 1 + k, 0), (int)Wi - 1);
+                row += p[(size_t)yy * Wi + xx] * wx[k];
+            }
+            acc += row * wy[j];
+        }
+        const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z), is = c == 0 ? inv_std.x : (c == 1 ? inv_std.y : inv_std.z);
+        out[i] = (acc - m) * is;
+    }
+}
+
+// [B,3,S,S] float32 -> patch rows [B, (S/P)^2, P*P*3] half with the row laid out (kh, kw, c): the patch-embedding convolution
+// (kernel = stride = P, no bias) then is one dense GEMM against weights packed [Cout][kh][kw][3].
+__global__ void __launch_bounds__(256) k_patchify(const float *__restrict__ x, uint32_t B, uint32_t S, uint32_t P, _Float16 *__restrict__ out) {
+    const uint32_t G = S / P;
+    const size_t total = (size_t)B * 3 * S * S;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(i % 3);
+        size_t r = i / 3;
+        const uint32_t kw = (uint32_t)(r % P); r /= P;
+        const uint32_t kh = (uint32_t)(r % P); r /= P;
+        const uint32_t px = (uint32_t)(r % G); r /= G;
+        const uint32_t py = (uint32_t)(r % G);
+        const uint32_t b = (uint32_t)(r / G);
+        out[i] = (_Float16)x[(((size_t)b * 3 + c) * S + (size_t)py * P + kh) * S + (size_t)px * P + kw];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_img_bwd(const _Float16 *__restrict__ d_out, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo,
                                                  float *__restrict__ d_img) {
     const size_t total = (size_t)B * Ho * Wo;
@@ -580,6 +638,26 @@ int cnerf_sd_image_to_vae_input_backward(const void *d_out, uint32_t B, uint32_t
     hipStream_t st = CN_STREAM(stream);
     so_zero(d_img, (size_t)B * 3 * Hi * Wi, st);
     hipLaunchKernelGGL(k_img_bwd, dim3(so_blocks((size_t)B * Ho * Wo)), dim3(256), 0, st, (const _Float16 *)d_out, B, Hi, Wi, Ho, Wo, d_img);
+    return cn_launch_status();
+}
+
+int cnerf_sd_clip_preprocess(const float *img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t S, const float *mean3, const float *std3, float *out, void *stream) {
+    if (B == 0 || Hi == 0 || Wi == 0 || S == 0) return CNERF_EINVAL;
+    if (!img || !out || !mean3 || !std3) return CNERF_ENULL;
+    // torchvision Resize(int): the smaller edge becomes S, the other int(S * long / short); CenterCrop offsets are round((size - S) / 2)
+    uint32_t Hr, Wr;
+    if (Hi <= Wi) { Hr = S; Wr = (uint32_t)((uint64_t)S * Wi / Hi); } else { Wr = S; Hr = (uint32_t)((uint64_t)S * Hi / Wi); }
+    const uint32_t top = (uint32_t)lrintf((float)(Hr - S) / 2.0f), left = (uint32_t)lrintf((float)(Wr - S) / 2.0f);
+    for (int c = 0; c < 3; c++) if (!(std3[c] > 0.0f)) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_clip_preprocess, dim3(so_blocks((size_t)B * 3 * S * S)), dim3(256), 0, CN_STREAM(stream), img, B, Hi, Wi, Hr, Wr, S, top, left,
+                       make_float3(mean3[0], mean3[1], mean3[2]), make_float3(1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]), out);
+    return cn_launch_status();
+}
+
+int cnerf_sd_patchify(const float *x, uint32_t B, uint32_t S, uint32_t P, void *out, void *stream) {
+    if (B == 0 || S == 0 || P == 0 || S % P) return CNERF_EINVAL;
+    if (!x || !out) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_patchify, dim3(so_blocks((size_t)B * 3 * S * S)), dim3(256), 0, CN_STREAM(stream), x, B, S, P, (_Float16 *)out);
     return cn_launch_status();
 }
 

@@ -297,6 +297,30 @@ def image_to_vae_input_backward(d_out, B, Hi, Wi):
     return d_img
 
 
+def clip_preprocess(img, size=224, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
+    """torchvision Resize(size, BICUBIC, antialias=None) + CenterCrop(size) + Normalize(mean, std) (nerf/clip.py:13-17):
+    img [B, 3, H, W] float32 -> [B, 3, size, size] float32."""
+    import ctypes
+    require_cuda(img)
+    B, _, Hi, Wi = img.shape
+    img = img.contiguous().float()
+    out = torch.empty(B, 3, size, size, dtype=torch.float32, device=img.device)
+    m, sdev = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib.cnerf_sd_clip_preprocess(ptr(img), B, Hi, Wi, size, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sdev, ctypes.c_void_p), ptr(out), stream()),
+          "sd_clip_preprocess")
+    return out
+
+
+def patchify(x, patch):
+    """x [B, 3, S, S] float32 -> [B, (S/patch)^2, patch*patch*3] half, rows in (kh, kw, c) order (pack.pack_conv's K order)."""
+    require_cuda(x)
+    B, _, S, _ = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(B, (S // patch) ** 2, patch * patch * 3, dtype=torch.float16, device=x.device)
+    check(lib.cnerf_sd_patchify(ptr(x), B, S, patch, ptr(out), stream()), "sd_patchify")
+    return out
+
+
 def timestep_embedding(t, dim):
     """t [B] float32 (device) -> [B, dim] half (cos | sin)."""
     out = torch.empty(t.shape[0], dim, dtype=torch.float16, device=t.device)

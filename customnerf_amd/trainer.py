@@ -10,12 +10,40 @@ import torch.nn.functional as F
 from .optim import FusedAdam
 
 
+def flat_grad_buffer(parameters):
+    """Give every trainable parameter a persistent, zeroed `.grad` that is a view into ONE flat fp32 buffer (parameter order), so that
+    the per-step all-reduce runs in place on that buffer: no gather / scatter copies around the collective.  autograd accumulates into an
+    existing `.grad` in place and the fused Adam step zeroes it in place, so the views stay bound."""
+    ps = [p for p in parameters if p.requires_grad]
+    if not ps:
+        return None
+    flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+    off = 0
+    for p in ps:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
+def _grads_alias_flat(grads, flat):
+    off = flat.data_ptr()
+    for g in grads:
+        if g.dtype != flat.dtype or not g.is_contiguous() or g.data_ptr() != off:
+            return False
+        off += g.numel() * flat.element_size()
+    return off == flat.data_ptr() + flat.numel() * flat.element_size()
+
+
 def allreduce_grads_flat(parameters, flat, world_size):
     """One flattened all-reduce (sum) of all gradients (RCCL over xGMI on GPUs, gloo in the CPU tests); returns the flat buffer
-    for reuse.  The 1/world factor is NOT applied here (folded into the Adam un-scale).  Shared by ReconTrainer and EditTrainer."""
+    for reuse.  In place when the gradients are views of `flat` (flat_grad_buffer), through a staging copy otherwise.  The 1/world
+    factor is NOT applied here (folded into the Adam un-scale).  Shared by ReconTrainer and EditTrainer."""
     if world_size <= 1:
         return flat
     grads = [p.grad for p in parameters if p.grad is not None]
+    if flat is not None and _grads_alias_flat(grads, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
     n = sum(g.numel() for g in grads)
     if flat is None or flat.numel() != n:
         flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
@@ -40,10 +68,7 @@ class ReconTrainer:
             self.optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
         self.fused_adam = fused_adam
         self.global_step = 0
-        self._flat = None
-        for p in self.model.parameters():                    # persistent, pre-zeroed .grad buffers (zeroed by the fused step)
-            if p.requires_grad and p.grad is None:
-                p.grad = torch.zeros_like(p)
+        self._flat = flat_grad_buffer(self.model.parameters())   # persistent, pre-zeroed .grad views of one flat buffer (zeroed by the fused step)
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)      # main.py:189

@@ -117,6 +117,15 @@ int cnerf_sd_image_to_vae_input(const float *img, uint32_t B, uint32_t Hi, uint3
 int cnerf_sd_image_to_vae_input_backward(const void *d_out, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t Ho, uint32_t Wo,
                                          float *d_img, void *stream);
 
+/* CLIP image front-end of the view classifier (nerf/clip.py:13-17 `transformCLIP`, used at utils_init_nerf.py:256):
+ * torchvision Resize(S, BICUBIC, antialias=None) -- smaller edge to S, aspect kept, torch's bicubic (A = -0.75, align_corners=False,
+ * no antialias filter) -- then CenterCrop(S) and Normalize(mean, std).  img [B,3,Hi,Wi] float32 -> out [B,3,S,S] float32.
+ * mean3 / std3 are HOST pointers to 3 floats.  cnerf_sd_patchify: x [B,3,S,S] float32 -> patch rows [B,(S/P)^2, P*P*3] half in
+ * (kh, kw, c) order, the A operand of the ViT patch-embedding convolution (`visual.conv1`, kernel = stride = P) as a dense GEMM. */
+int cnerf_sd_clip_preprocess(const float *img, uint32_t B, uint32_t Hi, uint32_t Wi, uint32_t S, const float *mean3, const float *std3,
+                             float *out, void *stream);
+int cnerf_sd_patchify(const float *x, uint32_t B, uint32_t S, uint32_t P, void *out, void *stream);
+
 /* Diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b][0:dim/2] = cos(t_b w_i),
  * out[b][dim/2:] = sin(t_b w_i), w_i = exp(-ln(10000) i / (dim/2)); half output [B, dim]. */
 int cnerf_sd_timestep_embedding(const float *t, uint32_t B, uint32_t dim, void *out, void *stream);

@@ -175,3 +175,68 @@ def clip_text_forward(sd, cfg, input_ids):
         f = _lin(n, sd, p + "mlp.fc1")
         h = h + _lin(f * torch.sigmoid(1.702 * f), sd, p + "mlp.fc2")
     return F.layer_norm(h, (W,), sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"], cfg["eps"])
+
+
+# ---- CLIP view classifier (nerf/clip.py, utils_init_nerf.py:254-258) ------------------------------------------------------------------------
+# OpenAI `clip` is third-party and absent offline (PARITY UNPINNED like the rest of this file): restated from the published
+# clip/model.py — VisionTransformer (conv1 patch embedding, class token, ln_pre, ResidualAttentionBlocks, ln_post, proj), the text
+# transformer (causal mask, ln_final, EOT pooling, text_projection) and CLIP.forward's normalised, logit_scale.exp()-scaled logits.
+def clip_preprocess(img, size=224, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
+    """torchvision T.Resize(size, BICUBIC, antialias=None) on a tensor (smaller edge -> size, F.interpolate bicubic without antialias),
+    T.CenterCrop(size), T.Normalize — nerf/clip.py:13-17, written with torch ops only (torchvision is not needed)."""
+    B, C, H, W = img.shape
+    if H <= W:
+        nh, nw = size, int(size * W / H)
+    else:
+        nh, nw = int(size * H / W), size
+    x = F.interpolate(img.float(), size=(nh, nw), mode="bicubic", align_corners=False)
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    x = x[:, :, top:top + size, left:left + size]
+    return (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+
+
+def _clip_blocks(h, sd, prefix, layers, heads, eps, mask):
+    n_, T, W = h.shape
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        x = F.layer_norm(h, (W,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
+        qkv = x @ sd[p + "attn.in_proj_weight"].t() + sd[p + "attn.in_proj_bias"]
+        q, k, v = (t.view(n_, T, heads, W // heads).transpose(1, 2) for t in qkv.split(W, dim=-1))
+        s = q @ k.transpose(-1, -2) / math.sqrt(W // heads)
+        if mask is not None:
+            s = s + mask
+        a = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(n_, T, W)
+        h = h + a @ sd[p + "attn.out_proj.weight"].t() + sd[p + "attn.out_proj.bias"]
+        x = F.layer_norm(h, (W,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
+        f = x @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"]
+        h = h + (f * torch.sigmoid(1.702 * f)) @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"]
+    return h
+
+
+def clip_encode_image(sd, cfg, image):
+    x = F.conv2d(image, sd["visual.conv1.weight"], stride=cfg["vision_patch_size"])
+    B, W = x.shape[0], x.shape[1]
+    x = x.reshape(B, W, -1).permute(0, 2, 1)
+    x = torch.cat([sd["visual.class_embedding"].expand(B, 1, W), x], 1) + sd["visual.positional_embedding"]
+    x = F.layer_norm(x, (W,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], cfg["eps"])
+    x = _clip_blocks(x, sd, "visual.transformer.", cfg["vision_layers"], cfg["vision_heads"], cfg["eps"], None)
+    x = F.layer_norm(x[:, 0, :], (W,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg["eps"])
+    return x @ sd["visual.proj"]
+
+
+def clip_encode_text(sd, cfg, text):
+    n_, T = text.shape
+    W = cfg["transformer_width"]
+    x = sd["token_embedding.weight"][text] + sd["positional_embedding"][:T]
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    x = _clip_blocks(x, sd, "transformer.", cfg["transformer_layers"], cfg["transformer_heads"], cfg["eps"], mask)
+    x = F.layer_norm(x, (W,), sd["ln_final.weight"], sd["ln_final.bias"], cfg["eps"])
+    return x[torch.arange(n_), text.argmax(dim=-1)] @ sd["text_projection"]
+
+
+def clip_forward(sd, cfg, image, text):
+    """CLIP.forward: (logits_per_image [B, n], logits_per_text [n, B])"""
+    i, t = clip_encode_image(sd, cfg, image), clip_encode_text(sd, cfg, text)
+    i, t = i / i.norm(dim=1, keepdim=True), t / t.norm(dim=1, keepdim=True)
+    li = sd["logit_scale"].exp() * i @ t.t()
+    return li, li.t()

@@ -48,8 +48,11 @@ tr = ReconTrainer(m, Opt(), world_size=world, fused_adam=False)
 # each rank produces a different local gradient (its own shard of the "rays")
 g = torch.Generator().manual_seed(100 + rank)
 m.a.grad.copy_(torch.randn(37, generator=g)); m.b.grad.copy_(torch.randn(5, 3, generator=g))
-local_a = m.a.grad.clone()
+from customnerf_amd.trainer import _grads_alias_flat
+assert _grads_alias_flat([m.a.grad, m.b.grad], tr._flat)          # .grad are views of one flat buffer: the collective runs in place
+flat_ptr = tr._flat.data_ptr()
 tr.allreduce_grads()
+assert tr._flat.data_ptr() == flat_ptr and m.a.grad.data_ptr() == flat_ptr
 # reference: sum over ranks of what each rank generated
 exp_a = sum(torch.randn(37, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
 assert torch.allclose(m.a.grad, exp_a, atol=1e-6), (m.a.grad - exp_a).abs().max()
@@ -62,6 +65,16 @@ tr.optimizer.step()
 pa = [torch.empty_like(m.a.data) for _ in range(world)]
 dist.all_gather(pa, m.a.data)
 assert all(torch.equal(pa[0], x) for x in pa)
+# autograd accumulates into the views in place (they stay bound to the flat buffer) ...
+m.a.grad.zero_(); m.b.grad.zero_()
+((m.a * (rank + 1)).sum() + (m.b * 2).sum()).backward()
+assert _grads_alias_flat([m.a.grad, m.b.grad], tr._flat)
+tr.allreduce_grads()
+assert torch.allclose(m.a.grad, torch.full((37,), float(sum(r + 1 for r in range(world))))) and torch.allclose(m.b.grad, torch.full((5, 3), 2.0 * world))
+# ... and a re-bound gradient falls back to the staging copy with the same result
+m.b.grad = torch.full((5, 3), float(rank))
+tr.allreduce_grads()
+assert torch.allclose(m.b.grad, torch.full((5, 3), float(sum(range(world)))))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

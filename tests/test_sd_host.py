@@ -96,3 +96,23 @@ def test_sd_oracle_sanity():
     emb = so.timestep_embedding(torch.tensor([0.0, 1.0]), 8)
     np.testing.assert_allclose(emb[0].numpy(), [1, 1, 1, 1, 0, 0, 0, 0], atol=1e-7)                           # cos | sin, flip_sin_to_cos
     np.testing.assert_allclose(emb[1, 4].item(), np.sin(1.0), atol=1e-6)
+
+
+def test_clip_vitb32_parameter_table_and_oracle_preprocess():
+    """The OpenAI CLIP ViT-B/32 state dict (what nerf/clip.py loads) has 151,277,313 parameters; the oracle front-end is
+    torchvision's Resize(224, bicubic) + CenterCrop + Normalize written with torch ops."""
+    import torch
+    from customnerf_amd.sd import clip_view as cv
+    from oracle import sd_oracle as so
+    n = sum(int(torch.Size(s).numel()) for _, s in cv.clip_params(cv.CLIP_VITB32))
+    assert n == 151_277_313
+    names = [k for k, _ in cv.clip_params(cv.CLIP_VITB32)]
+    assert len(names) == len(set(names)) and "visual.transformer.resblocks.11.attn.in_proj_weight" in names and "transformer.resblocks.11.mlp.c_proj.bias" in names
+    img = torch.full((1, 3, 40, 60), 0.5)
+    out = so.clip_preprocess(img, 32)
+    assert out.shape == (1, 3, 32, 32)
+    exp = torch.tensor([(0.5 - m) / s for m, s in zip(cv.CLIP_MEAN, cv.CLIP_STD)]).view(1, 3, 1, 1).expand_as(out)
+    assert torch.allclose(out, exp, atol=1e-5)                         # bicubic weights sum to one: a constant image stays constant
+    sd = cv.random_clip_state_dict(cv.CLIP_TINY, 0)
+    li, lt = so.clip_forward(sd, cv.CLIP_TINY, torch.randn(2, 3, 64, 64), torch.randint(1, 999, (3, 77)))
+    assert li.shape == (2, 3) and torch.equal(li.t(), lt)
