@@ -145,6 +145,7 @@ def main_edit(args, world, rank, dev):
 
     for i in range(max(args.warmup, V // world + 1)):                   # warm-up also fills the per-view cache of the pretrained render
         step(i)
+    good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -155,6 +156,7 @@ def main_edit(args, world, rank, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    skipped = args.steps - (trainer.scaler.good_steps() - good0) if trainer.scaler is not None else 0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -165,7 +167,8 @@ def main_edit(args, world, rank, dev):
               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
               "config": {"workload": f"cfg3 synthetic: {H}x{W} view/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on the CFG pair "
                                      "at 64x64 latents + VAE encoder fwd/input-grad at 512x512, lambda_sd=0.01, keep_bg=1000, LGIE global/local alternation, fwd+bwd+Adam",
-                         "parallelism": f"dp{world} (view-parallel SDS, RCCL grad all-reduce)" if world > 1 else "single GPU", "final_loss": float(loss)}}
+                         "parallelism": f"dp{world} (view-parallel SDS, RCCL grad all-reduce)" if world > 1 else "single GPU", "final_loss": float(loss),
+                         "loss_scale": f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}", "steps_skipped_on_overflow": skipped}}
     if not args.no_roofline:
         prof = []
         guidance.use_graph = False                                       # eager launches so that each GEMM can be bracketed by events
@@ -254,6 +257,7 @@ def main():
         step(i)
     prof = [] if not args.no_roofline else None
     ge.set_profile(prof)
+    good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -280,7 +284,9 @@ def main():
             "config": {"workload": f"cfg2 synthetic {H}x{W} view/GPU, hash grid L16 T2^19 (6.12M entries), "
                                    + ("run() path 64+64 samples/ray" if args.path == "run" else "run_cuda() occupancy-march path, unit-sphere occupancy")
                                    + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays, "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single GPU",
-                       "path": args.path, "final_loss": float(loss)},
+                       "path": args.path, "final_loss": float(loss),
+                       "loss_scale": (f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}" if trainer.scaler is not None else "none (fp32)"),
+                       "steps_skipped_on_overflow": (args.steps - (trainer.scaler.good_steps() - good0)) if trainer.scaler is not None else 0},
         }
         if args.path == "march":
             result["config"]["samples_per_ray"] = out.get('num_points', 0) / n_rays

@@ -48,6 +48,9 @@ SIGNATURES = {
     "cnerf_composite_run": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp],
     "cnerf_composite_run_backward": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
+    "cnerf_scaler_check": [vp, u64, vp, vp],
+    "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],
+    "cnerf_scaler_update": [vp, f32, f32, u32, vp],
     # ---- include/customnerf_sd.h (score-distillation primitives)
     "cnerf_sd_gemm": [vp, vp, u64, vp],
     "cnerf_sd_gemm_workspace_bytes": [vp, vp],

@@ -12,7 +12,7 @@ import os
 import torch
 
 
-def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, full=False):
+def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None):
     state = {'epoch': int(epoch), 'global_step': int(global_step),
              'stats': stats if stats is not None else {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}}
     if getattr(model, 'cuda_ray', False):
@@ -20,14 +20,16 @@ def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, 
         state['mean_density'] = model.mean_density
     if full and optimizer is not None:
         state['optimizer'] = optimizer.state_dict()
+    if full and scaler is not None:
+        state['scaler'] = scaler.state_dict()                           # GradScaler keys (:797-798)
     state['model'] = model.state_dict()
     return state
 
 
-def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, full=False):
+def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None):
     """utils_init_nerf.py:779-815 (`best` bookkeeping and checkpoint rotation are the caller's)."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save(checkpoint_state(model, epoch, global_step, stats, optimizer, full), path)
+    torch.save(checkpoint_state(model, epoch, global_step, stats, optimizer, full, scaler), path)
     return path
 
 
@@ -36,7 +38,7 @@ def latest_checkpoint(ckpt_dir):
     return files[-1] if files else None
 
 
-def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_location=None, log=print):
+def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_location=None, log=print, scaler=None):
     """utils_init_nerf.py:838-901.  `checkpoint`: path or an already loaded dict.  Returns a dict with what was restored:
     {'epoch', 'global_step', 'stats', 'missing_keys', 'unexpected_keys'} (epoch / step / stats None when absent or model_only)."""
     ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
@@ -70,4 +72,9 @@ def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_loc
             optimizer.load_state_dict(ck['optimizer'])
         except Exception as e:                                          # the reference swallows this too (:885-890)
             log(f"[WARN] Failed to load optimizer: {e!r}")
+    if scaler is not None and 'scaler' in ck:                           # :896-901
+        try:
+            scaler.load_state_dict(ck['scaler'])
+        except Exception as e:
+            log(f"[WARN] Failed to load scaler: {e!r}")
     return out

@@ -82,6 +82,82 @@ __global__ void __launch_bounds__(256) k_adam(float *__restrict__ p, float *__re
     }
 }
 
+// ---- dynamic loss scaling (torch.cuda.amp.GradScaler semantics, utils_init_nerf.py: scaler.scale(loss).backward(); scaler.step(); scaler.update())
+// entirely on the device: state = float[4] {scale, growth_tracker, found_inf, good_steps}; no host read anywhere in the step.
+__global__ void __launch_bounds__(256) k_scaler_check(const float *__restrict__ g, uint64_t n, float *__restrict__ state) {
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(g)[i];
+        // x - x is 0 for every finite x and NaN for +-inf / NaN
+        const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad = bad || (t != 0.0f);
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bad = bad || ((g[i] - g[i]) != 0.0f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;          // benign race: every writer stores the same value
+}
+
+__global__ void k_scaler_update(float *state, float growth, float backoff, float interval) {
+    if (state[2] != 0.0f) { state[0] *= backoff; state[1] = 0.0f; }
+    else {
+        state[3] += 1.0f;
+        const float t = state[1] + 1.0f;
+        if (t >= interval) { state[0] *= growth; state[1] = 0.0f; } else state[1] = t;
+    }
+    state[2] = 0.0f;
+}
+
+// k_adam with the gradient scale, the skip decision and the step count taken from the scaler state (see cnerf_adam_step_scaled)
+__global__ void __launch_bounds__(256) k_adam_scaled(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                     __half *__restrict__ ph, uint64_t n, float lr, float beta1, float beta2, float eps,
+                                                     const float *__restrict__ state, float extra_inv, int zero_grad) {
+    const bool skip = state[2] != 0.0f;
+    const float gscale = extra_inv / state[0];
+    const double step = (double)state[3] + 1.0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1), rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const uint64_t n4 = n / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (skip) {                                                           // non-finite gradients: optimizer.step() is skipped, gradients are still cleared
+        if (zero_grad) {
+            for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) reinterpret_cast<float4 *>(g)[i] = make_float4(0, 0, 0, 0);
+            for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = 0;
+        }
+        return;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float gk = ga[k] * gscale;
+            ma[k] = beta1 * ma[k] + (1.0f - beta1) * gk;
+            va[k] = beta2 * va[k] + (1.0f - beta2) * gk * gk;
+            pa[k] -= step_size * ma[k] / (sqrtf(va[k]) * rsqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = make_float4(0, 0, 0, 0);
+        if (ph) {
+            union { __half2 h[2]; uint2 u; } o;
+            o.h[0] = __floats2half2_rn(pp.x, pp.y);
+            o.h[1] = __floats2half2_rn(pp.z, pp.w);
+            reinterpret_cast<uint2 *>(ph)[i] = o.u;
+        }
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gk = g[i] * gscale;
+        const float mk = beta1 * m[i] + (1.0f - beta1) * gk;
+        const float vk = beta2 * v[i] + (1.0f - beta2) * gk * gk;
+        const float pk = p[i] - step_size * mk / (sqrtf(vk) * rsqrt_bc2 + eps);
+        m[i] = mk; v[i] = vk; p[i] = pk;
+        if (zero_grad) g[i] = 0;
+        if (ph) ph[i] = __float2half_rn(pk);
+    }
+}
+
 extern "C" {
 
 int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
@@ -111,6 +187,36 @@ int cnerf_adam_step(float *p, float *g, float *m, float *v, void *p_half, uint64
     const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, CN_STREAM(stream), p, g, m, v, (__half *)p_half, n, step_size, beta1, beta2, eps,
                        rsqrt_bc2, grad_scale_inv, zero_grad);
+    return cn_launch_status();
+}
+
+int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream) {
+    if (!state || (!g && n)) return CNERF_ENULL;
+    if (n == 0) return CNERF_OK;
+    if (((uintptr_t)g) & 15) return CNERF_EINVAL;
+    const uint64_t want = cn_div_up64(cn_div_up64(n, 4), 256);
+    const uint32_t blocks = (uint32_t)(want < 2048 ? (want ? want : 1) : 2048);
+    hipLaunchKernelGGL(k_scaler_check, dim3(blocks), dim3(256), 0, CN_STREAM(stream), g, n, state);
+    return cn_launch_status();
+}
+
+int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream) {
+    if (!state) return CNERF_ENULL;
+    if (!(growth_factor >= 1.0f) || !(backoff_factor > 0.0f && backoff_factor <= 1.0f) || growth_interval == 0) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(1), 0, CN_STREAM(stream), state, growth_factor, backoff_factor, (float)growth_interval);
+    return cn_launch_status();
+}
+
+int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2, float eps,
+                           const float *state, float extra_inv, int zero_grad, void *stream) {
+    if (!p || !g || !m || !v || !state) return CNERF_ENULL;
+    if (n == 0) return CNERF_OK;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CNERF_EINVAL;
+    if (p_half && (((uintptr_t)p_half) & 7)) return CNERF_EINVAL;
+    const uint64_t want = cn_div_up64(cn_div_up64(n, 4), 256);
+    const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(k_adam_scaled, dim3(blocks), dim3(256), 0, CN_STREAM(stream), p, g, m, v, (__half *)p_half, n, lr, beta1, beta2, eps, state,
+                       extra_inv, zero_grad);
     return cn_launch_status();
 }
 

@@ -12,6 +12,45 @@ def adam_step(p, g, m, v, lr, betas=(0.9, 0.99), eps=1e-15, step=1, grad_scale_i
                               float(eps), int(step), float(grad_scale_inv), int(zero_grad), stream()), "adam_step")
 
 
+class DynamicLossScaler:
+    """torch.cuda.amp.GradScaler's policy (the reference trainer's fp16 recipe: init 65536, x2 every 2000 clean steps, x0.5 and a
+    skipped optimiser step on inf/NaN) with the whole state on the device: `state` = float32[4] {scale, growth_tracker, found_inf,
+    good_steps}.  Nothing in a step reads it back, so the step stays free of host syncs (GradScaler.step() does an .item())."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def scale(self, loss):
+        return loss * self.state[0]
+
+    def check(self, flat_grads):
+        """found_inf |= any non-finite value (call on the all-reduced flat gradient buffer: every rank then takes the same decision)"""
+        require_cuda(flat_grads)
+        check(lib.cnerf_scaler_check(ptr(flat_grads), flat_grads.numel(), ptr(self.state), stream()), "scaler_check")
+
+    def update(self):
+        check(lib.cnerf_scaler_update(ptr(self.state), float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval), stream()), "scaler_update")
+
+    def get_scale(self):
+        return float(self.state[0])                                    # host read: diagnostics only
+
+    def good_steps(self):
+        return int(self.state[3])
+
+    def state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict() keys (what the reference checkpoints under 'scaler', utils_init_nerf.py:797-798),
+        plus the count of non-skipped optimiser steps that drives Adam's bias correction here."""
+        st = self.state.detach().cpu().tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(st[1]), "_good_steps": int(st[3])}
+
+    def load_state_dict(self, sd):
+        good = sd.get("_good_steps", int(self.state[3]))
+        self.state.copy_(torch.tensor([float(sd["scale"]), float(sd.get("_growth_tracker", 0)), 0.0, float(good)]))
+        self.growth_factor, self.backoff_factor, self.growth_interval = sd["growth_factor"], sd["backoff_factor"], sd["growth_interval"]
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam-compatible surface (param groups with per-group lr) over cnerf_adam_step.
     `half_shadows`: {param: fp16 tensor} refreshed in the same pass (GridEncoder.set_half_table)."""
@@ -21,6 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.zero_grad_in_step = zero_grad_in_step
         self.half_shadows = {}
         self.grad_scale_inv = 1.0
+        self.scaler = None              # DynamicLossScaler: gradient scale, skip decision and step count come from its device state
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -34,8 +74,14 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
-                adam_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], group['lr'], group['betas'], group['eps'], st['step'],
-                          self.grad_scale_inv, self.zero_grad_in_step, self.half_shadows.get(p))
+                if self.scaler is not None:
+                    require_cuda(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], self.half_shadows.get(p))
+                    check(lib.cnerf_adam_step_scaled(ptr(p.data), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), ptr(self.half_shadows.get(p)),
+                                                     p.numel(), float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                                                     ptr(self.scaler.state), float(self.grad_scale_inv), int(self.zero_grad_in_step), stream()), "adam_step_scaled")
+                else:
+                    adam_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], group['lr'], group['betas'], group['eps'], st['step'],
+                              self.grad_scale_inv, self.zero_grad_in_step, self.half_shadows.get(p))
                 # the kernel writes through the raw pointer, which does not bump torch's version counter:
                 # advance our own epoch so caches keyed on the parameter (GridEncoder.half_table) notice.
                 p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1

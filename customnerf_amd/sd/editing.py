@@ -9,12 +9,12 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ..optim import FusedAdam
-from ..trainer import allreduce_grads_flat, flat_grad_buffer
+from ..optim import DynamicLossScaler, FusedAdam
+from ..trainer import allreduce_grads_flat, check_grads_finite, flat_grad_buffer
 
 
 class EditTrainer:
-    def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale=128.0, seed=0,
+    def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale='dynamic', seed=0,
                  clip_guidance=None, clip_match_text=None):
         """text_z / text_z_fg: the [2, 77, 768] (uncond, cond) embeddings of the global / local prompt; with `opt.clip_view` they are
         LISTS of three such tensors for the ", front view" / ", side view" / ", back view" prompts (prepare_text_embeddings,
@@ -30,11 +30,13 @@ class EditTrainer:
             if not (isinstance(text_z, (list, tuple)) and isinstance(text_z_fg, (list, tuple)) and len(text_z) == len(text_z_fg) == clip_match_text.shape[0]):
                 raise ValueError("opt.clip_view needs one (text_z, text_z_fg) pair per view prompt")
         self.fp16, self.world_size = fp16, world_size
-        self.loss_scale = loss_scale if fp16 else 1.0
+        self.scaler = DynamicLossScaler(next(model.parameters()).device) if (fp16 and loss_scale == 'dynamic') else None     # GradScaler policy, on device
+        self.loss_scale = 1.0 if (not fp16 or self.scaler is not None) else float(loss_scale)
         lr = opt.lr if lr is None else lr
         groups = model.get_params(lr)
         self.base_lrs = [g['lr'] for g in groups]
         self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+        self.optimizer.scaler = self.scaler
         self.global_step = 0
         self.pt_dict = {}
         self._flat = flat_grad_buffer(self.model.parameters())          # .grad views of one flat buffer: the all-reduce runs in place
@@ -128,12 +130,17 @@ class EditTrainer:
         """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""
         self.model.train()
         pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing(data)
-        (loss * self.loss_scale).backward()
+        (self.scaler.scale(loss) if self.scaler is not None else loss * self.loss_scale).backward()
         self.allreduce_grads()
         f = self.lr_factor()
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
             g['lr'] = base * f
         self.optimizer.grad_scale_inv = 1.0 / (self.loss_scale * self.world_size)
-        self.optimizer.step()
+        if self.scaler is not None:
+            check_grads_finite(self.scaler, list(self.model.parameters()), self._flat)
+            self.optimizer.step()
+            self.scaler.update()
+        else:
+            self.optimizer.step()
         self.global_step += 1
         return loss.detach(), loss_dict

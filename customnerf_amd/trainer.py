@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from .optim import FusedAdam
+from .optim import DynamicLossScaler, FusedAdam
 
 
 def flat_grad_buffer(parameters):
@@ -17,12 +17,16 @@ def flat_grad_buffer(parameters):
     ps = [p for p in parameters if p.requires_grad]
     if not ps:
         return None
-    flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+    flat = torch.zeros(sum(_slot(p.numel()) for p in ps), dtype=torch.float32, device=ps[0].device)
     off = 0
     for p in ps:
         p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
+        off += _slot(p.numel())
     return flat
+
+
+def _slot(n):
+    return (n + 3) // 4 * 4            # every view starts 16-byte aligned (the fused Adam kernel loads float4); pad elements stay zero
 
 
 def _grads_alias_flat(grads, flat):
@@ -30,7 +34,7 @@ def _grads_alias_flat(grads, flat):
     for g in grads:
         if g.dtype != flat.dtype or not g.is_contiguous() or g.data_ptr() != off:
             return False
-        off += g.numel() * flat.element_size()
+        off += _slot(g.numel()) * flat.element_size()
     return off == flat.data_ptr() + flat.numel() * flat.element_size()
 
 
@@ -46,24 +50,41 @@ def allreduce_grads_flat(parameters, flat, world_size):
         return flat
     n = sum(g.numel() for g in grads)
     if flat is None or flat.numel() != n:
-        flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+        flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)       # staging buffer (the caller keeps it for the next step)
     torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     torch._foreach_copy_([g.reshape(-1) for g in grads], list(flat.split([g.numel() for g in grads])))
     return flat
 
 
+def check_grads_finite(scaler, parameters, flat):
+    """GradScaler's inf check on the (all-reduced) gradients: one pass over the flat buffer when the gradients alias it."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if flat is not None and _grads_alias_flat(grads, flat):
+        scaler.check(flat)
+    else:
+        for g in grads:
+            scaler.check(g.contiguous())
+
+
 class ReconTrainer:
-    def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale=128.0):
+    def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic'):
+        """loss_scale: 'dynamic' = the reference's GradScaler policy (utils_init_nerf.py `self.scaler = GradScaler(enabled=self.fp16)`:
+        init 65536, x2 / 2000 clean steps, x0.5 + skipped step on inf) kept on the device (optim.DynamicLossScaler, fused Adam only);
+        a float = static scale."""
         self.model, self.opt = model, opt
         self.fp16 = fp16
         self.world_size = world_size
-        self.loss_scale = loss_scale if fp16 else 1.0        # static scale (tcnn uses a fixed 128x loss scale)
+        if loss_scale == 'dynamic' and not (fp16 and fused_adam):
+            loss_scale = 128.0
+        self.scaler = DynamicLossScaler(next(model.parameters()).device) if loss_scale == 'dynamic' else None
+        self.loss_scale = 1.0 if (not fp16 or self.scaler is not None) else float(loss_scale)
         lr = opt.lr if lr is None else lr
         groups = model.get_params(lr)                        # grid lr x10 (network_grid.py:196-206)
         self.base_lrs = [g['lr'] for g in groups]
         if fused_adam:
             self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+            self.optimizer.scaler = self.scaler
         else:
             self.optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
         self.fused_adam = fused_adam
@@ -90,7 +111,7 @@ class ReconTrainer:
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
             loss = self.loss(outputs, rgbs, mask)
-        (loss * self.loss_scale).backward()
+        (self.scaler.scale(loss) if self.scaler is not None else loss * self.loss_scale).backward()
         self.allreduce_grads()
         f = self.lr_factor()
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
@@ -98,7 +119,12 @@ class ReconTrainer:
         inv = 1.0 / (self.loss_scale * self.world_size)
         if self.fused_adam:
             self.optimizer.grad_scale_inv = inv
-            self.optimizer.step()
+            if self.scaler is not None:
+                check_grads_finite(self.scaler, list(self.model.parameters()), self._flat)      # on the all-reduced gradients: every rank takes the same skip decision
+                self.optimizer.step()
+                self.scaler.update()
+            else:
+                self.optimizer.step()
         else:
             if inv != 1.0:
                 torch._foreach_mul_([p.grad for p in self.model.parameters() if p.grad is not None], inv)

@@ -236,6 +236,23 @@ int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas,
 int cnerf_adam_step(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2,
                     float eps, uint32_t step, float grad_scale_inv, int zero_grad, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic loss scaling with torch.cuda.amp.GradScaler's semantics (the reference trainer's fp16 recipe:
+ * `self.scaler = GradScaler(enabled=fp16)`, scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()),
+ * kept on the device so that a training step has no host read:
+ *   state = float32[4] {scale, growth_tracker, found_inf, good_steps}  (initialise to {65536, 0, 0, 0}).
+ * cnerf_scaler_check     : found_inf |= any non-finite value in g[0..n)  (call on the all-reduced gradients).
+ * cnerf_adam_step_scaled : cnerf_adam_step with g multiplied by extra_inv / scale, the 1-based step = good_steps + 1 (bias
+ *                          correction in the kernel) and the whole update skipped when found_inf is set (gradients are still
+ *                          zeroed if zero_grad) — what scaler.step() does.
+ * cnerf_scaler_update    : found_inf ? {scale *= backoff, tracker = 0} : {good_steps += 1, tracker += 1, tracker == interval ?
+ *                          {scale *= growth, tracker = 0}}; found_inf = 0.  Call once per step after every adam_step_scaled.
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream);
+int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2,
+                           float eps, const float *state, float extra_inv, int zero_grad, void *stream);
+int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

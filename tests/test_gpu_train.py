@@ -1,6 +1,6 @@
 """GPU: the reconstruction step of the reference's trainer (utils_init_nerf.py:194-241, main.py:182-189) on the fused path
-actually learns — loss on a learnable synthetic target drops — in fp32 and in fp16 (static 128x loss scale), and the fused
-Adam keeps the fp16 grid shadow in sync."""
+actually learns — loss on a learnable synthetic target drops — in fp32 and in fp16 (GradScaler policy on the device), the fused
+Adam keeps the fp16 grid shadow in sync, and the device-side loss scaler follows torch.cuda.amp.GradScaler step for step."""
 import numpy as np
 import pytest
 import torch
@@ -99,3 +99,48 @@ def test_train_one_epoch_on_a_disk_scene(tmp_path):
     before = tr.global_step
     train_one_epoch(tr, views, shard=(1, 2))
     assert tr.global_step - before == len(range(1, len(views), 2))
+
+
+def test_dynamic_loss_scaler_matches_torch_gradscaler():
+    """optim.DynamicLossScaler + FusedAdam against torch.cuda.amp.GradScaler + torch.optim.Adam on the same gradient sequence with
+    injected inf / NaN steps: same skipped steps, same scale trajectory (growth and backoff), same parameters (bias correction counts
+    only the non-skipped steps)."""
+    from customnerf_amd.optim import DynamicLossScaler, FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1003,), (37, 16), (8,)]
+    p_ref = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    p_our = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+    opt_ref = torch.optim.Adam([{'params': p_ref[:1], 'lr': 1e-2}, {'params': p_ref[1:], 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15)
+    opt_our = FusedAdam([{'params': p_our[:1], 'lr': 1e-2}, {'params': p_our[1:], 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15)
+    ref = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=4)
+    ref.scale(torch.zeros(1, device="cuda"))                         # GradScaler creates its device state lazily
+    our = DynamicLossScaler("cuda", init_scale=1024.0, growth_interval=4)
+    opt_our.scaler = our
+    from customnerf_amd.trainer import flat_grad_buffer, check_grads_finite
+    flat = flat_grad_buffer(p_our)
+    bad_steps = {3: float('inf'), 4: float('nan'), 11: float('-inf')}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for step in range(20):
+        grads = [torch.randn(s, device="cuda", generator=g) for s in shapes]
+        if step in bad_steps:
+            grads[step % 3].view(-1)[5] = bad_steps[step]
+        scale_ref = ref.get_scale()
+        assert abs(our.get_scale() - scale_ref) < 1e-6 * scale_ref, (step, our.get_scale(), scale_ref)
+        for p, q, gr in zip(p_ref, p_our, grads):
+            p.grad = gr * scale_ref                                   # what backward of the scaled loss leaves behind
+            q.grad.copy_(gr * scale_ref)
+        ref.step(opt_ref)
+        ref.update()
+        opt_ref.zero_grad()
+        check_grads_finite(our, p_our, flat)
+        opt_our.step()
+        our.update()
+        for p, q in zip(p_ref, p_our):
+            assert torch.all(q.grad == 0)
+            assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), (step, float((p - q).abs().max()))
+    assert our.good_steps() == 20 - len(bad_steps)
+    sd = our.state_dict()
+    assert set(ref.state_dict()) <= set(sd) and sd["scale"] == ref.get_scale() and sd["_growth_tracker"] == ref.state_dict()["_growth_tracker"]
+    again = DynamicLossScaler("cuda")
+    again.load_state_dict(ref.state_dict())                          # a reference checkpoint's 'scaler' entry loads
+    assert again.get_scale() == ref.get_scale()
