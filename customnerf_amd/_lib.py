@@ -32,11 +32,13 @@ SIGNATURES = {
     "cnerf_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp],
     "cnerf_compact_rays_alive": [vp, u32, vp, vp, vp],
     "cnerf_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
+    "cnerf_grid_encode_forward_strided": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, u32, vp],
     "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp, u64, vp],
     "cnerf_grid_encode_backward_workspace_bytes": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
     "cnerf_cast_f32_to_f16": [vp, vp, u64, vp],
     "cnerf_field_forward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, vp],
+    "cnerf_field_forward_strided": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, u32, vp],
     "cnerf_field_backward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp],
     "cnerf_field_backward_workspace_bytes": [u32, u32, u32, u32, i32, vp],
     "cnerf_mlp_forward": [vp, u32, vp, u32, u32, u32, u32, u32, i32, vp, u32, i32, vp],
@@ -45,8 +47,11 @@ SIGNATURES = {
     "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "cnerf_sample_coarse": [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp],
+    "cnerf_sample_fine_merge_split": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp],
     "cnerf_composite_run": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp],
     "cnerf_composite_run_backward": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp],
+    "cnerf_composite_run_indexed": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp, vp, vp, vp],
+    "cnerf_composite_run_backward_indexed": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
     "cnerf_scaler_check": [vp, u64, vp, vp],
     "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],

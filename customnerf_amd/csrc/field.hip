@@ -162,7 +162,7 @@ template <bool H, int SENC, int NGEO>
 __global__ void __launch_bounds__(FLD_THREADS) k_field_fwd(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
                                                            uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                            const float *__restrict__ pden, const float *__restrict__ prgb,
-                                                           float *__restrict__ sigma, float *__restrict__ rgbc) {
+                                                           float *__restrict__ sigma, float *__restrict__ rgbc, uint32_t enc_stride) {
     using PR = Prec<H>;
     using frag_t = typename PR::frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char fld_lds[];
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_fwd(const void *__restric
         const bool valid = p < P_;
 
         frag_t x0[SENC];
-        fld_load_enc<H, SENC>(enc, P_, dm.L, p, valid, hi, x0);
+        fld_load_enc<H, SENC>(enc, enc_stride, dm.L, p, valid, hi, x0);      // enc_stride = samples per level of the enc buffer (>= P_)
 
         cn_f16v acc[2];
         frag_t h[2 * PR::FR];                    // 64 features as B fragments
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_fwd(const void *__restric
 // ------------------------------------------------------------------------------------------------ C-ABI
 template <bool H>
 static int fld_launch_fwd(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm,
-                          const float *pnet, const float *pden, const float *prgb, float *sigma, float *rgbc, hipStream_t st) {
+                          const float *pnet, const float *pden, const float *prgb, float *sigma, float *rgbc, hipStream_t st, uint32_t enc_stride) {
     const FieldLds lo = fld_lds_layout<H>(dm);
     const uint32_t lds_bytes = lo.off[7] * sizeof(typename Prec<H>::elem_t);
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
@@ -254,7 +254,7 @@ static int fld_launch_fwd(const void *enc, const float *xyz, const float *dirs, 
     {                                                                                                                                  \
         auto kern = k_field_fwd<H, SE, NG>;                                                                                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);        \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, sigma, rgbc); \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, sigma, rgbc, enc_stride); \
     }
     const uint32_t se16 = dm.enc_pad / 16;               // 1..4
     if (dm.n_hidden_geo == 1) {
@@ -292,19 +292,29 @@ static int fld_dims(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out,
 
 extern "C" {
 
-int cnerf_field_forward(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
-                        uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
-                        float *sigma, float *rgbc, int dtype, void *stream) {
+int cnerf_field_forward_strided(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
+                                uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
+                                float *sigma, float *rgbc, int dtype, uint32_t enc_level_stride, void *stream) {
     FieldDims dm;
     int rc = fld_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
     if (rc) return rc;
     if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if (enc_level_stride == 0) enc_level_stride = P_;
+    if (enc_level_stride < P_) return CNERF_EINVAL;
     if (P_ == 0) return CNERF_OK;
     if (!enc || !xyz || !params_net || !params_den || !sigma) return CNERF_ENULL;
     if (rgbc && (!dirs || !params_rgb || dir_group == 0)) return CNERF_ENULL;
     if (rgbc && (((uintptr_t)rgbc) & 15)) return CNERF_EINVAL;
-    if (dtype == CNERF_F16) return fld_launch_fwd<true>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, sigma, rgbc, CN_STREAM(stream));
-    return fld_launch_fwd<false>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, sigma, rgbc, CN_STREAM(stream));
+    if (dtype == CNERF_F16)
+        return fld_launch_fwd<true>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, sigma, rgbc, CN_STREAM(stream), enc_level_stride);
+    return fld_launch_fwd<false>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, sigma, rgbc, CN_STREAM(stream), enc_level_stride);
+}
+
+int cnerf_field_forward(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
+                        uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
+                        float *sigma, float *rgbc, int dtype, void *stream) {
+    return cnerf_field_forward_strided(enc, xyz, dirs, dir_group, P_, enc_dim, n_hidden_geo, n_rgb_out, params_net, params_den, params_rgb, sigma, rgbc, dtype,
+                                       P_, stream);
 }
 
 }  // extern "C"

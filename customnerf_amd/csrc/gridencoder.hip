@@ -16,7 +16,8 @@
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid, const GridLevels lv,
                                                        T *__restrict__ outputs, uint32_t B, uint32_t L, uint32_t n_levels, uint32_t nb,
-                                                       T *__restrict__ dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int swizzle) {
+                                                       T *__restrict__ dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int swizzle,
+                                                       uint32_t ostride) {
     uint32_t level, pb;
     if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
     const uint32_t b = pb * GE_BLOCK + threadIdx.x;
@@ -24,7 +25,7 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
 
     using Vec = FeatVec<T, C>;
     const Vec *__restrict__ table = reinterpret_cast<const Vec *>(grid) + lv.offset[level];
-    Vec *out = reinterpret_cast<Vec *>(outputs) + ((size_t)level * B + b);
+    Vec *out = reinterpret_cast<Vec *>(outputs) + ((size_t)level * ostride + b);      // ostride = rows per level of the output buffer (>= B)
 
     float in[D];
     bool oob = false;
@@ -319,15 +320,15 @@ static int ge_swizzle_default() {
 
 template <typename T, int D>
 static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *out, uint32_t B, uint32_t C, uint32_t L, uint32_t nl, T *dy_dx,
-                    uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+                    uint32_t gridtype, int ac, uint32_t interp, hipStream_t st, uint32_t ostride) {
     const uint32_t nb = cn_div_up(B, GE_BLOCK);
     const dim3 grid(nb * nl), block(GE_BLOCK);
     const int sw = ge_swizzle_default();
     switch (C) {
-        case 1: hipLaunchKernelGGL((k_grid_fwd<T, D, 1>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
-        case 2: hipLaunchKernelGGL((k_grid_fwd<T, D, 2>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
-        case 4: hipLaunchKernelGGL((k_grid_fwd<T, D, 4>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
-        case 8: hipLaunchKernelGGL((k_grid_fwd<T, D, 8>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw); break;
+        case 1: hipLaunchKernelGGL((k_grid_fwd<T, D, 1>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;
+        case 2: hipLaunchKernelGGL((k_grid_fwd<T, D, 2>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;
+        case 4: hipLaunchKernelGGL((k_grid_fwd<T, D, 4>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;
+        case 8: hipLaunchKernelGGL((k_grid_fwd<T, D, 8>), grid, block, 0, st, inputs, emb, lv, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;
         default: return CNERF_EINVAL;
     }
     return cn_launch_status();
@@ -335,12 +336,12 @@ static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *
 
 template <typename T>
 static int ge_fwd_D(const float *inputs, const T *emb, const GridLevels &lv, T *out, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t nl,
-                    T *dy_dx, uint32_t gridtype, int ac, uint32_t interp, hipStream_t st) {
+                    T *dy_dx, uint32_t gridtype, int ac, uint32_t interp, hipStream_t st, uint32_t ostride) {
     switch (D) {
-        case 2: return ge_fwd_C<T, 2>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
-        case 3: return ge_fwd_C<T, 3>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
-        case 4: return ge_fwd_C<T, 4>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
-        case 5: return ge_fwd_C<T, 5>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st);
+        case 2: return ge_fwd_C<T, 2>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st, ostride);
+        case 3: return ge_fwd_C<T, 3>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st, ostride);
+        case 4: return ge_fwd_C<T, 4>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st, ostride);
+        case 5: return ge_fwd_C<T, 5>(inputs, emb, lv, out, B, C, L, nl, dy_dx, gridtype, ac, interp, st, ostride);
         default: return CNERF_EINVAL;
     }
 }
@@ -410,9 +411,9 @@ int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, flo
 
 extern "C" {
 
-int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
-                              uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
-                              uint32_t interp, int dtype, void *stream) {
+int cnerf_grid_encode_forward_strided(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
+                                      uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                                      uint32_t interp, int dtype, uint32_t out_level_stride, void *stream) {
     if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
     GridLevels lv;
     const uint32_t nl = max_level < L ? max_level : L;
@@ -420,13 +421,22 @@ int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const
     if (rc) return rc;
     if (D < 2 || D > 5 || !(C == 1 || C == 2 || C == 4 || C == 8)) return CNERF_EINVAL;
     if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if (out_level_stride == 0) out_level_stride = B;
+    if (out_level_stride < B) return CNERF_EINVAL;
     if (B == 0 || nl == 0) return CNERF_OK;
     if (!inputs || !embeddings || !outputs) return CNERF_ENULL;
     if (dtype == CNERF_F32)
-        return ge_fwd_D<float>(inputs, (const float *)embeddings, lv, (float *)outputs, B, D, C, L, nl, (float *)dy_dx, gridtype, align_corners, interp, CN_STREAM(stream));
-    if (dtype == CNERF_F16)
-        return ge_fwd_D<__half>(inputs, (const __half *)embeddings, lv, (__half *)outputs, B, D, C, L, nl, (__half *)dy_dx, gridtype, align_corners, interp, CN_STREAM(stream));
-    return CNERF_EINVAL;
+        return ge_fwd_D<float>(inputs, (const float *)embeddings, lv, (float *)outputs, B, D, C, L, nl, (float *)dy_dx, gridtype, align_corners, interp,
+                               CN_STREAM(stream), out_level_stride);
+    return ge_fwd_D<__half>(inputs, (const __half *)embeddings, lv, (__half *)outputs, B, D, C, L, nl, (__half *)dy_dx, gridtype, align_corners, interp,
+                            CN_STREAM(stream), out_level_stride);
+}
+
+int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
+                              uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                              uint32_t interp, int dtype, void *stream) {
+    return cnerf_grid_encode_forward_strided(inputs, embeddings, offsets_host, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype, align_corners, interp,
+                                             dtype, B, stream);
 }
 
 int cnerf_grid_encode_backward_workspace_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,

@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
                                                                   const float *__restrict__ nears, const float *__restrict__ fars,
                                                                   const float *__restrict__ aabb, const float *__restrict__ z_vals,
                                                                   const float *__restrict__ sigmas, const float *__restrict__ u_rand, uint32_t N,
-                                                                  uint32_t T, uint32_t t, float *__restrict__ z_all, float *__restrict__ xyz_all) {
+                                                                  uint32_t T, uint32_t t, float *__restrict__ z_all, float *__restrict__ xyz_all,
+                                                                  float *__restrict__ xyz_fine, uint32_t *__restrict__ src_index) {
     __shared__ float s_z[RN_WAVES][RN_MAXS], s_w[RN_WAVES][RN_MAXS], s_cdf[RN_WAVES][RN_MAXS], s_bin[RN_WAVES][RN_MAXS], s_nz[RN_WAVES][RN_MAXS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
@@ -150,15 +151,22 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
     // merge by rank: position of a coarse sample = its index + #fine < it; of a fine sample = its rank among the fine ones
     // (ties by index) + #coarse <= it.  Equal values give equal samples, so any tie order reproduces torch.sort's output.
     const float *o = rays_o + (size_t)n * 3, *d = rays_d + (size_t)n * 3;
-    float *za = z_all + (size_t)n * (T + t), *xa = xyz_all + (size_t)n * (T + t) * 3;
+    // Two output forms.  Merged (xyz_all): positions in sorted order, what the reference evaluates.  Split (xyz_fine + src_index): the
+    // new samples stay in their own block [N, t, 3] behind the coarse block [N, T, 3] (whose grid features are already computed),
+    // and src_index[n][pos] = row of the sorted sample `pos` in that [coarse | fine] sample list — the compositing kernels read through it.
+    float *za = z_all + (size_t)n * (T + t), *xa = xyz_all ? xyz_all + (size_t)n * (T + t) * 3 : nullptr;
+    uint32_t *si = src_index ? src_index + (size_t)n * (T + t) : nullptr;
     for (uint32_t i = lane; i < T; i += 64) {
         const float v = zz[i];
         uint32_t pos = i;
         for (uint32_t m = 0; m < t; m++) pos += (nz[m] < v) ? 1u : 0u;
-        float p[3];
-        rn_point(o, d, v, aabb, p);
         za[pos] = v;
-        xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2];
+        if (xa) {
+            float p[3];
+            rn_point(o, d, v, aabb, p);
+            xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2];
+        }
+        if (si) si[pos] = n * T + i;
     }
     for (uint32_t m = lane; m < t; m += 64) {
         const float v = nz[m];
@@ -171,7 +179,12 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
         float p[3];
         rn_point(o, d, v, aabb, p);
         za[pos] = v;
-        xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2];
+        if (xa) { xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2]; }
+        if (xyz_fine) {
+            float *xf = xyz_fine + ((size_t)n * t + m) * 3;
+            xf[0] = p[0]; xf[1] = p[1]; xf[2] = p[2];
+        }
+        if (si) si[pos] = N * T + n * t + m;
     }
 }
 
@@ -187,14 +200,16 @@ __device__ __forceinline__ float rn_variant_scale(int v, float e) { return v == 
 __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbc,
                                                                   const float *__restrict__ z_vals, const float *__restrict__ nears,
                                                                   const float *__restrict__ fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft,
-                                                                  float thr, float *__restrict__ out_ray, float *__restrict__ out_w) {
+                                                                  float thr, float *__restrict__ out_ray, float *__restrict__ out_w,
+                                                                  const uint32_t *__restrict__ src_index, float *__restrict__ sigma_m,
+                                                                  float *__restrict__ rgbc_m) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
     if (n >= N) return;
     const float near = nears[n], far = fars[n];
     const float sd = (far - near) / (float)num_steps;
-    const float *zr = z_vals + (size_t)n * S, *sr = sigmas + (size_t)n * S;
-    const float4 *cr = reinterpret_cast<const float4 *>(rgbc) + (size_t)n * S;
+    const float *zr = z_vals + (size_t)n * S;
+    const float4 *c4 = reinterpret_cast<const float4 *>(rgbc);
     float carry[3] = {1.0f, 1.0f, 1.0f};
     float acc[3][6];
 #pragma unroll
@@ -209,8 +224,11 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *_
         if (ok) {
             z = zr[i];
             delta = (i + 1 < S) ? zr[i + 1] - z : sd;
-            sigma = sr[i];
-            c = cr[i];
+            const size_t row = src_index ? (size_t)src_index[(size_t)n * S + i] : (size_t)n * S + i;     // sorted position -> sample row
+            sigma = sigmas[row];
+            c = c4[row];
+            if (sigma_m) sigma_m[(size_t)n * S + i] = sigma;                                               // sorted-order copies for the result dict
+            if (rgbc_m) reinterpret_cast<float4 *>(rgbc_m)[(size_t)n * S + i] = c;
         }
         const float zn = rn_norm_depth(z, near, far);
         const float e = rn_edit(c.w, soft, thr);
@@ -243,14 +261,15 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
                                                                   const float *__restrict__ rgbc, const float *__restrict__ z_vals,
                                                                   const float *__restrict__ nears, const float *__restrict__ fars, uint32_t N, uint32_t S,
                                                                   uint32_t num_steps, int soft, float thr, int detach_bg, int detach_mask,
-                                                                  float *__restrict__ g_sigma, float *__restrict__ g_rgbc) {
+                                                                  float *__restrict__ g_sigma, float *__restrict__ g_rgbc,
+                                                                  const uint32_t *__restrict__ src_index) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
     if (n >= N) return;
     const float near = nears[n], far = fars[n];
     const float sd = (far - near) / (float)num_steps;
-    const float *zr = z_vals + (size_t)n * S, *sr = sigmas + (size_t)n * S;
-    const float4 *cr = reinterpret_cast<const float4 *>(rgbc) + (size_t)n * S;
+    const float *zr = z_vals + (size_t)n * S;
+    const float4 *c4 = reinterpret_cast<const float4 *>(rgbc);
     float go[3][6];
 #pragma unroll
     for (int v = 0; v < 3; v++)
@@ -266,7 +285,11 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
             const bool ok = i < S;
             float z = 0, delta = 0, sigma = 0;
             float4 c = make_float4(0, 0, 0, 0);
-            if (ok) { z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd; sigma = sr[i]; c = cr[i]; }
+            if (ok) {
+                z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd;
+                const size_t row = src_index ? (size_t)src_index[(size_t)n * S + i] : (size_t)n * S + i;
+                sigma = sigmas[row]; c = c4[row];
+            }
             const float zn = rn_norm_depth(z, near, far);
             const float e = rn_edit(c.w, soft, thr);
 #pragma unroll
@@ -287,7 +310,12 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
         const bool ok = i < S;
         float z = 0, delta = 0, sigma = 0;
         float4 c = make_float4(0, 0, 0, 0);
-        if (ok) { z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd; sigma = sr[i]; c = cr[i]; }
+        size_t row = 0;
+        if (ok) {
+            z = zr[i]; delta = (i + 1 < S) ? zr[i + 1] - z : sd;
+            row = src_index ? (size_t)src_index[(size_t)n * S + i] : (size_t)n * S + i;
+            sigma = sigmas[row]; c = c4[row];
+        }
         const float zn = rn_norm_depth(z, near, far);
         const float e = rn_edit(c.w, soft, thr);
         float gs = 0.0f, ge = 0.0f;
@@ -315,8 +343,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
         }
         if (soft) gc.w += ge * 100.0f * e * (1.0f - e);                                    // edit = sigmoid((conf - thr) * 100), renderer.py:387
         if (ok) {
-            g_sigma[(size_t)n * S + i] = gs;
-            reinterpret_cast<float4 *>(g_rgbc)[(size_t)n * S + i] = gc;
+            g_sigma[row] = gs;
+            reinterpret_cast<float4 *>(g_rgbc)[row] = gc;
         }
     }
 }
@@ -333,37 +361,60 @@ int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *n
     return cn_launch_status();
 }
 
+int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *z_vals,
+                                  const float *sigmas, const float *u, uint32_t N, uint32_t T, uint32_t t, float *z_all, float *xyz_all, float *xyz_fine,
+                                  uint32_t *src_index, void *stream) {
+    if (T < 3 || T > RN_MAXS || t < 2 || t > RN_MAXS) return CNERF_EINVAL;
+    if ((uint64_t)N * (T + t) >= 0xFFFFFFFFull) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !sigmas || !z_all) return CNERF_ENULL;
+    if (!xyz_all && !(xyz_fine && src_index)) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_fine_merge, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb,
+                       z_vals, sigmas, u, N, T, t, z_all, xyz_all, xyz_fine, src_index);
+    return cn_launch_status();
+}
+
 int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *z_vals,
                             const float *sigmas, const float *u, uint32_t N, uint32_t T, uint32_t t, float *z_all, float *xyz_all, void *stream) {
-    if (T < 3 || T > RN_MAXS || t < 2 || t > RN_MAXS) return CNERF_EINVAL;
+    if (!xyz_all) return CNERF_ENULL;
+    return cnerf_sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, u, N, T, t, z_all, xyz_all, nullptr, nullptr, stream);
+}
+
+int cnerf_composite_run_indexed(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars, uint32_t N, uint32_t S,
+                                uint32_t num_steps, int soft_mask, float conf_thr, const uint32_t *src_index, float *out_ray, float *out_weights,
+                                float *sigma_sorted, float *rgbc_sorted, void *stream) {
+    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
-    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !sigmas || !z_all || !xyz_all) return CNERF_ENULL;
-    hipLaunchKernelGGL(k_sample_fine_merge, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb,
-                       z_vals, sigmas, u, N, T, t, z_all, xyz_all);
+    if (!sigmas || !rgbc || !z_vals || !nears || !fars || !out_ray) return CNERF_ENULL;
+    if ((((uintptr_t)rgbc) | ((uintptr_t)rgbc_sorted)) & 15) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_composite_run_fwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), sigmas, rgbc, z_vals, nears, fars, N, S,
+                       num_steps, soft_mask, conf_thr, out_ray, out_weights, src_index, sigma_sorted, rgbc_sorted);
     return cn_launch_status();
 }
 
 int cnerf_composite_run(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars, uint32_t N, uint32_t S,
                         uint32_t num_steps, int soft_mask, float conf_thr, float *out_ray, float *out_weights, void *stream) {
+    return cnerf_composite_run_indexed(sigmas, rgbc, z_vals, nears, fars, N, S, num_steps, soft_mask, conf_thr, nullptr, out_ray, out_weights, nullptr,
+                                       nullptr, stream);
+}
+
+int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
+                                         const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
+                                         int detach_mask_from_field, const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream) {
     if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
-    if (!sigmas || !rgbc || !z_vals || !nears || !fars || !out_ray) return CNERF_ENULL;
-    if (((uintptr_t)rgbc) & 15) return CNERF_EINVAL;
-    hipLaunchKernelGGL(k_composite_run_fwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), sigmas, rgbc, z_vals, nears, fars, N, S,
-                       num_steps, soft_mask, conf_thr, out_ray, out_weights);
+    if (!grad_out_ray || !sigmas || !rgbc || !z_vals || !nears || !fars || !grad_sigmas || !grad_rgbc) return CNERF_ENULL;
+    if ((((uintptr_t)rgbc) | ((uintptr_t)grad_rgbc)) & 15) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_composite_run_bwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), grad_out_ray, sigmas, rgbc, z_vals, nears,
+                       fars, N, S, num_steps, soft_mask, conf_thr, detach_bg, detach_mask_from_field, grad_sigmas, grad_rgbc, src_index);
     return cn_launch_status();
 }
 
 int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
                                  const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
                                  int detach_mask_from_field, float *grad_sigmas, float *grad_rgbc, void *stream) {
-    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
-    if (N == 0) return CNERF_OK;
-    if (!grad_out_ray || !sigmas || !rgbc || !z_vals || !nears || !fars || !grad_sigmas || !grad_rgbc) return CNERF_ENULL;
-    if ((((uintptr_t)rgbc) | ((uintptr_t)grad_rgbc)) & 15) return CNERF_EINVAL;
-    hipLaunchKernelGGL(k_composite_run_bwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), grad_out_ray, sigmas, rgbc, z_vals, nears,
-                       fars, N, S, num_steps, soft_mask, conf_thr, detach_bg, detach_mask_from_field, grad_sigmas, grad_rgbc);
-    return cn_launch_status();
+    return cnerf_composite_run_backward_indexed(grad_out_ray, sigmas, rgbc, z_vals, nears, fars, N, S, num_steps, soft_mask, conf_thr, detach_bg,
+                                                detach_mask_from_field, nullptr, grad_sigmas, grad_rgbc, stream);
 }
 
 }  // extern "C"

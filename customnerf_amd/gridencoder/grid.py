@@ -116,6 +116,30 @@ class _grid_encode(Function):
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 
+class _grid_attach(Function):
+    """Backward half of _grid_encode for a feature buffer that was filled by GridEncoder.encode_into calls: forward hands the buffer
+    on unchanged, backward scatters d(loss)/d(features) [L,B,C] into the table gradient for ALL B rows of `inputs`."""
+
+    @staticmethod
+    def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation):
+        L, B, C = enc.shape
+        ctx.save_for_backward(inputs)
+        ctx.cfg = (offsets_host, B, inputs.shape[1], C, L, float(np.log2(per_level_scale)), int(base_resolution), gridtype, interpolation, align_corners,
+                   tuple(embeddings.shape))
+        return enc.detach()
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, = ctx.saved_tensors
+        offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, eshape = ctx.cfg
+        grad = grad.contiguous()
+        grad_embeddings = torch.zeros(eshape, device=grad.device, dtype=torch.float32)
+        ws, ws_bytes = _bwd_workspace(offsets_host, B, D, C, L, L, S, H, dtype_id(grad), grad.device)
+        check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H, None, None,
+                                             gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
+        return None, None, grad_embeddings, None, None, None, None, None, None
+
+
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False, interpolation=0, max_level=None):
     """Functional form with the reference's signature (grid.py:27,99): returns [B, L*C]."""
@@ -207,6 +231,35 @@ class GridEncoder(nn.Module):
         table = self.half_table() if half else self.embeddings.detach()
         return _grid_encode.apply(inputs, self.embeddings, table, self._offsets_host, self.per_level_scale, self.base_resolution,
                                   inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
+
+    @torch.no_grad()
+    def encode_into(self, inputs_unit, out, row0, half=None):
+        """Gather the features of `inputs_unit` [B, D] (already mapped to [0,1]) into rows row0 .. row0+B of the kernel-layout buffer
+        `out` [L, P, C] (P >= row0 + B).  No autograd: pair with attach_backward once the buffer is complete."""
+        if half is None:
+            half = torch.is_autocast_enabled() and self.level_dim % 2 == 0
+        table = self.half_table() if half else self.embeddings.detach()
+        require_cuda(inputs_unit, out, table)
+        inputs_unit = inputs_unit.contiguous().float()
+        B, D = inputs_unit.shape
+        L, P, C = out.shape
+        assert out.is_contiguous() and out.dtype == table.dtype and C == table.shape[1] and row0 + B <= P and L == self._offsets_host.shape[0] - 1
+        prof = _PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dst = out.data_ptr() + row0 * C * out.element_size()
+        check(lib.cnerf_grid_encode_forward_strided(ptr(inputs_unit), ptr(table), self._offsets_host.ctypes.data, dst, B, D, C, L, L,
+                                                    float(np.log2(self.per_level_scale)), int(self.base_resolution), None, self.gridtype_id,
+                                                    int(self.align_corners), self.interp_id, dtype_id(table), P, stream()), "grid_encode_forward_strided")
+        if prof is not None:
+            e1.record()
+            prof.append((e0, e1, B, L, table.element_size()))
+
+    def attach_backward(self, enc, inputs_unit):
+        """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table."""
+        return _grid_attach.apply(enc, inputs_unit.contiguous().float(), self.embeddings, self._offsets_host, self.per_level_scale, self.base_resolution,
+                                  self.gridtype_id, self.align_corners, self.interp_id)
 
     def forward(self, inputs, bound=1, max_level=None, return_kernel_layout=False):
         """grid.py:151-168: [..., D] -> [..., L*C]."""

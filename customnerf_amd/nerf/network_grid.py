@@ -130,6 +130,43 @@ class NeRFNetwork(NeRFRenderer):
             return {'sigma': sigma}
         return {'sigma': self._geo(x)[1]}
 
+    # ---- split evaluation (renderer._run_fused): the grid features of a sample list are gathered block by block into ONE kernel-layout
+    # buffer, so the coarse samples of run() — whose features the density pass needs anyway — are not gathered a second time for the
+    # full evaluation (the reference encodes them twice: renderer.py:327 and :375).  Same arithmetic per sample, one gather less.
+    @property
+    def supports_split_eval(self):
+        return bool(self._fused_cfg())
+
+    def split_buffers(self, P, device):
+        """-> (enc [L, P, 2] feature buffer, unit [P, 3] grid coordinates) to be filled by split_encode"""
+        dt = torch.float16 if self._half() else torch.float32
+        L = self.pos_en.num_levels
+        return torch.empty(L, P, 2, dtype=dt, device=device), torch.empty(P, 3, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def split_encode(self, enc, unit, x, row0):
+        """gather the features of x [B, 3] into rows row0.. of enc (and their [0,1] grid coordinates into unit)"""
+        B = x.shape[0]
+        u = unit[row0:row0 + B]
+        torch.add(x, self.opt.bound, out=u)                                         # grid.py:156: (x + bound) / (2 bound)
+        u.div_(2 * self.opt.bound)
+        self.pos_en.encode_into(u, enc, row0, half=self._half())
+
+    @torch.no_grad()
+    def split_density(self, enc, x):
+        """sigma of the first len(x) rows of enc (network_grid.py:180-193)"""
+        enc_dim, n_geo, n_rgb = self._fused_cfg()
+        sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None, with_rgb=False)
+        return sigma
+
+    def split_forward(self, enc, unit, x, d, dir_group):
+        """forward() on a complete feature buffer: (sigma [P], rgbc [P, 4]); gradients reach the table through attach_backward"""
+        enc_dim, n_geo, n_rgb = self._fused_cfg()
+        enc = self.pos_en.attach_backward(enc, unit) if torch.is_grad_enabled() and self.pos_en.embeddings.requires_grad else enc
+        sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
+                            self.rgb_network.params)
+        return sigma, rgbc
+
     def get_params(self, lr):
         """network_grid.py:196-206: grid lr x10."""
         return [

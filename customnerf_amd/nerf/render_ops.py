@@ -6,12 +6,14 @@ from torch.autograd import Function
 from .._lib import lib, check, ptr, stream, require_cuda
 
 
-def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None):
-    """-> z_vals [N,T], xyzs [N,T,3]   (renderer.py:310-322; noise [N,T] = the torch.rand draw of :317 or None)"""
-    require_cuda(rays_o, rays_d, nears, fars, aabb, noise)
+def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None, xyz_out=None):
+    """-> z_vals [N,T], xyzs [N,T,3]   (renderer.py:310-322; noise [N,T] = the torch.rand draw of :317 or None).
+    xyz_out: optional contiguous [N,T,3] float32 destination (e.g. the head of a larger sample list)."""
+    require_cuda(rays_o, rays_d, nears, fars, aabb, noise, xyz_out)
     N = rays_o.shape[0]
     z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
-    xyz = torch.empty(N, T, 3, dtype=torch.float32, device=rays_o.device)
+    xyz = xyz_out if xyz_out is not None else torch.empty(N, T, 3, dtype=torch.float32, device=rays_o.device)
+    assert xyz.is_contiguous() and xyz.dtype == torch.float32 and xyz.numel() == N * T * 3
     check(lib.cnerf_sample_coarse(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, int(T), ptr(z), ptr(xyz), stream()),
           "sample_coarse")
     return z, xyz
@@ -26,6 +28,58 @@ def sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=No
     check(lib.cnerf_sample_fine_merge(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(z_vals), ptr(sigmas), ptr(u), N, int(T), int(t),
                                       ptr(z_all), ptr(xyz_all), stream()), "sample_fine_merge")
     return z_all, xyz_all
+
+
+def sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=None, xyz_fine_out=None):
+    """Split form: -> z_all [N,T+t] (sorted), xyz_fine [N,t,3] (the new samples in their own block), src_index [N,T+t] int32 = row of
+    every sorted position in the sample list [coarse N*T rows | fine N*t rows]."""
+    require_cuda(z_vals, sigmas, u, xyz_fine_out)
+    N, T = z_vals.shape
+    z_all = torch.empty(N, T + t, dtype=torch.float32, device=z_vals.device)
+    xyz_fine = xyz_fine_out if xyz_fine_out is not None else torch.empty(N, t, 3, dtype=torch.float32, device=z_vals.device)
+    assert xyz_fine.is_contiguous() and xyz_fine.dtype == torch.float32 and xyz_fine.numel() == N * t * 3
+    src = torch.empty(N, T + t, dtype=torch.int32, device=z_vals.device)
+    check(lib.cnerf_sample_fine_merge_split(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(z_vals), ptr(sigmas), ptr(u), N, int(T), int(t),
+                                            ptr(z_all), None, ptr(xyz_fine), ptr(src), stream()), "sample_fine_merge_split")
+    return z_all, xyz_fine, src
+
+
+class _CompositeRunIndexed(Function):
+    """_CompositeRun reading its samples through src_index (sample_fine_merge_split); also returns the sorted-order sigma / rgbc copies"""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask):
+        sigmas = sigmas.contiguous().float()
+        rgbc = rgbc.contiguous().float()
+        N, S = z_vals.shape
+        dev = z_vals.device
+        out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=dev)
+        out_w = torch.empty(3, N, S, dtype=torch.float32, device=dev)
+        sig_s = torch.empty(N, S, dtype=torch.float32, device=dev)
+        rgbc_s = torch.empty(N, S, 4, dtype=torch.float32, device=dev)
+        check(lib.cnerf_composite_run_indexed(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
+                                              ptr(src_index), ptr(out_ray), ptr(out_w), ptr(sig_s), ptr(rgbc_s), stream()), "composite_run_indexed")
+        ctx.save_for_backward(sigmas, rgbc, z_vals, src_index, nears, fars)
+        ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
+        ctx.mark_non_differentiable(out_w, sig_s, rgbc_s)
+        return out_ray, out_w, sig_s, rgbc_s
+
+    @staticmethod
+    def backward(ctx, g_ray, g_w, g_s, g_c):
+        sigmas, rgbc, z_vals, src_index, nears, fars = ctx.saved_tensors
+        num_steps, soft, thr, dbg, dmask = ctx.cfg
+        N, S = z_vals.shape
+        g_ray = g_ray.contiguous().float()
+        g_sigma = torch.empty_like(sigmas)                      # src_index is a permutation of the rows: every element is written
+        g_rgbc = torch.empty_like(rgbc)
+        check(lib.cnerf_composite_run_backward_indexed(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr,
+                                                       dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward_indexed")
+        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None, None
+
+
+def composite_run_indexed(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False):
+    """sigmas [P], rgbc [P,4] in sample-list order; -> out_ray [3,N,6], weights [3,N,S], sigma_sorted [N,S], rgbc_sorted [N,S,4]"""
+    return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask)
 
 
 class _CompositeRun(Function):

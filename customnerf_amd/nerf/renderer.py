@@ -185,24 +185,45 @@ class NeRFRenderer(nn.Module):
         draws = _draws or {}
         aabb = self.aabb_train if self.training else self.aabb_infer
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        S = num_steps + upsample_steps
+        soft, thr = bool(getattr(self.opt, 'soft_mask', False)), float(getattr(self.opt, 'conf_thr', 0.5))
+        dbg, dmask = bool(getattr(self.opt, 'detach_bg', False)), bool(getattr(self.opt, 'detach_mask_from_field', False))
+        split = (num_steps == upsample_steps and getattr(self.opt, 'split_eval', True) and getattr(self, 'supports_split_eval', False)
+                 and not getattr(self.opt, 'eval_fine_density', False))
         with torch.no_grad():
             noise = None
             if perturb:
                 noise = draws['z'].to(device).contiguous() if 'z' in draws else torch.rand(N, num_steps, device=device)
-            z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
-            sig_c = self.density(xyzs.view(-1, 3))['sigma'].float().contiguous()
             if self.training:
-                u = draws['u'].to(device).contiguous() if 'u' in draws else torch.rand(N, upsample_steps, device=device)
+                u_draw = lambda: draws['u'].to(device).contiguous() if 'u' in draws else torch.rand(N, upsample_steps, device=device)
             else:
-                u = None                                                      # det=True (sample_pdf :33-35)
-            z_all, xyz_all = render_ops.sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u)
-            if getattr(self.opt, 'eval_fine_density', False):
-                self.density(xyz_all.view(-1, 3))
-        S = num_steps + upsample_steps
-        sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
-        out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps,
-                                                  bool(getattr(self.opt, 'soft_mask', False)), float(getattr(self.opt, 'conf_thr', 0.5)),
-                                                  bool(getattr(self.opt, 'detach_bg', False)), bool(getattr(self.opt, 'detach_mask_from_field', False)))
+                u_draw = lambda: None                                         # det=True (sample_pdf :33-35)
+            if split:
+                # sample list = [coarse block N*T | fine block N*t]; the coarse block's grid features are gathered once (density pass) and
+                # stay in `enc` for the full evaluation; the sorted order only exists as an index (src) for the compositing kernels.
+                Pc, P = N * num_steps, N * S
+                xyz_list = torch.empty(P, 3, dtype=torch.float32, device=device)
+                enc, unit = self.split_buffers(P, device)
+                z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3))
+                self.split_encode(enc, unit, xyz_list[:Pc], 0)
+                sig_c = self.split_density(enc, xyz_list[:Pc])
+                z_all, xyz_f, src = render_ops.sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw(),
+                                                                        xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3))
+                self.split_encode(enc, unit, xyz_list[Pc:], Pc)
+            else:
+                z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
+                sig_c = self.density(xyzs.view(-1, 3))['sigma'].float().contiguous()
+                z_all, xyz_all = render_ops.sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw())
+                if getattr(self.opt, 'eval_fine_density', False):
+                    self.density(xyz_all.view(-1, 3))
+        if split:
+            # both blocks hold num_steps samples per ray, so "one direction per num_steps consecutive samples" covers the list with [d | d]
+            sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, torch.cat([rays_d, rays_d], 0), num_steps)
+            out_ray, out_w, sig_s, rgbc_s = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
+            sigmas, rgbc = sig_s, rgbc_s                                     # sorted-order per-sample outputs (detached copies) for the result dict
+        else:
+            sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
+            out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps, soft, thr, dbg, dmask)
         mask = (nears < fars).reshape(*prefix)
 
         def pack(v):

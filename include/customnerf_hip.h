@@ -114,6 +114,13 @@ int cnerf_compact_rays_alive(const int32_t *rays_alive_in, uint32_t n, int32_t *
 int cnerf_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                               void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream);
+/* Same, writing into a larger output buffer: outputs [L, out_level_stride, C] with out_level_stride >= B rows per level (0 = B);
+ * the caller offsets `outputs` to the first row it wants written.  Lets several gathers (the coarse and the importance samples of
+ * NeRFRenderer.run, renderer.py:327-363) fill one feature buffer, so that the coarse samples are not gathered a second time. */
+int cnerf_grid_encode_forward_strided(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
+                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                      void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                      uint32_t out_level_stride, void *stream);
 
 /* grid_encode_backward — gridencoder.h:13, kernels gridencoder.cu:247-339 (+ :342-368 when dy_dx != NULL).
  * grad [L,B,C] (dtype).  grad_embeddings is ALWAYS float32 [offsets[L], C], pre-zeroed by the caller
@@ -156,6 +163,11 @@ int cnerf_cast_f32_to_f16(const float *src, void *dst, uint64_t n, void *stream)
 int cnerf_field_forward(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
                         uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
                         const float *params_rgb, float *sigma, float *rgbc, int dtype, void *stream);
+/* Same, reading the first P samples of an enc buffer that holds enc_level_stride >= P samples per level (0 = P). */
+int cnerf_field_forward_strided(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                                uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                                const float *params_rgb, float *sigma, float *rgbc, int dtype, uint32_t enc_level_stride,
+                                void *stream);
 
 /* Backward of cnerf_field_forward (activations are recomputed, nothing is saved by the forward).
  * grad_sigma [P] and grad_rgbc [P,4] (16-byte aligned) in; grad_enc [L,P,2] (dtype) out = d(loss)/d(grid features) in the
@@ -212,6 +224,15 @@ int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *n
 int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
                             const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
                             uint32_t T, uint32_t t, float *z_all, float *xyz_all, void *stream);
+/* Split form of the same step: the new samples are NOT merged into the coarse ones in memory.  z_all [N,T+t] is the sorted merge as
+ * above; xyz_fine [N,t,3] receives the new samples in their own block; src_index [N,T+t] (uint32) maps every sorted position to its
+ * row in the sample list [coarse block N*T rows | fine block N*t rows]: coarse i of ray n -> n*T + i, fine m -> N*T + n*t + m.
+ * The field is then evaluated on that list (the coarse block's grid features are already there from the density pass) and the
+ * compositing entries below read through src_index.  xyz_all may be NULL here (or non-NULL to get both forms). */
+int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                                  const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
+                                  uint32_t T, uint32_t t, float *z_all, float *xyz_all, float *xyz_fine, uint32_t *src_index,
+                                  void *stream);
 /* weights_sum_i x3 (renderer.py:384-402, 407-474) in one pass over [N,S] samples: all / fg (sigma*edit_mask) /
  * bg (sigma*(1-edit_mask)) composites.  soft_mask: edit = sigmoid((conf-thr)*100) else conf>0.5.
  * rgbc [N,S,4] (rgb + confidence), sigmas [N,S], z_vals [N,S].
@@ -226,6 +247,17 @@ int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas,
                                  const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
                                  int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
                                  float *grad_sigmas, float *grad_rgbc, void *stream);
+/* Indexed forms: sample n,i (sorted position) lives at row src_index[n*S+i] of sigmas / rgbc / grad_* (NULL = row n*S+i, i.e. the
+ * plain forms).  sigma_sorted [N,S] / rgbc_sorted [N,S,4] (may be NULL) receive the per-sample inputs in sorted order — the
+ * `sigma` / `rgbs` entries of run()'s result dict (renderer.py:396-398). */
+int cnerf_composite_run_indexed(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars,
+                                uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr,
+                                const uint32_t *src_index, float *out_ray, float *out_weights, float *sigma_sorted,
+                                float *rgbc_sorted, void *stream);
+int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals,
+                                         const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
+                                         int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
+                                         const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step used by the reference's recipe (main.py:182: Adam betas (0.9,0.99) eps 1e-15, no weight decay),

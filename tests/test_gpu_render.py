@@ -369,3 +369,89 @@ def test_fused_run_matches_reference_golden(golden, tag):
     for sub in ("fg", "bg"):
         for k in ("image", "depth", "render_mask", "weights_sum"):
             np.testing.assert_allclose(res[sub][k].cpu().numpy(), g[f"{tag}__{sub}_{k}"], rtol=0, atol=1e-4, err_msg=f"{tag}:{sub}.{k}")
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_split_evaluation_equals_merged_evaluation(fp16):
+    """run() with the coarse samples' grid features gathered once (split sample list + src_index compositing) against the
+    reference's order (sorted merged list, coarse samples encoded twice): same outputs bit for bit (the field is evaluated
+    per sample, the compositing kernels do the same operations in the same order), same gradients up to summation order."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    tcnn.set_default_dtype(torch.float16 if fp16 else torch.float32)
+    try:
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=fp16, num_levels=16)
+        model = NeRFNetwork(opt).cuda().train()
+        with torch.no_grad():
+            model.pos_en.embeddings.uniform_(-0.5, 0.5)
+        H = W = 24
+        o, d = generate_rays(torch.from_numpy(sc.poses(1)).cuda(), *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+        o, d = o.view(1, H * W, 3), d.view(1, H * W, 3)
+        g = torch.Generator().manual_seed(5)
+        draws = dict(z=torch.rand(H * W, 32, generator=g), u=torch.rand(H * W, 32, generator=g))
+        rgb_gt, m_gt = sc.targets(1, H, W, seed=3)
+        res, grads = {}, {}
+        for mode in (True, False):
+            opt.split_eval = mode
+            model.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.float16, enabled=fp16):
+                r = model.run(o, d, num_steps=32, upsample_steps=32, perturb=True, _draws=draws)
+            loss = ((r['image'].reshape(-1, 3) - rgb_gt[0].cuda()) ** 2).mean() + 0.1 * ((r['render_mask'].reshape(-1) - m_gt[0].reshape(-1).cuda()) ** 2).mean() \
+                + 0.1 * r['fg']['image'].mean() + 0.1 * r['bg']['depth'].mean()
+            loss.backward()
+            res[mode] = r
+            grads[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights", "sigma", "rgbs", "edit_mask", "z_vals"):
+            assert torch.equal(res[True][k], res[False][k]), k
+        for sub in ("fg", "bg"):
+            for k in ("image", "depth", "render_mask", "weights_sum", "weights"):
+                assert torch.equal(res[True][sub][k], res[False][sub][k]), (sub, k)
+        assert set(grads[True]) == set(grads[False]) and "pos_en.embeddings" in grads[True]
+        for n in grads[True]:
+            a, b = grads[True][n].float(), grads[False][n].float()
+            scale = float(b.abs().max())
+            assert scale > 0, n
+            assert float((a - b).abs().max()) <= (2e-3 if fp16 else 1e-5) * scale, (n, float((a - b).abs().max()), scale)
+    finally:
+        tcnn.set_default_dtype(torch.float16)
+
+
+def test_strided_gather_and_indexed_composite_reduce_to_the_plain_forms():
+    from customnerf_amd.gridencoder import GridEncoder
+    from customnerf_amd.nerf import render_ops
+    torch.manual_seed(1)
+    enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = torch.rand(3000, 3, device="cuda")
+    xs = x * 2 - 1
+    full = enc.encode(xs, bound=1, half=False)                         # [L, 3000, 2]
+    unit = (xs + 1) / 2                                                # the [0,1] coordinates encode() derives (grid.py:156), bit for bit
+    buf = torch.full((8, 3000 + 77, 2), -7.0, device="cuda")
+    enc.encode_into(unit[:1000], buf, 0, half=False)
+    enc.encode_into(unit[1000:], buf, 1000, half=False)
+    assert torch.equal(buf[:, :3000], full) and bool((buf[:, 3000:] == -7.0).all())      # rows outside the gathers are untouched
+    # indexed composite with the identity index == plain composite; with a per-ray permutation == plain composite of the permuted inputs
+    N, S = 150, 96
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sig = torch.rand(N * S, device="cuda", generator=g) * 5
+    rgbc = torch.rand(N * S, 4, device="cuda", generator=g)
+    z = torch.sort(torch.rand(N, S, device="cuda", generator=g) * 3 + 0.5, dim=1)[0]
+    nears, fars = torch.full((N,), 0.5, device="cuda"), torch.full((N,), 3.5, device="cuda")
+    ident = torch.arange(N * S, device="cuda", dtype=torch.int32).view(N, S)
+    plain = render_ops.composite_run(sig.view(N, S), rgbc.view(N, S, 4), z, nears, fars, 48, True, 0.5)
+    idx = render_ops.composite_run_indexed(sig, rgbc, z, ident, nears, fars, 48, True, 0.5)
+    assert torch.equal(plain[0], idx[0]) and torch.equal(plain[1], idx[1])
+    assert torch.equal(idx[2].view(-1), sig) and torch.equal(idx[3].view(-1, 4), rgbc)
+    perm = torch.stack([torch.randperm(S, device="cuda", generator=g) for _ in range(N)]).to(torch.int32) + (torch.arange(N, device="cuda", dtype=torch.int32) * S)[:, None]
+    sig_p, rgbc_p = sig[perm.long().view(-1)], rgbc[perm.long().view(-1)]
+    sig_l, rgbc_l = sig.clone().requires_grad_(True), rgbc.clone().requires_grad_(True)
+    sig_m, rgbc_m = sig_p.clone().requires_grad_(True), rgbc_p.clone().requires_grad_(True)
+    a = render_ops.composite_run_indexed(sig_l, rgbc_l, z, perm.contiguous(), nears, fars, 48, True, 0.5)
+    b = render_ops.composite_run(sig_m.view(N, S), rgbc_m.view(N, S, 4), z, nears, fars, 48, True, 0.5)
+    assert torch.equal(a[0], b[0])
+    w = torch.rand(3, N, 6, device="cuda", generator=g)
+    (a[0] * w).sum().backward(); (b[0] * w).sum().backward()
+    assert torch.equal(sig_l.grad[perm.long().view(-1)], sig_m.grad) and torch.equal(rgbc_l.grad[perm.long().view(-1)], rgbc_m.grad)
