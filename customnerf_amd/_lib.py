@@ -34,6 +34,8 @@ SIGNATURES = {
     "cnerf_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
     "cnerf_grid_encode_forward_strided": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, u32, vp],
     "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp, u64, vp],
+    "cnerf_grid_encode_backward_prepare": [vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp, vp],
+    "cnerf_grid_encode_backward_prepared": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp],
     "cnerf_grid_encode_backward_workspace_bytes": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
     "cnerf_cast_f32_to_f16": [vp, vp, u64, vp],

@@ -406,7 +406,9 @@ static int ge_tv_C(const float *inputs, const float *emb, float *grad, const Gri
 bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv);
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype);
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
-                uint32_t interp, int dtype, void *workspace, hipStream_t st);
+                uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared);
+int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
+               void *workspace, hipStream_t st);
 #define BN_MIN_UPDATES (1u << 20)        // below this many (point, level) pairs the plain atomic kernel is cheaper than five launches
 
 extern "C" {
@@ -469,12 +471,53 @@ int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int3
     if (dy_dx && !grad_inputs) return CNERF_ENULL;
     if (workspace && !dy_dx && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) &&
         workspace_bytes >= bn_workspace_bytes(B, nl, lv, dtype) && !(((uintptr_t)workspace) & 255))
-        return bn_backward(grad, inputs, lv, grad_embeddings, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream));
+        return bn_backward(grad, inputs, lv, grad_embeddings, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream), false);
     if (dtype == CNERF_F32)
         return ge_bwd_D<float>((const float *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const float *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
     if (dtype == CNERF_F16)
         return ge_bwd_D<__half>((const __half *)grad, inputs, lv, grad_embeddings, B, D, C, L, nl, (const __half *)dy_dx, grad_inputs, gridtype, align_corners, interp, CN_STREAM(stream));
     return CNERF_EINVAL;
+}
+
+// The coordinate-only half of the binned backward (histogram + scans), issued ahead of time — typically on a second stream right after
+// the samples exist, so that it overlaps the forward and the field backward.  Returns CNERF_OK with *prepared = 1 when the binned path
+// applies and the plan now sits in `workspace`; *prepared = 0 (nothing launched) when cnerf_grid_encode_backward would take the atomic
+// kernel for this shape.  The matching cnerf_grid_encode_backward_prepared must get the same inputs / shape / workspace.
+int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                       uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                       void *workspace, uint64_t workspace_bytes, int *prepared, void *stream) {
+    if (!prepared) return CNERF_ENULL;
+    *prepared = 0;
+    if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
+    GridLevels lv;
+    const uint32_t nl = max_level < L ? max_level : L;
+    int rc = ge_levels(offsets_host, L, nl, S, H, lv);
+    if (rc) return rc;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if (B == 0 || nl == 0) return CNERF_OK;
+    if (!inputs) return CNERF_ENULL;
+    if (!(workspace && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) && workspace_bytes >= bn_workspace_bytes(B, nl, lv, dtype) &&
+          !(((uintptr_t)workspace) & 255)))
+        return CNERF_OK;
+    rc = bn_prepare(inputs, lv, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream));
+    if (rc == 0) *prepared = 1;
+    return rc;
+}
+
+int cnerf_grid_encode_backward_prepared(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                        uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                        int align_corners, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
+    GridLevels lv;
+    const uint32_t nl = max_level < L ? max_level : L;
+    int rc = ge_levels(offsets_host, L, nl, S, H, lv);
+    if (rc) return rc;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    if (!grad_embeddings || !grad || !inputs || !workspace) return CNERF_ENULL;
+    if (!((uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) && workspace_bytes >= bn_workspace_bytes(B, nl, lv, dtype) &&
+          !(((uintptr_t)workspace) & 255)))
+        return CNERF_EINVAL;                                  // prepare() would have reported *prepared = 0 for this shape
+    return bn_backward(grad, inputs, lv, grad_embeddings, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream), true);
 }
 
 int cnerf_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host, float weight, uint32_t B,

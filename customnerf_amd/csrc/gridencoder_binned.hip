@@ -362,9 +362,10 @@ uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int d
     return bn_layout(plan, B, nl, dtype, nullptr, nullptr);
 }
 
-template <typename T>
-static int bn_run(const T *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
-                  uint32_t interp, int dtype, void *workspace, hipStream_t st) {
+// phase 1 (needs the sample coordinates only): histogram + scans.  phase 2 (needs the gradients): emit + accumulate.
+// The two phases may be issued separately (cnerf_grid_encode_backward_prepare) so that phase 1 overlaps the forward / field backward.
+static int bn_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
+                     void *workspace, hipStream_t st) {
     BinPlan plan;
     bn_plan(lv, nl, B, plan);
     BinWs ws;
@@ -373,6 +374,17 @@ static int bn_run(const T *grad, const float *inputs, const GridLevels &lv, floa
     hipLaunchKernelGGL(k_bin_hist, grid1, dim3(BN_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins);
+    return cn_launch_status();
+}
+
+template <typename T>
+static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                     uint32_t interp, int dtype, void *workspace, hipStream_t st) {
+    BinPlan plan;
+    bn_plan(lv, nl, B, plan);
+    BinWs ws;
+    bn_layout(plan, B, nl, dtype, &ws, workspace);
+    const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL((k_bin_emit<T>), grid1, dim3(BN_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, (BinRec<T> *)ws.records, B,
                        gridtype, ac, interp);
     // upper bound of accumulate workgroups: every bin may add one partial segment
@@ -388,8 +400,17 @@ static int bn_run(const T *grad, const float *inputs, const GridLevels &lv, floa
     return cn_launch_status();
 }
 
+int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
+               void *workspace, hipStream_t st) {
+    return bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
+}
+
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
-                uint32_t interp, int dtype, void *workspace, hipStream_t st) {
-    if (dtype == CNERF_F16) return bn_run<__half>((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
-    return bn_run<float>((const float *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
+                uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
+    if (!prepared) {
+        const int rc = bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
+        if (rc) return rc;
+    }
+    if (dtype == CNERF_F16) return bn_phase2<__half>((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
+    return bn_phase2<float>((const float *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, dtype, workspace, st);
 }

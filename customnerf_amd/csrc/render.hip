@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
         za[pos] = v;
         if (xa) { xa[pos * 3] = p[0]; xa[pos * 3 + 1] = p[1]; xa[pos * 3 + 2] = p[2]; }
         if (xyz_fine) {
+            // draw order, NOT sorted along the ray: measured 1 % faster end to end (sorted neighbours collide in the scatter's LDS atomics)
             float *xf = xyz_fine + ((size_t)n * t + m) * 3;
             xf[0] = p[0]; xf[1] = p[1]; xf[2] = p[2];
         }

@@ -8,6 +8,9 @@ Deliberate differences:
     reference re-casts the whole table on every call, grid.py:45-46);
   * gradients are accumulated in float32 for both table dtypes (the reference scatters __half2 atomics for fp16).
 """
+import os
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -116,16 +119,64 @@ class _grid_encode(Function):
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 
+_SIDE = {}          # device -> {'stream': side stream, 'ws': workspace of the prepared plan, 'owner': weakref to the plan waiting for its backward}
+
+
+class _Plan:
+    """a prepared scatter plan (lives on the autograd node: dropped with the graph if the backward never runs)"""
+    __slots__ = ('ws', 'event', '__weakref__')
+
+    def __init__(self, ws, event):
+        self.ws, self.event = ws, event
+
+
+def _side(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = {'stream': torch.cuda.Stream(device=device), 'ws': None, 'owner': None}
+    return st
+
+
+def _side_busy(side):
+    return side['owner'] is not None and side['owner']() is not None
+
+
 class _grid_attach(Function):
     """Backward half of _grid_encode for a feature buffer that was filled by GridEncoder.encode_into calls: forward hands the buffer
-    on unchanged, backward scatters d(loss)/d(features) [L,B,C] into the table gradient for ALL B rows of `inputs`."""
+    on unchanged, backward scatters d(loss)/d(features) [L,B,C] into the table gradient for ALL B rows of `inputs`.
+    The coordinate-only half of that scatter (histogram + scans of the binned backward) is issued here, in the forward, on a second
+    stream: it overlaps the rest of the forward pass and the field backward instead of sitting on the critical path."""
 
     @staticmethod
-    def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation):
+    def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation, overlap):
+        import ctypes
         L, B, C = enc.shape
+        D = inputs.shape[1]
+        S, H = float(np.log2(per_level_scale)), int(base_resolution)
+        dt = dtype_id(enc)
         ctx.save_for_backward(inputs)
-        ctx.cfg = (offsets_host, B, inputs.shape[1], C, L, float(np.log2(per_level_scale)), int(base_resolution), gridtype, interpolation, align_corners,
-                   tuple(embeddings.shape))
+        ctx.cfg = (offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, tuple(embeddings.shape))
+        ctx.plan = None
+        side = _side(enc.device) if overlap else None
+        if side is not None and not _side_busy(side):
+            need = ctypes.c_uint64(0)
+            check(lib.cnerf_grid_encode_backward_workspace_bytes(offsets_host.ctypes.data, B, D, C, L, L, S, H, dt, ctypes.addressof(need)),
+                  "grid_encode_backward_workspace_bytes")
+            if need.value:
+                if side['ws'] is None or side['ws'].numel() < need.value:
+                    side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=enc.device)
+                ws = side['ws']
+                cur = torch.cuda.current_stream()
+                side['stream'].wait_stream(cur)                              # the coordinates were produced on the current stream
+                ok = ctypes.c_int(0)
+                check(lib.cnerf_grid_encode_backward_prepare(ptr(inputs), offsets_host.ctypes.data, B, D, C, L, L, S, H, gridtype, int(align_corners),
+                                                             interpolation, dt, ptr(ws), ws.numel(), ctypes.addressof(ok), side['stream'].cuda_stream),
+                      "grid_encode_backward_prepare")
+                if ok.value:
+                    ev = torch.cuda.Event()
+                    ev.record(side['stream'])
+                    ctx.plan = _Plan(ws, ev)
+                    side['owner'] = weakref.ref(ctx.plan)
         return enc.detach()
 
     @staticmethod
@@ -134,10 +185,20 @@ class _grid_attach(Function):
         offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, eshape = ctx.cfg
         grad = grad.contiguous()
         grad_embeddings = torch.zeros(eshape, device=grad.device, dtype=torch.float32)
-        ws, ws_bytes = _bwd_workspace(offsets_host, B, D, C, L, L, S, H, dtype_id(grad), grad.device)
-        check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H, None, None,
-                                             gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
-        return None, None, grad_embeddings, None, None, None, None, None, None
+        if ctx.plan is not None:
+            ws, ev = ctx.plan.ws, ctx.plan.event
+            torch.cuda.current_stream().wait_event(ev)
+            try:
+                check(lib.cnerf_grid_encode_backward_prepared(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H,
+                                                              gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws.numel(), stream()),
+                      "grid_encode_backward_prepared")
+            finally:
+                ctx.plan = None                                                 # releases the side workspace for the next plan
+        else:
+            ws, ws_bytes = _bwd_workspace(offsets_host, B, D, C, L, L, S, H, dtype_id(grad), grad.device)
+            check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H, None, None,
+                                                 gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
+        return None, None, grad_embeddings, None, None, None, None, None, None, None
 
 
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
@@ -256,10 +317,11 @@ class GridEncoder(nn.Module):
             e1.record()
             prof.append((e0, e1, B, L, table.element_size()))
 
-    def attach_backward(self, enc, inputs_unit):
-        """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table."""
+    def attach_backward(self, enc, inputs_unit, overlap=True):
+        """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table.
+        overlap: issue the coordinate-only half of the backward scatter now, on a second stream (see _grid_attach)."""
         return _grid_attach.apply(enc, inputs_unit.contiguous().float(), self.embeddings, self._offsets_host, self.per_level_scale, self.base_resolution,
-                                  self.gridtype_id, self.align_corners, self.interp_id)
+                                  self.gridtype_id, self.align_corners, self.interp_id, bool(overlap))
 
     def forward(self, inputs, bound=1, max_level=None, return_kernel_layout=False):
         """grid.py:151-168: [..., D] -> [..., L*C]."""

@@ -5,6 +5,8 @@ Same module tree and parameter names as the reference so its state dicts line up
 Grid geometry defaults to the reference's hard-coded values (tiled, log2 T = 21, finest 8192; network_grid.py:89-96)
 and can be overridden through `opt.grid_type / opt.log2_hashmap_size / opt.desired_resolution / opt.num_levels`.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -162,7 +164,9 @@ class NeRFNetwork(NeRFRenderer):
     def split_forward(self, enc, unit, x, d, dir_group):
         """forward() on a complete feature buffer: (sigma [P], rgbc [P, 4]); gradients reach the table through attach_backward"""
         enc_dim, n_geo, n_rgb = self._fused_cfg()
-        enc = self.pos_en.attach_backward(enc, unit) if torch.is_grad_enabled() and self.pos_en.embeddings.requires_grad else enc
+        if torch.is_grad_enabled() and self.pos_en.embeddings.requires_grad:
+            overlap = getattr(self.opt, 'overlap_scatter_plan', True) and os.environ.get('CNERF_GRID_OVERLAP', '1') != '0'
+            enc = self.pos_en.attach_backward(enc, unit, overlap=overlap)
         sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
                             self.rgb_network.params)
         return sigma, rgbc

@@ -134,6 +134,18 @@ int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int3
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                const void *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
                                uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes, void *stream);
+/* Two-phase form of the binned backward.  _prepare runs the part that needs only the sample coordinates (per-chunk histogram and
+ * scans) into `workspace` — issue it early, on a second stream, and it overlaps the forward pass and the field backward; *prepared
+ * tells whether the binned path applies to this shape (0: nothing was launched, use cnerf_grid_encode_backward).  _prepared then runs
+ * the gradient-dependent part (record emit + LDS accumulation) and must see the same inputs, shape and workspace, after _prepare's
+ * work has completed (event / stream order is the caller's). */
+int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                       uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                       int dtype, void *workspace, uint64_t workspace_bytes, int *prepared, void *stream);
+int cnerf_grid_encode_backward_prepared(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                        uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *workspace,
+                                        uint64_t workspace_bytes, void *stream);
 /* *bytes = scratch size the binned scatter wants for this problem (0: the atomic path will be used). */
 int cnerf_grid_encode_backward_workspace_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                                uint32_t max_level, float S, uint32_t H, int dtype, uint64_t *bytes);
@@ -226,7 +238,7 @@ int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const floa
                             uint32_t T, uint32_t t, float *z_all, float *xyz_all, void *stream);
 /* Split form of the same step: the new samples are NOT merged into the coarse ones in memory.  z_all [N,T+t] is the sorted merge as
  * above; xyz_fine [N,t,3] receives the new samples in their own block; src_index [N,T+t] (uint32) maps every sorted position to its
- * row in the sample list [coarse block N*T rows | fine block N*t rows]: coarse i of ray n -> n*T + i, fine m -> N*T + n*t + m.
+ * row in the sample list [coarse block N*T rows | fine block N*t rows]: coarse i of ray n -> n*T + i, fine m (draw order) -> N*T + n*t + m.
  * The field is then evaluated on that list (the coarse block's grid features are already there from the density pass) and the
  * compositing entries below read through src_index.  xyz_all may be NULL here (or non-NULL to get both forms). */
 int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
