@@ -350,6 +350,51 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ reconstruction loss
+// train_step_pretrain's loss (utils_init_nerf.py:220-234) and its gradient in one launch instead of ~35 elementwise / reduce launches:
+//   loss = w_rgb * mean((image - rgb_gt)^2) + w_conf * mean((render_mask - mask_gt)^2)      (image / render_mask of the `all` composite)
+// writes d(loss)/d(out_ray) [3][N][6] (zero outside the `all` variant's image and render_mask slots) and per-workgroup partial sums;
+// a one-wave second launch adds them in a fixed order into loss[0].
+#define RL_BLOCKS 64
+__global__ void __launch_bounds__(256) k_recon_loss(const float *__restrict__ out_ray, const float *__restrict__ rgb_gt, const float *__restrict__ mask_gt,
+                                                    uint32_t N, float k_rgb, float k_m, float *__restrict__ partial, float *__restrict__ g_out) {
+    __shared__ float red[2][4];
+    float s_rgb = 0.0f, s_m = 0.0f;
+    for (uint32_t n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        const float *r = out_ray + (size_t)n * 6;
+        float g[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = r[c] - rgb_gt[(size_t)n * 3 + c];
+            s_rgb += d * d;
+            g[c] = 2.0f * k_rgb * d;
+        }
+        if (mask_gt) {
+            const float d = r[5] - mask_gt[n];
+            s_m += d * d;
+            g[5] = 2.0f * k_m * d;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            g_out[(size_t)n * 6 + c] = g[c];
+            g_out[((size_t)N + n) * 6 + c] = 0.0f;
+            g_out[((size_t)2 * N + n) * 6 + c] = 0.0f;
+        }
+    }
+    s_rgb = rn_wave_sum(s_rgb);
+    s_m = rn_wave_sum(s_m);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s_rgb; red[1][wave] = s_m; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = k_rgb * (red[0][0] + red[0][1] + red[0][2] + red[0][3]) + k_m * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+}
+
+__global__ void __launch_bounds__(64) k_recon_loss_sum(const float *__restrict__ partial, uint32_t n, float *__restrict__ loss) {
+    const float v = rn_wave_sum(threadIdx.x < n ? partial[threadIdx.x] : 0.0f);           // fixed order: deterministic
+    if (threadIdx.x == 0) loss[0] = v;
+}
+
 extern "C" {
 
 int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
@@ -416,6 +461,19 @@ int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas,
                                  int detach_mask_from_field, float *grad_sigmas, float *grad_rgbc, void *stream) {
     return cnerf_composite_run_backward_indexed(grad_out_ray, sigmas, rgbc, z_vals, nears, fars, N, S, num_steps, soft_mask, conf_thr, detach_bg,
                                                 detach_mask_from_field, nullptr, grad_sigmas, grad_rgbc, stream);
+}
+
+int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf, float *loss,
+                     float *grad_out_ray, void *stream) {
+    if (N == 0) return CNERF_EINVAL;
+    if (!out_ray || !rgb_gt || !loss || !grad_out_ray) return CNERF_ENULL;
+    // the tail of grad_out_ray is written last by the same launch, so its first floats can carry the partial sums until the second launch
+    // has read them?  No: keep it simple and exact — the partials live in loss[1 .. RL_BLOCKS] (loss must hold 1 + 64 floats).
+    const uint32_t blocks = cn_div_up(N, 256) < RL_BLOCKS ? cn_div_up(N, 256) : RL_BLOCKS;
+    hipLaunchKernelGGL(k_recon_loss, dim3(blocks), dim3(256), 0, CN_STREAM(stream), out_ray, rgb_gt, mask_gt, N, w_rgb / (3.0f * (float)N),
+                       mask_gt ? w_conf / (float)N : 0.0f, loss + 1, grad_out_ray);
+    hipLaunchKernelGGL(k_recon_loss_sum, dim3(1), dim3(64), 0, CN_STREAM(stream), loss + 1, blocks, loss);
+    return cn_launch_status();
 }
 
 }  // extern "C"

@@ -57,7 +57,8 @@ class FieldFunction(Function):
         g_sigma = g_sigma.contiguous().float()
         g_rgbc = g_rgbc.contiguous().float()
         g_enc = torch.empty_like(enc)
-        g_net, g_den, g_rgb = torch.zeros_like(p_net), torch.zeros_like(p_den), torch.zeros_like(p_rgb)
+        g_all = torch.zeros(p_net.numel() + p_den.numel() + p_rgb.numel(), dtype=torch.float32, device=p_net.device)      # one fill, three views
+        g_net, g_den, g_rgb = (t.view_as(p) for t, p in zip(g_all.split([p_net.numel(), p_den.numel(), p_rgb.numel()]), (p_net, p_den, p_rgb)))
         ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
         check(lib.cnerf_field_backward(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
                                        ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),

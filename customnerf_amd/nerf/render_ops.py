@@ -62,10 +62,13 @@ class _CompositeRunIndexed(Function):
         ctx.save_for_backward(sigmas, rgbc, z_vals, src_index, nears, fars)
         ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
         ctx.mark_non_differentiable(out_w, sig_s, rgbc_s)
+        ctx.set_materialize_grads(False)                        # no zero-filled gradients for the three non-differentiable outputs
         return out_ray, out_w, sig_s, rgbc_s
 
     @staticmethod
     def backward(ctx, g_ray, g_w, g_s, g_c):
+        if g_ray is None:
+            return (None,) * 11
         sigmas, rgbc, z_vals, src_index, nears, fars = ctx.saved_tensors
         num_steps, soft, thr, dbg, dmask = ctx.cfg
         N, S = z_vals.shape
@@ -97,10 +100,13 @@ class _CompositeRun(Function):
         ctx.save_for_backward(sigmas, rgbc, z_vals, nears, fars)
         ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
         ctx.mark_non_differentiable(out_w)
+        ctx.set_materialize_grads(False)
         return out_ray, out_w
 
     @staticmethod
     def backward(ctx, g_ray, g_w):
+        if g_ray is None:
+            return (None,) * 10
         sigmas, rgbc, z_vals, nears, fars = ctx.saved_tensors
         num_steps, soft, thr, dbg, dmask = ctx.cfg
         N, S = z_vals.shape
@@ -114,3 +120,30 @@ class _CompositeRun(Function):
 
 def composite_run(sigmas, rgbc, z_vals, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False):
     return _CompositeRun.apply(sigmas, rgbc, z_vals, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask)
+
+
+class _ReconLoss(Function):
+    """loss [] = w_rgb * mse(image, rgb_gt) + w_conf * mse(render_mask, mask_gt) on out_ray [3,N,6]; the gradient comes out of the same launch"""
+
+    @staticmethod
+    def forward(ctx, out_ray, rgb_gt, mask_gt, w_rgb, w_conf):
+        require_cuda(out_ray, rgb_gt, mask_gt)
+        out_ray = out_ray.contiguous().float()
+        N = out_ray.shape[1]
+        rgb_gt = rgb_gt.reshape(N, 3).contiguous().float()
+        mask_gt = mask_gt.reshape(N).contiguous().float() if mask_gt is not None else None
+        loss = torch.empty(65, dtype=torch.float32, device=out_ray.device)       # [0] = loss, [1:] = partial sums
+        g = torch.empty_like(out_ray)
+        check(lib.cnerf_recon_loss(ptr(out_ray), ptr(rgb_gt), ptr(mask_gt), N, float(w_rgb), float(w_conf), ptr(loss), ptr(g), stream()), "recon_loss")
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        g, = ctx.saved_tensors
+        return g * g_loss, None, None, None, None
+
+
+def recon_loss(out_ray, rgb_gt, mask_gt, w_rgb, w_conf):
+    """utils_init_nerf.py:220-234 on the fused renderer's raw composite output (results['_out_ray'])"""
+    return _ReconLoss.apply(out_ray, rgb_gt, mask_gt, w_rgb, w_conf)

@@ -45,6 +45,39 @@ def sample_pdf(bins, weights, n_samples, det=False, u=None):
     return bins_b + t * (bins_a - bins_b)
 
 
+class _Lazy:
+    """a result-dict entry that is computed on first access (entries the training loop never reads cost no launches)"""
+    __slots__ = ('fn', 'value', 'done')
+
+    def __init__(self, fn):
+        self.fn, self.value, self.done = fn, None, False
+
+    def get(self):
+        if not self.done:
+            self.value, self.done, self.fn = self.fn(), True, None
+        return self.value
+
+
+class _LazyResults(dict):
+    """dict whose _Lazy values are materialised by [] / get / items / values (keys, `in` and len behave as for a plain dict)"""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _Lazy):
+            v = v.get()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -224,21 +257,23 @@ class NeRFRenderer(nn.Module):
         else:
             sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
             out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps, soft, thr, dbg, dmask)
-        mask = (nears < fars).reshape(*prefix)
+        mask = _Lazy(lambda: (nears < fars).reshape(*prefix))
 
         def pack(v):
             r = out_ray[v]
-            return {'image': r[:, 0:3].reshape(*prefix, 3), 'depth': r[:, 3].reshape(*prefix), 'weights_sum': r[:, 4],
-                    'render_mask': r[:, 5].reshape(*prefix, 1), 'weights': out_w[v], 'mask': mask}
+            return _LazyResults({'image': r[:, 0:3].reshape(*prefix, 3), 'depth': r[:, 3].reshape(*prefix), 'weights_sum': r[:, 4],
+                                 'render_mask': r[:, 5].reshape(*prefix, 1), 'weights': out_w[v], 'mask': mask})
         results = pack(0)
         conf = rgbc.view(N, S, 4)[..., 3:4]
         results['sigma'] = sigmas.view(N, S, 1)
         results['rgbs'] = rgbc.view(N, S, 4)[..., :3]
         if getattr(self.opt, 'soft_mask', False):
-            results['edit_mask'] = torch.sigmoid((conf.detach() - self.opt.conf_thr) * 100)
+            thr_ = self.opt.conf_thr
+            results['edit_mask'] = _Lazy(lambda: torch.sigmoid((conf.detach() - thr_) * 100))
         else:
-            results['edit_mask'] = conf.detach() > 0.5
+            results['edit_mask'] = _Lazy(lambda: conf.detach() > 0.5)
         results['z_vals'] = z_all
+        results['_out_ray'] = out_ray                                        # [3, N, 6] raw composite output (trainer.ReconTrainer's fused loss)
         results['fg'] = pack(1)
         results['bg'] = pack(2)
         return results

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
-from ..trainer import allreduce_grads_flat, check_grads_finite, flat_grad_buffer
+from ..trainer import allreduce_grads_flat, check_grads_finite, flat_grad_buffer, refresh_half_shadow, register_half_shadow
 
 
 class EditTrainer:
@@ -37,6 +37,7 @@ class EditTrainer:
         self.base_lrs = [g['lr'] for g in groups]
         self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
         self.optimizer.scaler = self.scaler
+        register_half_shadow(self.optimizer, model, fp16)
         self.global_step = 0
         self.pt_dict = {}
         self._flat = flat_grad_buffer(self.model.parameters())          # .grad views of one flat buffer: the all-reduce runs in place
@@ -142,5 +143,6 @@ class EditTrainer:
             self.scaler.update()
         else:
             self.optimizer.step()
+        refresh_half_shadow(self.optimizer, self.model)
         self.global_step += 1
         return loss.detach(), loss_dict

@@ -57,6 +57,19 @@ def allreduce_grads_flat(parameters, flat, world_size):
     return flat
 
 
+def register_half_shadow(optimizer, model, fp16):
+    """Let the fused Adam refresh the grid table's fp16 shadow in its own pass (no separate cast launch per step)."""
+    enc = getattr(model, 'pos_en', None)
+    if fp16 and enc is not None and hasattr(enc, 'half_table') and enc.embeddings.is_cuda and enc.level_dim % 2 == 0:
+        optimizer.half_shadows[enc.embeddings] = enc.half_table()
+
+
+def refresh_half_shadow(optimizer, model):
+    enc = getattr(model, 'pos_en', None)
+    if enc is not None and enc.embeddings in optimizer.half_shadows:
+        enc.set_half_table(optimizer.half_shadows[enc.embeddings])   # the step just rewrote it: mark it current
+
+
 def check_grads_finite(scaler, parameters, flat):
     """GradScaler's inf check on the (all-reduced) gradients: one pass over the flat buffer when the gradients alias it."""
     grads = [p.grad for p in parameters if p.grad is not None]
@@ -85,6 +98,7 @@ class ReconTrainer:
         if fused_adam:
             self.optimizer = FusedAdam(groups, betas=(0.9, 0.99), eps=1e-15)
             self.optimizer.scaler = self.scaler
+            register_half_shadow(self.optimizer, model, fp16)
         else:
             self.optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
         self.fused_adam = fused_adam
@@ -96,6 +110,11 @@ class ReconTrainer:
 
     def loss(self, outputs, rgbs, mask):
         """utils_init_nerf.py:220-234"""
+        if '_out_ray' in outputs and outputs['_out_ray'].is_cuda and getattr(self.opt, 'fused_loss', True):
+            from .nerf.render_ops import recon_loss                   # loss + gradient in one launch on the fused renderer's composite output
+            with_mask = bool(getattr(self.opt, 'train_conf', 0)) and 'render_mask' in outputs
+            return recon_loss(outputs['_out_ray'], rgbs, mask if with_mask else None, getattr(self.opt, 'train_rgb', 1.0),
+                              getattr(self.opt, 'train_conf', 0) if with_mask else 0.0)
         pred_rgb = outputs['image']
         loss = getattr(self.opt, 'train_rgb', 1.0) * F.mse_loss(pred_rgb.reshape(-1, 3).float(), rgbs.reshape(-1, 3))
         if getattr(self.opt, 'train_conf', 0) and 'render_mask' in outputs:
@@ -125,6 +144,7 @@ class ReconTrainer:
                 self.scaler.update()
             else:
                 self.optimizer.step()
+            refresh_half_shadow(self.optimizer, self.model)
         else:
             if inv != 1.0:
                 torch._foreach_mul_([p.grad for p in self.model.parameters() if p.grad is not None], inv)

@@ -271,6 +271,14 @@ int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float 
                                          int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
                                          const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream);
 
+/* Loss of the reconstruction step (Trainer_Nerf.train_step_pretrain, utils_init_nerf.py:220-234) with its gradient, one launch:
+ *   loss = w_rgb * mean((image - rgb_gt)^2) + w_conf * mean((render_mask - mask_gt)^2)
+ * on the `all` composite of out_ray [3][N][6] (cnerf_composite_run); rgb_gt [N,3], mask_gt [N] (NULL: no mask term).
+ * loss float32[65]: loss[0] = the loss, loss[1..64] = scratch (per-workgroup partial sums, added in a fixed order);
+ * grad_out_ray [3][N][6] = d(loss)/d(out_ray), ready for cnerf_composite_run_backward. */
+int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf,
+                     float *loss, float *grad_out_ray, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step used by the reference's recipe (main.py:182: Adam betas (0.9,0.99) eps 1e-15, no weight decay),
  * fused with gradient un-scaling, the fp16 shadow-table refresh and gradient zeroing.

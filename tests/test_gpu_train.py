@@ -144,3 +144,21 @@ def test_dynamic_loss_scaler_matches_torch_gradscaler():
     again = DynamicLossScaler("cuda")
     again.load_state_dict(ref.state_dict())                          # a reference checkpoint's 'scaler' entry loads
     assert again.get_scale() == ref.get_scale()
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_fused_recon_loss_matches_the_torch_formulation(with_mask):
+    """cnerf_recon_loss (loss + gradient in one launch) against utils_init_nerf.py:220-234 written with F.mse_loss"""
+    import torch.nn.functional as F
+    from customnerf_amd.nerf.render_ops import recon_loss
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N = 5000
+    out_a = torch.rand(3, N, 6, device="cuda", generator=g).requires_grad_(True)
+    out_b = out_a.detach().clone().requires_grad_(True)
+    rgb, mask = torch.rand(N, 3, device="cuda", generator=g), (torch.rand(N, device="cuda", generator=g) > 0.5).float()
+    la = recon_loss(out_a, rgb, mask if with_mask else None, 1.0, 0.3 if with_mask else 0.0)
+    lb = F.mse_loss(out_b[0, :, 0:3], rgb) + (0.3 * F.mse_loss(out_b[0, :, 5], mask) if with_mask else 0.0)
+    assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, float(lb))
+    (la * 7.0).backward(); (lb * 7.0).backward()
+    assert torch.allclose(out_a.grad, out_b.grad, atol=1e-9, rtol=1e-5)
+    assert bool((out_a.grad[1:] == 0).all())
