@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan_blocks(uint32_t *__restrict__
 // ---- sweep 1c: scan over bins: record base per bin and accumulate-workgroup base per bin (one workgroup)
 // bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
 __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
-                                                        uint32_t *__restrict__ seg_first, uint32_t total_bins) {
+                                                        uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records) {
     __shared__ uint32_t wt_r[16], wt_s[16];
     __shared__ uint32_t carry_r, carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_tota
     for (uint32_t start = 0; start < total_bins; start += 1024) {
         const uint32_t i = start + tid;
         const uint32_t r = i < total_bins ? bin_total[i] : 0;
-        const uint32_t s = (r + BN_SEG - 1) / BN_SEG;
+        const uint32_t s = (r + seg_records - 1) / seg_records;
         const uint32_t ir = cn_wave_incl_scan(r), is = cn_wave_incl_scan(s);
         if (lane == 63) { wt_r[wave] = ir; wt_s[wave] = is; }
         __syncthreads();
@@ -317,6 +317,223 @@ __global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict_
     }
 }
 
+
+// ================================================================================================ fp16 records, second form
+// What the first form above pays for (rocprofv3, 2.1 M samples x 16 levels): 2.1 GB of records written by 16-byte stores that land in
+// up to 128 bins per wave instruction, then read back — emit 1.0 ms + accumulate 0.55 ms, one after the other.  Measured on the side
+// (scratch/mall_bench.hip, scratch/lds_atomic_bench.hip): (i) the LDS integer atomics are NOT the accumulate's limit (>= 1.6 T
+// ds_add_u64/s against the 0.92 T/s it runs at) — its record stream is; (ii) scattered partial-line stores into a slab that is re-used
+// pass after pass (and so stays in the 256 MiB Infinity Cache) cost 2.7x less than into a fresh 2 GB range.  Hence:
+//   * ONE 8-byte record per x-PAIR of corners: {entry-in-chunk:12 | t:4 | fx:16, half2(w_yz * g)}.  The two entries of a pair differ by
+//     i0 ^ i1 = 2^(t+1) - 1 (dense: i1 = i0 + 1; hashed: the x term of the hash is x itself, so i1 = i0 ^ x ^ (x+1) — either way a run of
+//     low ones), and their weights are (1 - fx) * w_yz and fx * w_yz: the accumulate workgroup rebuilds both corner updates.  Pairs that
+//     straddle a chunk border (1 in 4096 on dense levels) become two single records (t = 15).  Half the bytes of the first form.
+// Measured and dropped: processing the levels in groups through two alternating slabs with the emit of group g+1 overlapping the accumulate
+// of group g on a second stream (3.49 ms/step at 2 levels per group, 3.20 at 4, against 3.00 for the single pass: the passes underfill
+// the chip and the cross-stream hand-offs cost more than the on-die re-read saves).
+// Sums stay 64-bit fixed point with 24 fractional bits (order-independent, so bit-deterministic wherever one workgroup owns a chunk);
+// the per-corner products are rounded to that grid instead of to binary16 (the reference rounds w*g to half, gridencoder.cu:328: the
+// difference is below one half ulp of each product).
+#define B2_THREADS 1024
+#define B2_SEG (1u << 17)                          // records per accumulate workgroup
+#define B2_SINGLE 15u
+
+struct Bin2Plan {
+    uint32_t bin_first[GE_MAX_LEVELS + 1];         // first bin of each SLOT; slot i serves level lv.order[i] (coarse / fine interleaved)
+    uint32_t nb;                                   // point blocks per level
+    uint32_t total_bins;
+};
+
+struct Bin2Ws {
+    uint32_t *hist, *bin_base, *seg_first;
+    uint2 *slab;
+};
+
+// the four (y, z) corner pairs of a sample on one level: entries of the x and x+1 corner, the weight of the pair, the x fraction
+__device__ __forceinline__ void b2_pairs(const float (&in)[3], const GridLevels &lv, uint32_t level, uint32_t gridtype, bool align_corners,
+                                         uint32_t interp, uint32_t (&i0)[4], uint32_t (&i1)[4], float (&wyz)[4], float &fx) {
+    const uint32_t hashmap_size = lv.size[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    float pos[3];
+    uint32_t pos_grid[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        pos[d] = cn_fma(in[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) pos[d] = ge_smoothstep(pos[d]);
+    }
+    fx = pos[0];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t pgl[3] = {pos_grid[0], pos_grid[1] + (q & 1), pos_grid[2] + (q >> 1)};
+        wyz[q] = ((q & 1) ? pos[1] : 1 - pos[1]) * ((q >> 1) ? pos[2] : 1 - pos[2]);
+        i0[q] = ge_index<3>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        pgl[0] += 1;
+        i1[q] = ge_index<3>(gridtype, align_corners, hashmap_size, resolution, pgl);
+    }
+}
+
+// can the pair travel as one record?  (same chunk, and the two entries differ by a run of low ones)
+__device__ __forceinline__ bool b2_paired(uint32_t i0, uint32_t i1) {
+    const uint32_t m = i0 ^ i1;
+    return m != 0 && (m >> BN_CHUNK_LOG2) == 0 && (m & (m + 1)) == 0;
+}
+
+template <int PTS>
+__global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restrict__ inputs, const GridLevels lv, const Bin2Plan plan,
+                                                          uint32_t *__restrict__ hist, uint32_t B, uint32_t gridtype, int align_corners,
+                                                          uint32_t interp) {
+    __shared__ uint32_t cnt[BN_MAX_CHUNKS];
+    const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
+    const uint32_t level = lv.order[slot];
+    const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
+    if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PTS / B2_THREADS; i++) {
+        const uint32_t b = pb * PTS + i * B2_THREADS + threadIdx.x;
+        float in[3];
+        if (!bn_load_point(inputs, b, B, in)) continue;
+        uint32_t i0[4], i1[4];
+        float wyz[4], fx;
+        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            atomicAdd(&cnt[i0[q] >> BN_CHUNK_LOG2], 1u);
+            if (!b2_paired(i0[q], i1[q])) atomicAdd(&cnt[i1[q] >> BN_CHUNK_LOG2], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[slot] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
+}
+
+template <int PTS>
+__global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+                                                          const Bin2Plan plan, const uint32_t *__restrict__ hist,
+                                                          const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
+                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0) {
+    __shared__ uint32_t cursor[BN_MAX_CHUNKS];
+    const uint32_t slot = slot0 + blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
+    const uint32_t level = lv.order[slot];
+    const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
+    if (threadIdx.x < nch) {
+        const uint32_t bin = plan.bin_first[slot] + threadIdx.x;
+        cursor[threadIdx.x] = bin_base[bin] + hist[(size_t)bin * plan.nb + pb] - bin_base[plan.bin_first[slot0]];     // slab-relative
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PTS / B2_THREADS; i++) {
+        const uint32_t b = pb * PTS + i * B2_THREADS + threadIdx.x;
+        float in[3];
+        if (!bn_load_point(inputs, b, B, in)) continue;
+        uint32_t i0[4], i1[4];
+        float wyz[4], fx;
+        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
+        const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
+        const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
+        const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
+        union { __half2 h; uint32_t u; } v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t c0 = i0[q] >> BN_CHUNK_LOG2;
+            if (b2_paired(i0[q], i1[q])) {
+                const uint32_t t = 31u - (uint32_t)__clz((int)(i0[q] ^ i1[q]));
+                v.h = __floats2half2_rn(wyz[q] * g0, wyz[q] * g1);
+                const uint32_t pos = atomicAdd(&cursor[c0], 1u);
+                slab[pos] = make_uint2((i0[q] & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
+            } else {
+                const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
+                v.h = __floats2half2_rn(w0 * g0, w0 * g1);
+                const uint32_t pos0 = atomicAdd(&cursor[c0], 1u);
+                slab[pos0] = make_uint2((i0[q] & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+                v.h = __floats2half2_rn(w1 * g0, w1 * g1);
+                const uint32_t pos1 = atomicAdd(&cursor[i1[q] >> BN_CHUNK_LOG2], 1u);
+                slab[pos1] = make_uint2((i1[q] & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+            }
+        }
+    }
+}
+
+// the LDS image keeps the two channels in separate halves (acc[e], acc[BN_CHUNK + e]): random 8-byte atomics at a 16-byte stride reach
+// only half of the bank pairs (scratch/lds_atomic_peak.hip: 2.6 T ds_add_u64/s interleaved, 3.8 T/s split)
+__device__ __forceinline__ void b2_add(long long *acc, uint32_t e, float a, float b) {
+    // |a| <= 65504: a * 2^24 < 2^41, rounded to the fixed-point grid
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), (unsigned long long)__float2ll_rn(a * 16777216.0f));
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), (unsigned long long)__float2ll_rn(b * 16777216.0f));
+}
+
+__device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
+    union { uint32_t u; __half2 h; } v;
+    v.u = r.y;
+    const float2 f = __half22float2(v.h);
+    const uint32_t e = r.x & (BN_CHUNK - 1), t = (r.x >> 12) & 15u;
+    if (t == B2_SINGLE) {
+        b2_add(acc, e, f.x, f.y);
+    } else {
+        const float w1 = (float)(r.x >> 16) * (1.0f / 65536.0f), w0 = 1.0f - w1;
+        b2_add(acc, e, w0 * f.x, w0 * f.y);
+        b2_add(acc, e ^ ((2u << t) - 1u), w1 * f.x, w1 * f.y);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
+                                                     const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
+                                                     float *__restrict__ grad_grid, uint32_t slot0, uint32_t slot1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
+    long long *acc = reinterpret_cast<long long *>(bn_lds);
+    uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
+    const uint32_t bin_lo = plan.bin_first[slot0], bin_hi = plan.bin_first[slot1];
+    const uint32_t gseg = blockIdx.x + seg_first[bin_lo];
+    if (gseg >= seg_first[bin_hi]) return;
+    if (threadIdx.x == 0) {                                            // upper_bound(seg_first, gseg) - 1 inside the group
+        uint32_t lo = bin_lo, hi = bin_hi;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_first[mid + 1] <= gseg) lo = mid + 1; else hi = mid;
+        }
+        s_bin = lo;
+    }
+    for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t seg = gseg - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
+    const uint32_t rec_off = bin_base[bin_lo];
+    const uint32_t r0 = bin_base[bin] - rec_off, r1 = bin_base[bin + 1] - rec_off;
+    const uint32_t begin = r0 + seg * B2_SEG, end = min(begin + B2_SEG, r1);
+    constexpr int UNR = 4;
+    uint32_t i = begin + threadIdx.x;
+    for (; i + (UNR - 1) * 1024 < end; i += UNR * 1024) {
+        uint2 r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) r[u] = slab[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) b2_add_record(acc, r[u]);
+    }
+    for (; i < end; i += 1024) b2_add_record(acc, slab[i]);
+    __syncthreads();
+    uint32_t slot = slot0;
+    while (plan.bin_first[slot + 1] <= bin) slot++;
+    const uint32_t level = lv.order[slot];
+    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
+    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
+    float *__restrict__ dst = grad_grid + ((size_t)lv.offset[level] + e0) * 2;
+    if (nseg == 1) {
+        for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024) {             // two entries x two channels per thread
+            float4 g = reinterpret_cast<float4 *>(dst)[j];
+            g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
+            g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
+            reinterpret_cast<float4 *>(dst)[j] = g;
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) {
+            const float a = bn_acc_to_float<__half>(acc[(j & 1) * BN_CHUNK + (j >> 1)]);
+            if (a != 0.0f) unsafeAtomicAdd(&dst[j], a);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline uint64_t bn_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
 
@@ -348,6 +565,93 @@ static uint64_t bn_layout(const BinPlan &plan, uint32_t B, uint32_t nl, int dtyp
     return off;
 }
 
+
+// ---- second form, host side
+static int b2_env(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static bool b2_enabled(int dtype) {
+    static int v1 = -1;
+    if (v1 < 0) v1 = b2_env("CNERF_BIN_V1", 0);
+    return dtype == CNERF_F16 && !v1;
+}
+
+// points per block and level in the hist / emit sweeps
+static uint32_t b2_pts() {
+    static int p = -1;
+    if (p < 0) { p = b2_env("CNERF_B2_PTS", 2048); if (p != 1024 && p != 2048 && p != 4096 && p != 8192) p = 2048; }
+    return (uint32_t)p;
+}
+
+static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &plan) {
+    plan.nb = cn_div_up(B, b2_pts());
+    uint32_t acc = 0;
+    for (uint32_t s = 0; s < nl; s++) {
+        plan.bin_first[s] = acc;
+        acc += cn_div_up(lv.size[lv.order[s]], BN_CHUNK);
+    }
+    for (uint32_t s = nl; s <= GE_MAX_LEVELS; s++) plan.bin_first[s] = acc;
+    plan.total_bins = acc;
+}
+
+static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws *ws, void *base) {
+    uint64_t off = 0;
+    const uint64_t o_hist = off; off = bn_align(off + (uint64_t)plan.total_bins * plan.nb * 4);
+    const uint64_t o_base = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
+    const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
+    const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
+    const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
+    if (ws) {
+        char *p = (char *)base;
+        ws->hist = (uint32_t *)(p + o_hist);
+        ws->bin_base = (uint32_t *)(p + o_base);
+        ws->seg_first = (uint32_t *)(p + o_seg);
+        ws->slab = (uint2 *)(p + o_s0);
+    }
+    return off;
+}
+
+static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
+                     hipStream_t st) {
+    Bin2Plan plan;
+    b2_plan(lv, nl, B, plan);
+    Bin2Ws ws;
+    b2_layout(plan, B, nl, &ws, workspace);
+    switch (b2_pts()) {
+#define B2_HIST(P) case P: hipLaunchKernelGGL(k_bin2_hist<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp); break;
+        B2_HIST(1024) B2_HIST(2048) B2_HIST(4096) B2_HIST(8192)
+#undef B2_HIST
+    }
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, B2_SEG);
+    return cn_launch_status();
+}
+
+static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                     uint32_t interp, void *workspace, hipStream_t st) {
+    Bin2Plan plan;
+    b2_plan(lv, nl, B, plan);
+    Bin2Ws ws;
+    b2_layout(plan, B, nl, &ws, workspace);
+    const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(long long) + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_accum), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    switch (b2_pts()) {
+#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u); break;
+        B2_EMIT(1024) B2_EMIT(2048) B2_EMIT(4096) B2_EMIT(8192)
+#undef B2_EMIT
+    }
+    // upper bound of accumulate workgroups: every bin may add one partial segment
+    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64((uint64_t)B * nl * 8, B2_SEG);
+    hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
+                       gemb, 0u, nl);
+    return cn_launch_status();
+}
+
 // used by gridencoder.hip
 bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv) {
     if (D != 3 || C != 2 || nl == 0) return false;
@@ -357,6 +661,11 @@ bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLeve
 }
 
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
+    if (b2_enabled(dtype)) {
+        Bin2Plan p2;
+        b2_plan(lv, nl, B, p2);
+        return b2_layout(p2, B, nl, nullptr, nullptr);
+    }
     BinPlan plan;
     bn_plan(lv, nl, B, plan);
     return bn_layout(plan, B, nl, dtype, nullptr, nullptr);
@@ -373,7 +682,7 @@ static int bn_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
     const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL(k_bin_hist, grid1, dim3(BN_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, BN_SEG);
     return cn_launch_status();
 }
 
@@ -402,11 +711,19 @@ static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, f
 
 int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
                void *workspace, hipStream_t st) {
+    if (b2_enabled(dtype)) return b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);
     return bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
 }
 
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
+    if (b2_enabled(dtype)) {
+        if (!prepared) {
+            const int rc = b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);
+            if (rc) return rc;
+        }
+        return b2_phase2((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
+    }
     if (!prepared) {
         const int rc = bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
         if (rc) return rc;

@@ -14,6 +14,10 @@ __global__ void __launch_bounds__(1024) k(const uint32_t* __restrict__ idx, floa
         else if (MODE == 2) { unsafeAtomicAdd(&acc[e], 1.0f); unsafeAtomicAdd(&acc[e + 8192], 2.0f); }       // SoA channels
         else if (MODE == 3) { acc[e * 2] += 1.0f; acc[e * 2 + 1] += 2.0f; }                                    // racy plain
         else if (MODE == 4) { atomicAdd((unsigned long long*)&acc[e * 2], 0x0000000200000001ull); }           // one 64-bit int atomic
+        else if (MODE == 5) { atomicAdd((uint32_t*)&acc[e], 1u); }
+        else if (MODE == 6) { atomicAdd((unsigned long long*)&acc[(e & 4095) * 4], 3ull); atomicAdd((unsigned long long*)&acc[(e & 4095) * 4 + 2], 5ull); }
+        else if (MODE == 7) { unsafeAtomicAdd(&acc[e], 1.0f); }
+        else if (MODE == 8) { __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) __attribute__((ext_vector_type(2))) _Float16*)(&acc[e]), (__attribute__((ext_vector_type(2))) _Float16){(_Float16)1.0f, (_Float16)2.0f}); }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 16384; i += 1024) if (acc[i] != 0) out[blockIdx.x * 16384 + i] = acc[i];
@@ -42,6 +46,10 @@ int main() {
         run<2>(d, out, mask, "ds_add_f32 x2 (SoA)");
         run<3>(d, out, mask, "plain rmw x2 (racy)");
         run<4>(d, out, mask, "ds_add_u64 x1");
+        run<5>(d, out, mask, "ds_add_u32 x1");
+        run<6>(d, out, mask, "ds_add_u64 x2 (AoS, 4096 entries)");
+        run<7>(d, out, mask, "ds_add_f32 x1");
+        run<8>(d, out, mask, "ds_pk_add_f16 x1");
     }
     return 0;
 }
