@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 #define GE_MAX_LEVELS 32
 #define GE_BLOCK 256
@@ -67,6 +68,56 @@ __device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corne
     }
     if (gridtype == 0 && stride > hashmap_size) index = ge_fast_hash<D>(p);
     return index % hashmap_size;
+}
+
+// Level-uniform shortcuts of ge_index (same results, bit for bit).  The generic form costs a 32-bit remainder per corner (~30 VALU
+// instructions, eight times per sample and level); which branch it takes depends on the level only:
+//   GE_MODE_DENSE   every dimension enters the stride product and the product fits the table: index = sum p[d] * step^d < size, no wrap
+//   GE_MODE_HASH2   hashed level whose table size is a power of two: index = hash & (size - 1)
+//   GE_MODE_GENERIC anything else (tiled levels that wrap, odd table sizes)
+#define GE_MODE_GENERIC 0
+#define GE_MODE_DENSE 1
+#define GE_MODE_HASH2 2
+template <int D>
+__device__ __forceinline__ int ge_level_mode(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+    uint32_t stride = 1;
+    bool all = true;
+    const uint32_t step = align_corners ? resolution : (resolution + 1);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        if (stride <= hashmap_size) stride *= step;
+        else all = false;
+    }
+    if (all && stride <= hashmap_size) return GE_MODE_DENSE;
+    if (gridtype == 0 && stride > hashmap_size && (hashmap_size & (hashmap_size - 1)) == 0) return GE_MODE_HASH2;
+    return GE_MODE_GENERIC;
+}
+
+template <int D, int MODE>
+__device__ __forceinline__ uint32_t ge_index_m(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                               const uint32_t (&p)[D]) {
+    if constexpr (MODE == GE_MODE_HASH2) {
+        return ge_fast_hash<D>(p) & (hashmap_size - 1);
+    } else if constexpr (MODE == GE_MODE_DENSE) {
+        const uint32_t step = align_corners ? resolution : (resolution + 1);
+        uint32_t stride = step, index = p[0];
+#pragma unroll
+        for (int d = 1; d < D; d++) {
+            index += p[d] * stride;
+            stride *= step;
+        }
+        return index;
+    } else {
+        return ge_index<D>(gridtype, align_corners, hashmap_size, resolution, p);
+    }
+}
+
+// run f(std::integral_constant<int, MODE>) for the level's mode (the branch is wave-uniform: the level is a function of blockIdx)
+template <typename F>
+__device__ __forceinline__ void ge_dispatch_mode(int mode, F &&f) {
+    if (mode == GE_MODE_HASH2) f(std::integral_constant<int, GE_MODE_HASH2>{});
+    else if (mode == GE_MODE_DENSE) f(std::integral_constant<int, GE_MODE_DENSE>{});
+    else f(std::integral_constant<int, GE_MODE_GENERIC>{});
 }
 
 // does ge_index take the hash branch on this level (gridtype hash only)?

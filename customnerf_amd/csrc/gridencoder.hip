@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
     if constexpr (sizeof(Vec) == 4) {
         quad = gridtype == 0 && ((lv.offset[level] | hashmap_size) & 3u) == 0 && ge_is_hashed<D>(align_corners, hashmap_size, resolution);
     }
+    ge_dispatch_mode(ge_level_mode<D>(gridtype, align_corners, hashmap_size, resolution), [&](auto mode_c) {
 #pragma unroll
     for (int q = 0; q < (1 << (D - 1)); q++) {
         uint32_t pgl[D];
@@ -99,9 +100,9 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
         }
         wgt[2 * q] = w0; wgt[2 * q + 1] = w1;
         pgl[0] = pos_grid[0];
-        const uint32_t i0 = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        const uint32_t i0 = ge_index_m<D, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
         pgl[0] = pos_grid[0] + 1;
-        const uint32_t i1 = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        const uint32_t i1 = ge_index_m<D, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
         if (quad) {
             if constexpr (sizeof(Vec) == 4) {
                 const VecQuad v = *reinterpret_cast<const VecQuad *>(table + (i0 & ~3u));
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
             corner[2 * q + 1] = (i0 == lo) ? e_hi : e_lo;
         }
     }
+    });
     Vec res;
 #pragma unroll
     for (int c = 0; c < C; c++) res.v[c] = ge_from_float<T>(0.0f);
