@@ -118,29 +118,41 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_hist(const float *__restrict
     if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[level] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
 }
 
-// ---- sweep 1b: per bin, exclusive scan over the point blocks (in place) and the bin total
-__global__ void __launch_bounds__(1024) k_bin_scan_blocks(uint32_t *__restrict__ hist, uint32_t *__restrict__ bin_total, uint32_t nb) {
-    __shared__ uint32_t wave_tot[16];
+// ---- sweep 1b: per bin, exclusive scan over the point blocks (in place) and the bin total.  256-thread workgroups: this runs beside the
+// forward pass on a second stream, where a 1024-thread workgroup waits a long time for sixteen free wave slots on one CU.
+#define BN_SCAN_THREADS 256
+__global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin_scan_blocks(uint32_t *__restrict__ hist, uint32_t *__restrict__ bin_total, uint32_t nb) {
+    constexpr uint32_t NW = BN_SCAN_THREADS / 64;
+    __shared__ uint32_t wave_tot[NW];
     __shared__ uint32_t carry;
     uint32_t *h = hist + (size_t)blockIdx.x * nb;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (uint32_t start = 0; start < nb; start += 1024) {
-        const uint32_t i = start + tid;
-        const uint32_t v = i < nb ? h[i] : 0;
-        const uint32_t incl = cn_wave_incl_scan(v);
+    for (uint32_t start = 0; start < nb; start += BN_SCAN_THREADS * 4) {
+        // four consecutive counts per thread
+        const uint32_t i = start + tid * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < nb ? h[i + k] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = cn_wave_incl_scan(mine);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 16; w++) {
+        for (uint32_t w = 0; w < NW; w++) {
             const uint32_t t = wave_tot[w];
             if (w < wave) wbase += t;
             tot += t;
         }
         const uint32_t base = carry;
-        if (i < nb) h[i] = base + wbase + incl - v;
+        uint32_t run = base + wbase + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < nb) h[i + k] = run;
+            run += v[k];
+        }
         __syncthreads();
         if (tid == 0) carry = base + tot;
         __syncthreads();
@@ -347,6 +359,8 @@ struct Bin2Plan {
 struct Bin2Ws {
     uint32_t *hist, *bin_base, *seg_first;
     uint2 *slab;
+    float *partial;
+    uint64_t max_seg;
 };
 
 // the four (y, z) corner pairs of a sample on one level: entries of the x and x+1 corner, the weight of the pair, the x fraction
@@ -383,6 +397,20 @@ __device__ __forceinline__ bool b2_paired(uint32_t i0, uint32_t i1) {
     return m != 0 && (m >> BN_CHUNK_LOG2) == 0 && (m & (m + 1)) == 0;
 }
 
+// LDS counter ticket, wave-aggregated when every active lane wants the same counter — the rule on the dense levels, where a wave's samples
+// (neighbours on one ray) fall into one chunk and 64 same-address atomics would serialise; hashed levels take the per-lane atomic.
+__device__ __forceinline__ uint32_t b2_ticket(uint32_t *counters, uint32_t c) {
+    const uint64_t act = __ballot(1);
+    const uint32_t c_lead = __builtin_amdgcn_readfirstlane(c);
+    if (__ballot(c == c_lead) == act) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        uint32_t base = 0;
+        if (rank == 0) base = atomicAdd(&counters[c_lead], (uint32_t)__popcll(act));
+        return __builtin_amdgcn_readfirstlane(base) + rank;                         // the first active lane is the rank-0 lane
+    }
+    return atomicAdd(&counters[c], 1u);
+}
+
 template <int PTS>
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restrict__ inputs, const GridLevels lv, const Bin2Plan plan,
                                                           uint32_t *__restrict__ hist, uint32_t B, uint32_t gridtype, int align_corners,
@@ -403,7 +431,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restric
         b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            atomicAdd(&cnt[i0[q] >> BN_CHUNK_LOG2], 1u);
+            (void)b2_ticket(cnt, i0[q] >> BN_CHUNK_LOG2);
             if (!b2_paired(i0[q], i1[q])) atomicAdd(&cnt[i1[q] >> BN_CHUNK_LOG2], 1u);
         }
     }
@@ -443,7 +471,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
             if (b2_paired(i0[q], i1[q])) {
                 const uint32_t t = 31u - (uint32_t)__clz((int)(i0[q] ^ i1[q]));
                 v.h = __floats2half2_rn(wyz[q] * g0, wyz[q] * g1);
-                const uint32_t pos = atomicAdd(&cursor[c0], 1u);
+                const uint32_t pos = b2_ticket(cursor, c0);
                 slab[pos] = make_uint2((i0[q] & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
             } else {
                 const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
@@ -475,10 +503,12 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
     uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(b2s_lds + (size_t)B2S_CAP * 9);
     uint32_t *gdelta = cursor + BN_MAX_CHUNKS;                                     // staging slot -> slab position (wrapping uint32 arithmetic)
-    uint32_t *s_total = gdelta + BN_MAX_CHUNKS;
+    uint32_t *s_off = gdelta + BN_MAX_CHUNKS, *s_cnt = s_off + BN_MAX_CHUNKS;      // staging offset and record count of each bin
+    uint32_t *s_total = s_cnt + BN_MAX_CHUNKS;
     const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t level = lv.order[slot];
     const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
+    const bool spread = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
     if (threadIdx.x < 64) {
         // counts of this block per bin (difference of the scanned histogram), two bins per lane -> staging offsets
         const uint32_t lane = threadIdx.x;
@@ -500,6 +530,8 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
         const uint32_t ib = cn_wave_incl_scan(cnt[1]);
         const uint32_t oa = ia - cnt[0], ob = tot_a + ib - cnt[1];
         cursor[lane] = oa; cursor[lane + 64] = ob;
+        s_off[lane] = oa; s_off[lane + 64] = ob;
+        s_cnt[lane] = cnt[0]; s_cnt[lane + 64] = cnt[1];
         gdelta[lane] = gpos[0] - oa; gdelta[lane + 64] = gpos[1] - ob;
         if (lane == 63) *s_total = tot_a + ib;
     }
@@ -517,7 +549,15 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
         const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t word, uint32_t val) {
-            const uint32_t sl = atomicAdd(&cursor[c], 1u);
+            uint32_t sl = b2_ticket(cursor, c);
+            if (spread) {
+                // dense level: neighbouring tickets are neighbouring samples of one ray, i.e. the same table entries.  Scatter them over the
+                // bin's run (odd multiplier on the largest power-of-two prefix) so that an accumulate wave holds 64 unrelated records
+                // instead of ~7-way same-address LDS atomics.
+                const uint32_t o = s_off[c], n = s_cnt[c], rk = sl - o;
+                const uint32_t k = 31u - (uint32_t)__clz((int)(n | 1u));
+                if (rk < (1u << k)) sl = o + ((rk * ((0x9E3779B1u >> (32u - k)) | 1u)) & ((1u << k) - 1u));
+            }
             if (sl < B2S_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
             else slab[gdelta[c] + sl] = make_uint2(word, val);
         };
@@ -566,7 +606,7 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
 
 __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
-                                                     float *__restrict__ grad_grid, uint32_t slot0, uint32_t slot1) {
+                                                     float *__restrict__ grad_grid, float *__restrict__ partial, uint32_t slot0, uint32_t slot1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
@@ -613,11 +653,37 @@ __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ s
             reinterpret_cast<float4 *>(dst)[j] = g;
         }
     } else {
-        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) {
-            const float a = bn_acc_to_float<__half>(acc[(j & 1) * BN_CHUNK + (j >> 1)]);
-            if (a != 0.0f) unsafeAtomicAdd(&dst[j], a);
-        }
+        // a split bin (the small dense levels): park the partial image; k_bin2_reduce_split adds the segments in order.  (Flushing with
+        // float atomics cost 3.1 M memory-side atomics = 0.15 ms per scatter, and their order is not reproducible.)
+        float4 *__restrict__ img = reinterpret_cast<float4 *>(partial + (size_t)gseg * (BN_CHUNK * 2));
+        for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024)
+            img[j] = make_float4(bn_acc_to_float<__half>(acc[j * 2]), bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]),
+                                 bn_acc_to_float<__half>(acc[j * 2 + 1]), bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]));
     }
+}
+
+// sum the partial images of the split bins, segment by segment in index order, into the gradient table (grid: total_bins x 8 tiles)
+__global__ void __launch_bounds__(256) k_bin2_reduce_split(const float *__restrict__ partial, const uint32_t *__restrict__ seg_first, const GridLevels lv,
+                                                           const Bin2Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
+    const uint32_t bin = blockIdx.x;
+    const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
+    if (nseg <= 1) return;
+    uint32_t slot = 0;
+    while (slot + 1 < n_slots && plan.bin_first[slot + 1] <= bin) slot++;
+    const uint32_t level = lv.order[slot];
+    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
+    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // float4 index inside the chunk image
+    if (j >= n_entries / 2) return;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t s = 0; s < nseg; s++) {
+        const float4 v = reinterpret_cast<const float4 *>(partial + (size_t)(s0 + s) * (BN_CHUNK * 2))[j];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
+    float4 g = *dst;
+    g.x += sum.x; g.y += sum.y; g.z += sum.z; g.w += sum.w;
+    *dst = g;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -688,12 +754,16 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
     const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
     const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
+    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, B2_SEG);       // every bin may add one partial segment
+    const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 4);                 // partial images of split bins (sparsely used)
     if (ws) {
         char *p = (char *)base;
         ws->hist = (uint32_t *)(p + o_hist);
         ws->bin_base = (uint32_t *)(p + o_base);
         ws->seg_first = (uint32_t *)(p + o_seg);
         ws->slab = (uint2 *)(p + o_s0);
+        ws->partial = (float *)(p + o_part);
+        ws->max_seg = max_seg;
     }
     return off;
 }
@@ -709,7 +779,7 @@ static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
         B2_HIST(1024) B2_HIST(2048) B2_HIST(4096) B2_HIST(8192)
 #undef B2_HIST
     }
-    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, B2_SEG);
     return cn_launch_status();
 }
@@ -729,20 +799,20 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     static int staged = -1;
     if (staged < 0) {
         staged = b2_env("CNERF_B2_STAGED", 1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + BN_MAX_CHUNKS * 8 + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + BN_MAX_CHUNKS * 16 + 16);
     }
     if (staged && b2_pts() == B2S_PTS)
-        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + BN_MAX_CHUNKS * 8 + 16, st, grad, inputs, lv, plan, ws.hist,
+        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + BN_MAX_CHUNKS * 16 + 16, st, grad, inputs, lv, plan, ws.hist,
                            ws.bin_base, ws.slab, B, gridtype, ac, interp);
     else switch (b2_pts()) {
 #define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u); break;
         B2_EMIT(1024) B2_EMIT(2048) B2_EMIT(4096) B2_EMIT(8192)
 #undef B2_EMIT
     }
-    // upper bound of accumulate workgroups: every bin may add one partial segment
-    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64((uint64_t)B * nl * 8, B2_SEG);
-    hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
-                       gemb, 0u, nl);
+    hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
+                       gemb, ws.partial, 0u, nl);
+    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const float *)ws.partial, ws.seg_first, lv, plan,
+                       gemb, nl);
     return cn_launch_status();
 }
 
@@ -775,7 +845,7 @@ static int bn_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
     bn_layout(plan, B, nl, dtype, &ws, workspace);
     const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL(k_bin_hist, grid1, dim3(BN_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp);
-    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(1024), 0, st, ws.hist, ws.bin_base, plan.nb);
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, BN_SEG);
     return cn_launch_status();
 }
