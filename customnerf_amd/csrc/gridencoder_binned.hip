@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ s
     }
 }
 
-// sum the partial images of the split bins, segment by segment in index order, into the gradient table (grid: total_bins x 8 tiles)
+// sum the partial images of the split bins, segment by segment in index order, into the gradient table (one workgroup per bin)
 __global__ void __launch_bounds__(256) k_bin2_reduce_split(const float *__restrict__ partial, const uint32_t *__restrict__ seg_first, const GridLevels lv,
                                                            const Bin2Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
     const uint32_t bin = blockIdx.x;
@@ -673,17 +673,17 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const float *__restri
     const uint32_t level = lv.order[slot];
     const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
     const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
-    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // float4 index inside the chunk image
-    if (j >= n_entries / 2) return;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t s = 0; s < nseg; s++) {
-        const float4 v = reinterpret_cast<const float4 *>(partial + (size_t)(s0 + s) * (BN_CHUNK * 2))[j];
-        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 256) {                  // float4 index inside the chunk image
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t s = 0; s < nseg; s++) {
+            const float4 v = reinterpret_cast<const float4 *>(partial + (size_t)(s0 + s) * (BN_CHUNK * 2))[j];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
+        float4 g = *dst;
+        g.x += sum.x; g.y += sum.y; g.z += sum.z; g.w += sum.w;
+        *dst = g;
     }
-    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
-    float4 g = *dst;
-    g.x += sum.x; g.y += sum.y; g.z += sum.z; g.w += sum.w;
-    *dst = g;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -811,7 +811,7 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     }
     hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
                        gemb, ws.partial, 0u, nl);
-    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const float *)ws.partial, ws.seg_first, lv, plan,
+    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins), dim3(256), 0, st, (const float *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
     return cn_launch_status();
 }

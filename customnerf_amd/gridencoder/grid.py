@@ -148,8 +148,10 @@ class _grid_attach(Function):
     stream: it overlaps the rest of the forward pass and the field backward instead of sitting on the critical path."""
 
     @staticmethod
-    def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation, overlap):
+    def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation, overlap,
+                grad_in_place=False):
         import ctypes
+        ctx.param = embeddings if grad_in_place else None
         L, B, C = enc.shape
         D = inputs.shape[1]
         S, H = float(np.log2(per_level_scale)), int(base_resolution)
@@ -184,7 +186,12 @@ class _grid_attach(Function):
         inputs, = ctx.saved_tensors
         offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, eshape = ctx.cfg
         grad = grad.contiguous()
-        grad_embeddings = torch.zeros(eshape, device=grad.device, dtype=torch.float32)
+        # grad_in_place (the trainers' persistent flat .grad buffer): the scatter is a read-modify-write of its destination anyway, so it
+        # accumulates straight into embeddings.grad — no 49 MB zero-fill and no AccumulateGrad add pass (~45 us per step at T = 2^19)
+        tgt = ctx.param.grad if ctx.param is not None else None
+        in_place = (tgt is not None and tgt.dtype == torch.float32 and tgt.is_contiguous() and tuple(tgt.shape) == tuple(eshape)
+                    and tgt.device == grad.device)
+        grad_embeddings = tgt if in_place else torch.zeros(eshape, device=grad.device, dtype=torch.float32)
         if ctx.plan is not None:
             ws, ev = ctx.plan.ws, ctx.plan.event
             torch.cuda.current_stream().wait_event(ev)
@@ -198,7 +205,7 @@ class _grid_attach(Function):
             ws, ws_bytes = _bwd_workspace(offsets_host, B, D, C, L, L, S, H, dtype_id(grad), grad.device)
             check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H, None, None,
                                                  gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
-        return None, None, grad_embeddings, None, None, None, None, None, None, None
+        return None, None, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None
 
 
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
@@ -321,7 +328,7 @@ class GridEncoder(nn.Module):
         """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table.
         overlap: issue the coordinate-only half of the backward scatter now, on a second stream (see _grid_attach)."""
         return _grid_attach.apply(enc, inputs_unit.contiguous().float(), self.embeddings, self._offsets_host, self.per_level_scale, self.base_resolution,
-                                  self.gridtype_id, self.align_corners, self.interp_id, bool(overlap))
+                                  self.gridtype_id, self.align_corners, self.interp_id, bool(overlap), bool(getattr(self, 'grad_in_place', False)))
 
     def forward(self, inputs, bound=1, max_level=None, return_kernel_layout=False):
         """grid.py:151-168: [..., D] -> [..., L*C]."""

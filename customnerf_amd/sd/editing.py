@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
-from ..trainer import allreduce_grads_flat, check_grads_finite, flat_grad_buffer, refresh_half_shadow, register_half_shadow
+from ..trainer import allreduce_grads_flat, check_grads_finite, enable_grad_in_place, flat_grad_buffer, refresh_half_shadow, register_half_shadow
 
 
 class EditTrainer:
@@ -41,6 +41,7 @@ class EditTrainer:
         self.global_step = 0
         self.pt_dict = {}
         self._flat = flat_grad_buffer(self.model.parameters())          # .grad views of one flat buffer: the all-reduce runs in place
+        enable_grad_in_place(model)
         self._rng = np.random.RandomState(seed)
         guidance.set_system(self)
         self._render_kw = {k: v for k, v in vars(opt).items() if k != 'bg_color'}       # bg_color is passed explicitly (utils_init_nerf.py:365)

@@ -25,6 +25,14 @@ def flat_grad_buffer(parameters):
     return flat
 
 
+def enable_grad_in_place(model):
+    """With persistent .grad views (flat_grad_buffer) the grid scatter may add straight into embeddings.grad (GridEncoder.grad_in_place):
+    autograd then has nothing to accumulate for the table."""
+    enc = getattr(model, 'pos_en', None)
+    if enc is not None and hasattr(enc, 'attach_backward'):
+        enc.grad_in_place = True
+
+
 def _slot(n):
     return (n + 3) // 4 * 4            # every view starts 16-byte aligned (the fused Adam kernel loads float4); pad elements stay zero
 
@@ -104,6 +112,8 @@ class ReconTrainer:
         self.fused_adam = fused_adam
         self.global_step = 0
         self._flat = flat_grad_buffer(self.model.parameters())   # persistent, pre-zeroed .grad views of one flat buffer (zeroed by the fused step)
+        if fused_adam:
+            enable_grad_in_place(model)                          # (torch.optim.Adam + zero_grad keeps the views too, but stay on the plain path there)
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)      # main.py:189
