@@ -368,25 +368,47 @@ static int sg_check(const CnerfSdGemm *g) {
     return CNERF_OK;
 }
 
-// output-tile width: 64 when the last 128-wide tile would be at most half full, or when 128-wide tiles cannot fill the chip
-static int sg_pick_nt(const CnerfSdGemm *g) {
-    const uint32_t rem = g->N % 128;
-    if (rem != 0 && rem <= 64) return 1;
-    const uint32_t tiles128 = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, 128) * g->batch_outer * g->batch_inner;
-    return tiles128 < 384 ? 1 : 2;
+// Tile width (128 x 64 or 128 x 128) and split-K factor from a small cost model fitted to a sweep over the UNet / VAE shapes
+// (scratch/gemm_sweep.py, MI355X): a workgroup costs (K steps + 8) x t_k microseconds (t_k = 1.0 for the 64-wide tile, 1.5 for the
+// 128-wide one, two workgroups resident per CU); 512 workgroups run at once, more cost further rounds; a split adds the fp32
+// partial round trip and one launch.  The old rule (ceil(512 / tiles) splits, only below 256 tiles) overshot 512 workgroups and paid a
+// second, nearly empty round on the 32x32 / 16x16 UNet levels: 1.3-1.4x slower there.
+struct SgPlan { int nt; uint32_t splits, kps; };
+static int sg_env(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
 }
-
-static uint32_t sg_splits(const CnerfSdGemm *g, int nt, uint32_t &k_tiles_per_split) {
-    const uint32_t tiles = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, 64 * nt);
+static SgPlan sg_plan(const CnerfSdGemm *g) {
     const uint32_t n_ktiles = cn_div_up(g->K, SG_BK);
-    k_tiles_per_split = n_ktiles;
-    if (g->batch_outer * g->batch_inner != 1 || tiles >= 256 || n_ktiles < 16) return 1;
-    uint32_t want = cn_div_up(512, tiles);
-    if (want > n_ktiles / 8) want = n_ktiles / 8;          // at least 8 K steps (512 k) per split
-    if (want > 32) want = 32;
-    if (want <= 1) return 1;
-    k_tiles_per_split = cn_div_up(n_ktiles, want);
-    return cn_div_up(n_ktiles, k_tiles_per_split);
+    const uint32_t batch = g->batch_outer * g->batch_inner;
+    static const int force_nt = sg_env("CNERF_SG_NT"), force_sp = sg_env("CNERF_SG_SPLITS");  // tuning hooks (scratch/gemm_sweep.py)
+    SgPlan best = {1, 1, n_ktiles};
+    double best_cost = 1e30;
+    for (int nt = 1; nt <= 2; nt++) {
+        if (force_nt && nt != force_nt) continue;
+        const uint32_t tiles = cn_div_up(g->M, SG_BM) * cn_div_up(g->N, 64 * nt) * batch;
+        const double t_k = nt == 1 ? 1.0 : 1.5;
+        const uint32_t max_sp = batch != 1 ? 1 : 32;
+        for (uint32_t sp = 1; sp <= max_sp; sp++) {
+            if (force_sp && sp != (uint32_t)force_sp && !(batch != 1 && sp == 1)) continue;
+            const uint32_t kps = cn_div_up(n_ktiles, sp);
+            if (sp > 1 && (kps < 8 || cn_div_up(n_ktiles, kps) != sp)) continue;           // at least 8 K steps per split; no empty splits
+            const uint64_t blocks = (uint64_t)tiles * sp;
+            const double rounds = (double)((blocks + 511) / 512);                             // measured: 640 workgroups cost two full rounds
+            double cost = rounds * (kps + 8.0) * t_k;
+            if (blocks < 256) cost *= 0.6 + 0.4 * (double)blocks / 256.0;                     // a lone workgroup on a CU runs its K steps faster
+            if (sp > 1) cost += 3.0 + 2.0 * (double)g->M * g->N * 4.0 * sp / 4.0e6;
+            if (cost < best_cost) { best_cost = cost; best = {nt, sp, kps}; }
+        }
+    }
+    return best;
+}
+static int sg_pick_nt(const CnerfSdGemm *g) { return sg_plan(g).nt; }
+static uint32_t sg_splits(const CnerfSdGemm *g, int nt, uint32_t &k_tiles_per_split) {
+    (void)nt;
+    const SgPlan p = sg_plan(g);
+    k_tiles_per_split = p.kps;
+    return p.splits;
 }
 
 template <int AMODE, int NT, bool SPLIT>
