@@ -359,7 +359,7 @@ struct Bin2Plan {
 struct Bin2Ws {
     uint32_t *hist, *bin_base, *seg_first;
     uint2 *slab;
-    float *partial;
+    long long *partial;
     uint64_t max_seg;
 };
 
@@ -606,7 +606,7 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
 
 __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
-                                                     float *__restrict__ grad_grid, float *__restrict__ partial, uint32_t slot0, uint32_t slot1) {
+                                                     float *__restrict__ grad_grid, long long *__restrict__ partial, uint32_t slot0, uint32_t slot1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
@@ -653,18 +653,17 @@ __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ s
             reinterpret_cast<float4 *>(dst)[j] = g;
         }
     } else {
-        // a split bin (the small dense levels): park the partial image; k_bin2_reduce_split adds the segments in order.  (Flushing with
-        // float atomics cost 3.1 M memory-side atomics = 0.15 ms per scatter, and their order is not reproducible.)
-        float4 *__restrict__ img = reinterpret_cast<float4 *>(partial + (size_t)gseg * (BN_CHUNK * 2));
-        for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024)
-            img[j] = make_float4(bn_acc_to_float<__half>(acc[j * 2]), bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]),
-                                 bn_acc_to_float<__half>(acc[j * 2 + 1]), bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]));
+        // a split bin (the small dense levels): park the fixed-point partial image; k_bin2_reduce_split adds the segments exactly and rounds
+        // once.  (Flushing with float atomics cost 3.1 M memory-side atomics = 0.15 ms per scatter, and neither they nor float partial
+        // images are reproducible: which records fall into which segment depends on the ticket order.)
+        long long *__restrict__ img = partial + (size_t)gseg * (BN_CHUNK * 2);
+        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) img[j] = acc[(j & 1) * BN_CHUNK + (j >> 1)];      // interleaved (entry, channel) order
     }
 }
 
-// sum the partial images of the split bins, segment by segment in index order, into the gradient table (one workgroup per bin)
-__global__ void __launch_bounds__(256) k_bin2_reduce_split(const float *__restrict__ partial, const uint32_t *__restrict__ seg_first, const GridLevels lv,
-                                                           const Bin2Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
+// sum the fixed-point partial images of the split bins into the gradient table (grid: bins x 8 tiles; exact, so order-independent)
+__global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
+                                                           const GridLevels lv, const Bin2Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
     const uint32_t bin = blockIdx.x;
     const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
     if (nseg <= 1) return;
@@ -673,17 +672,21 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const float *__restri
     const uint32_t level = lv.order[slot];
     const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
     const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
-    for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 256) {                  // float4 index inside the chunk image
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t s = 0; s < nseg; s++) {
-            const float4 v = reinterpret_cast<const float4 *>(partial + (size_t)(s0 + s) * (BN_CHUNK * 2))[j];
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-        }
-        float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
-        float4 g = *dst;
-        g.x += sum.x; g.y += sum.y; g.z += sum.z; g.w += sum.w;
-        *dst = g;
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // group of four values (two entries x two channels)
+    if (j >= n_entries / 2) return;
+    long long sum[4] = {0, 0, 0, 0};
+    const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
+#pragma unroll 4
+    for (uint32_t s = 0; s < nseg; s++) {
+        const longlong2 v0 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[0];
+        const longlong2 v1 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[1];
+        sum[0] += v0.x; sum[1] += v0.y; sum[2] += v1.x; sum[3] += v1.y;
     }
+    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
+    float4 g = *dst;
+    g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
+    g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
+    *dst = g;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -755,14 +758,14 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
     const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
     const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, B2_SEG);       // every bin may add one partial segment
-    const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 4);                 // partial images of split bins (sparsely used)
+    const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);                 // fixed-point partial images of split bins (sparsely used)
     if (ws) {
         char *p = (char *)base;
         ws->hist = (uint32_t *)(p + o_hist);
         ws->bin_base = (uint32_t *)(p + o_base);
         ws->seg_first = (uint32_t *)(p + o_seg);
         ws->slab = (uint2 *)(p + o_s0);
-        ws->partial = (float *)(p + o_part);
+        ws->partial = (long long *)(p + o_part);
         ws->max_seg = max_seg;
     }
     return off;
@@ -811,7 +814,7 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     }
     hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
                        gemb, ws.partial, 0u, nl);
-    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins), dim3(256), 0, st, (const float *)ws.partial, ws.seg_first, lv, plan,
+    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
     return cn_launch_status();
 }

@@ -68,10 +68,9 @@ def test_fp16_scatter_is_bit_deterministic_and_adjoint_full_size():
         out = enc.encode(x, bound=2.0, half=True)
         out.backward(G)
         grads.append(enc.embeddings.grad.clone())
-    # exact 64-bit fixed-point sums: bit-deterministic wherever one workgroup owns a chunk — all ten hashed levels (offsets from
-    # 876984); the small dense levels are split over several workgroups whose partial images meet in float atomics (rounding-level)
-    assert torch.equal(grads[0][876984:], grads[1][876984:])
-    assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-6)
+    # exact 64-bit fixed-point sums, the split bins of the small dense levels included (fixed-point partial images, added exactly):
+    # the whole table gradient is bit-reproducible, whatever order the records were written in
+    assert torch.equal(grads[0], grads[1])
     # <enc, G> vs <T_half, scatter(G)>: the records are fp16-rounded w*g products (gridencoder.cu:328) -> 1e-3 relative
     lhs = float((out.detach().double() * G.double()).sum())
     rhs = float((enc.half_table().double() * grads[0].double()).sum())
