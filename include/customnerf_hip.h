@@ -127,9 +127,10 @@ int cnerf_grid_encode_forward_strided(const float *inputs, const void *embedding
  * (grid.py:83) and accumulated with float32 atomics (the reference uses __half2 atomics for fp16 tables).
  * grad_inputs float32 [B,D] (written, not accumulated) when dy_dx != NULL.
  * workspace (optional, 256-byte aligned device scratch of at least cnerf_grid_encode_backward_workspace_bytes()):
- * when given, large D=3/C=2 scatters run the atomic-free binned path (records partitioned by 8192-entry table
- * chunk, summed in LDS, written back with plain coalesced stores); with NULL, or for other shapes / small B, the
- * scatter uses global float atomics.  Both produce the same sums up to float reassociation. */
+ * when given, large D=3/C=2 scatters run the atomic-free binned path (records partitioned by 4096-entry table
+ * chunk, summed in LDS — exact 64-bit fixed point for fp16 tables, hence bit-reproducible — and added to grad_embeddings
+ * with plain coalesced read-modify-writes); with NULL, or for other shapes / small B, the scatter uses global float
+ * atomics.  Both produce the same sums up to float reassociation (fp16: up to the rounding of each w*g product). */
 int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                const void *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
