@@ -36,9 +36,17 @@ __device__ __forceinline__ float ge_opaque(float x) {
     asm("" : "+v"(x));
     return x;
 }
+// The half + half sum is the native v_add_f16: float32 holds the sum of two binary16 values exactly enough (24 >= 2 * 11 + 2 bits)
+// that "add in float32, round to half" and the correctly rounded half add are the same function.
 __device__ __forceinline__ void ge_accum(__half &acc, float w, __half g) {
     const float prod = ge_opaque(w * __half2float(g));
-    acc = __float2half_rn(ge_opaque(__half2float(acc) + __half2float(__float2half_rn(prod))));
+    acc = __hadd(acc, __float2half_rn(prod));
+}
+// two channels at once (v_pk_add_f16)
+__device__ __forceinline__ void ge_accum2(__half2 &acc, float w, __half2 g) {
+    const float2 gf = __half22float2(g);
+    const float p0 = ge_opaque(w * gf.x), p1 = ge_opaque(w * gf.y);
+    acc = __hadd2(acc, __floats2half2_rn(p0, p1));
 }
 
 __device__ __forceinline__ float ge_smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }

@@ -127,12 +127,19 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
     }
     });
     Vec res;
+    if constexpr (sizeof(T) == 2 && C == 2) {
+        __half2 r2 = __floats2half2_rn(0.0f, 0.0f);
 #pragma unroll
-    for (int c = 0; c < C; c++) res.v[c] = ge_from_float<T>(0.0f);
+        for (int idx = 0; idx < (1 << D); idx++) ge_accum2(r2, wgt[idx], *reinterpret_cast<const __half2 *>(&corner[idx]));
+        res = *reinterpret_cast<const Vec *>(&r2);
+    } else {
 #pragma unroll
-    for (int idx = 0; idx < (1 << D); idx++) {
+        for (int c = 0; c < C; c++) res.v[c] = ge_from_float<T>(0.0f);
 #pragma unroll
-        for (int c = 0; c < C; c++) ge_accum(res.v[c], wgt[idx], corner[idx].v[c]);
+        for (int idx = 0; idx < (1 << D); idx++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) ge_accum(res.v[c], wgt[idx], corner[idx].v[c]);
+        }
     }
     *out = res;
 
