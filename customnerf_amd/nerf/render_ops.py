@@ -45,28 +45,24 @@ def sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t
 
 
 class _CompositeRunIndexed(Function):
-    """_CompositeRun reading its samples through src_index (sample_fine_merge_split); also returns the sorted-order sigma / rgbc copies"""
+    """_CompositeRun reading its samples through src_index (sample_fine_merge_split).  The per-sample by-products of the launch (weights of
+    the three composites, sorted-order sigma / rgbc copies: 67 MB of writes at 128x128x128) are NOT produced here: the backward recomputes
+    what it needs from sigma / rgbc, and the result dict asks for them lazily (composite_run_indexed_aux)."""
 
     @staticmethod
     def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask):
         sigmas = sigmas.contiguous().float()
         rgbc = rgbc.contiguous().float()
         N, S = z_vals.shape
-        dev = z_vals.device
-        out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=dev)
-        out_w = torch.empty(3, N, S, dtype=torch.float32, device=dev)
-        sig_s = torch.empty(N, S, dtype=torch.float32, device=dev)
-        rgbc_s = torch.empty(N, S, 4, dtype=torch.float32, device=dev)
+        out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=z_vals.device)
         check(lib.cnerf_composite_run_indexed(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
-                                              ptr(src_index), ptr(out_ray), ptr(out_w), ptr(sig_s), ptr(rgbc_s), stream()), "composite_run_indexed")
+                                              ptr(src_index), ptr(out_ray), None, None, None, stream()), "composite_run_indexed")
         ctx.save_for_backward(sigmas, rgbc, z_vals, src_index, nears, fars)
         ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
-        ctx.mark_non_differentiable(out_w, sig_s, rgbc_s)
-        ctx.set_materialize_grads(False)                        # no zero-filled gradients for the three non-differentiable outputs
-        return out_ray, out_w, sig_s, rgbc_s
+        return out_ray
 
     @staticmethod
-    def backward(ctx, g_ray, g_w, g_s, g_c):
+    def backward(ctx, g_ray):
         if g_ray is None:
             return (None,) * 11
         sigmas, rgbc, z_vals, src_index, nears, fars = ctx.saved_tensors
@@ -81,8 +77,25 @@ class _CompositeRunIndexed(Function):
 
 
 def composite_run_indexed(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False):
-    """sigmas [P], rgbc [P,4] in sample-list order; -> out_ray [3,N,6], weights [3,N,S], sigma_sorted [N,S], rgbc_sorted [N,S,4]"""
+    """sigmas [P], rgbc [P,4] in sample-list order -> out_ray [3,N,6] (differentiable in sigmas / rgbc)"""
     return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask)
+
+
+@torch.no_grad()
+def composite_run_indexed_aux(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr):
+    """The detached per-sample by-products of composite_run_indexed, by a second launch of the same kernel:
+    weights [3,N,S], sigma_sorted [N,S], rgbc_sorted [N,S,4]."""
+    sigmas = sigmas.detach().contiguous().float()
+    rgbc = rgbc.detach().contiguous().float()
+    N, S = z_vals.shape
+    dev = z_vals.device
+    out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=dev)
+    out_w = torch.empty(3, N, S, dtype=torch.float32, device=dev)
+    sig_s = torch.empty(N, S, dtype=torch.float32, device=dev)
+    rgbc_s = torch.empty(N, S, 4, dtype=torch.float32, device=dev)
+    check(lib.cnerf_composite_run_indexed(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
+                                          ptr(src_index), ptr(out_ray), ptr(out_w), ptr(sig_s), ptr(rgbc_s), stream()), "composite_run_indexed")
+    return out_w, sig_s, rgbc_s
 
 
 class _CompositeRun(Function):

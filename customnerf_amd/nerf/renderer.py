@@ -252,26 +252,33 @@ class NeRFRenderer(nn.Module):
         if split:
             # both blocks hold num_steps samples per ray, so "one direction per num_steps consecutive samples" covers the list with [d | d]
             sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, torch.cat([rays_d, rays_d], 0), num_steps)
-            out_ray, out_w, sig_s, rgbc_s = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
-            sigmas, rgbc = sig_s, rgbc_s                                     # sorted-order per-sample outputs (detached copies) for the result dict
+            out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
+            # per-sample by-products (weights, sorted-order sigma / rgbc copies, detached): a second launch, only if somebody reads them
+            aux = _Lazy(lambda: render_ops.composite_run_indexed_aux(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr))
+            weights_of = lambda v: _Lazy(lambda: aux.get()[0][v])
+            sigma_e = _Lazy(lambda: aux.get()[1].view(N, S, 1))
+            rgbs_e = _Lazy(lambda: aux.get()[2].view(N, S, 4)[..., :3])
+            conf_of = lambda: aux.get()[2].view(N, S, 4)[..., 3:4]
         else:
             sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
             out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps, soft, thr, dbg, dmask)
+            weights_of = lambda v: out_w[v]
+            sigma_e, rgbs_e = sigmas.view(N, S, 1), rgbc.view(N, S, 4)[..., :3]
+            conf_of = lambda: rgbc.view(N, S, 4)[..., 3:4]
         mask = _Lazy(lambda: (nears < fars).reshape(*prefix))
 
         def pack(v):
             r = out_ray[v]
             return _LazyResults({'image': r[:, 0:3].reshape(*prefix, 3), 'depth': r[:, 3].reshape(*prefix), 'weights_sum': r[:, 4],
-                                 'render_mask': r[:, 5].reshape(*prefix, 1), 'weights': out_w[v], 'mask': mask})
+                                 'render_mask': r[:, 5].reshape(*prefix, 1), 'weights': weights_of(v), 'mask': mask})
         results = pack(0)
-        conf = rgbc.view(N, S, 4)[..., 3:4]
-        results['sigma'] = sigmas.view(N, S, 1)
-        results['rgbs'] = rgbc.view(N, S, 4)[..., :3]
+        results['sigma'] = sigma_e
+        results['rgbs'] = rgbs_e
         if getattr(self.opt, 'soft_mask', False):
             thr_ = self.opt.conf_thr
-            results['edit_mask'] = _Lazy(lambda: torch.sigmoid((conf.detach() - thr_) * 100))
+            results['edit_mask'] = _Lazy(lambda: torch.sigmoid((conf_of().detach() - thr_) * 100))
         else:
-            results['edit_mask'] = _Lazy(lambda: conf.detach() > 0.5)
+            results['edit_mask'] = _Lazy(lambda: conf_of().detach() > 0.5)
         results['z_vals'] = z_all
         results['_out_ray'] = out_ray                                        # [3, N, 6] raw composite output (trainer.ReconTrainer's fused loss)
         results['fg'] = pack(1)

@@ -442,16 +442,17 @@ def test_strided_gather_and_indexed_composite_reduce_to_the_plain_forms():
     nears, fars = torch.full((N,), 0.5, device="cuda"), torch.full((N,), 3.5, device="cuda")
     ident = torch.arange(N * S, device="cuda", dtype=torch.int32).view(N, S)
     plain = render_ops.composite_run(sig.view(N, S), rgbc.view(N, S, 4), z, nears, fars, 48, True, 0.5)
-    idx = render_ops.composite_run_indexed(sig, rgbc, z, ident, nears, fars, 48, True, 0.5)
-    assert torch.equal(plain[0], idx[0]) and torch.equal(plain[1], idx[1])
-    assert torch.equal(idx[2].view(-1), sig) and torch.equal(idx[3].view(-1, 4), rgbc)
+    idx_ray = render_ops.composite_run_indexed(sig, rgbc, z, ident, nears, fars, 48, True, 0.5)
+    idx_w, idx_sig, idx_rgbc = render_ops.composite_run_indexed_aux(sig, rgbc, z, ident, nears, fars, 48, True, 0.5)      # the lazy by-products
+    assert torch.equal(plain[0], idx_ray) and torch.equal(plain[1], idx_w)
+    assert torch.equal(idx_sig.view(-1), sig) and torch.equal(idx_rgbc.view(-1, 4), rgbc)
     perm = torch.stack([torch.randperm(S, device="cuda", generator=g) for _ in range(N)]).to(torch.int32) + (torch.arange(N, device="cuda", dtype=torch.int32) * S)[:, None]
     sig_p, rgbc_p = sig[perm.long().view(-1)], rgbc[perm.long().view(-1)]
     sig_l, rgbc_l = sig.clone().requires_grad_(True), rgbc.clone().requires_grad_(True)
     sig_m, rgbc_m = sig_p.clone().requires_grad_(True), rgbc_p.clone().requires_grad_(True)
     a = render_ops.composite_run_indexed(sig_l, rgbc_l, z, perm.contiguous(), nears, fars, 48, True, 0.5)
     b = render_ops.composite_run(sig_m.view(N, S), rgbc_m.view(N, S, 4), z, nears, fars, 48, True, 0.5)
-    assert torch.equal(a[0], b[0])
+    assert torch.equal(a, b[0])
     w = torch.rand(3, N, 6, device="cuda", generator=g)
-    (a[0] * w).sum().backward(); (b[0] * w).sum().backward()
+    (a * w).sum().backward(); (b[0] * w).sum().backward()
     assert torch.equal(sig_l.grad[perm.long().view(-1)], sig_m.grad) and torch.equal(rgbc_l.grad[perm.long().view(-1)], rgbc_m.grad)
