@@ -44,38 +44,58 @@ __global__ void __launch_bounds__(256) k_sample_coarse(const float *__restrict__
     xyzs[(size_t)idx * 3] = p[0]; xyzs[(size_t)idx * 3 + 1] = p[1]; xyzs[(size_t)idx * 3 + 2] = p[2];
 }
 
+// Wave scans on the DPP data path (row_shr inside the 16-lane rows, row_bcast:15 / :31 across them): no LDS-crossbar round trips
+// (ds_bpermute) in the per-ray dependency chains.  `old` is what a lane keeps when its DPP source lane does not exist (the identity).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float rn_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+#define RN_ROW_SHR(n) (0x110 + (n))
+#define RN_ROW_BCAST15 0x142
+#define RN_ROW_BCAST31 0x143
+#define RN_WAVE_SHR1 0x138
+
+__device__ __forceinline__ float rn_wave_incl_prod(float x) {
+    x *= rn_dpp<RN_ROW_SHR(1)>(1.0f, x);
+    x *= rn_dpp<RN_ROW_SHR(2)>(1.0f, x);
+    x *= rn_dpp<RN_ROW_SHR(4)>(1.0f, x);
+    x *= rn_dpp<RN_ROW_SHR(8)>(1.0f, x);
+    x *= rn_dpp<RN_ROW_BCAST15, 0xA>(1.0f, x);
+    x *= rn_dpp<RN_ROW_BCAST31, 0xC>(1.0f, x);
+    return x;
+}
+__device__ __forceinline__ float rn_wave_incl_sum(float x) {
+    x += rn_dpp<RN_ROW_SHR(1)>(0.0f, x);
+    x += rn_dpp<RN_ROW_SHR(2)>(0.0f, x);
+    x += rn_dpp<RN_ROW_SHR(4)>(0.0f, x);
+    x += rn_dpp<RN_ROW_SHR(8)>(0.0f, x);
+    x += rn_dpp<RN_ROW_BCAST15, 0xA>(0.0f, x);
+    x += rn_dpp<RN_ROW_BCAST31, 0xC>(0.0f, x);
+    return x;
+}
+__device__ __forceinline__ float rn_lane63(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // exclusive multiplicative scan of v over the 64 lanes, times carry; returns the wave total (times carry) in `carry`
 __device__ __forceinline__ float rn_excl_prod_scan(float v, float &carry, uint32_t lane) {
-    float incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl *= o;
-    }
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
+    (void)lane;
+    const float incl = rn_wave_incl_prod(v);
+    const float excl = rn_dpp<RN_WAVE_SHR1>(1.0f, incl);
     const float res = excl * carry;
-    carry = carry * __shfl(incl, 63, 64);
+    carry = carry * rn_lane63(incl);
     return res;
 }
 
 __device__ __forceinline__ float rn_incl_sum_scan(float v, float &carry, uint32_t lane) {
-    float incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl += o;
-    }
+    (void)lane;
+    const float incl = rn_wave_incl_sum(v);
     const float res = incl + carry;
-    carry = carry + __shfl(incl, 63, 64);
+    carry = carry + rn_lane63(incl);
     return res;
 }
 
-__device__ __forceinline__ float rn_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float rn_wave_sum(float v) { return rn_lane63(rn_wave_incl_sum(v)); }
 
 __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                                   const float *__restrict__ nears, const float *__restrict__ fars,

@@ -183,7 +183,9 @@ def test_run_end_to_end_vs_oracle_cfg1():
     for name, a, b in (("grid", model.pos_en.embeddings.grad, ref.pos_en.embeddings.grad), ("net", model.network.params.grad, ref.network.grad),
                        ("den", model.density_network.params.grad, ref.density_network.grad), ("rgb", model.rgb_network.params.grad, ref.rgb_network.grad)):
         b = b.numpy()
-        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-3, atol=2e-4 * max(1e-3, float(np.abs(b).max())), err_msg=name)
+        # the wave scans (transmittance products, CDF sums) associate differently from torch's sequential cumprod / cumsum: rounding-level
+        # differences that survive the cancellation in the smallest weight-gradient elements (5e-7 absolute floor)
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-3, atol=5e-4 * max(1e-3, float(np.abs(b).max())), err_msg=name)
 
 
 def test_run_cuda_train_and_eval_vs_oracle():
@@ -214,7 +216,9 @@ def test_run_cuda_train_and_eval_vs_oracle():
     for name, a, b in (("grid", model.pos_en.embeddings.grad, ref.pos_en.embeddings.grad), ("net", model.network.params.grad, ref.network.grad),
                        ("den", model.density_network.params.grad, ref.density_network.grad), ("rgb", model.rgb_network.params.grad, ref.rgb_network.grad)):
         b = b.numpy()
-        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-3, atol=2e-4 * max(1e-3, float(np.abs(b).max())), err_msg=name)
+        # the wave scans (transmittance products, CDF sums) associate differently from torch's sequential cumprod / cumsum: rounding-level
+        # differences that survive the cancellation in the smallest weight-gradient elements (5e-7 absolute floor)
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-3, atol=5e-4 * max(1e-3, float(np.abs(b).max())), err_msg=name)
     # --- inference branch
     model.eval()
     with torch.no_grad():
