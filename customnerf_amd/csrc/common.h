@@ -26,20 +26,26 @@ __device__ __forceinline__ float cn_clamp(float x, float lo, float hi) { return 
 // wave-level helpers (wave64)
 __device__ __forceinline__ uint32_t cn_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// wave scans / sums on the DPP data path (row_shr inside the 16-lane rows, row_bcast:15 / :31 across them) — no ds_bpermute round trips
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T cn_dpp_zero(T src) {      // lanes without a source lane (or masked rows) get 0
+    static_assert(sizeof(T) == 4, "32-bit types only");
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+
 template <typename T>
 __device__ __forceinline__ T cn_wave_incl_scan(T v) {   // inclusive prefix sum across the 64 lanes
-    const uint32_t lane = cn_lane();
-#pragma unroll
-    for (int off = 1; off < CN_WAVE; off <<= 1) {
-        T n = __shfl_up(v, off, CN_WAVE);
-        if ((int)lane >= off) v += n;
-    }
+    v += cn_dpp_zero<0x111, 0xF>(v);
+    v += cn_dpp_zero<0x112, 0xF>(v);
+    v += cn_dpp_zero<0x114, 0xF>(v);
+    v += cn_dpp_zero<0x118, 0xF>(v);
+    v += cn_dpp_zero<0x142, 0xA>(v);                     // row_bcast:15 into rows 1 and 3
+    v += cn_dpp_zero<0x143, 0xC>(v);                     // row_bcast:31 into rows 2 and 3
     return v;
 }
 
 template <typename T>
 __device__ __forceinline__ T cn_wave_sum(T v) {
-#pragma unroll
-    for (int off = CN_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, CN_WAVE);
-    return v;
+    v = cn_wave_incl_scan(v);
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
