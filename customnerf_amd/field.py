@@ -40,7 +40,8 @@ class FieldFunction(Function):
     (positions / directions get no gradient on CustomNeRF's path).  Nothing is saved but the inputs: the backward recomputes."""
 
     @staticmethod
-    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb):
+    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False):
+        ctx.params = (p_net, p_den, p_rgb) if grad_in_place else None          # the Parameter objects themselves (their .grad is the target)
         xyz = xyz.contiguous().float()
         dirs = dirs.contiguous().float()
         sigma, rgbc = field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, True)
@@ -57,14 +58,23 @@ class FieldFunction(Function):
         g_sigma = g_sigma.contiguous().float()
         g_rgbc = g_rgbc.contiguous().float()
         g_enc = torch.empty_like(enc)
-        g_all = torch.zeros(p_net.numel() + p_den.numel() + p_rgb.numel(), dtype=torch.float32, device=p_net.device)      # one fill, three views
-        g_net, g_den, g_rgb = (t.view_as(p) for t, p in zip(g_all.split([p_net.numel(), p_den.numel(), p_rgb.numel()]), (p_net, p_den, p_rgb)))
+        # the reduction of the per-workgroup partials ADDS into its destination: with persistent .grad buffers (trainer.flat_grad_buffer)
+        # it adds straight into them — no zero-fill and no AccumulateGrad passes for the three parameter vectors
+        in_place = ctx.params is not None and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and
+                                                  p.grad.device == p.device for p in ctx.params)
+        if in_place:
+            g_net, g_den, g_rgb = (p.grad for p in ctx.params)
+        else:
+            g_all = torch.zeros(p_net.numel() + p_den.numel() + p_rgb.numel(), dtype=torch.float32, device=p_net.device)  # one fill, three views
+            g_net, g_den, g_rgb = (t.view_as(p) for t, p in zip(g_all.split([p_net.numel(), p_den.numel(), p_rgb.numel()]), (p_net, p_den, p_rgb)))
         ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
         check(lib.cnerf_field_backward(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
                                        ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
                                        ptr(ws), ws.numel(), dt, stream()), "field_backward")
-        return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb
+        if in_place:
+            return g_enc, None, None, None, None, None, None, None, None, None, None
+        return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb, None
 
 
-def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb):
-    return FieldFunction.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb)
+def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False):
+    return FieldFunction.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place)

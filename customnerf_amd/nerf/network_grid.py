@@ -168,7 +168,7 @@ class NeRFNetwork(NeRFRenderer):
             overlap = getattr(self.opt, 'overlap_scatter_plan', True) and os.environ.get('CNERF_GRID_OVERLAP', '1') != '0'
             enc = self.pos_en.attach_backward(enc, unit, overlap=overlap)
         sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
-                            self.rgb_network.params)
+                            self.rgb_network.params, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
         return sigma, rgbc
 
     def get_params(self, lr):

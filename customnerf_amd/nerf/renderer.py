@@ -225,10 +225,16 @@ class NeRFRenderer(nn.Module):
                  and not getattr(self.opt, 'eval_fine_density', False))
         with torch.no_grad():
             noise = None
+            both = None
+            if perturb and self.training and 'z' not in draws and 'u' not in draws:
+                # rand(N,T) then rand(N,t) (renderer.py:317, :37) drawn by one generator launch: the first N*T values are the jitter
+                both = torch.rand(N * (num_steps + upsample_steps), device=device)
             if perturb:
-                noise = draws['z'].to(device).contiguous() if 'z' in draws else torch.rand(N, num_steps, device=device)
+                noise = (draws['z'].to(device).contiguous() if 'z' in draws else
+                         (both[:N * num_steps].view(N, num_steps) if both is not None else torch.rand(N, num_steps, device=device)))
             if self.training:
-                u_draw = lambda: draws['u'].to(device).contiguous() if 'u' in draws else torch.rand(N, upsample_steps, device=device)
+                u_draw = lambda: (draws['u'].to(device).contiguous() if 'u' in draws else
+                                  (both[N * num_steps:].view(N, upsample_steps) if both is not None else torch.rand(N, upsample_steps, device=device)))
             else:
                 u_draw = lambda: None                                         # det=True (sample_pdf :33-35)
             if split:

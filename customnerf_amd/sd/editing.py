@@ -132,7 +132,10 @@ class EditTrainer:
         """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""
         self.model.train()
         pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing(data)
-        (self.scaler.scale(loss) if self.scaler is not None else loss * self.loss_scale).backward()
+        if self.scaler is not None:
+            self.scaler.backward(loss)
+        else:
+            (loss * self.loss_scale).backward()
         self.allreduce_grads()
         f = self.lr_factor()
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):

@@ -31,6 +31,7 @@ def enable_grad_in_place(model):
     enc = getattr(model, 'pos_en', None)
     if enc is not None and hasattr(enc, 'attach_backward'):
         enc.grad_in_place = True
+    model.grad_in_place = True                          # the fused field's three parameter vectors (NeRFNetwork.split_forward)
 
 
 def _slot(n):
@@ -140,7 +141,10 @@ class ReconTrainer:
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
             loss = self.loss(outputs, rgbs, mask)
-        (self.scaler.scale(loss) if self.scaler is not None else loss * self.loss_scale).backward()
+        if self.scaler is not None:
+            self.scaler.backward(loss)
+        else:
+            (loss * self.loss_scale).backward()
         self.allreduce_grads()
         f = self.lr_factor()
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
