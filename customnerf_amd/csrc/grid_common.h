@@ -13,6 +13,7 @@ struct GridLevels {
     uint32_t resolution[GE_MAX_LEVELS];
     float scale[GE_MAX_LEVELS];
     uint8_t order[GE_MAX_LEVELS];         // work-list position -> level (coarse/fine interleave)
+    uint32_t xcd_first[CN_NXCD + 1];      // swizzle 2: first work item of each XCD's slice of the level-major list (cost-balanced)
 };
 
 template <typename T, int C>
@@ -144,7 +145,14 @@ __device__ __forceinline__ bool ge_is_hashed(bool align_corners, uint32_t hashma
 __device__ __forceinline__ bool ge_work_item(uint32_t nb, uint32_t n_levels, int swizzle, const GridLevels &lv, uint32_t &level, uint32_t &pb) {
     const uint32_t total = nb * n_levels;
     uint32_t w = blockIdx.x;
-    if (swizzle) {
+    if (swizzle == 2) {
+        // cost-balanced slices: dense levels are cheap (their corners hit L1), hashed levels cost ~4 L2 requests per sample, and 16 levels
+        // do not divide into 8 equal-cost pairs — the XCDs holding two hashed levels finished last with the others idle.  The host cuts
+        // the list where the prefix COST crosses k/8 (ge_balance); slices are shorter where the items are dearer, surplus blocks exit.
+        const uint32_t xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
+        w = lv.xcd_first[xcd] + k;
+        if (w >= lv.xcd_first[xcd + 1]) return false;
+    } else if (swizzle) {
         // bijective chunking for any total: XCD x gets q+1 items if x < r else q (q = total/8, r = total%8)
         const uint32_t q = total / CN_NXCD, r = total % CN_NXCD;
         const uint32_t xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
@@ -172,6 +180,43 @@ static inline int ge_levels(const int32_t *offsets_host, uint32_t L, uint32_t n_
     // coarse/fine interleave: 0, n-1, 1, n-2, ... so each XCD's slice holds one cheap and one expensive level
     uint32_t lo = 0, hi = n_levels;
     for (uint32_t i = 0; i < n_levels; i++) lv.order[i] = (uint8_t)((i & 1) ? --hi : lo++);
+    for (uint32_t x = 0; x <= CN_NXCD; x++) lv.xcd_first[x] = 0;
     return CNERF_OK;
+}
+
+// cost-balanced XCD slices of the level-major work list (nb blocks per level, list order lv.order): weight 1 for levels whose table is
+// larger than what a wave's neighbouring samples keep re-hitting in L1 (hashed, or dense beyond `dense_entries`), `dense_w` otherwise.
+// Returns the longest slice (blocks per XCD) — the launch needs 8 x that many workgroups.
+static inline uint32_t ge_balance(GridLevels &lv, uint32_t n_levels, uint32_t nb, uint32_t D, uint32_t gridtype, bool align_corners, double dense_w) {
+    double w[GE_MAX_LEVELS], total = 0;
+    for (uint32_t i = 0; i < n_levels; i++) {
+        const uint32_t l = lv.order[i];
+        const uint64_t step = align_corners ? lv.resolution[l] : lv.resolution[l] + 1;
+        uint64_t cells = 1;
+        for (uint32_t d = 0; d < D; d++) cells *= step;
+        const bool dense = cells <= lv.size[l];
+        w[i] = dense ? dense_w : 1.0;
+        (void)gridtype;
+        total += w[i] * nb;
+    }
+    uint32_t longest = 0;
+    lv.xcd_first[0] = 0;
+    uint32_t pos = 0;                 // work item index
+    double acc = 0;                   // cost before `pos`
+    uint32_t i = 0, in_level = 0;     // current list position and blocks of it already consumed
+    for (uint32_t x = 1; x <= CN_NXCD; x++) {
+        const double target = total * x / CN_NXCD;
+        while (i < n_levels) {
+            const double left = (nb - in_level) * w[i];
+            if (acc + left <= target + 1e-9) { acc += left; pos += nb - in_level; in_level = 0; i++; continue; }
+            const uint32_t take = (uint32_t)((target - acc) / w[i]);
+            acc += take * w[i]; pos += take; in_level += take;
+            break;
+        }
+        if (x == CN_NXCD) pos = nb * n_levels;
+        lv.xcd_first[x] = pos;
+        if (pos - lv.xcd_first[x - 1] > longest) longest = pos - lv.xcd_first[x - 1];
+    }
+    return longest;
 }
 
