@@ -16,6 +16,16 @@ struct GridLevels {
     uint32_t xcd_first[CN_NXCD + 1];      // swizzle 2: first work item of each XCD's slice of the level-major list (cost-balanced)
 };
 
+// one sample's D coordinates in one load (global_load_dwordx2 / x3 / x4: 4-byte alignment is enough) instead of D strided dword loads
+template <int D>
+struct GeCoords { float v[D]; };
+template <int D>
+__device__ __forceinline__ void ge_load_coords(const float *__restrict__ inputs, size_t b, float (&in)[D]) {
+    const GeCoords<D> c = reinterpret_cast<const GeCoords<D> *>(inputs)[b];
+#pragma unroll
+    for (int d = 0; d < D; d++) in[d] = c.v[d];
+}
+
 template <typename T, int C>
 struct alignas(sizeof(T) * C) FeatVec {
     T v[C];

@@ -29,11 +29,9 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
 
     float in[D];
     bool oob = false;
+    ge_load_coords<D>(inputs, b, in);
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
-        oob = oob || (in[d] < 0 || in[d] > 1);
-    }
+    for (int d = 0; d < D; d++) oob = oob || (in[d] < 0 || in[d] > 1);
     if (oob) {
         Vec z;
 #pragma unroll

@@ -80,11 +80,9 @@ __device__ __forceinline__ void bn_corners(const float (&in)[3], const GridLevel
 __device__ __forceinline__ bool bn_load_point(const float *__restrict__ inputs, uint32_t b, uint32_t B, float (&in)[3]) {
     if (b >= B) return false;
     bool ok = true;
+    ge_load_coords<3>(inputs, b, in);
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        in[d] = inputs[(size_t)b * 3 + d];
-        ok = ok && !(in[d] < 0 || in[d] > 1);
-    }
+    for (int d = 0; d < 3; d++) ok = ok && !(in[d] < 0 || in[d] > 1);
     return ok;
 }
 
