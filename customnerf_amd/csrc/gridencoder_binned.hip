@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin_scan_blocks(uint32_t *_
 // ---- sweep 1c: scan over bins: record base per bin and accumulate-workgroup base per bin (one workgroup)
 // bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
 __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
-                                                        uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records) {
+                                                        uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records,
+                                                        uint32_t *__restrict__ seg_bin) {
     __shared__ uint32_t wt_r[16], wt_s[16];
     __shared__ uint32_t carry_r, carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -181,7 +182,12 @@ __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_tota
             tr += wt_r[w]; ts += wt_s[w];
         }
         const uint32_t cr = carry_r, cs = carry_s;
-        if (i < total_bins) { bin_base[i] = cr + br + ir - r; seg_first[i] = cs + bs + is - s; }
+        if (i < total_bins) {
+            bin_base[i] = cr + br + ir - r;
+            seg_first[i] = cs + bs + is - s;
+            if (seg_bin)                                            // segment -> bin map: the accumulate workgroups look their bin up in one load
+                for (uint32_t k = 0; k < s; k++) seg_bin[cs + bs + is - s + k] = i;
+        }
         __syncthreads();
         if (tid == 0) { carry_r = cr + tr; carry_s = cs + ts; }
         __syncthreads();
@@ -358,6 +364,7 @@ struct Bin2Ws {
     uint32_t *hist, *bin_base, *seg_first;
     uint2 *slab;
     long long *partial;
+    uint32_t *seg_bin;
     uint64_t max_seg;
 };
 
@@ -615,21 +622,15 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
 
 __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
-                                                     float *__restrict__ grad_grid, long long *__restrict__ partial, uint32_t slot0, uint32_t slot1) {
+                                                     float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin, uint32_t slot0,
+                                                     uint32_t slot1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
     const uint32_t bin_lo = plan.bin_first[slot0], bin_hi = plan.bin_first[slot1];
     const uint32_t gseg = blockIdx.x + seg_first[bin_lo];
     if (gseg >= seg_first[bin_hi]) return;
-    if (threadIdx.x == 0) {                                            // upper_bound(seg_first, gseg) - 1 inside the group
-        uint32_t lo = bin_lo, hi = bin_hi;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (seg_first[mid + 1] <= gseg) lo = mid + 1; else hi = mid;
-        }
-        s_bin = lo;
-    }
+    if (threadIdx.x == 0) s_bin = seg_bin[gseg];                       // (a binary search over seg_first was ~11 dependent loads per workgroup)
     for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t bin = s_bin;
@@ -781,6 +782,7 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
     const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
     const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, B2_SEG);       // every bin may add one partial segment
+    const uint64_t o_segbin = off; off = bn_align(off + max_seg * 4);
     const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);                 // fixed-point partial images of split bins (sparsely used)
     if (ws) {
         char *p = (char *)base;
@@ -789,6 +791,7 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
         ws->seg_first = (uint32_t *)(p + o_seg);
         ws->slab = (uint2 *)(p + o_s0);
         ws->partial = (long long *)(p + o_part);
+        ws->seg_bin = (uint32_t *)(p + o_segbin);
         ws->max_seg = max_seg;
     }
     return off;
@@ -806,7 +809,7 @@ static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
 #undef B2_HIST
     }
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, B2_SEG);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, B2_SEG, ws.seg_bin);
     return cn_launch_status();
 }
 
@@ -836,7 +839,7 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
 #undef B2_EMIT
     }
     hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
-                       gemb, ws.partial, 0u, nl);
+                       gemb, ws.partial, ws.seg_bin, 0u, nl);
     hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
     return cn_launch_status();
@@ -872,7 +875,7 @@ static int bn_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
     const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL(k_bin_hist, grid1, dim3(BN_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, BN_SEG);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, BN_SEG, (uint32_t *)nullptr);
     return cn_launch_status();
 }
 
