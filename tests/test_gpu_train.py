@@ -162,3 +162,41 @@ def test_fused_recon_loss_matches_the_torch_formulation(with_mask):
     (la * 7.0).backward(); (lb * 7.0).backward()
     assert torch.allclose(out_a.grad, out_b.grad, atol=1e-9, rtol=1e-5)
     assert bool((out_a.grad[1:] == 0).all())
+
+
+def test_in_place_gradient_accumulation_matches_autograd_accumulation():
+    """The trainers let the grid scatter and the field's weight-gradient reduction add straight into the persistent .grad buffers
+    (GridEncoder.grad_in_place / NeRFNetwork.grad_in_place, trainer.enable_grad_in_place).  Same draws, same loss: the gradients must equal
+    what autograd's AccumulateGrad produces on the plain path — and accumulate over two backward passes the same way."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import enable_grad_in_place, flat_grad_buffer
+    tcnn.set_default_dtype(torch.float16)
+    try:
+        H = W = 32
+        o, d, rgb, mask = _target_scene(H, W, 1)
+        g = torch.Generator().manual_seed(7)
+        draws = dict(light=torch.randn(3, generator=g), z=torch.rand(H * W, 32, generator=g), u=torch.rand(H * W, 32, generator=g))
+        grads = []
+        for in_place in (False, True):
+            torch.manual_seed(0)
+            opt = sc.make_opt(fp16=True, num_levels=16, log2_hashmap_size=19, desired_resolution=2048)
+            model = NeRFNetwork(opt).cuda().train()
+            with torch.no_grad():
+                model.pos_en.embeddings.uniform_(-0.3, 0.3)
+            flat = flat_grad_buffer(model.parameters())                 # persistent zeroed .grad views in both runs
+            if in_place:
+                enable_grad_in_place(model)
+            for _ in range(2):                                          # two passes: the second must ADD to the first
+                with torch.autocast('cuda', dtype=torch.float16):
+                    res = model.render(o[0], d[0], staged=False, perturb=True, force_all_rays=True, num_steps=32, upsample_steps=32, _draws=draws)
+                    loss = ((res['image'].reshape(-1, 3).float() - rgb[0]) ** 2).mean() + 0.1 * res['render_mask'].float().mean()
+                (loss * 1024.0).backward()
+            assert all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters())      # the views stayed bound
+            grads.append([p.grad.clone() for p in model.parameters()])
+        for a, b in zip(*grads):
+            assert float(b.abs().max()) > 0
+            # grid: exact fixed-point sums either way, but the plain path rounds each pass to float32 before adding: rounding-level difference
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    finally:
+        tcnn.set_default_dtype(torch.float32)
