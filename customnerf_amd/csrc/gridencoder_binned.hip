@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict_
 // the per-corner products are rounded to that grid instead of to binary16 (the reference rounds w*g to half, gridencoder.cu:328: the
 // difference is below one half ulp of each product).
 #define B2_THREADS 1024
-#define B2_SEG (1u << 17)                          // records per accumulate workgroup
+#define B2_SEG_MIN ((1u << 16) + (1u << 13))       // records per accumulate workgroup, see b2_seg()
 #define B2_SINGLE 15u
 
 struct Bin2Plan {
@@ -623,7 +623,7 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
 __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin, uint32_t slot0,
-                                                     uint32_t slot1) {
+                                                     uint32_t slot1, uint32_t seg_records) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ s
     const uint32_t seg = gseg - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
     const uint32_t rec_off = bin_base[bin_lo];
     const uint32_t r0 = bin_base[bin] - rec_off, r1 = bin_base[bin + 1] - rec_off;
-    const uint32_t begin = r0 + seg * B2_SEG, end = min(begin + B2_SEG, r1);
+    const uint32_t begin = r0 + seg * seg_records, end = min(begin + seg_records, r1);
     // the kernel is bound by its record stream (stream alone 0.29 of 0.43 ms): 16-byte loads, two consecutive records per lane
     // (consecutive records often hit the same entry: in one lane they are successive instructions, not same-address lanes of one)
     uint32_t b2 = begin, e2 = end;
@@ -763,6 +763,15 @@ static uint32_t b2_pts() {
     return (uint32_t)p;
 }
 
+// Records per accumulate workgroup: 1/8 above the expected size of a hashed level's bin (4 pair records per sample over 128 bins), so
+// that those bins keep one owner each (plain read-modify-write flush) while the crowded bins of the small dense levels split into
+// workgroups of about the same length (uniform durations pack the last round of workgroups better: 0.40 -> 0.38 ms).
+static uint32_t b2_seg(uint32_t B) {
+    const uint64_t hashed_bin = (uint64_t)B * 4 / BN_MAX_CHUNKS;
+    const uint64_t s = hashed_bin + hashed_bin / 8;
+    return (uint32_t)(s < B2_SEG_MIN ? B2_SEG_MIN : s);
+}
+
 static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &plan) {
     plan.nb = cn_div_up(B, b2_pts());
     uint32_t acc = 0;
@@ -781,7 +790,7 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
     const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
     const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
-    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, B2_SEG);       // every bin may add one partial segment
+    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, b2_seg(B));    // every bin may add one partial segment
     const uint64_t o_segbin = off; off = bn_align(off + max_seg * 4);
     const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);                 // fixed-point partial images of split bins (sparsely used)
     if (ws) {
@@ -809,7 +818,7 @@ static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
 #undef B2_HIST
     }
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, B2_SEG, ws.seg_bin);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, b2_seg(B), ws.seg_bin);
     return cn_launch_status();
 }
 
@@ -839,7 +848,7 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
 #undef B2_EMIT
     }
     hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
-                       gemb, ws.partial, ws.seg_bin, 0u, nl);
+                       gemb, ws.partial, ws.seg_bin, 0u, nl, b2_seg(B));
     hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
     return cn_launch_status();
