@@ -79,7 +79,7 @@ def test_argument_validation_without_launch():
     assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 1000, 3, 2, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0 and need.value == 0
     assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 4, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0 and need.value == 0
     assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 1, ctypes.addressof(need)) == 0
-    assert 2097152 * 16 * 8 * 8 <= need.value < 2097152 * 16 * 8 * 8 * 1.15        # records (worst case) + histogram + fixed-point partial images of split bins
+    assert 2097152 * 16 * 8 * 8 <= need.value < 2097152 * 16 * 8 * 8 * 1.20        # records (worst case) + histogram + fixed-point partial images of split bins (worst case: every segment)
     assert lib.cnerf_grid_encode_backward_workspace_bytes(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 0, ctypes.addressof(need)) == 0
     assert 2097152 * 16 * 8 * 12 <= need.value < 2097152 * 16 * 8 * 12 * 1.05
     # empty work is accepted without a launch
