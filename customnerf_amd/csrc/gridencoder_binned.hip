@@ -28,7 +28,7 @@
 #define BN_THREADS 256
 #define BN_PPT 4                                   // points per thread in the hist / emit sweeps
 #define BN_PTS (BN_THREADS * BN_PPT)               // points per block
-#define BN_MAX_CHUNKS 128                          // 2^19-entry level / 4096
+#define BN_MAX_CHUNKS 512                          // 2^21-entry level / 4096 (the reference's bear table); the staged emit serves <= B2S_MAX_CHUNKS
 #define BN_SEG (1u << 18)                          // records per accumulate workgroup (split unit for oversized bins)
 
 struct BinPlan {
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_hist(const float *__restrict
     __shared__ uint32_t cnt[BN_MAX_CHUNKS];
     const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
-    if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    for (uint32_t c = threadIdx.x; c < BN_MAX_CHUNKS; c += BN_THREADS) cnt[c] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < BN_PPT; i++) {
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_hist(const float *__restrict
         }
     }
     __syncthreads();
-    if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[level] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
+    for (uint32_t c = threadIdx.x; c < nch; c += BN_THREADS) hist[(size_t)(plan.bin_first[level] + c) * plan.nb + pb] = cnt[c];
 }
 
 // ---- sweep 1b: per bin, exclusive scan over the point blocks (in place) and the bin total.  256-thread workgroups: this runs beside the
@@ -204,9 +204,9 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ g
     __shared__ uint32_t cursor[BN_MAX_CHUNKS];
     const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
-    if (threadIdx.x < nch) {
-        const uint32_t bin = plan.bin_first[level] + threadIdx.x;
-        cursor[threadIdx.x] = bin_base[bin] + hist[(size_t)bin * plan.nb + pb];
+    for (uint32_t c = threadIdx.x; c < nch; c += BN_THREADS) {
+        const uint32_t bin = plan.bin_first[level] + c;
+        cursor[c] = bin_base[bin] + hist[(size_t)bin * plan.nb + pb];
     }
     __syncthreads();
 #pragma unroll
@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
 // records of one (block, bin) run, i.e. whole cache lines per store instruction.  Records beyond the staging capacity (blocks with
 // many chunk-straddling pairs) take the direct store; slot -> position is the same map either way.
 #define B2S_PTS 2048
+#define B2S_MAX_CHUNKS 128                        // bins per level the staging area's tables (and its one-byte bin ids) cover
 #define B2S_CAP (B2S_PTS * 4 + 256)
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                                  const Bin2Plan plan, const uint32_t *__restrict__ hist,
@@ -507,9 +508,9 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
     uint2 *s_rec = reinterpret_cast<uint2 *>(b2s_lds);
     uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(b2s_lds + (size_t)B2S_CAP * 9);
-    uint32_t *gdelta = cursor + BN_MAX_CHUNKS;                                     // staging slot -> slab position (wrapping uint32 arithmetic)
-    uint32_t *s_off = gdelta + BN_MAX_CHUNKS, *s_cnt = s_off + BN_MAX_CHUNKS;      // staging offset and record count of each bin
-    uint32_t *s_total = s_cnt + BN_MAX_CHUNKS;
+    uint32_t *gdelta = cursor + B2S_MAX_CHUNKS;                                     // staging slot -> slab position (wrapping uint32 arithmetic)
+    uint32_t *s_off = gdelta + B2S_MAX_CHUNKS, *s_cnt = s_off + B2S_MAX_CHUNKS;      // staging offset and record count of each bin
+    uint32_t *s_total = s_cnt + B2S_MAX_CHUNKS;
     const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t level = lv.order[slot];
     const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
@@ -766,10 +767,16 @@ static uint32_t b2_pts() {
 // Records per accumulate workgroup: 1/8 above the expected size of a hashed level's bin (4 pair records per sample over 128 bins), so
 // that those bins keep one owner each (plain read-modify-write flush) while the crowded bins of the small dense levels split into
 // workgroups of about the same length (uniform durations pack the last round of workgroups better: 0.40 -> 0.38 ms).
-static uint32_t b2_seg(uint32_t B) {
-    const uint64_t hashed_bin = (uint64_t)B * 4 / BN_MAX_CHUNKS;
+static uint32_t b2_seg(uint32_t B, uint32_t max_chunks = 128) {
+    const uint64_t hashed_bin = (uint64_t)B * 4 / (max_chunks ? max_chunks : 1);
     const uint64_t s = hashed_bin + hashed_bin / 8;
     return (uint32_t)(s < B2_SEG_MIN ? B2_SEG_MIN : s);
+}
+
+static uint32_t b2_max_chunks(const Bin2Plan &plan, uint32_t nl) {
+    uint32_t m = 1;
+    for (uint32_t s = 0; s < nl; s++) m = m > plan.bin_first[s + 1] - plan.bin_first[s] ? m : plan.bin_first[s + 1] - plan.bin_first[s];
+    return m;
 }
 
 static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &plan) {
@@ -790,7 +797,7 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
     const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
     const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
-    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, b2_seg(B));    // every bin may add one partial segment
+    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, b2_seg(B, b2_max_chunks(plan, nl)));    // every bin may add one partial segment
     const uint64_t o_segbin = off; off = bn_align(off + max_seg * 4);
     const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);                 // fixed-point partial images of split bins (sparsely used)
     if (ws) {
@@ -818,7 +825,7 @@ static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
 #undef B2_HIST
     }
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, b2_seg(B), ws.seg_bin);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, b2_seg(B, b2_max_chunks(plan, nl)), ws.seg_bin);
     return cn_launch_status();
 }
 
@@ -837,10 +844,11 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     static int staged = -1;
     if (staged < 0) {
         staged = b2_env("CNERF_B2_STAGED", 1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + BN_MAX_CHUNKS * 16 + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + B2S_MAX_CHUNKS * 16 + 16);
     }
-    if (staged && b2_pts() == B2S_PTS)
-        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + BN_MAX_CHUNKS * 16 + 16, st, grad, inputs, lv, plan, ws.hist,
+    const uint32_t max_chunks = b2_max_chunks(plan, nl);
+    if (staged && b2_pts() == B2S_PTS && max_chunks <= B2S_MAX_CHUNKS)          // larger tables (T = 2^20, 2^21): direct emit below
+        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 16 + 16, st, grad, inputs, lv, plan, ws.hist,
                            ws.bin_base, ws.slab, B, gridtype, ac, interp);
     else switch (b2_pts()) {
 #define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u); break;
@@ -848,7 +856,7 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
 #undef B2_EMIT
     }
     hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
-                       gemb, ws.partial, ws.seg_bin, 0u, nl, b2_seg(B));
+                       gemb, ws.partial, ws.seg_bin, 0u, nl, b2_seg(B, b2_max_chunks(plan, nl)));
     hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
     return cn_launch_status();

@@ -141,7 +141,10 @@ BINNED_CONFIGS = [CONFIGS[0], CONFIGS[1],
                   ("hash_L16_T19_smooth_align", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                                      desired_resolution=2048, gridtype='hash', align_corners=True, interpolation='smoothstep')),
                   ("tiled_L12_T17_odd", dict(input_dim=3, num_levels=12, level_dim=2, base_resolution=12, log2_hashmap_size=17,
-                                             per_level_scale=1.38, gridtype='tiled'))]
+                                             per_level_scale=1.38, gridtype='tiled')),
+                  # the reference's bear table (tiled, T = 2^21, desired 8192): 512 chunks per level -> the direct (unstaged) record emit
+                  ("tiled_L16_T21_8192_bear", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=21,
+                                                   desired_resolution=8192, gridtype='tiled'))]
 
 
 @pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
