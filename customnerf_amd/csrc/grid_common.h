@@ -97,6 +97,7 @@ __device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corne
 #define GE_MODE_GENERIC 0
 #define GE_MODE_DENSE 1
 #define GE_MODE_HASH2 2
+#define GE_MODE_TILED2 3        // tiled level that wraps, power-of-two table: the strided sum of ge_index, masked instead of divided
 template <int D>
 __device__ __forceinline__ int ge_level_mode(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
     uint32_t stride = 1;
@@ -109,6 +110,7 @@ __device__ __forceinline__ int ge_level_mode(uint32_t gridtype, bool align_corne
     }
     if (all && stride <= hashmap_size) return GE_MODE_DENSE;
     if (gridtype == 0 && stride > hashmap_size && (hashmap_size & (hashmap_size - 1)) == 0) return GE_MODE_HASH2;
+    if (gridtype == 1 && (hashmap_size & (hashmap_size - 1)) == 0) return GE_MODE_TILED2;
     return GE_MODE_GENERIC;
 }
 
@@ -126,6 +128,17 @@ __device__ __forceinline__ uint32_t ge_index_m(uint32_t gridtype, bool align_cor
             stride *= step;
         }
         return index;
+    } else if constexpr (MODE == GE_MODE_TILED2) {
+        uint32_t stride = 1, index = 0;
+        const uint32_t step = align_corners ? resolution : (resolution + 1);
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (stride <= hashmap_size) {                   // dimensions beyond the table's span are dropped, as in ge_index
+                index += p[d] * stride;
+                stride *= step;
+            }
+        }
+        return index & (hashmap_size - 1);
     } else {
         return ge_index<D>(gridtype, align_corners, hashmap_size, resolution, p);
     }
@@ -136,6 +149,7 @@ template <typename F>
 __device__ __forceinline__ void ge_dispatch_mode(int mode, F &&f) {
     if (mode == GE_MODE_HASH2) f(std::integral_constant<int, GE_MODE_HASH2>{});
     else if (mode == GE_MODE_DENSE) f(std::integral_constant<int, GE_MODE_DENSE>{});
+    else if (mode == GE_MODE_TILED2) f(std::integral_constant<int, GE_MODE_TILED2>{});
     else f(std::integral_constant<int, GE_MODE_GENERIC>{});
 }
 
