@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--path", choices=["run", "march"], default="run")
     ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
     ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--grid", choices=["synthetic", "bear"], default="synthetic",
+                    help="synthetic = the benchmark scene of SURVEY.md 8d (hash, T=2^19, desired 2048; the headline number); "
+                         "bear = the reference field's own table (tiledgrid, T=2^21, desired 8192; network_grid.py:89-96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -231,7 +234,8 @@ def main():
     fp16 = args.dtype == "f16"
     tcnn.set_default_dtype(torch.float16 if fp16 else torch.float32)
     torch.manual_seed(0)
-    opt = sc.make_opt(cuda_ray=(args.path == "march"), fp16=fp16)
+    grid_kw = dict(grid_type='tiledgrid', log2_hashmap_size=21, desired_resolution=8192) if args.grid == "bear" else {}
+    opt = sc.make_opt(cuda_ray=(args.path == "march"), fp16=fp16, **grid_kw)
     model = NeRFNetwork(opt).to(dev)
     H = W = args.res
     V = 8
@@ -281,7 +285,8 @@ def main():
             "metric": "training rays/s", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"cfg2 synthetic {H}x{W} view/GPU, hash grid L16 T2^19 (6.12M entries), "
+            "config": {"workload": f"cfg2 synthetic {H}x{W} view/GPU, " + ("tiled grid L16 T2^21 desired 8192 (23.97M entries, the reference field's own table), "
+                                                                         if args.grid == "bear" else "hash grid L16 T2^19 (6.12M entries), ")
                                    + ("run() path 64+64 samples/ray" if args.path == "run" else "run_cuda() occupancy-march path, unit-sphere occupancy")
                                    + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays, "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single GPU",
                        "path": args.path, "final_loss": float(loss),
