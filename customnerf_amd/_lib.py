@@ -26,6 +26,8 @@ SIGNATURES = {
     "cnerf_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cnerf_march_rays_train_count": [vp, vp, vp, f32, f32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp],
     "cnerf_march_rays_train_write": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cnerf_march_rays_train_count_hits": [vp, vp, vp, f32, f32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp],
+    "cnerf_march_rays_train_write_hits": [vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "cnerf_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, u32, vp],
     "cnerf_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, u32, vp],
     "cnerf_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],

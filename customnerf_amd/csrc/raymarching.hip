@@ -150,8 +150,9 @@ __device__ __forceinline__ MarchConst rm_consts(float bound, float dt_gamma, uin
     return k;
 }
 
-// One probe of the occupancy bitfield at parameter t; on a miss t is advanced past the voxel (DDA-like skip).
-__device__ __forceinline__ Probe rm_probe(const RayState &r, float &t, const MarchConst &k, const uint8_t *__restrict__ grid) {
+// One probe of the occupancy bitfield at parameter t.  On a miss `tt` is the parameter at which the ray leaves the empty voxel
+// (the DDA-like skip target of raymarching.cu:452-461); t itself is not touched.
+__device__ __forceinline__ Probe rm_probe_at(const RayState &r, const float t, const MarchConst &k, const uint8_t *__restrict__ grid, float &tt) {
     Probe s;
     s.x = cn_clamp(cn_fma(t, r.dx, r.ox), -k.bound, k.bound);
     s.y = cn_clamp(cn_fma(t, r.dy, r.oy), -k.bound, k.bound);
@@ -171,11 +172,18 @@ __device__ __forceinline__ Probe rm_probe(const RayState &r, float &t, const Mar
     const uint32_t index = (uint32_t)cn_fma((float)level, k.H3, (float)rm_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
     s.occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;
 
+    const float tx = cn_fma(cn_fma((nx + 0.5f + 0.5f * rm_signf(r.dx)) * k.rH, 2.0f, -1.0f), mip_bound, -s.x) * r.rdx;
+    const float ty = cn_fma(cn_fma((ny + 0.5f + 0.5f * rm_signf(r.dy)) * k.rH, 2.0f, -1.0f), mip_bound, -s.y) * r.rdy;
+    const float tz = cn_fma(cn_fma((nz + 0.5f + 0.5f * rm_signf(r.dz)) * k.rH, 2.0f, -1.0f), mip_bound, -s.z) * r.rdz;
+    tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return s;
+}
+
+// One probe at t; on a miss t is advanced past the voxel.
+__device__ __forceinline__ Probe rm_probe(const RayState &r, float &t, const MarchConst &k, const uint8_t *__restrict__ grid) {
+    float tt;
+    const Probe s = rm_probe_at(r, t, k, grid, tt);
     if (!s.occ) {
-        const float tx = cn_fma(cn_fma((nx + 0.5f + 0.5f * rm_signf(r.dx)) * k.rH, 2.0f, -1.0f), mip_bound, -s.x) * r.rdx;
-        const float ty = cn_fma(cn_fma((ny + 0.5f + 0.5f * rm_signf(r.dy)) * k.rH, 2.0f, -1.0f), mip_bound, -s.y) * r.rdy;
-        const float tz = cn_fma(cn_fma((nz + 0.5f + 0.5f * rm_signf(r.dz)) * k.rH, 2.0f, -1.0f), mip_bound, -s.z) * r.rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         do {
             t += cn_clamp(t * k.dt_gamma, k.dt_min, k.dt_max);
         } while (t < tt);
@@ -196,7 +204,8 @@ __global__ void __launch_bounds__(RM_BLOCK) k_march_train_count(const float *__r
                                                                 const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                                 const float *__restrict__ nears, const float *__restrict__ fars,
-                                                                int *__restrict__ rays, const float *__restrict__ noises) {
+                                                                int *__restrict__ rays, const float *__restrict__ noises,
+                                                                float2 *__restrict__ hits) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
     const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
@@ -205,9 +214,16 @@ __global__ void __launch_bounds__(RM_BLOCK) k_march_train_count(const float *__r
     float t = nears[n];
     t = cn_fma(cn_clamp(t * dt_gamma, k.dt_min, k.dt_max), noises[n], t);
     uint32_t num_steps = 0;
+    float2 *__restrict__ hl = hits ? hits + (size_t)n * max_steps : nullptr;
+    // (measured and dropped: probing the next four parameters of the recurrence together and replaying the serial decisions — bit-identical,
+    // but 0.59 -> 0.79 ms: the loop is bound by the probe's arithmetic under 64-ray divergence, not by the occupancy-grid round trip)
     while (t < far && num_steps < max_steps) {
+        const float t_probe = t;
         const Probe s = rm_probe(r, t, k, grid);
-        if (s.occ) { num_steps++; t += s.dt; }
+        if (s.occ) {
+            if (hl) hl[num_steps] = make_float2(t_probe, s.dt);      // (parameter, step) of the occupied probe: the write pass needs nothing else
+            num_steps++; t += s.dt;
+        }
     }
     rays[n * 3] = (int)n;
     rays[n * 3 + 2] = (int)num_steps;
@@ -277,6 +293,38 @@ __global__ void __launch_bounds__(RM_BLOCK) k_march_train_write(const float *__r
             px += 3; pd += 3; pl += 2;
             step++;
         }
+    }
+}
+
+// pass 3, from the hit list of pass 1 (no second march): one wave per ray, its samples on the lanes.  Same arithmetic as the serial
+// writer: position = clamp(o + t d), deltas = (dt, (t + dt) - previous (t + dt)), the first sample measured from the jittered start.
+__global__ void __launch_bounds__(256) k_march_train_write_hits(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound,
+                                                                float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                                const float *__restrict__ nears, const float *__restrict__ noises,
+                                                                const float2 *__restrict__ hits, const int *__restrict__ rays,
+                                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || point_index + num_steps > M) return;
+    const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
+    const RayState r = rm_load_ray(rays_o, rays_d, n);
+    float t0 = nears[n];
+    t0 = cn_fma(cn_clamp(t0 * dt_gamma, k.dt_min, k.dt_max), noises[n], t0);       // the jittered start of the march kernels
+    const float2 *__restrict__ hl = hits + (size_t)n * max_steps;
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t s = base + lane;
+        if (s >= num_steps) continue;
+        const float2 h = hl[s];
+        float last_t = t0;
+        if (s > 0) { const float2 hp = hl[s - 1]; last_t = hp.x + hp.y; }
+        const size_t m = (size_t)point_index + s;
+        xyzs[m * 3] = cn_clamp(cn_fma(h.x, r.dx, r.ox), -bound, bound);
+        xyzs[m * 3 + 1] = cn_clamp(cn_fma(h.x, r.dy, r.oy), -bound, bound);
+        xyzs[m * 3 + 2] = cn_clamp(cn_fma(h.x, r.dz, r.oz), -bound, bound);
+        dirs[m * 3] = r.dx; dirs[m * 3 + 1] = r.dy; dirs[m * 3 + 2] = r.dz;
+        deltas[m * 2] = h.y;
+        deltas[m * 2 + 1] = (h.x + h.y) - last_t;
     }
 }
 
@@ -591,8 +639,34 @@ int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
-    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
+    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises,
+                       (float2 *)nullptr);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays_train_count_hits(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears, const float *fars,
+                                      int32_t *rays, int32_t *counter, const float *noises, float *hits, void *stream) {
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises || !hits) return CNERF_ENULL;
+    if (((uintptr_t)hits) & 7) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises,
+                       reinterpret_cast<float2 *>(hits));
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
+    return cn_launch_status();
+}
+
+int cnerf_march_rays_train_write_hits(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                                      uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises, const float *hits,
+                                      const int32_t *rays, float *xyzs, float *dirs, float *deltas, void *stream) {
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
+    if (N == 0 || M == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !noises || !hits || !rays || !xyzs || !dirs || !deltas) return CNERF_ENULL;
+    if (((uintptr_t)hits) & 7) return CNERF_EINVAL;
+    hipLaunchKernelGGL(k_march_train_write_hits, dim3(cn_div_up(N, 4)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                       nears, noises, reinterpret_cast<const float2 *>(hits), rays, xyzs, dirs, deltas);
     return cn_launch_status();
 }
 

@@ -82,6 +82,17 @@ def packbits(grid, thresh, bitfield=None):
 
 
 # ---------------------------------------------------------------------------------------------- training
+_HITS = {}
+
+
+def _hits_scratch(N, max_steps, device):
+    """per-device scratch for the occupied-probe list of march_rays_train (grown on demand, never shrunk)"""
+    buf = _HITS.get(device)
+    if buf is None or buf.numel() < N * max_steps * 2:
+        buf = _HITS[device] = torch.empty(N * max_steps * 2, dtype=torch.float32, device=device)
+    return buf
+
+
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
                      perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, noises=None):
     """raymarching.py:162-236 -> (xyzs [M,3], dirs [M,3], deltas [M,2], rays [N,3] int32).
@@ -119,8 +130,11 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     # count -> size -> write: allocates exactly the samples that exist (+ alignment padding, zero-filled as in the
     # reference where the tail of the zero-initialised buffers is returned, raymarching.py:206-208,226-230)
     base = step_counter[0:1].clone()
-    check(lib.cnerf_march_rays_train_count(*args, ptr(nears), ptr(fars), ptr(rays), ptr(step_counter), ptr(noises), stream()),
-          "march_rays_train_count")
+    # the counting march records (t, dt) of every occupied probe: the write pass then needs no second march (hits: caller-owned scratch,
+    # N x max_steps x 8 bytes, uninitialised; only the first num_steps entries of a ray's row are written and read)
+    hits = _hits_scratch(N, int(max_steps), dev)
+    check(lib.cnerf_march_rays_train_count_hits(*args, ptr(nears), ptr(fars), ptr(rays), ptr(step_counter), ptr(noises), ptr(hits), stream()),
+          "march_rays_train_count_hits")
     m = int(step_counter[0].item())            # D2H sync (same point as raymarching.py:225)
     if base.item() != 0:
         raise ValueError("march_rays_train: step_counter must be zeroed by the caller (renderer.py:619-620)")
@@ -130,8 +144,9 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     deltas = torch.empty(m_alloc, 2, dtype=torch.float32, device=dev)
     if m_alloc > m:
         xyzs[m:].zero_(); dirs[m:].zero_(); deltas[m:].zero_()
-    check(lib.cnerf_march_rays_train_write(*args, m_alloc, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
-                                           ptr(noises), stream()), "march_rays_train_write")
+    check(lib.cnerf_march_rays_train_write_hits(ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), m_alloc,
+                                                ptr(nears), ptr(noises), ptr(hits), ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), stream()),
+          "march_rays_train_write_hits")
     return xyzs, dirs, deltas, rays
 
 

@@ -74,6 +74,18 @@ int cnerf_march_rays_train_write(const float *rays_o, const float *rays_d, const
                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                                  const float *fars, float *xyzs, float *dirs, float *deltas, const int32_t *rays,
                                  const float *noises, void *stream);
+/* The two passes without the second march: _count_hits additionally records (t, dt) of every occupied probe of ray n at
+ * hits[n][step] (hits float32 [N, max_steps, 2], 8-byte aligned, caller-owned scratch; only the first num_steps_n entries of a row are
+ * written); _write_hits turns the list into xyzs / dirs / deltas — one wave per ray, no occupancy lookups — with the arithmetic of
+ * _write, bit for bit. */
+int cnerf_march_rays_train_count_hits(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears,
+                                      const float *fars, int32_t *rays, int32_t *counter, const float *noises, float *hits,
+                                      void *stream);
+int cnerf_march_rays_train_write_hits(const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                      uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *noises,
+                                      const float *hits, const int32_t *rays, float *xyzs, float *dirs, float *deltas,
+                                      void *stream);
 
 /* composite_rays_train_forward / _backward — raymarching.h:14-15 (the `_sdf` twins :16-17 are byte-identical
  * duplicates in the reference and map to the same entry points); kernels raymarching.cu:500-577, 691-772.
