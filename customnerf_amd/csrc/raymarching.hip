@@ -329,75 +329,12 @@ __global__ void __launch_bounds__(256) k_march_train_write_hits(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------ compositing (training)
-template <int RS>
-__global__ void __launch_bounds__(RM_BLOCK) k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                                                  const float *__restrict__ deltas, const int *__restrict__ rays, uint32_t M,
-                                                                  uint32_t N, float T_thresh, float *__restrict__ weights_sum,
-                                                                  float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
-    if (!(num_steps == 0 || offset + num_steps > M)) {
-        const float *ps = sigmas + offset, *pc = rgbs + (size_t)offset * RS;
-        const float2 *pl = reinterpret_cast<const float2 *>(deltas) + offset;
-        for (uint32_t step = 0; step < num_steps; step++) {
-            const float2 dl = pl[step];
-            const float alpha = 1.0f - __expf(-ps[step] * dl.x);
-            const float weight = alpha * T;
-            r = cn_fma(weight, pc[0], r); g = cn_fma(weight, pc[1], g); b = cn_fma(weight, pc[2], b);
-            t += dl.y;
-            d = cn_fma(weight, t, d);
-            ws += weight;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;
-            pc += RS;
-        }
-    }
-    weights_sum[index] = ws;
-    depth[index] = d;
-    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
-}
-
-template <int RS>
-__global__ void __launch_bounds__(RM_BLOCK) k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
-                                                                  const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                                                  const float *__restrict__ deltas, const int *__restrict__ rays,
-                                                                  const float *__restrict__ weights_sum, const float *__restrict__ image,
-                                                                  uint32_t M, uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
-                                                                  float *__restrict__ grad_rgbs) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    if (num_steps == 0 || offset + num_steps > M) return;
-    const float gws = grad_weights_sum[index];
-    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
-    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
-    const float ws_final = weights_sum[index];
-    const float *ps = sigmas + offset, *pc = rgbs + (size_t)offset * RS;
-    const float2 *pl = reinterpret_cast<const float2 *>(deltas) + offset;
-    float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * RS;
-    float T = 1.0f, r = 0, g = 0, b = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const float dl = pl[step].x;
-        const float alpha = 1.0f - __expf(-ps[step] * dl);
-        const float weight = alpha * T;
-        const float c0 = pc[0], c1 = pc[1], c2 = pc[2];
-        r = cn_fma(weight, c0, r); g = cn_fma(weight, c1, g); b = cn_fma(weight, c2, b);
-        T *= 1.0f - alpha;
-        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
-        gs[step] = dl * (gi0 * cn_fma(T, c0, -(r_final - r)) + gi1 * cn_fma(T, c1, -(g_final - g)) +
-                         gi2 * cn_fma(T, c2, -(b_final - b)) + gws * (1 - ws_final));
-        if (T < T_thresh) break;
-        pc += RS; gc += RS;
-    }
-}
-
-// ---- the same two kernels with one WAVE per ray: the ray's samples sit on the 64 lanes (chunks of 64), transmittance and the running
-// colour / path-length sums are DPP wave scans.  The thread-per-ray form above keeps 16384 serial loops of ~125 dependent iterations on
-// one wave per CU (0.35 + 0.38 ms per 128x128 view); this form reads every sample once, coalesced.  Association of the sums / products
-// differs from the serial loop (rounding level); a sample is kept iff it is the first or the transmittance before it is >= T_thresh —
-// the serial loop's `if (T < T_thresh) break` after the update, restated per sample.
+// composite_rays_train forward / backward (raymarching.cu:500-577, 691-772) with one WAVE per ray: the ray's samples sit on the 64 lanes
+// (chunks of 64), transmittance and the running colour / path-length sums are DPP wave scans.  The reference's thread-per-ray form keeps
+// 16384 serial loops of ~125 dependent iterations on one wave per CU (measured here: 0.35 + 0.38 ms per 128x128 view); this form reads
+// every sample once, coalesced.  Association of the sums / products differs from the serial loop (rounding level); a sample is kept iff
+// it is the first or the transmittance before it is >= T_thresh — the serial loop's `if (T < T_thresh) break` after the update,
+// restated per sample.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float rm_dpp(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
