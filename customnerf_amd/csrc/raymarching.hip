@@ -123,6 +123,11 @@ __global__ void __launch_bounds__(RM_BLOCK) k_packbits(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ marching core
+// DPP lane exchange: `old` is what a lane keeps when its source lane does not exist
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float rm_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
 struct RayState {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
 };
@@ -199,34 +204,81 @@ __device__ __forceinline__ RayState rm_load_ray(const float *__restrict__ rays_o
     return r;
 }
 
-// pass 1: count occupied steps per ray; rays[n] = (n, <unset>, num_steps)
-__global__ void __launch_bounds__(RM_BLOCK) k_march_train_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+// pass 1: count occupied steps per ray; rays[n] = (n, <unset>, num_steps); optionally record (t, dt) of every occupied probe.
+// One WAVE per ray (the reference's thread-per-ray loop, raymarching.cu:311-480, measured here at 0.59 ms per 128x128 view: 256 waves of
+// divergent serial chains; a four-probe look-ahead inside that loop was bit-identical but slower, 0.79 ms).  Whatever the occupancy grid says, the serial march only ever visits points of the recurrence
+// t_{k+1} = t_k + dt(t_k): one step after a hit, as many as it takes to reach the empty voxel's exit tt after a miss.  So: the 64 lanes
+// hold 64 consecutive points of the recurrence (built by a lane-to-lane DPP chain: every value is the same sequence of float additions the
+// serial loop performs), all 64 are probed at once, and the serial decisions are then replayed on the ballot masks — "probe the first
+// point with t >= skip target; hit: take the whole run of hits behind it; miss: new skip target" — a few scalar iterations per chunk
+// instead of one occupancy-grid round trip per probe on a single wave per CU.  Same accepted points and counts, bit for bit.
+__global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                                 const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                                 const float *__restrict__ nears, const float *__restrict__ fars,
                                                                 int *__restrict__ rays, const float *__restrict__ noises,
                                                                 float2 *__restrict__ hits) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= N) return;
+    const uint32_t lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;                                                   // whole waves leave together
     const MarchConst k = rm_consts(bound, dt_gamma, max_steps, C, H);
     const RayState r = rm_load_ray(rays_o, rays_d, n);
     const float far = fars[n];
-    float t = nears[n];
-    t = cn_fma(cn_clamp(t * dt_gamma, k.dt_min, k.dt_max), noises[n], t);
+    float t_base = nears[n];
+    t_base = cn_fma(cn_clamp(t_base * dt_gamma, k.dt_min, k.dt_max), noises[n], t_base);
     uint32_t num_steps = 0;
+    float T_skip = -INFINITY;                                            // probe a point iff t >= T_skip
     float2 *__restrict__ hl = hits ? hits + (size_t)n * max_steps : nullptr;
-    // (measured and dropped: probing the next four parameters of the recurrence together and replaying the serial decisions — bit-identical,
-    // but 0.59 -> 0.79 ms: the loop is bound by the probe's arithmetic under 64-ray divergence, not by the occupancy-grid round trip)
-    while (t < far && num_steps < max_steps) {
-        const float t_probe = t;
-        const Probe s = rm_probe(r, t, k, grid);
-        if (s.occ) {
-            if (hl) hl[num_steps] = make_float2(t_probe, s.dt);      // (parameter, step) of the occupied probe: the write pass needs nothing else
-            num_steps++; t += s.dt;
+    bool done = !(t_base < far);
+    while (!done) {
+        // the chunk's 64 points: lane l = t_base advanced l times
+        float t = t_base;
+        for (int i = 0; i < 63; i++) {
+            const float prev = rm_dpp<0x138>(t, t);                     // lane l-1's value (lane 0 keeps its own)
+            const float step = lane == 0 ? 0.0f : cn_clamp(prev * k.dt_gamma, k.dt_min, k.dt_max);
+            t = prev + step;                                             // lanes <= i are final and recompute themselves
         }
+        float tt;
+        const Probe s = rm_probe_at(r, t, k, grid, tt);
+        const uint64_t occm = __ballot(s.occ), validm = __ballot(t < far);
+        uint64_t acc = 0;
+        uint32_t cur = 0;
+        while (cur < 64) {
+            const uint64_t cand = __ballot(t >= T_skip) & (~0ull << cur);
+            if (cand == 0) break;                                        // the rest of the chunk lies inside the skipped voxel
+            const uint32_t l = (uint32_t)__builtin_ctzll(cand);
+            if (!((validm >> l) & 1ull) || num_steps >= max_steps) { done = true; break; }      // the serial loop's condition fails at this probe
+            if ((occm >> l) & 1ull) {
+                // a hit is followed by the very next point: take the whole run of hits (while the loop condition holds)
+                const uint64_t ok = (occm & validm) >> l;
+                uint32_t len = ~ok == 0 ? 64u : (uint32_t)__builtin_ctzll(~ok);
+                len = min(len, 64u - l);
+                len = min(len, max_steps - num_steps);
+                acc |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << l;
+                num_steps += len;
+                cur = l + len;
+                T_skip = -INFINITY;
+            } else {
+                T_skip = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), (int)l));
+                cur = l + 1;
+            }
+        }
+        if (hl && acc) {
+            const uint32_t before = num_steps - (uint32_t)__builtin_popcountll(acc);
+            if ((acc >> lane) & 1ull) {
+                const uint32_t rank = (uint32_t)__builtin_popcountll(acc & ((1ull << lane) - 1ull));
+                hl[before + rank] = make_float2(t, s.dt);
+            }
+        }
+        if (done) break;
+        // next chunk starts one step behind lane 63
+        const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+        t_base = t63 + cn_clamp(t63 * k.dt_gamma, k.dt_min, k.dt_max);
+        if (!(t_base < far)) done = true;
     }
-    rays[n * 3] = (int)n;
-    rays[n * 3 + 2] = (int)num_steps;
+    if (lane == 0) {
+        rays[n * 3] = (int)n;
+        rays[n * 3 + 2] = (int)num_steps;
+    }
 }
 
 // pass 2: exclusive scan of num_steps in ray order (one workgroup; wave shuffles + one LDS hop).
@@ -335,10 +387,6 @@ __global__ void __launch_bounds__(256) k_march_train_write_hits(const float *__r
 // every sample once, coalesced.  Association of the sums / products differs from the serial loop (rounding level); a sample is kept iff
 // it is the first or the transmittance before it is >= T_thresh — the serial loop's `if (T < T_thresh) break` after the update,
 // restated per sample.
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float rm_dpp(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
-}
 __device__ __forceinline__ float rm_incl_prod(float x) {
     x *= rm_dpp<0x111>(1.0f, x); x *= rm_dpp<0x112>(1.0f, x); x *= rm_dpp<0x114>(1.0f, x); x *= rm_dpp<0x118>(1.0f, x);
     x *= rm_dpp<0x142, 0xA>(1.0f, x); x *= rm_dpp<0x143, 0xC>(1.0f, x);
@@ -576,8 +624,8 @@ int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
-    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises,
-                       (float2 *)nullptr);
+    hipLaunchKernelGGL(k_march_train_count_wave, dim3(cn_div_up(N, 4)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, nears, fars, rays, noises, (float2 *)nullptr);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
     return cn_launch_status();
 }
@@ -589,8 +637,8 @@ int cnerf_march_rays_train_count_hits(const float *rays_o, const float *rays_d, 
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises || !hits) return CNERF_ENULL;
     if (((uintptr_t)hits) & 7) return CNERF_EINVAL;
-    hipLaunchKernelGGL(k_march_train_count, RM_GRID(N), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises,
-                       reinterpret_cast<float2 *>(hits));
+    hipLaunchKernelGGL(k_march_train_count_wave, dim3(cn_div_up(N, 4)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, nears, fars, rays, noises, reinterpret_cast<float2 *>(hits));
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
     return cn_launch_status();
 }
