@@ -15,7 +15,7 @@ except Exception as e:
 acc = collections.defaultdict(list)
 for r in rows:
     acc[r['Kernel_Name'][:40]].append(float(r['Counter_Value']))
-keys = [k for k in acc if any(s in k for s in ('k_bin2', 'k_grid_fwd', 'k_field_bwd_mma', 'k_field_fwd', 'k_bin_scan_blocks'))]
+keys = [k for k in acc if any(s in k for s in ("k_bin2", "k_grid_fwd", "k_field_bwd_mma", "k_field_fwd"))]
 print('$c', {k: round(sum(acc[k]) / len(acc[k]), 3) for k in keys})
 E
   rm -f gpurun_out/$tag/$c/b_kernel_trace.csv
