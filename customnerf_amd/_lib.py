@@ -52,6 +52,8 @@ SIGNATURES = {
     "cnerf_sample_coarse": [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge_split": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp],
+    "cnerf_sample_coarse_unit": [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, f32, vp],
+    "cnerf_sample_fine_merge_split_unit": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, f32, vp],
     "cnerf_composite_run": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp],
     "cnerf_composite_run_backward": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp],
     "cnerf_recon_loss": [vp, vp, vp, u32, f32, f32, vp, vp, vp],

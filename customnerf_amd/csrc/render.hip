@@ -31,7 +31,8 @@ __device__ __forceinline__ void rn_point(const float *o, const float *d, float z
 
 __global__ void __launch_bounds__(256) k_sample_coarse(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
                                                        const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
-                                                       uint32_t N, uint32_t T, float *__restrict__ z_vals, float *__restrict__ xyzs) {
+                                                       uint32_t N, uint32_t T, float *__restrict__ z_vals, float *__restrict__ xyzs,
+                                                       float *__restrict__ unit, float bound) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * T) return;
     const uint32_t n = idx / T, i = idx - n * T;
@@ -42,6 +43,11 @@ __global__ void __launch_bounds__(256) k_sample_coarse(const float *__restrict__
     rn_point(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, z, aabb, p);
     z_vals[idx] = z;
     xyzs[(size_t)idx * 3] = p[0]; xyzs[(size_t)idx * 3 + 1] = p[1]; xyzs[(size_t)idx * 3 + 2] = p[2];
+    if (unit) {                                               // the grid's [0,1] coordinates, (x + bound) / (2 bound) as gridencoder/grid.py:156 computes them
+        // torch divides a tensor by a host scalar as a multiplication by its float reciprocal (BinaryDivTrueKernel.cu): so does this
+        const float inv = 1.0f / (2.0f * bound);
+        unit[(size_t)idx * 3] = (p[0] + bound) * inv; unit[(size_t)idx * 3 + 1] = (p[1] + bound) * inv; unit[(size_t)idx * 3 + 2] = (p[2] + bound) * inv;
+    }
 }
 
 // Wave scans on the DPP data path (row_shr inside the 16-lane rows, row_bcast:15 / :31 across them): no LDS-crossbar round trips
@@ -102,7 +108,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
                                                                   const float *__restrict__ aabb, const float *__restrict__ z_vals,
                                                                   const float *__restrict__ sigmas, const float *__restrict__ u_rand, uint32_t N,
                                                                   uint32_t T, uint32_t t, float *__restrict__ z_all, float *__restrict__ xyz_all,
-                                                                  float *__restrict__ xyz_fine, uint32_t *__restrict__ src_index) {
+                                                                  float *__restrict__ xyz_fine, uint32_t *__restrict__ src_index, float *__restrict__ unit_fine,
+                                                                  float bound) {
     __shared__ float s_z[RN_WAVES][RN_MAXS], s_w[RN_WAVES][RN_MAXS], s_cdf[RN_WAVES][RN_MAXS], s_bin[RN_WAVES][RN_MAXS], s_nz[RN_WAVES][RN_MAXS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
@@ -204,6 +211,11 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
             // draw order, NOT sorted along the ray: measured 1 % faster end to end (sorted neighbours collide in the scatter's LDS atomics)
             float *xf = xyz_fine + ((size_t)n * t + m) * 3;
             xf[0] = p[0]; xf[1] = p[1]; xf[2] = p[2];
+            if (unit_fine) {                                  // grid coordinates of the new samples, as k_sample_coarse writes them
+                float *uf = unit_fine + ((size_t)n * t + m) * 3;
+                const float inv = 1.0f / (2.0f * bound);
+                uf[0] = (p[0] + bound) * inv; uf[1] = (p[1] + bound) * inv; uf[2] = (p[2] + bound) * inv;
+            }
         }
         if (si) si[pos] = N * T + n * t + m;
     }
@@ -423,7 +435,17 @@ int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *n
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs) return CNERF_ENULL;
     hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb, noise, N, T,
-                       z_vals, xyzs);
+                       z_vals, xyzs, (float *)nullptr, 0.0f);
+    return cn_launch_status();
+}
+
+int cnerf_sample_coarse_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
+                             uint32_t N, uint32_t T, float *z_vals, float *xyzs, float *unit, float bound, void *stream) {
+    if (T < 2 || T > RN_MAXS || !(bound > 0.0f)) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs || !unit) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb, noise, N, T,
+                       z_vals, xyzs, unit, bound);
     return cn_launch_status();
 }
 
@@ -436,7 +458,19 @@ int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, cons
     if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !sigmas || !z_all) return CNERF_ENULL;
     if (!xyz_all && !(xyz_fine && src_index)) return CNERF_ENULL;
     hipLaunchKernelGGL(k_sample_fine_merge, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb,
-                       z_vals, sigmas, u, N, T, t, z_all, xyz_all, xyz_fine, src_index);
+                       z_vals, sigmas, u, N, T, t, z_all, xyz_all, xyz_fine, src_index, (float *)nullptr, 0.0f);
+    return cn_launch_status();
+}
+
+int cnerf_sample_fine_merge_split_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb,
+                                       const float *z_vals, const float *sigmas, const float *u, uint32_t N, uint32_t T, uint32_t t, float *z_all,
+                                       float *xyz_fine, uint32_t *src_index, float *unit_fine, float bound, void *stream) {
+    if (T < 3 || T > RN_MAXS || t < 2 || t > RN_MAXS || !(bound > 0.0f)) return CNERF_EINVAL;
+    if ((uint64_t)N * (T + t) >= 0xFFFFFFFFull) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !sigmas || !z_all || !xyz_fine || !src_index || !unit_fine) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_fine_merge, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb,
+                       z_vals, sigmas, u, N, T, t, z_all, (float *)nullptr, xyz_fine, src_index, unit_fine, bound);
     return cn_launch_status();
 }
 

@@ -146,12 +146,14 @@ class NeRFNetwork(NeRFRenderer):
         return torch.empty(L, P, 2, dtype=dt, device=device), torch.empty(P, 3, dtype=torch.float32, device=device)
 
     @torch.no_grad()
-    def split_encode(self, enc, unit, x, row0):
-        """gather the features of x [B, 3] into rows row0.. of enc (and their [0,1] grid coordinates into unit)"""
+    def split_encode(self, enc, unit, x, row0, unit_ready=False):
+        """gather the features of x [B, 3] into rows row0.. of enc (and their [0,1] grid coordinates into unit; unit_ready: the sampling
+        kernel already wrote them)"""
         B = x.shape[0]
         u = unit[row0:row0 + B]
-        torch.add(x, self.opt.bound, out=u)                                         # grid.py:156: (x + bound) / (2 bound)
-        u.div_(2 * self.opt.bound)
+        if not unit_ready:
+            torch.add(x, self.opt.bound, out=u)                                     # grid.py:156: (x + bound) / (2 bound)
+            u.div_(2 * self.opt.bound)
         self.pos_en.encode_into(u, enc, row0, half=self._half())
 
     @torch.no_grad()

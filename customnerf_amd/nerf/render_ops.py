@@ -6,14 +6,20 @@ from torch.autograd import Function
 from .._lib import lib, check, ptr, stream, require_cuda
 
 
-def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None, xyz_out=None):
+def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None, xyz_out=None, unit_out=None, bound=None):
     """-> z_vals [N,T], xyzs [N,T,3]   (renderer.py:310-322; noise [N,T] = the torch.rand draw of :317 or None).
-    xyz_out: optional contiguous [N,T,3] float32 destination (e.g. the head of a larger sample list)."""
-    require_cuda(rays_o, rays_d, nears, fars, aabb, noise, xyz_out)
+    xyz_out: optional contiguous [N,T,3] float32 destination (e.g. the head of a larger sample list).
+    unit_out (+ bound): also write the grid's [0,1] coordinates (xyz + bound) / (2 bound) of the samples there (grid.py:156)."""
+    require_cuda(rays_o, rays_d, nears, fars, aabb, noise, xyz_out, unit_out)
     N = rays_o.shape[0]
     z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
     xyz = xyz_out if xyz_out is not None else torch.empty(N, T, 3, dtype=torch.float32, device=rays_o.device)
     assert xyz.is_contiguous() and xyz.dtype == torch.float32 and xyz.numel() == N * T * 3
+    if unit_out is not None:
+        assert unit_out.is_contiguous() and unit_out.dtype == torch.float32 and unit_out.numel() == N * T * 3 and bound is not None
+        check(lib.cnerf_sample_coarse_unit(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, int(T), ptr(z), ptr(xyz),
+                                           ptr(unit_out), float(bound), stream()), "sample_coarse_unit")
+        return z, xyz
     check(lib.cnerf_sample_coarse(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, int(T), ptr(z), ptr(xyz), stream()),
           "sample_coarse")
     return z, xyz
@@ -30,7 +36,7 @@ def sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=No
     return z_all, xyz_all
 
 
-def sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=None, xyz_fine_out=None):
+def sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=None, xyz_fine_out=None, unit_fine_out=None, bound=None):
     """Split form: -> z_all [N,T+t] (sorted), xyz_fine [N,t,3] (the new samples in their own block), src_index [N,T+t] int32 = row of
     every sorted position in the sample list [coarse N*T rows | fine N*t rows]."""
     require_cuda(z_vals, sigmas, u, xyz_fine_out)
@@ -39,6 +45,13 @@ def sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t
     xyz_fine = xyz_fine_out if xyz_fine_out is not None else torch.empty(N, t, 3, dtype=torch.float32, device=z_vals.device)
     assert xyz_fine.is_contiguous() and xyz_fine.dtype == torch.float32 and xyz_fine.numel() == N * t * 3
     src = torch.empty(N, T + t, dtype=torch.int32, device=z_vals.device)
+    if unit_fine_out is not None:                        # also the new samples' [0,1] grid coordinates (see sample_coarse)
+        require_cuda(unit_fine_out)
+        assert unit_fine_out.is_contiguous() and unit_fine_out.dtype == torch.float32 and unit_fine_out.numel() == N * t * 3 and bound is not None
+        check(lib.cnerf_sample_fine_merge_split_unit(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(z_vals), ptr(sigmas), ptr(u), N, int(T),
+                                                     int(t), ptr(z_all), ptr(xyz_fine), ptr(src), ptr(unit_fine_out), float(bound), stream()),
+              "sample_fine_merge_split_unit")
+        return z_all, xyz_fine, src
     check(lib.cnerf_sample_fine_merge_split(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(z_vals), ptr(sigmas), ptr(u), N, int(T), int(t),
                                             ptr(z_all), None, ptr(xyz_fine), ptr(src), stream()), "sample_fine_merge_split")
     return z_all, xyz_fine, src

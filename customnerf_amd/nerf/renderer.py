@@ -243,12 +243,15 @@ class NeRFRenderer(nn.Module):
                 Pc, P = N * num_steps, N * S
                 xyz_list = torch.empty(P, 3, dtype=torch.float32, device=device)
                 enc, unit = self.split_buffers(P, device)
-                z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3))
-                self.split_encode(enc, unit, xyz_list[:Pc], 0)
+                bnd = float(self.opt.bound)                                  # the samplers also write the grid's [0,1] coordinates (no elementwise pass)
+                z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3),
+                                                         unit_out=unit[:Pc].view(N, num_steps, 3), bound=bnd)
+                self.split_encode(enc, unit, xyz_list[:Pc], 0, unit_ready=True)
                 sig_c = self.split_density(enc, xyz_list[:Pc])
                 z_all, xyz_f, src = render_ops.sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw(),
-                                                                        xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3))
-                self.split_encode(enc, unit, xyz_list[Pc:], Pc)
+                                                                        xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3),
+                                                                        unit_fine_out=unit[Pc:].view(N, upsample_steps, 3), bound=bnd)
+                self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True)
             else:
                 z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
                 sig_c = self.density(xyzs.view(-1, 3))['sigma'].float().contiguous()

@@ -258,6 +258,17 @@ int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, cons
                                   const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
                                   uint32_t T, uint32_t t, float *z_all, float *xyz_all, float *xyz_fine, uint32_t *src_index,
                                   void *stream);
+/* The same two samplers also writing the grid's [0,1] coordinates of their points, unit = (xyz + bound) / (2 bound) — the map
+ * GridEncoder.forward applies first (gridencoder/grid.py:156) — so that the gather needs no elementwise pass in between.
+ * unit [N,T,3] / unit_fine [N,t,3] float32, same arithmetic as the torch expression on a GPU (float add, then a multiplication by the
+ * float reciprocal of 2*bound: that is how torch divides a tensor by a host scalar). */
+int cnerf_sample_coarse_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb,
+                             const float *noise, uint32_t N, uint32_t T, float *z_vals, float *xyzs, float *unit, float bound,
+                             void *stream);
+int cnerf_sample_fine_merge_split_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                                       const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
+                                       uint32_t T, uint32_t t, float *z_all, float *xyz_fine, uint32_t *src_index,
+                                       float *unit_fine, float bound, void *stream);
 /* weights_sum_i x3 (renderer.py:384-402, 407-474) in one pass over [N,S] samples: all / fg (sigma*edit_mask) /
  * bg (sigma*(1-edit_mask)) composites.  soft_mask: edit = sigmoid((conf-thr)*100) else conf>0.5.
  * rgbc [N,S,4] (rgb + confidence), sigmas [N,S], z_vals [N,S].

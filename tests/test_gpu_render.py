@@ -460,3 +460,28 @@ def test_strided_gather_and_indexed_composite_reduce_to_the_plain_forms():
     w = torch.rand(3, N, 6, device="cuda", generator=g)
     (a * w).sum().backward(); (b[0] * w).sum().backward()
     assert torch.equal(sig_l.grad[perm.long().view(-1)], sig_m.grad) and torch.equal(rgbc_l.grad[perm.long().view(-1)], rgbc_m.grad)
+
+
+def test_samplers_write_the_grid_coordinates_bit_for_bit():
+    """cnerf_sample_coarse_unit / cnerf_sample_fine_merge_split_unit: the [0,1] grid coordinates they emit equal torch's
+    (xyz + bound) / (2 bound) on the positions they emit (gridencoder/grid.py:156), for a power-of-two and a non-power-of-two bound."""
+    from customnerf_amd.nerf import render_ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, T, t = 777, 48, 40
+    for bound in (2.0, 1.3):
+        o = (torch.rand(N, 3, device="cuda", generator=g) - 0.5) * bound
+        d = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+        aabb = torch.tensor([-bound] * 3 + [bound] * 3, device="cuda")
+        nears, fars = torch.full((N,), 0.05, device="cuda"), torch.full((N,), 2.5 * bound, device="cuda")
+        noise, u = torch.rand(N, T, device="cuda", generator=g), torch.rand(N, t, device="cuda", generator=g)
+        unit_c = torch.empty(N, T, 3, device="cuda")
+        z, xyz = render_ops.sample_coarse(o, d, nears, fars, aabb, T, noise, unit_out=unit_c, bound=bound)
+        z_ref, xyz_ref = render_ops.sample_coarse(o, d, nears, fars, aabb, T, noise)
+        assert torch.equal(z, z_ref) and torch.equal(xyz, xyz_ref)
+        assert torch.equal(unit_c, (xyz + bound) / (2 * bound))
+        sig = torch.rand(N, T, device="cuda", generator=g) * 3
+        unit_f = torch.empty(N, t, 3, device="cuda")
+        za, xf, src = render_ops.sample_fine_merge_split(o, d, nears, fars, aabb, z, sig, t, u, unit_fine_out=unit_f, bound=bound)
+        zb, xg, srb = render_ops.sample_fine_merge_split(o, d, nears, fars, aabb, z, sig, t, u)
+        assert torch.equal(za, zb) and torch.equal(xf, xg) and torch.equal(src, srb)
+        assert torch.equal(unit_f, (xf + bound) / (2 * bound))
