@@ -770,7 +770,8 @@ static uint32_t b2_pts() {
 static uint32_t b2_seg(uint32_t B, uint32_t max_chunks = 128) {
     const uint64_t hashed_bin = (uint64_t)B * 4 / (max_chunks ? max_chunks : 1);
     const uint64_t s = hashed_bin + hashed_bin / 8;
-    return (uint32_t)(s < B2_SEG_MIN ? B2_SEG_MIN : s);
+    // small tables (few bins per level) would otherwise get a handful of million-record workgroups: cap, and let those bins split
+    return (uint32_t)(s < B2_SEG_MIN ? B2_SEG_MIN : (s > (1u << 17) ? (1u << 17) : s));
 }
 
 static uint32_t b2_max_chunks(const Bin2Plan &plan, uint32_t nl) {
