@@ -139,6 +139,7 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     if base.item() != 0:
         raise ValueError("march_rays_train: step_counter must be zeroed by the caller (renderer.py:619-620)")
     m_alloc = m + (align - m % align) if align > 0 else m
+    m_alloc = min(m_alloc, N * int(max_steps))          # the reference slices a buffer of N * max_steps rows (raymarching.py:196,226-230)
     xyzs = torch.empty(m_alloc, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(m_alloc, 3, dtype=torch.float32, device=dev)
     deltas = torch.empty(m_alloc, 2, dtype=torch.float32, device=dev)

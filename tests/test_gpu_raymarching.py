@@ -101,6 +101,28 @@ def test_march_rays_train_bit_exact(rm, scene, H, dt_gamma, perturb):
     np.testing.assert_array_equal(l.cpu().numpy(), lr)
 
 
+@pytest.mark.parametrize("max_steps,dt_gamma", [(96, 0.0), (17, 0.0), (200, 1.0 / 64)])
+def test_march_rays_train_step_cap_bit_exact(rm, scene, max_steps, dt_gamma):
+    """The wave-per-ray march replays the serial loop's `num_steps < max_steps` condition on ballot masks: rays that hit the cap in the
+    middle of a 64-point chunk (and, with dt_gamma > 0, a step that grows along the ray) must stop at exactly the serial loop's sample."""
+    sc, _, bitfield = scene
+    bitfield = np.full_like(bitfield, 0xFF)                               # everything occupied: the path through the box is longer than max_steps steps
+    bitfield[::7] = 0x5A                                                   # ... with holes, so that hits and skips alternate on the way
+    o, d = rays_for(sc, 48, 48, view=1)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = co.near_far_from_aabb(o, d, aabb, 0.2)
+    N = o.shape[0]
+    noises = np.random.default_rng(3).random(N).astype(np.float32)
+    xr, dr, lr, rr = co.march_rays_train(o, d, 2.0, bitfield, 2, 128, nears, fars, None, -1, noises, 128, True, dt_gamma, max_steps)
+    counter = torch.zeros(2, dtype=torch.int32).cuda()
+    x, dd, l, r = rm.march_rays_train(cuda(o), cuda(d), 2.0, cuda(bitfield), 2, 128, cuda(nears), cuda(fars), counter, -1, True, 128,
+                                      True, dt_gamma, max_steps, noises=cuda(noises))
+    np.testing.assert_array_equal(r.cpu().numpy(), rr)
+    assert int(rr[:, 2].max()) == max_steps or dt_gamma > 0                # dt_gamma = 0: the cap is actually reached
+    np.testing.assert_array_equal(x.cpu().numpy(), xr)
+    np.testing.assert_array_equal(l.cpu().numpy(), lr)
+
+
 def test_march_rays_train_mean_count_budget(rm, scene):
     """fixed budget M < total: overflowing rays are dropped exactly like raymarching.cu:416."""
     sc, _, bitfield = scene
