@@ -12,7 +12,7 @@ import os
 import torch
 
 
-def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None):
+def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None, lr_scheduler=None, ema=None):
     state = {'epoch': int(epoch), 'global_step': int(global_step),
              'stats': stats if stats is not None else {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}}
     if getattr(model, 'cuda_ray', False):
@@ -20,16 +20,21 @@ def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, 
         state['mean_density'] = model.mean_density
     if full and optimizer is not None:
         state['optimizer'] = optimizer.state_dict()
+    if full and lr_scheduler is not None:
+        state['lr_scheduler'] = lr_scheduler.state_dict()               # :795 (any object with state_dict(): LambdaLR, ...)
     if full and scaler is not None:
         state['scaler'] = scaler.state_dict()                           # GradScaler keys (:797-798)
+    if full and ema is not None:
+        state['ema'] = ema.state_dict()                                 # torch_ema's ExponentialMovingAverage (:799-800)
     state['model'] = model.state_dict()
     return state
 
 
-def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None):
-    """utils_init_nerf.py:779-815 (`best` bookkeeping and checkpoint rotation are the caller's)."""
+def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None, lr_scheduler=None, ema=None):
+    """utils_init_nerf.py:779-815 (`best` bookkeeping and checkpoint rotation are the caller's).  A `full` checkpoint carries the same
+    optional entries as the reference's: 'optimizer', 'lr_scheduler', 'scaler', 'ema' (each only when the object is passed)."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save(checkpoint_state(model, epoch, global_step, stats, optimizer, full, scaler), path)
+    torch.save(checkpoint_state(model, epoch, global_step, stats, optimizer, full, scaler, lr_scheduler, ema), path)
     return path
 
 
@@ -38,7 +43,7 @@ def latest_checkpoint(ckpt_dir):
     return files[-1] if files else None
 
 
-def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_location=None, log=print, scaler=None):
+def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_location=None, log=print, scaler=None, lr_scheduler=None, ema=None):
     """utils_init_nerf.py:838-901.  `checkpoint`: path or an already loaded dict.  Returns a dict with what was restored:
     {'epoch', 'global_step', 'stats', 'missing_keys', 'unexpected_keys'} (epoch / step / stats None when absent or model_only)."""
     ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
@@ -58,7 +63,12 @@ def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_loc
     if unexpected:
         log(f"[WARN] unexpected keys: {unexpected}")
     if hasattr(model, 'pos_en') and hasattr(model.pos_en, 'invalidate_half_table'):
-        model.pos_en.invalidate_half_table()
+        model.pos_en.invalidate_half_table()                            # the fp16 shadow of the grid table is re-cast on next use
+    if ema is not None and 'ema' in ck:                                 # :862-867 (restored even when model_only, as in the reference)
+        try:
+            ema.load_state_dict(ck['ema'])
+        except Exception as e:
+            log(f"[WARN] failed to load EMA: {e!r}")
     if getattr(model, 'cuda_ray', False):
         if 'mean_count' in ck:
             model.mean_count = ck['mean_count']
@@ -72,6 +82,11 @@ def load_checkpoint(model, checkpoint, model_only=False, optimizer=None, map_loc
             optimizer.load_state_dict(ck['optimizer'])
         except Exception as e:                                          # the reference swallows this too (:885-890)
             log(f"[WARN] Failed to load optimizer: {e!r}")
+    if lr_scheduler is not None and 'lr_scheduler' in ck:               # :889-894
+        try:
+            lr_scheduler.load_state_dict(ck['lr_scheduler'])
+        except Exception as e:
+            log(f"[WARN] Failed to load scheduler: {e!r}")
     if scaler is not None and 'scaler' in ck:                           # :896-901
         try:
             scaler.load_state_dict(ck['scaler'])

@@ -80,14 +80,17 @@ __device__ __forceinline__ void fld_c_to_b(const cn_f16v (&acc)[2], typename Pre
 #pragma unroll
         for (int sub = 0; sub < P::FR; sub++) {
             if constexpr (H) {
-                cn_h8 f;
+                // round first, then ReLU on the packed halves (v_cvt_pk_f16_f32 + v_pk_max_f16 per two values): rounding is monotonic and
+                // keeps the sign, so relu(round(x)) == round(relu(x)); fmaxf on the fp32 accumulators costs two v_max_f32 per value (the
+                // compiler canonicalises MFMA results before a max)
+                union { cn_h8 h; cn_h2 p[4]; } f;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    float v = acc[u][8 * sub + j];
-                    if (RELU) v = fmaxf(v, 0.0f);
-                    f[j] = (_Float16)v;
+                for (int j = 0; j < 4; j++) {
+                    cn_h2 v = {(_Float16)acc[u][8 * sub + 2 * j], (_Float16)acc[u][8 * sub + 2 * j + 1]};
+                    if (RELU) v = __builtin_elementwise_max(v, cn_h2{(_Float16)0, (_Float16)0});
+                    f.p[j] = v;
                 }
-                b[u * P::FR + sub] = f;
+                b[u * P::FR + sub] = f.h;
             } else {
                 float v = acc[u][sub];
                 if (RELU) v = fmaxf(v, 0.0f);
@@ -158,8 +161,11 @@ __device__ __forceinline__ void fld_dir_frags(const float *__restrict__ dirs, ui
 __device__ __forceinline__ float fld_round_half(float v) { return (float)(_Float16)v; }
 
 // ------------------------------------------------------------------------------------------------ forward kernel
+// fp16 mode asks for two workgroups per CU-SIMD set (launch bound 2 waves per SIMD): with at most 256 registers per lane the compiler
+// selects the VGPR-destination form of the MFMAs; with the 512-register budget every MFMA result lands in an accumulation register and
+// costs one v_accvgpr_read per value before the VALU can touch it (the kernel was VALU-bound on exactly those moves).
 template <bool H, int SENC, int NGEO>
-__global__ void __launch_bounds__(FLD_THREADS) k_field_fwd(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
+__global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
                                                            uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                            const float *__restrict__ pden, const float *__restrict__ prgb,
                                                            float *__restrict__ sigma, float *__restrict__ rgbc, uint32_t enc_stride) {

@@ -15,6 +15,7 @@
 #include "common.h"
 
 typedef _Float16 cn_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cn_h2 __attribute__((ext_vector_type(2)));
 typedef float cn_f16v __attribute__((ext_vector_type(16)));
 
 #define FLD_THREADS 256

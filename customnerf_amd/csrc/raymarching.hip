@@ -283,9 +283,16 @@ __global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__r
 
 // pass 2: exclusive scan of num_steps in ray order (one workgroup; wave shuffles + one LDS hop).
 // rays[n*3+1] = base + sum_{m<n} num_steps[m];  counter[0] += total, counter[1] += N.
+// Fixed-budget callers (M < 2^32 - 1): when the call overflows its budget (base + total > M) the rays whose segments end beyond M are
+// dropped (raymarching.cu:416).  With a scan that always starts at ray 0 those would always be the highest-numbered rays — the bottom
+// rows of a whole-view batch — whereas the reference drops rays in atomicAdd arrival order, unrelated to image position.  On overflow
+// the scan therefore starts at ray rot = floor(noises[0] * N) and wraps around: which rays are dropped moves with the per-call jitter
+// draw (and stays a deterministic function of the inputs).  Calls that fit their budget keep the plain ray order.
 #define SCAN_THREADS 1024
-__global__ void __launch_bounds__(SCAN_THREADS) k_march_train_scan(int *__restrict__ rays, int *__restrict__ counter, uint32_t N) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_march_train_scan(int *__restrict__ rays, int *__restrict__ counter, uint32_t N, uint32_t M,
+                                                                   const float *__restrict__ noises) {
     __shared__ uint32_t wave_tot[SCAN_THREADS / CN_WAVE];
+    __shared__ uint32_t prefix_rot;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t chunk = (N + SCAN_THREADS - 1) / SCAN_THREADS;
     const uint32_t begin = min(tid * chunk, N), end = min(begin + chunk, N);
@@ -302,9 +309,21 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_march_train_scan(int *__restri
         total += v;
     }
     const uint32_t base = (uint32_t)counter[0];
-    uint32_t run = base + wave_base + incl - local;
+    const uint32_t first = wave_base + incl - local;                      // samples of the rays before this thread's chunk
+    uint32_t rot = 0;
+    if (M != 0xFFFFFFFFu && (uint64_t)base + total > M) rot = min((uint32_t)(noises[0] * (float)N), N - 1);   // workgroup-uniform
+    if (rot) {
+        if (rot >= begin && rot < end) {
+            uint32_t run = first;
+            for (uint32_t n = begin; n < rot; n++) run += (uint32_t)rays[n * 3 + 2];
+            prefix_rot = run;
+        }
+        __syncthreads();
+    }
+    const uint32_t pr = rot ? prefix_rot : 0;
+    uint32_t run = first;
     for (uint32_t n = begin; n < end; n++) {
-        rays[n * 3 + 1] = (int)run;
+        rays[n * 3 + 1] = (int)(base + (n >= rot ? run - pr : total - pr + run));
         run += (uint32_t)rays[n * 3 + 2];
     }
     __syncthreads();   // every thread has read counter[0] before it is updated
@@ -618,16 +637,23 @@ int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t 
     return cn_launch_status();
 }
 
-int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
-                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears, const float *fars,
-                                 int32_t *rays, int32_t *counter, const float *noises, void *stream) {
+// budget = the caller's sample budget M (fixed-budget march: enables the overflow rotation of k_march_train_scan) or 0xFFFFFFFF
+static int rm_count_budget(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                           uint32_t C, uint32_t H, const float *nears, const float *fars, int32_t *rays, int32_t *counter, const float *noises,
+                           uint32_t budget, void *stream) {
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises) return CNERF_ENULL;
     hipLaunchKernelGGL(k_march_train_count_wave, dim3(cn_div_up(N, 4)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
                        C, H, nears, fars, rays, noises, (float2 *)nullptr);
-    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N, budget, noises);
     return cn_launch_status();
+}
+
+int cnerf_march_rays_train_count(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float *nears, const float *fars,
+                                 int32_t *rays, int32_t *counter, const float *noises, void *stream) {
+    return rm_count_budget(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, noises, 0xFFFFFFFFu, stream);
 }
 
 int cnerf_march_rays_train_count_hits(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
@@ -639,7 +665,7 @@ int cnerf_march_rays_train_count_hits(const float *rays_o, const float *rays_d, 
     if (((uintptr_t)hits) & 7) return CNERF_EINVAL;
     hipLaunchKernelGGL(k_march_train_count_wave, dim3(cn_div_up(N, 4)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
                        C, H, nears, fars, rays, noises, reinterpret_cast<float2 *>(hits));
-    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, CN_STREAM(stream), rays, counter, N, 0xFFFFFFFFu, noises);
     return cn_launch_status();
 }
 
@@ -671,7 +697,7 @@ int cnerf_march_rays_train_write(const float *rays_o, const float *rays_d, const
 int cnerf_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
                            uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
                            float *deltas, int32_t *rays, int32_t *counter, const float *noises, void *stream) {
-    int rc = cnerf_march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, noises, stream);
+    int rc = rm_count_budget(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, noises, M, stream);
     if (rc) return rc;
     return cnerf_march_rays_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
                                         noises, stream);

@@ -5,7 +5,8 @@ Deliberate differences:
   * the kernel-layout output [L,B,C] is also reachable (`forward(..., return_kernel_layout=True)`) so the fused field
     kernel can consume it without the permute+reshape copy of grid.py:63;
   * under autocast the fp16 table is a cached shadow copy refreshed only when the fp32 parameter changes (the
-    reference re-casts the whole table on every call, grid.py:45-46);
+    reference re-casts the whole table on every call, grid.py:45-46); the change is detected through the parameter's version
+    counter, so writes through `.data` must be followed by invalidate_half_table();
   * gradients are accumulated in float32 for both table dtypes (the reference scatters __half2 atomics for fp16).
 """
 import os
@@ -265,6 +266,7 @@ class GridEncoder(nn.Module):
     def reset_parameters(self):
         std = 1e-4                                                                # grid.py:144-146
         self.embeddings.data.uniform_(-std, std)
+        self.invalidate_half_table()                                              # a `.data` write does not move the version counter
 
     def __repr__(self):
         return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
@@ -283,6 +285,12 @@ class GridEncoder(nn.Module):
             check(lib.cnerf_cast_f32_to_f16(ptr(emb), ptr(self._half_table), emb.numel(), stream()), "cast_f32_to_f16")
             self._half_version = key
         return self._half_table
+
+    def invalidate_half_table(self):
+        """Force the next half-precision gather to re-cast the table.  The shadow is keyed on the parameter's autograd version counter,
+        which writes through `.data` do NOT move (reset_parameters, torch_ema's copy_to / restore, `param.data.copy_` in a drop-in
+        trainer): whoever writes the table that way calls this afterwards (load_checkpoint and reset_parameters do)."""
+        self._half_version = None
 
     def set_half_table(self, table, version_key=None):
         """Let a fused optimiser hand over the fp16 shadow it wrote while updating the parameter."""

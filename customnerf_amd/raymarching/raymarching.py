@@ -2,9 +2,12 @@
 `raymarching/raymarching.py` (cited per function), backed by libcustomnerf_hip.so through ctypes.
 
 Differences that are deliberate:
-  * march_rays_train lays samples out in ray order (deterministic) instead of atomics order, never allocates or
-    zero-fills the N*max_steps worst case, and synchronises with the host only to size its outputs (the reference does
-    the same `.item()` at raymarching.py:225);
+  * march_rays_train lays samples out in ray order (deterministic) instead of atomics order, never zero-fills the
+    N*max_steps worst case of xyzs / dirs / deltas, and synchronises with the host only to size its outputs (the reference
+    does the same `.item()` at raymarching.py:225).  The exact-size path keeps an UNINITIALISED per-device scratch of
+    N*max_steps*8 bytes for the occupied-probe list (capped at _HITS_MAX_BYTES, released when requests shrink; larger calls
+    re-march instead); in the fixed-budget path a call that overflows its budget drops a run of rays that starts at a
+    jitter-dependent ray (see cnerf_march_rays_train), not always the last image rows;
   * composite ops accept rgbs with 3 or 4 channels per sample (the 4th, confidence, is ignored) so the renderer can
     pass the field output without a slice copy;
   * there is no CPU path: tensors are moved to the GPU exactly like the reference does (raymarching.py:35-36).
@@ -83,13 +86,22 @@ def packbits(grid, thresh, bitfield=None):
 
 # ---------------------------------------------------------------------------------------------- training
 _HITS = {}
+_HITS_MAX_BYTES = 512 << 20          # above this the write pass re-marches (cnerf_march_rays_train_write) instead of keeping a probe list
 
 
 def _hits_scratch(N, max_steps, device):
-    """per-device scratch for the occupied-probe list of march_rays_train (grown on demand, never shrunk)"""
+    """Per-device scratch for the occupied-probe list of march_rays_train: N * max_steps (t, dt) pairs, uninitialised.  Grown on demand,
+    released when a request needs less than a quarter of what is held (one full-image call must not pin its worst case for the life of
+    the process), and never larger than _HITS_MAX_BYTES: returns None beyond that and the caller takes the re-marching writer."""
+    need = N * max_steps * 2
+    if need * 4 > _HITS_MAX_BYTES:
+        _HITS.pop(device, None)
+        return None
     buf = _HITS.get(device)
-    if buf is None or buf.numel() < N * max_steps * 2:
-        buf = _HITS[device] = torch.empty(N * max_steps * 2, dtype=torch.float32, device=device)
+    if buf is None or buf.numel() < need or buf.numel() > 4 * need:
+        _HITS.pop(device, None)
+        buf = None                                                  # drop the old block before asking for the new one
+        buf = _HITS[device] = torch.empty(need, dtype=torch.float32, device=device)
     return buf
 
 
@@ -133,10 +145,14 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     # the counting march records (t, dt) of every occupied probe: the write pass then needs no second march (hits: caller-owned scratch,
     # N x max_steps x 8 bytes, uninitialised; only the first num_steps entries of a ray's row are written and read)
     hits = _hits_scratch(N, int(max_steps), dev)
-    check(lib.cnerf_march_rays_train_count_hits(*args, ptr(nears), ptr(fars), ptr(rays), ptr(step_counter), ptr(noises), ptr(hits), stream()),
-          "march_rays_train_count_hits")
-    m = int(step_counter[0].item())            # D2H sync (same point as raymarching.py:225)
-    if base.item() != 0:
+    if hits is not None:
+        check(lib.cnerf_march_rays_train_count_hits(*args, ptr(nears), ptr(fars), ptr(rays), ptr(step_counter), ptr(noises), ptr(hits), stream()),
+              "march_rays_train_count_hits")
+    else:
+        check(lib.cnerf_march_rays_train_count(*args, ptr(nears), ptr(fars), ptr(rays), ptr(step_counter), ptr(noises), stream()),
+              "march_rays_train_count")
+    b0, m = torch.cat([base, step_counter[0:1]]).tolist()          # ONE D2H sync (same point as raymarching.py:225)
+    if b0 != 0:
         raise ValueError("march_rays_train: step_counter must be zeroed by the caller (renderer.py:619-620)")
     m_alloc = m + (align - m % align) if align > 0 else m
     m_alloc = min(m_alloc, N * int(max_steps))          # the reference slices a buffer of N * max_steps rows (raymarching.py:196,226-230)
@@ -145,9 +161,13 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     deltas = torch.empty(m_alloc, 2, dtype=torch.float32, device=dev)
     if m_alloc > m:
         xyzs[m:].zero_(); dirs[m:].zero_(); deltas[m:].zero_()
-    check(lib.cnerf_march_rays_train_write_hits(ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), m_alloc,
-                                                ptr(nears), ptr(noises), ptr(hits), ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), stream()),
-          "march_rays_train_write_hits")
+    if hits is not None:
+        check(lib.cnerf_march_rays_train_write_hits(ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), m_alloc,
+                                                    ptr(nears), ptr(noises), ptr(hits), ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), stream()),
+              "march_rays_train_write_hits")
+    else:
+        check(lib.cnerf_march_rays_train_write(*args, m_alloc, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(noises), stream()),
+              "march_rays_train_write")
     return xyzs, dirs, deltas, rays
 
 

@@ -20,9 +20,17 @@ def set_profile(records):
     _PROFILE = records
 
 
+_WS_RETIRED = []          # outgrown workspaces stay allocated: HIP graphs captured earlier (UNet.graphed) hold their addresses
+
+
 def _workspace(nbytes, device):
+    """Split-K scratch shared by all GEMM launches on `device`.  When a later GEMM needs more than the current buffer, the old one is
+    RETIRED, not freed: a captured graph replays its GEMM nodes with the pointer it was captured with, and a freed block would be
+    handed to some other tensor by the caching allocator while those replays keep writing partial sums into it."""
     buf = _WS.get(device)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
         _WS[device] = buf
     return buf

@@ -58,7 +58,9 @@ int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t 
 /* march_rays_train — raymarching.h:13, kernel raymarching.cu:311-480.
  * Same arguments as the reference binding.  Unlike the reference (atomics-ordered, nondeterministic slots) the
  * sample segments are laid out in RAY ORDER by an exclusive scan: rays[n] = (n, offset_n, num_steps_n).
- * counter[0] += total samples, counter[1] += N.  Rays with offset+num_steps > M are dropped (as :416).
+ * counter[0] += total samples, counter[1] += N.  Rays with offset+num_steps > M are dropped (as :416); a call that overflows its
+ * budget (counter[0] + total > M) starts the scan at ray floor(noises[0] * N) and wraps, so that the dropped rays move with the
+ * per-call jitter draw instead of always being the highest-numbered ones (the reference drops in atomics arrival order).
  * xyzs/dirs [M,3], deltas [M,2], rays [N,3] int32, counter [2] int32, noises [N]. */
 int cnerf_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,

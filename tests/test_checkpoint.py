@@ -53,3 +53,47 @@ def test_checkpoint_reference_style_inputs(tmp_path):
     bad = {'model': dict(sd, **{"pos_en.embeddings": torch.zeros(10, 2)})}
     with pytest.raises(ValueError):
         ck.load_checkpoint(_model(), bad)
+
+
+def test_full_checkpoint_carries_lr_scheduler_and_ema(tmp_path):
+    """the optional entries of the reference's `full` checkpoint (utils_init_nerf.py:794-800) and their restore (:862-894)"""
+    from customnerf_amd import checkpoint as ck
+
+    class Ema:                                                      # torch_ema's interface: state_dict / load_state_dict
+        def __init__(self, v):
+            self.v = v
+
+        def state_dict(self):
+            return {'decay': 0.95, 'shadow_params': [self.v.clone()]}
+
+        def load_state_dict(self, sd):
+            self.v = sd['shadow_params'][0].clone()
+
+    m = _model()
+    opt = torch.optim.Adam(m.get_params(1e-3), betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / 100, 1))          # main.py:189
+    for _ in range(5):
+        opt.step(); sched.step()
+    ema = Ema(torch.arange(4.0))
+    path = ck.save_checkpoint(str(tmp_path / "df_ep0001.pth"), m, epoch=1, global_step=5, optimizer=opt, full=True, lr_scheduler=sched, ema=ema)
+    raw = torch.load(path, weights_only=False)
+    assert {'optimizer', 'lr_scheduler', 'ema'} <= set(raw) and 'scaler' not in raw
+    m2 = _model()
+    opt2 = torch.optim.Adam(m2.get_params(1e-3), betas=(0.9, 0.99), eps=1e-15)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lambda it: 0.1 ** min(it / 100, 1))
+    ema2 = Ema(torch.zeros(4))
+    ck.load_checkpoint(m2, path, optimizer=opt2, lr_scheduler=sched2, ema=ema2)
+    assert sched2.last_epoch == sched.last_epoch == 5 and torch.equal(ema2.v, torch.arange(4.0))
+
+
+def test_half_table_invalidation_hooks():
+    """`.data` writes do not move the version counter the fp16 shadow is keyed on: reset_parameters() and load_checkpoint() invalidate it"""
+    from customnerf_amd import checkpoint as ck
+    m = _model()
+    enc = m.pos_en
+    enc._half_version = ("stale",)
+    enc.reset_parameters()
+    assert enc._half_version is None
+    enc._half_version = ("stale",)
+    ck.load_checkpoint(m, {'model': m.state_dict()}, model_only=True, log=lambda *_: None)
+    assert enc._half_version is None

@@ -252,3 +252,47 @@ def test_linear_fused_geglu(M, C):
     y = ops.linear(x.half().cuda(), wi.half().cuda(), bias=bi.cuda(), act=ops.ACT_GEGLU)
     assert y.shape == (M, 4 * C)
     close(y, a * F.gelu(gate), 3e-3, 3e-3)
+
+
+def test_splitk_workspace_outgrown_after_graph_capture():
+    """A captured graph keeps the split-K workspace pointer it was captured with (UNet.graphed).  When a later, larger GEMM outgrows
+    the shared workspace, the old buffer must stay allocated: otherwise the caching allocator hands its block to another tensor and
+    the replay's split-K partial sums land in that tensor (and eps itself is summed from whatever the other owner wrote)."""
+    from customnerf_amd.sd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 128, 1280, 11520                              # a split-K shape (test_linear covers its numerics)
+    x = h(torch.randn(M, K, generator=g)).half().cuda()
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    saved = ops._WS.pop(dev, None)
+    try:
+        ops._WS[dev] = torch.empty(32 << 20, dtype=torch.uint8, device=dev)       # small enough to be outgrown below
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ops.linear(x, w, out=out)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ops.linear(x, w, out=out)
+        graph.replay()
+        torch.cuda.synchronize()
+        first = out.clone()
+        old = ops._WS[dev]
+        old_ptr, old_bytes = old.data_ptr(), old.numel()
+        del old
+        grown = ops._workspace(old_bytes + (16 << 20), dev)                       # what a larger post-capture GEMM does
+        assert grown.data_ptr() != old_ptr
+        assert any(b.data_ptr() == old_ptr for b in ops._WS_RETIRED), "the outgrown workspace must be kept alive"
+        # anything allocated now must not alias the retired block; poison fresh allocations of the same size class and replay
+        poison = [torch.full((old_bytes,), 0x7f, dtype=torch.uint8, device=dev) for _ in range(2)]
+        assert all(p.data_ptr() != old_ptr for p in poison)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+        assert all(bool((p == 0x7f).all()) for p in poison), "a graph replay wrote into memory it no longer owns"
+    finally:
+        if saved is not None:
+            ops._WS[dev] = saved
