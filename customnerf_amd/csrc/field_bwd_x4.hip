@@ -610,52 +610,397 @@ __global__ void __launch_bounds__(FLD_THREADS, 2) k_field_bwd_x4(const void *__r
     }
 }
 
+// ================================================================================================ two-pipeline form
+// The four-role kernel above keeps ONE tile in flight per CU and its chain waves are latency-bound (one wave per SIMD: every layer is an LDS
+// round trip plus a dependent conversion pass; measured 4.5 k cycles per tile on the critical wave against 1.5 k cycles of MFMA issue).
+// This form goes back to two producer/consumer pairs per workgroup — two tiles per phase — and keeps the weight gradients in the chain
+// waves themselves: with the 512-register budget their 24 persistent accumulator tiles live in accumulation registers, which only MFMAs
+// ever touch (no v_accvgpr traffic for them), and their operands come from WAVE-LOCAL images: each wave publishes its activation / gradient
+// fragments to its own LDS scratch and reads them back through ds_read_b64_tr_b16 (DS operations of one wave execute in order, so no
+// barrier and no double buffering).  Only fea and dz_3 cross between the two waves of a pair.  The independent dW MFMAs fill the issue
+// slots that the chain's dependent load -> MFMA -> convert sequence leaves empty.
+#define X2_FEA 0                              // 2 x 4 KiB, A -> B
+#define X2_Z3 (2 * 4 * X4_K)                  // 2 x 4 KiB, B -> A
+#define X2_A (X2_Z3 + 2 * 4 * X4_K)           // wave A's images: x0 2, h1 4, h2 4, z2 4, z1 4 KiB
+#define X2_A_X0 0
+#define X2_A_H1 (2 * X4_K)
+#define X2_A_H2 (6 * X4_K)
+#define X2_A_Z2 (10 * X4_K)
+#define X2_A_Z1 (14 * X4_K)
+#define X2_B (X2_A + 18 * X4_K)               // wave B's images: hd 4, hr 4, dir 2, zr 4, zd 4, bro 2, bdo 2 KiB
+#define X2_B_HD 0
+#define X2_B_HR (4 * X4_K)
+#define X2_B_DIR (8 * X4_K)
+#define X2_B_ZR (10 * X4_K)
+#define X2_B_ZD (14 * X4_K)
+#define X2_B_BRO (18 * X4_K)
+#define X2_B_BDO (20 * X4_K)
+#define X2_PAIR_BYTES (X2_B + 22 * X4_K)      // 56 KiB per pair
+
+template <int NGEO>
+__global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
+                                                              uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
+                                                              const float *__restrict__ pden, const float *__restrict__ prgb,
+                                                              const float *__restrict__ g_sigma, const float *__restrict__ g_rgbc,
+                                                              void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate) {
+    constexpr bool H = true;
+    constexpr int SENC = 2;                                   // enc_pad == 32
+    using PR = Prec<H>;
+    using frag_t = typename PR::frag_t;
+    using elem_t = typename PR::elem_t;
+    __shared__ __attribute__((aligned(16))) elem_t x2_w[FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fld_lds[];
+    elem_t *wl = x2_w;
+    const FieldLds lo = fld_lds_layout<H>(dm);
+    const MmOff po = x4_offsets(dm);
+
+    constexpr uint32_t S64 = FLD_HID / PR::KS, SDIR = FLD_DIR / PR::KS, SR0 = S64 + SDIR;
+    const uint32_t in_r0 = FLD_HID + FLD_DIR;
+    const float *n0 = pnet, *n1 = pnet + FLD_HID * dm.enc_pad;
+    const float *n2 = n1 + (NGEO == 2 ? FLD_HID * FLD_HID : 0);
+    const float *d0 = pden, *dO = pden + FLD_HID * FLD_HID;
+    const float *r0 = prgb, *rO = prgb + FLD_HID * in_r0;
+
+    fb_stage_layer<H, 0>(wl + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, SENC, dm.enc_pad);
+    if (NGEO == 2) fb_stage_layer<H, 1>(wl + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1>(wl + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1>(wl + lo.off[3], d0, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1>(wl + lo.off[4], dO, 16, FLD_HID, 1, S64, FLD_HID);
+    fb_stage_layer<H, 2>(wl + lo.off[5], r0, FLD_HID, in_r0, 2, SR0, in_r0);
+    fb_stage_layer<H, 1>(wl + lo.off[6], rO, 16, FLD_HID, 1, S64, FLD_HID);
+    // the second K-step of the output-gradient images (features 16..31 of their padded 32-row tile) is never written: zero it once
+    for (uint32_t i = threadIdx.x; i < 2 * 2 * (X4_K / 4); i += FLD_THREADS) {
+        const uint32_t pr_ = i / (2 * (X4_K / 4)), w = i % (2 * (X4_K / 4));
+        const uint32_t which = w / (X4_K / 4), k = w % (X4_K / 4);
+        reinterpret_cast<uint32_t *>(fld_lds + pr_ * X2_PAIR_BYTES + X2_B + (which ? X2_B_BDO : X2_B_BRO) + X4_K)[k] = 0u;
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = wave & 1;
+    unsigned char *xch = fld_lds + pair * X2_PAIR_BYTES;
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(x2_w);
+    unsigned long long tw_ = 0, tb_ = 0;
+    const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
+    const uint32_t G = gridDim.x * 2, gp = blockIdx.x * 2 + pair;                   // tile pipelines of the whole launch / this one
+    const uint32_t n_iter = (n_tiles + G - 1) / G;                                  // workgroup-uniform: same barrier count for every wave
+    const uint32_t n_phase = (n_iter + 3) & ~1u;                                    // n_iter + 2 phases drain the pipeline; even: unrolled by two
+    float *part = partials + (size_t)gp * po.total;
+    const uint32_t off_n0 = lo.off[0] * 2, off_n1 = lo.off[1] * 2, off_n2 = lo.off[2] * 2, off_d0 = lo.off[3] * 2, off_dO = lo.off[4] * 2,
+                   off_r0 = lo.off[5] * 2, off_rO = lo.off[6] * 2;
+    const uint32_t lw = x4_lane_off_w(lane, false), lwn = x4_lane_off_w(lane, true);
+    const uint32_t lc = x4_lane_off_img(lane, false), ln = x4_lane_off_img(lane, true);
+
+    if (role == 0) {
+        // ======================================================================== wave A: geometry network + dW_n2 / n1 / n0
+        cn_f16v wn2[2][2], wn1[2][2], wn0[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            x4_zero(wn0[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) { x4_zero(wn2[a][b]); x4_zero(wn1[a][b]); }
+        }
+        struct ASet { frag_t x0[SENC], h1[4], h2[4]; uint32_t p; bool v; };
+        ASet S0, S1;                                          // activations of the tiles with even / odd phase index (forward at p, backward at p+2)
+#pragma unroll
+        for (int s = 0; s < SENC; s++) S0.x0[s] = S1.x0[s] = PR::zero();
+#pragma unroll
+        for (int s = 0; s < 4; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = PR::zero();
+        S0.p = S1.p = 0; S0.v = S1.v = false;
+        frag_t N0[SENC], N1[SENC];                            // grid features requested one phase ahead (even / odd tiles)
+        x4_enc_request<SENC>(enc, P_, dm.L, gp * FLD_TILE + li, hi, N0);
+#pragma unroll
+        for (int s = 0; s < SENC; s++) N1[s] = PR::zero();
+        unsigned char *my = xch + X2_A;
+        auto phase = [&](uint32_t p, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC]) __attribute__((always_inline)) {
+            X4_T0();
+            asm volatile("" ::: "memory");
+            x4_enc_request<SENC>(enc, P_, dm.L, (gp + (p + 1) * G) * FLD_TILE + li, hi, xnext);
+            // ---- backward of tile p-2 (dz_3 was published by wave B in phase p-1); S still holds that tile
+            if (p >= 2 && p - 2 < n_iter && !(ablate & 1)) {
+                const unsigned char *z3i = xch + X2_Z3 + ((p - 2) & 1) * 4 * X4_K;
+                frag_t z3[4];
+                x4_fetch<4>(z3i, lane, z3);
+                x4_publish<SENC>(my + X2_A_X0, lane, S.x0);
+                x4_publish<4>(my + X2_A_H1, lane, S.h1);
+                if (NGEO == 2) x4_publish<4>(my + X2_A_H2, lane, S.h2);
+                cn_f16v acc[2];
+                fb_zero(acc);
+                x4_gemm_T<2, S64, S64>(wb + off_n2, lw, z3, acc);
+                {   // dW_n2 = dz3 . hlast^T
+                    const unsigned char *hl = my + ((NGEO == 2) ? X2_A_H2 : X2_A_H1);
+                    cn_h8 z[2][2], a[2][2];
+                    x4_load_block(z3i, lc, 0, z[0]); x4_load_block(z3i, lc, 1, z[1]);
+                    x4_load_block(hl, lc, 0, a[0]); x4_load_block(hl, lc, 1, a[1]);
+                    x4_dw(wn2[0][0], z[0], a[0]); x4_dw(wn2[0][1], z[0], a[1]); x4_dw(wn2[1][0], z[1], a[0]); x4_dw(wn2[1][1], z[1], a[1]);
+                }
+                frag_t z1[4];
+                if (NGEO == 2) {
+                    frag_t z2[4];
+                    x4_c_to_b_masked(acc, S.h2, z2);
+                    x4_publish<4>(my + X2_A_Z2, lane, z2);
+                    fb_zero(acc);
+                    x4_gemm_T<2, S64, S64>(wb + off_n1, lw, z2, acc);
+                    cn_h8 z[2][2], a[2][2];
+                    x4_load_block(my + X2_A_Z2, lc, 0, z[0]); x4_load_block(my + X2_A_Z2, lc, 1, z[1]);
+                    x4_load_block(my + X2_A_H1, lc, 0, a[0]); x4_load_block(my + X2_A_H1, lc, 1, a[1]);
+                    x4_dw(wn1[0][0], z[0], a[0]); x4_dw(wn1[0][1], z[0], a[1]); x4_dw(wn1[1][0], z[1], a[0]); x4_dw(wn1[1][1], z[1], a[1]);
+                }
+                x4_c_to_b_masked(acc, S.h1, z1);
+                x4_publish<4>(my + X2_A_Z1, lane, z1);
+                cn_f16v denc[1];
+                fb_zero(denc);
+                x4_gemm_T<1, S64, SENC>(wb + off_n0, lwn, z1, denc);
+                {
+                    cn_h8 z[2][2], a[2];
+                    x4_load_block(my + X2_A_Z1, lc, 0, z[0]); x4_load_block(my + X2_A_Z1, lc, 1, z[1]);
+                    x4_load_block(my + X2_A_X0, ln, 0, a);
+                    x4_dw(wn0[0], z[0], a); x4_dw(wn0[1], z[1], a);
+                }
+                if (S.v) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const uint32_t level = (uint32_t)fld_rho(r, (int)hi) >> 1;
+                        if (level < dm.L) {
+                            union { cn_h2 h; uint32_t u; } v;
+                            v.h = cn_h2{(_Float16)denc[0][r], (_Float16)denc[0][r + 1]};
+                            reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + S.p] = v.u;
+                        }
+                    }
+                }
+            }
+            // ---- forward of tile p (overwrites S)
+            if (p < n_iter && !(ablate & 2)) {
+                const uint32_t tile = gp + p * G;
+                S.p = tile * FLD_TILE + li;
+                S.v = S.p < P_;
+                x4_enc_mask<SENC>(xcur, dm.L, S.v, hi, S.x0);
+                cn_f16v acc[2];
+                fb_zero(acc);
+                x4_gemm<2, SENC>(wl + lo.off[0], SENC, 0, S.x0, lane, acc);
+                x4_c_to_b<true>(acc, S.h1);
+                if (NGEO == 2) {
+                    fb_zero(acc);
+                    x4_gemm<2, S64>(wl + lo.off[1], S64, 0, S.h1, lane, acc);
+                    x4_c_to_b<true>(acc, S.h2);
+                }
+                frag_t fea[4];
+                fb_zero(acc);
+                x4_gemm<2, S64>(wl + lo.off[2], S64, 0, (NGEO == 2) ? S.h2 : S.h1, lane, acc);
+                x4_c_to_b<false>(acc, fea);
+                x4_publish<4>(xch + X2_FEA + (p & 1) * 4 * X4_K, lane, fea);
+            } else {
+                S.v = false;
+            }
+            X4_T1();
+        };
+        for (uint32_t p = 0; p < n_phase; p += 2) {
+            phase(p, S0, N0, N1);
+            phase(p + 1, S1, N1, N0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            x4_store(part, po.n0, dm.enc_pad, 0, 64, dm.enc_pad, a, 0, li, hi, wn0[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                x4_store(part, po.n2, 64, 0, 64, 64, a, b, li, hi, wn2[a][b]);
+                if (NGEO == 2) x4_store(part, po.n1, 64, 0, 64, 64, a, b, li, hi, wn1[a][b]);
+            }
+        }
+    } else {
+        // ======================================================================== wave B: density and colour heads (tile p-1 in phase p) + their dW
+        cn_f16v wro[2], wrd[2], wrf[2][2], wdo[2], wd0[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            x4_zero(wro[a]); x4_zero(wrd[a]); x4_zero(wdo[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) { x4_zero(wrf[a][b]); x4_zero(wd0[a][b]); }
+        }
+        // per-sample inputs, requested unconditionally (clamped index) and masked at use: see x4_enc_request
+        struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; };
+        auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
+            BIn r;
+            const uint32_t p = min(tile * FLD_TILE + li, P_ - 1);
+            r.x = xyz[(size_t)p * 3]; r.y = xyz[(size_t)p * 3 + 1]; r.z = xyz[(size_t)p * 3 + 2];
+            r.gs = g_sigma[p];
+            r.gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
+            const float *dp = dirs + (size_t)(p / dir_group) * 3;
+            r.dx = dp[0]; r.dy = dp[1]; r.dz = dp[2];
+            return r;
+        };
+        BIn I0 = load_in(gp), I1 = I0;
+        unsigned char *my = xch + X2_B;
+        auto phase = [&](uint32_t p, const BIn &cur, BIn &nxt) __attribute__((always_inline)) {
+            X4_T0();
+            asm volatile("" ::: "memory");
+            if (p >= 1) nxt = load_in(gp + p * G);
+            if (p >= 1 && p - 1 < n_iter && !(ablate & 4)) {
+                const uint32_t i = p - 1;
+                const uint32_t tile = gp + i * G;
+                const bool valid = tile * FLD_TILE + li < P_;
+                const unsigned char *fe = xch + X2_FEA + (i & 1) * 4 * X4_K;
+                frag_t fea[4], dfr[SDIR];
+                x4_fetch<4>(fe, lane, fea);
+                fb_dir_frags_from<H>(cur.dx, cur.dy, cur.dz, valid, hi, dfr);
+                x4_publish<SDIR>(my + X2_B_DIR, lane, dfr);
+                // ---- forward of both heads
+                cn_f16v acc[2], out[1];
+                frag_t hd[4], hr[4];
+                fb_zero(acc);
+                x4_gemm<2, S64>(wl + lo.off[3], S64, 0, fea, lane, acc);
+                x4_c_to_b<true>(acc, hd);
+                x4_publish<4>(my + X2_B_HD, lane, hd);
+                fb_zero(out);
+                x4_gemm<1, S64>(wl + lo.off[4], S64, 0, hd, lane, out);
+                const float raw = (float)(_Float16)out[0][0];
+                fb_zero(acc);
+                x4_gemm<2, S64>(wl + lo.off[5], SR0, 0, fea, lane, acc);
+                x4_gemm<2, SDIR>(wl + lo.off[5], SR0, S64, dfr, lane, acc);
+                x4_c_to_b<true>(acc, hr);
+                x4_publish<4>(my + X2_B_HR, lane, hr);
+                fb_zero(out);
+                x4_gemm<1, S64>(wl + lo.off[6], S64, 0, hr, lane, out);
+                // ---- output-layer gradients (sigmoid', clamped exp': provider_utils.py:26-29)
+                frag_t bro[1], bdo[1];
+                {
+                    cn_h8 f = PR::zero(), g = PR::zero();
+                    if (valid && hi == 0) {
+                        const float x = cur.x, y = cur.y, z = cur.z;
+                        const float gg = 5.0f * __expf(-(x * x + y * y + z * z) * (1.0f / 0.08f));
+                        g[0] = (_Float16)(cur.gs * __expf(fminf(fmaxf(raw + gg, -15.0f), 15.0f)));
+                        const float gcv[4] = {cur.gc.x, cur.gc.y, cur.gc.z, cur.gc.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float sg = (float)(_Float16)__builtin_amdgcn_rcpf(1.0f + __expf(-out[0][k]));
+                            f[k] = (_Float16)((k < (int)dm.n_rgb_out) ? gcv[k] * sg * (1.0f - sg) : 0.0f);
+                        }
+                    }
+                    bro[0] = f; bdo[0] = g;
+                }
+                x4_publish<1>(my + X2_B_BRO, lane, bro);
+                x4_publish<1>(my + X2_B_BDO, lane, bdo);
+                cn_f16v dfea[2];
+                fb_zero(dfea);
+                // ---- colour head
+                {
+                    frag_t zr[4];
+                    fb_zero(acc);
+                    x4_gemm_T<2, 1, S64>(wb + off_rO, lw, bro, acc);
+                    x4_c_to_b_masked(acc, hr, zr);
+                    x4_publish<4>(my + X2_B_ZR, lane, zr);
+                    x4_gemm_T<2, S64, SR0>(wb + off_r0, lw, zr, dfea);
+                }
+                cn_h8 fa[2][2];                                                    // fea^T: second operand of dW_r0 (fea part) and dW_d0
+                x4_load_block(fe, lc, 0, fa[0]); x4_load_block(fe, lc, 1, fa[1]);
+                {   // dW_rO = d(out) . hr^T, dW_r0 = dz_r . [dir | fea]^T
+                    cn_h8 zo[2], z[2][2], a[2][2], d[2];
+                    x4_load_block(my + X2_B_BRO, lc, 0, zo);
+                    x4_load_block(my + X2_B_HR, lc, 0, a[0]); x4_load_block(my + X2_B_HR, lc, 1, a[1]);
+                    x4_dw(wro[0], zo, a[0]); x4_dw(wro[1], zo, a[1]);
+                    x4_load_block(my + X2_B_ZR, lc, 0, z[0]); x4_load_block(my + X2_B_ZR, lc, 1, z[1]);
+                    x4_load_block(my + X2_B_DIR, ln, 0, d);
+                    x4_dw(wrd[0], z[0], d); x4_dw(wrd[1], z[1], d);
+                    x4_dw(wrf[0][0], z[0], fa[0]); x4_dw(wrf[0][1], z[0], fa[1]); x4_dw(wrf[1][0], z[1], fa[0]); x4_dw(wrf[1][1], z[1], fa[1]);
+                }
+                // ---- density head
+                {
+                    frag_t zd[4];
+                    fb_zero(acc);
+                    x4_gemm_T<2, 1, S64>(wb + off_dO, lw, bdo, acc);
+                    x4_c_to_b_masked(acc, hd, zd);
+                    x4_publish<4>(my + X2_B_ZD, lane, zd);
+                    x4_gemm_T<2, S64, S64>(wb + off_d0, lw, zd, dfea);
+                }
+                {   // dW_dO = d(raw) . hd^T, dW_d0 = dz_d . fea^T
+                    cn_h8 zo[2], z[2][2], a[2][2];
+                    x4_load_block(my + X2_B_BDO, lc, 0, zo);
+                    x4_load_block(my + X2_B_HD, lc, 0, a[0]); x4_load_block(my + X2_B_HD, lc, 1, a[1]);
+                    x4_dw(wdo[0], zo, a[0]); x4_dw(wdo[1], zo, a[1]);
+                    x4_load_block(my + X2_B_ZD, lc, 0, z[0]); x4_load_block(my + X2_B_ZD, lc, 1, z[1]);
+                    x4_dw(wd0[0][0], z[0], fa[0]); x4_dw(wd0[0][1], z[0], fa[1]); x4_dw(wd0[1][0], z[1], fa[0]); x4_dw(wd0[1][1], z[1], fa[1]);
+                }
+                frag_t z3[4];
+                x4_c_to_b<false>(dfea, z3);
+                x4_publish<4>(xch + X2_Z3 + (i & 1) * 4 * X4_K, lane, z3);
+            }
+            X4_T1();
+        };
+        for (uint32_t p = 0; p < n_phase; p += 2) {
+            phase(p, I1, I0);
+            phase(p + 1, I0, I1);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            x4_store(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, li, hi, wro[b]);
+            x4_store(part, po.dO, 64, 0, 1, 64, 0, b, li, hi, wdo[b]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            x4_store(part, po.r0, 96, 0, 64, FLD_NDIR, a, 0, li, hi, wrd[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                x4_store(part, po.r0, 96, FLD_NDIR, 64, 64, a, b, li, hi, wrf[a][b]);
+                x4_store(part, po.d0, 64, 0, 64, 64, a, b, li, hi, wd0[a][b]);
+            }
+        }
+    }
+    if ((ablate & 32) && lane == 0) {
+        unsigned long long *tt = reinterpret_cast<unsigned long long *>(partials + (size_t)530 * po.total) + ((size_t)blockIdx.x * 4 + wave) * 2;
+        tt[0] = tw_; tt[1] = tb_;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host entry (called from field_bwd_fused.hip)
 void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
                         hipStream_t st);
 
-bool x4_eligible(const FieldDims &dm) {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("CNERF_FIELD_X4_BWD");
-        on = e ? atoi(e) : 1;
+static int x4_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CNERF_FIELD_X4_BWD");            // 2 (default): two-pipeline kernel; 4: four-role kernel; 0: the round-1 kernels
+        v = e ? atoi(e) : 2;
     }
-    return on && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2);
+    return v;
 }
+bool x4_eligible(const FieldDims &dm) { return x4_variant() != 0 && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2); }
 
 int x4_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
               uint32_t max_partials, hipStream_t st) {
     const FieldLds lo = fld_lds_layout<true>(dm);
-    const uint32_t lds_bytes = X4_XCH_BYTES;                    // dynamic part; the weight fragments are a 48 KiB static array
     if (lo.off[7] > FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID) return CNERF_EINVAL;
+    const bool two = x4_variant() == 2;
+    const uint32_t lds_bytes = two ? 2 * X2_PAIR_BYTES : X4_XCH_BYTES;          // dynamic part; the weight fragments are a 48 KiB static array
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
-    uint32_t blocks = n_tiles;
-    if (blocks > max_partials) blocks = max_partials;
+    uint32_t blocks = two ? cn_div_up(n_tiles, 2) : n_tiles;
+    const uint32_t per_block = two ? 2 : 1;                                     // partial-gradient rows per workgroup
+    if (blocks > max_partials / per_block) blocks = max_partials / per_block;
     if (blocks > 256) blocks = 256;
     const MmOff po = x4_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
     // the partial rows are only written where a layer has rows / columns: zero the rows in use (padding entries stay 0)
-    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)blocks * po.total * sizeof(float), st);
+    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)blocks * per_block * po.total * sizeof(float), st);
     if (e0 != hipSuccess) return (int)e0;
     static int ablate = -1;
     if (ablate < 0) {
-        const char *e = getenv("CNERF_X4_ABLATE");             // measurement aid: bit 0 A-bwd, 1 A-fwd, 2 B, 3 C, 4 D switched off (results wrong)
+        const char *e = getenv("CNERF_X4_ABLATE");             // measurement aid: bit 0 A-bwd, 1 A-fwd, 2 B, 3 C, 4 D switched off (results wrong), 5 timing
         ablate = e ? atoi(e) : 0;
     }
-    if (dm.n_hidden_geo == 2) {
-        auto kern = k_field_bwd_x4<2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc,
-                           partials, (uint32_t)ablate);
+#define X4_LAUNCH(KERN)                                                                                                                    \
+    {                                                                                                                                      \
+        auto kern = KERN;                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
+                           grad_enc, partials, (uint32_t)ablate);                                                                          \
+    }
+    if (two) {
+        if (dm.n_hidden_geo == 2) X4_LAUNCH(k_field_bwd_x2<2>) else X4_LAUNCH(k_field_bwd_x2<1>)
     } else {
-        auto kern = k_field_bwd_x4<1>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc,
-                           partials, (uint32_t)ablate);
+        if (dm.n_hidden_geo == 2) X4_LAUNCH(k_field_bwd_x4<2>) else X4_LAUNCH(k_field_bwd_x4<1>)
     }
     int rc = cn_launch_status();
     if (rc) return rc;
-    ff_reduce_partials(partials, blocks, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
+    ff_reduce_partials(partials, blocks * per_block, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
     return cn_launch_status();
 }

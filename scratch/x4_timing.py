@@ -26,7 +26,9 @@ for it in range(3):
 print("backward ms", t0.elapsed_time(t1))
 ws = fmod._WS[xs.device]
 total = 64 * 32 + 4096 * 3 + 1024 + 64 * 96 + 1024
-tt = ws[300 * total * 4: 300 * total * 4 + 256 * 4 * 2 * 8].view(torch.int64).view(256, 4, 2).cpu().numpy()
-n_phase = (P // 32 // 256 + 4) & ~1
-for r, name in enumerate("ABCD"):
+two = os.environ.get("CNERF_FIELD_X4_BWD", "2") == "2"
+row = 530 if two else 300
+tt = ws[row * total * 4: row * total * 4 + 256 * 4 * 2 * 8].view(torch.int64).view(256, 4, 2).cpu().numpy()
+n_phase = ((P // 32 // 512 + 3) & ~1) if two else ((P // 32 // 256 + 4) & ~1)
+for r, name in enumerate(["A0", "B0", "A1", "B1"] if two else "ABCD"):
     print(name, "work cycles/phase %.0f  barrier wait/phase %.0f" % (tt[:, r, 0].mean() / n_phase, tt[:, r, 1].mean() / n_phase))
