@@ -181,6 +181,8 @@ __global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     constexpr uint32_t S64 = FLD_HID / PR::KS, SDIR = FLD_DIR / PR::KS;
     const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
+    unsigned char *dir_scratch = fld_lds + lo.off[7] * sizeof(typename PR::elem_t) + wave * 64;       // 64 B per wave (fld_dir_frags_uniform)
+    const bool dir_uniform = H && (dir_group % FLD_TILE) == 0;
     for (uint32_t tile = blockIdx.x * FLD_WAVES + wave; tile < n_tiles; tile += gridDim.x * FLD_WAVES) {
         // keep the weight fragments in LDS: without this barrier the compiler hoists every fragment load out of the
         // persistent loop (hundreds of VGPRs, one wave per SIMD, spills in the backward)
@@ -217,13 +219,24 @@ __global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void
             float raw = out[0][0];                // row 0 of the padded 16-row output
             if (H) raw = fld_round_half(raw);
             const float x = xyz[(size_t)p * 3], y = xyz[(size_t)p * 3 + 1], z = xyz[(size_t)p * 3 + 2];
-            const float g = 5.0f * expf(-(x * x + y * y + z * z) / 0.08f);          // network_grid.py:150-156
-            sigma[p] = expf(raw + g);                                                 // trunc_exp forward (provider_utils.py:20-22)
+            // fp16 mode: the hardware exponential (v_exp_f32, ~1 ulp + the rounding of the log2(e) product: relative error < 2e-6 at |x| <= 25,
+            // far below the 1e-3 resolution of the half-precision `raw` it is applied to); float32 mode keeps the libm forms
+            const float g = H ? 5.0f * __expf(-(x * x + y * y + z * z) * (1.0f / 0.08f)) : 5.0f * expf(-(x * x + y * y + z * z) / 0.08f);   // network_grid.py:150-156
+            sigma[p] = H ? __expf(raw + g) : expf(raw + g);                           // trunc_exp forward (provider_utils.py:20-22)
         }
 
         if (with_rgb) {
             frag_t dfr[SDIR];
-            fld_dir_frags<H>(dirs, dir_group, p, valid, hi, dfr);
+            if constexpr (H) {
+                if (dir_uniform) {
+                    const float *dp = dirs + (size_t)(__builtin_amdgcn_readfirstlane(tile) * FLD_TILE / dir_group) * 3;      // one direction per tile
+                    fld_dir_frags_uniform(dp[0], dp[1], dp[2], lane, hi, dir_scratch, dfr);
+                } else {
+                    fld_dir_frags<H>(dirs, dir_group, p, valid, hi, dfr);
+                }
+            } else {
+                fld_dir_frags<H>(dirs, dir_group, p, valid, hi, dfr);
+            }
             constexpr uint32_t SR0 = S64 + SDIR;
             fld_zero(acc);
             fld_gemm<H, 2, S64>(wl + lo.off[5], SR0, 0, fea, lane, acc);
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void
                 float o4[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    float v = 1.0f / (1.0f + expf(-out[0][k]));
+                    float v = H ? __builtin_amdgcn_rcpf(1.0f + __expf(-out[0][k])) : 1.0f / (1.0f + expf(-out[0][k]));
                     if (H) v = fld_round_half(v);
                     o4[k] = (k < (int)dm.n_rgb_out) ? v : 0.0f;
                 }
@@ -250,7 +263,7 @@ template <bool H>
 static int fld_launch_fwd(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm,
                           const float *pnet, const float *pden, const float *prgb, float *sigma, float *rgbc, hipStream_t st, uint32_t enc_stride) {
     const FieldLds lo = fld_lds_layout<H>(dm);
-    const uint32_t lds_bytes = lo.off[7] * sizeof(typename Prec<H>::elem_t);
+    const uint32_t lds_bytes = lo.off[7] * sizeof(typename Prec<H>::elem_t) + FLD_WAVES * 64;       // weight fragments + per-wave direction scratch
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
     uint32_t blocks = cn_div_up(n_tiles, FLD_WAVES);
     const uint32_t max_blocks = H ? 768 : 256;            // persistent: LDS allows 3 (fp16) / 1 (fp32) workgroups per CU

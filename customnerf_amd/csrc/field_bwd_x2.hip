@@ -1,24 +1,18 @@
-// Fused field backward, four-role form (gfx950, fp16, enc_pad == 32) — the default backward of the fused field.
+// Fused field backward for gfx950 (fp16, enc_pad == 32) — the default backward of the fused field: k_field_bwd_x2.
 //
-// What was wrong with the two-role kernel (field_bwd_mma.hip): it needs 508 registers per lane, and with a register budget above 256 the
-// compiler selects the accumulation-register form of every MFMA, so each value of every layer output costs a v_accvgpr_read before the
-// vector ALU may touch it; together with the identity-MFMA transposes and their repacking the kernel issued ~13 vector instructions per
-// MFMA and was bound by the vector ALU (48 % of its cycles; the matrix pipe 28 %) — PMC passes of round 2, profiles/r02_*.
-//
-// Here every wave stays below 256 registers (launch bound: two waves per SIMD => VGPR-destination MFMAs, no accumulation-register moves)
-// and the weight-gradient products dW = dz . a^T — which need the SAMPLES along the MFMA contraction index, i.e. every operand transposed
-// with respect to how the activation chain holds it (lane = sample) — are fed by the LDS transposing read of CDNA4, ds_read_b64_tr_b16:
-// the chain waves publish their activation / gradient fragments to LDS exactly as they hold them (16-byte lane-linear stores), and the
-// weight-gradient waves read them back with the samples on the K slots.  No identity MFMAs, no repacking, and the transposed copy of the
-// weights is gone too: the W^T fragments of the data-gradient chain are transposing reads of the forward fragment store.
-//
-// Four waves per workgroup, one 32-sample tile per phase, one workgroup barrier per phase, software-pipelined:
-//   phase p   wave A (net)    forward of the geometry MLP for tile p (publishes fea), then dz_3 -> dz_1 and d(loss)/d(grid features) for tile p-2
-//             wave B (heads)  density + colour heads of tile p-1, forward and backward (publishes dz_3 = d(loss)/d(fea))
-//             wave C (dW)     dW_n2, dW_n1, dW_n0 for tile p-3 and dW_dO for tile p-2
-//             wave D (dW)     dW_rO, dW_r0 (direction and fea columns), dW_d0 for tile p-2; the direction features of tile p
-// Exchange buffers (fragment order, 1 KiB per 16 features x 32 samples): fea x3, dz_3 x3, {x0, h1, h2, dz_2, dz_1} x2, {hd, hr, dir, dz_r,
-// dz_d, d(out_rgb), d(out_sigma)} x2 — 104 KiB beside the 48 KiB of weight fragments.
+// History of this kernel (measurements: profiles/r02_*):
+//   * round 1, field_bwd_mma.hip: two producer/consumer wave pairs per workgroup, persistent weight-gradient tiles, operands transposed by
+//     identity MFMAs.  508 registers per lane; with a budget above 256 the compiler selects the accumulation-register form of EVERY MFMA,
+//     so each value of every layer output costs a v_accvgpr_read before the vector ALU may touch it; with the transposes' repacking the
+//     kernel issued ~13 vector instructions per MFMA: VALU 48 % of its cycles, matrix pipe 28 %.  632 us per 2.1 M samples.
+//   * round 2, first attempt (k_field_bwd_x4, removed again): four roles per workgroup (net chain, heads chain, two weight-gradient waves),
+//     every wave below 256 registers (VGPR-destination MFMAs), operands handed over as LDS images.  Correct, but ONE tile in flight per
+//     CU: the double-buffered images (104 KiB) beside the weights leave room for a single workgroup, and a chain wave alone on its SIMD
+//     is latency-bound (4.5 k cycles per tile against 1.5 k cycles of MFMA issue).  700 us.
+//   * this kernel: back to two pairs per workgroup, but the weight-gradient operands come from WAVE-LOCAL LDS images read with the
+//     transposing read of CDNA4 (ds_read_b64_tr_b16) instead of identity MFMAs, the transposed weight copy is gone (W^T fragments are
+//     transposing reads of the forward fragment store), ReLU / masks are packed 16-bit integer operations, every prefetch is
+//     unconditional with statically named buffers (no exposed global latency), weights and images are separate LDS objects.  517 us.
 #include "field_bwd_common.h"
 
 typedef short x4_s4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -41,28 +35,7 @@ __host__ __device__ __forceinline__ MmOff x4_offsets(const FieldDims &dm) {
     return o;
 }
 
-// ---- exchange area (byte offsets behind the weight fragments)
 #define X4_K 1024                            // one K-step image: 64 lanes x 16 B (16 features x 32 samples)
-#define X4_FEA 0                             // 3 x 4 KiB
-#define X4_Z3 (X4_FEA + 3 * 4 * X4_K)        // 3 x 4 KiB
-#define X4_AC (X4_Z3 + 3 * 4 * X4_K)         // 2 x {x0 2, h1 4, h2 4, z2 4, z1 4} KiB
-#define X4_AC_X0 0
-#define X4_AC_H1 (2 * X4_K)
-#define X4_AC_H2 (6 * X4_K)
-#define X4_AC_Z2 (10 * X4_K)
-#define X4_AC_Z1 (14 * X4_K)
-#define X4_AC_SIZE (18 * X4_K)
-#define X4_BD (X4_AC + 2 * X4_AC_SIZE)       // 2 x {hd 4, hr 4, dir 2, zr 4, zd 4, bro 2, bdo 2} KiB
-#define X4_BD_HD 0
-#define X4_BD_HR (4 * X4_K)
-#define X4_BD_DIR (8 * X4_K)
-#define X4_BD_ZR (10 * X4_K)
-#define X4_BD_ZD (14 * X4_K)
-#define X4_BD_BRO (18 * X4_K)                // K-step 0 = the output-layer gradient rows, K-step 1 stays zero (features 16..31 of the padded tile)
-#define X4_BD_BDO (20 * X4_K)
-#define X4_BD_SIZE (22 * X4_K)
-#define X4_XCH_BYTES (X4_BD + 2 * X4_BD_SIZE)
-
 __device__ __forceinline__ cn_h8 x4_tr_pair(const unsigned char *lds, uint32_t off0, uint32_t off1) {
     union { cn_h8 h; x4_s4 s[2]; } f;
     f.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(lds + off0));
@@ -105,9 +78,6 @@ __device__ __forceinline__ cn_h8 x4_frag_img(const unsigned char *img, uint32_t 
 // fragment loads during the previous layer's epilogue (one wave per SIMD: nothing else hides the LDS latency)
 template <int T, int NS>
 __device__ __forceinline__ void x4_gemm(const _Float16 *wf, uint32_t S, uint32_t s0, const cn_h8 *b, uint32_t lane, cn_f16v (&acc)[T]) {
-#ifdef X4_FENCE
-    asm volatile("" ::: "memory");
-#endif
 #pragma unroll
     for (int s = 0; s < NS; s++) {
 #pragma unroll
@@ -117,9 +87,6 @@ __device__ __forceinline__ void x4_gemm(const _Float16 *wf, uint32_t S, uint32_t
 
 template <int T, int NS, int S>
 __device__ __forceinline__ void x4_gemm_T(const unsigned char *layer, uint32_t lane_off, const cn_h8 *b, cn_f16v (&acc)[T]) {
-#ifdef X4_FENCE
-    asm volatile("" ::: "memory");
-#endif
 #pragma unroll
     for (int s = 0; s < NS; s++) {
 #pragma unroll
@@ -246,379 +213,19 @@ __device__ __forceinline__ void x4_zero(cn_f16v &a) {
     for (int r = 0; r < 16; r++) a[r] = 0.0f;
 }
 
-// measurement aid (CNERF_X4_ABLATE bit 5): per role, cycles between barriers spent working / waiting at the barrier, summed over the phases
+// measurement aid (CNERF_X2_ABLATE bit 5): per role, cycles between barriers spent working / waiting at the barrier, summed over the phases
 #define X4_T0() const unsigned long long t0_ = (ablate & 32) ? __builtin_readcyclecounter() : 0ull
 #define X4_T1() do { if (ablate & 32) { const unsigned long long t1_ = __builtin_readcyclecounter(); x4_barrier(); \
                                         const unsigned long long t2_ = __builtin_readcyclecounter(); tw_ += t1_ - t0_; tb_ += t2_ - t1_; } else x4_barrier(); } while (0)
 
-template <int NGEO>
-__global__ void __launch_bounds__(FLD_THREADS, 2) k_field_bwd_x4(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
-                                                                 uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
-                                                                 const float *__restrict__ pden, const float *__restrict__ prgb,
-                                                                 const float *__restrict__ g_sigma, const float *__restrict__ g_rgbc,
-                                                                 void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate) {
-    constexpr bool H = true;
-    constexpr int SENC = 2;                                   // enc_pad == 32
-    using PR = Prec<H>;
-    using frag_t = typename PR::frag_t;
-    using elem_t = typename PR::elem_t;
-    // Two LDS objects on purpose: the weight fragments (read-only after staging) in a static array, the exchange images in the dynamic
-    // region.  As one array the compiler must assume that every publish may alias every fragment load and keeps each layer's loads behind
-    // the previous layer's stores — with one wave per SIMD that exposes an LDS round trip per layer.
-    __shared__ __attribute__((aligned(16))) elem_t x4_w[FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID];
-    extern __shared__ __attribute__((aligned(16))) unsigned char fld_lds[];
-    elem_t *wl = x4_w;
-    const FieldLds lo = fld_lds_layout<H>(dm);
-    unsigned char *xch = fld_lds;
-    const MmOff po = x4_offsets(dm);
-
-    constexpr uint32_t S64 = FLD_HID / PR::KS, SDIR = FLD_DIR / PR::KS, SR0 = S64 + SDIR;
-    const uint32_t in_r0 = FLD_HID + FLD_DIR;
-    const float *n0 = pnet, *n1 = pnet + FLD_HID * dm.enc_pad;
-    const float *n2 = n1 + (NGEO == 2 ? FLD_HID * FLD_HID : 0);
-    const float *d0 = pden, *dO = pden + FLD_HID * FLD_HID;
-    const float *r0 = prgb, *rO = prgb + FLD_HID * in_r0;
-
-    fb_stage_layer<H, 0>(wl + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, SENC, dm.enc_pad);
-    if (NGEO == 2) fb_stage_layer<H, 1>(wl + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[3], d0, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[4], dO, 16, FLD_HID, 1, S64, FLD_HID);
-    fb_stage_layer<H, 2>(wl + lo.off[5], r0, FLD_HID, in_r0, 2, SR0, in_r0);
-    fb_stage_layer<H, 1>(wl + lo.off[6], rO, 16, FLD_HID, 1, S64, FLD_HID);
-    // the second K-step of the output-gradient images (features 16..31 of their padded 32-row tile) is never written: zero it once
-    for (uint32_t i = threadIdx.x; i < 2 * 2 * (X4_K / 4); i += FLD_THREADS) {
-        const uint32_t buf = i / (2 * (X4_K / 4)), w = i % (2 * (X4_K / 4));
-        const uint32_t which = w / (X4_K / 4), k = w % (X4_K / 4);
-        reinterpret_cast<uint32_t *>(xch + X4_BD + buf * X4_BD_SIZE + (which ? X4_BD_BDO : X4_BD_BRO) + X4_K)[k] = 0u;
-    }
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5;
-    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned char *wb = reinterpret_cast<const unsigned char *>(x4_w);
-    unsigned long long tw_ = 0, tb_ = 0;
-    const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
-    const uint32_t G = gridDim.x, gp = blockIdx.x;
-    const uint32_t n_iter = (n_tiles + G - 1) / G;                                  // workgroup-uniform: same barrier count for every wave
-    const uint32_t n_phase = (n_iter + 4) & ~1u;                                    // n_iter + 3 phases drain the pipeline; even: the loops are unrolled by two
-    float *part = partials + (size_t)gp * po.total;
-    const uint32_t off_n0 = lo.off[0] * 2, off_n1 = lo.off[1] * 2, off_n2 = lo.off[2] * 2, off_d0 = lo.off[3] * 2, off_dO = lo.off[4] * 2,
-                   off_r0 = lo.off[5] * 2, off_rO = lo.off[6] * 2;
-
-    if (role == 0) {
-        // ======================================================================== wave A: geometry network
-        // The phase loop is unrolled by two so that every value that lives across phases sits in a statically named register set: a
-        // rotation by copies makes the compiler wait for the prefetched loads at the END of the phase that issued them (the copies are
-        // placed in the loop latch), which exposes the whole memory latency once per tile.
-        const uint32_t lw = x4_lane_off_w(lane, false), lwn = x4_lane_off_w(lane, true);
-        struct ASet { frag_t x0[SENC], h1[4], h2[4]; uint32_t p; bool v; };
-        ASet S0, S1;                                          // activations of the tiles with even / odd phase index (forward at p, backward at p+2)
-#pragma unroll
-        for (int s = 0; s < SENC; s++) S0.x0[s] = S1.x0[s] = PR::zero();
-#pragma unroll
-        for (int s = 0; s < 4; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = PR::zero();
-        S0.p = S1.p = 0; S0.v = S1.v = false;
-        frag_t N0[SENC], N1[SENC];                            // grid features requested one phase ahead (even / odd tiles)
-        {
-            x4_enc_request<SENC>(enc, P_, dm.L, gp * FLD_TILE + li, hi, N0);
-#pragma unroll
-            for (int s = 0; s < SENC; s++) N1[s] = PR::zero();
-        }
-        auto phase = [&](uint32_t p, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC]) __attribute__((always_inline)) {
-            X4_T0();
-            asm volatile("" ::: "memory");
-            // ---- request the grid features of tile p+1
-            x4_enc_request<SENC>(enc, P_, dm.L, (gp + (p + 1) * G) * FLD_TILE + li, hi, xnext);
-            // ---- backward of tile p-2 (dz_3 was published by wave B in phase p-1); S still holds that tile
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 1)) {
-                unsigned char *ac = xch + X4_AC + ((p - 2) & 1) * X4_AC_SIZE;
-                frag_t z3[4];
-                x4_fetch<4>(xch + X4_Z3 + ((p - 2) % 3) * 4 * X4_K, lane, z3);
-                x4_publish<SENC>(ac + X4_AC_X0, lane, S.x0);
-                x4_publish<4>(ac + X4_AC_H1, lane, S.h1);
-                if (NGEO == 2) x4_publish<4>(ac + X4_AC_H2, lane, S.h2);
-                cn_f16v acc[2];
-                fb_zero(acc);
-                x4_gemm_T<2, S64, S64>(wb + off_n2, lw, z3, acc);
-                frag_t z1[4];
-                if (NGEO == 2) {
-                    frag_t z2[4];
-                    x4_c_to_b_masked(acc, S.h2, z2);
-                    x4_publish<4>(ac + X4_AC_Z2, lane, z2);
-                    fb_zero(acc);
-                    x4_gemm_T<2, S64, S64>(wb + off_n1, lw, z2, acc);
-                }
-                x4_c_to_b_masked(acc, S.h1, z1);
-                x4_publish<4>(ac + X4_AC_Z1, lane, z1);
-                cn_f16v denc[1];
-                fb_zero(denc);
-                x4_gemm_T<1, S64, SENC>(wb + off_n0, lwn, z1, denc);
-                if (S.v) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const uint32_t level = (uint32_t)fld_rho(r, (int)hi) >> 1;
-                        if (level < dm.L) {
-                            union { cn_h2 h; uint32_t u; } v;
-                            v.h = cn_h2{(_Float16)denc[0][r], (_Float16)denc[0][r + 1]};
-                            reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + S.p] = v.u;
-                        }
-                    }
-                }
-            }
-            // ---- forward of tile p (overwrites S)
-            if (p < n_iter && !(ablate & 2)) {
-                const uint32_t tile = gp + p * G;
-                S.p = tile * FLD_TILE + li;
-                S.v = S.p < P_;
-                x4_enc_mask<SENC>(xcur, dm.L, S.v, hi, S.x0);
-                cn_f16v acc[2];
-                fb_zero(acc);
-                x4_gemm<2, SENC>(wl + lo.off[0], SENC, 0, S.x0, lane, acc);
-                x4_c_to_b<true>(acc, S.h1);
-                if (NGEO == 2) {
-                    fb_zero(acc);
-                    x4_gemm<2, S64>(wl + lo.off[1], S64, 0, S.h1, lane, acc);
-                    x4_c_to_b<true>(acc, S.h2);
-                }
-                frag_t fea[4];
-                fb_zero(acc);
-                x4_gemm<2, S64>(wl + lo.off[2], S64, 0, (NGEO == 2) ? S.h2 : S.h1, lane, acc);
-                x4_c_to_b<false>(acc, fea);
-                x4_publish<4>(xch + X4_FEA + (p % 3) * 4 * X4_K, lane, fea);
-            } else {
-                S.v = false;
-            }
-            X4_T1();
-        };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, S0, N0, N1);
-            phase(p + 1, S1, N1, N0);
-        }
-    } else if (role == 1) {
-        // ======================================================================== wave B: density and colour heads (tile p-1 in phase p)
-        const uint32_t lw = x4_lane_off_w(lane, false);
-        // per-sample inputs, requested unconditionally (clamped index) and masked at use: see x4_enc_request
-        struct BIn { float x, y, z, gs; float4 gc; };
-        auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
-            BIn r;
-            const uint32_t p = min(tile * FLD_TILE + li, P_ - 1);
-            r.x = xyz[(size_t)p * 3]; r.y = xyz[(size_t)p * 3 + 1]; r.z = xyz[(size_t)p * 3 + 2];
-            r.gs = g_sigma[p];
-            r.gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
-            return r;
-        };
-        BIn I0 = load_in(gp), I1 = I0;         // per-sample inputs requested one phase ahead (statically named: see wave A)
-        auto phase = [&](uint32_t p, const BIn &cur, BIn &nxt) __attribute__((always_inline)) {
-            X4_T0();
-            asm volatile("" ::: "memory");
-            if (p >= 1) nxt = load_in(gp + p * G);
-            if (p >= 1 && p - 1 < n_iter && !(ablate & 4)) {
-                const uint32_t i = p - 1;
-                const uint32_t tile = gp + i * G;
-                const bool valid = tile * FLD_TILE + li < P_;
-                unsigned char *bd = xch + X4_BD + (i & 1) * X4_BD_SIZE;
-                frag_t fea[4], dfr[SDIR];
-                x4_fetch<4>(xch + X4_FEA + (i % 3) * 4 * X4_K, lane, fea);
-                x4_fetch<SDIR>(bd + X4_BD_DIR, lane, dfr);             // written by wave D in phase p-1
-                // ---- forward of both heads
-                cn_f16v acc[2], out[1];
-                frag_t hd[4], hr[4];
-                fb_zero(acc);
-                x4_gemm<2, S64>(wl + lo.off[3], S64, 0, fea, lane, acc);
-                x4_c_to_b<true>(acc, hd);
-                x4_publish<4>(bd + X4_BD_HD, lane, hd);
-                fb_zero(out);
-                x4_gemm<1, S64>(wl + lo.off[4], S64, 0, hd, lane, out);
-                const float raw = (float)(_Float16)out[0][0];
-                fb_zero(acc);
-                x4_gemm<2, S64>(wl + lo.off[5], SR0, 0, fea, lane, acc);
-                x4_gemm<2, SDIR>(wl + lo.off[5], SR0, S64, dfr, lane, acc);
-                x4_c_to_b<true>(acc, hr);
-                x4_publish<4>(bd + X4_BD_HR, lane, hr);
-                fb_zero(out);
-                x4_gemm<1, S64>(wl + lo.off[6], S64, 0, hr, lane, out);
-                // ---- output-layer gradients (sigmoid', clamped exp': provider_utils.py:26-29)
-                frag_t bro[1], bdo[1];
-                {
-                    cn_h8 f = PR::zero(), g = PR::zero();
-                    if (valid && hi == 0) {
-                        const float x = cur.x, y = cur.y, z = cur.z;
-                        const float gg = 5.0f * __expf(-(x * x + y * y + z * z) * (1.0f / 0.08f));
-                        g[0] = (_Float16)(cur.gs * __expf(fminf(fmaxf(raw + gg, -15.0f), 15.0f)));
-                        const float gcv[4] = {cur.gc.x, cur.gc.y, cur.gc.z, cur.gc.w};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const float sg = (float)(_Float16)__builtin_amdgcn_rcpf(1.0f + __expf(-out[0][k]));
-                            f[k] = (_Float16)((k < (int)dm.n_rgb_out) ? gcv[k] * sg * (1.0f - sg) : 0.0f);
-                        }
-                    }
-                    bro[0] = f; bdo[0] = g;
-                }
-                x4_publish<1>(bd + X4_BD_BRO, lane, bro);
-                x4_publish<1>(bd + X4_BD_BDO, lane, bdo);
-                cn_f16v dfea[2];
-                fb_zero(dfea);
-                // ---- colour head
-                {
-                    frag_t zr[4];
-                    fb_zero(acc);
-                    x4_gemm_T<2, 1, S64>(wb + off_rO, lw, bro, acc);
-                    x4_c_to_b_masked(acc, hr, zr);
-                    x4_publish<4>(bd + X4_BD_ZR, lane, zr);
-                    x4_gemm_T<2, S64, SR0>(wb + off_r0, lw, zr, dfea);
-                }
-                // ---- density head
-                {
-                    frag_t zd[4];
-                    fb_zero(acc);
-                    x4_gemm_T<2, 1, S64>(wb + off_dO, lw, bdo, acc);
-                    x4_c_to_b_masked(acc, hd, zd);
-                    x4_publish<4>(bd + X4_BD_ZD, lane, zd);
-                    x4_gemm_T<2, S64, S64>(wb + off_d0, lw, zd, dfea);
-                }
-                frag_t z3[4];
-                x4_c_to_b<false>(dfea, z3);
-                x4_publish<4>(xch + X4_Z3 + (i % 3) * 4 * X4_K, lane, z3);
-            }
-            X4_T1();
-        };
-        // tile i is processed in phase i+1: tile 0 uses I0 (requested before the loop), phase p >= 1 requests tile p into the other set
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, I1, I0);          // even phase p: tile p-1 (odd) sits in I1; request tile p into I0 (p = 0: I0 is already on its way)
-            phase(p + 1, I0, I1);
-        }
-    } else if (role == 2) {
-        // ======================================================================== wave C: dW of the geometry network (tile p-3), dW_dO (tile p-2)
-        const uint32_t lc = x4_lane_off_img(lane, false), ln = x4_lane_off_img(lane, true);
-        cn_f16v wn2[2][2], wn1[2][2], wn0[2], wdo[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            x4_zero(wn0[a]); x4_zero(wdo[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) { x4_zero(wn2[a][b]); x4_zero(wn1[a][b]); }
-        }
-        for (uint32_t p = 0; p < n_phase; p++) {
-            X4_T0();
-            asm volatile("" ::: "memory");
-            if (p >= 3 && p - 3 < n_iter && !(ablate & 8)) {
-                const uint32_t i = p - 3;
-                const unsigned char *ac = xch + X4_AC + (i & 1) * X4_AC_SIZE;
-                const unsigned char *z3i = xch + X4_Z3 + (i % 3) * 4 * X4_K;
-                const unsigned char *hl = ac + ((NGEO == 2) ? X4_AC_H2 : X4_AC_H1);
-                cn_h8 z[2][2], a[2][2];
-                x4_load_block(z3i, lc, 0, z[0]); x4_load_block(z3i, lc, 1, z[1]);
-                x4_load_block(hl, lc, 0, a[0]); x4_load_block(hl, lc, 1, a[1]);
-                x4_dw(wn2[0][0], z[0], a[0]); x4_dw(wn2[0][1], z[0], a[1]); x4_dw(wn2[1][0], z[1], a[0]); x4_dw(wn2[1][1], z[1], a[1]);
-                if (NGEO == 2) {
-                    x4_load_block(ac + X4_AC_Z2, lc, 0, z[0]); x4_load_block(ac + X4_AC_Z2, lc, 1, z[1]);
-                    x4_load_block(ac + X4_AC_H1, lc, 0, a[0]); x4_load_block(ac + X4_AC_H1, lc, 1, a[1]);
-                    x4_dw(wn1[0][0], z[0], a[0]); x4_dw(wn1[0][1], z[0], a[1]); x4_dw(wn1[1][0], z[1], a[0]); x4_dw(wn1[1][1], z[1], a[1]);
-                }
-                x4_load_block(ac + X4_AC_Z1, lc, 0, z[0]); x4_load_block(ac + X4_AC_Z1, lc, 1, z[1]);
-                x4_load_block(ac + X4_AC_X0, ln, 0, a[0]);
-                x4_dw(wn0[0], z[0], a[0]); x4_dw(wn0[1], z[1], a[0]);
-            }
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 8)) {
-                const unsigned char *bd = xch + X4_BD + ((p - 2) & 1) * X4_BD_SIZE;
-                cn_h8 z[2], a[2][2];
-                x4_load_block(bd + X4_BD_BDO, lc, 0, z);
-                x4_load_block(bd + X4_BD_HD, lc, 0, a[0]); x4_load_block(bd + X4_BD_HD, lc, 1, a[1]);
-                x4_dw(wdo[0], z, a[0]); x4_dw(wdo[1], z, a[1]);
-            }
-            X4_T1();
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            x4_store(part, po.n0, dm.enc_pad, 0, 64, dm.enc_pad, a, 0, li, hi, wn0[a]);
-            x4_store(part, po.dO, 64, 0, 1, 64, 0, a, li, hi, wdo[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                x4_store(part, po.n2, 64, 0, 64, 64, a, b, li, hi, wn2[a][b]);
-                if (NGEO == 2) x4_store(part, po.n1, 64, 0, 64, 64, a, b, li, hi, wn1[a][b]);
-            }
-        }
-    } else {
-        // ======================================================================== wave D: dW of the heads (tile p-2); direction features of tile p
-        const uint32_t lc = x4_lane_off_img(lane, false), ln = x4_lane_off_img(lane, true);
-        cn_f16v wro[2], wrd[2], wrf[2][2], wd0[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            x4_zero(wro[a]); x4_zero(wrd[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) { x4_zero(wrf[a][b]); x4_zero(wd0[a][b]); }
-        }
-        auto load_dir = [&](uint32_t tile, bool on, float3 &d, bool &v) __attribute__((always_inline)) {
-            const uint32_t ps = tile * FLD_TILE + li;
-            v = on && ps < P_;
-            const float *dp = dirs + (size_t)(min(ps, P_ - 1) / dir_group) * 3;          // unconditional request, masked at use (fb_dir_frags_from)
-            d = make_float3(dp[0], dp[1], dp[2]);
-        };
-        float3 D0, D1;                                        // raw directions requested one phase ahead (statically named: see wave A)
-        bool V0, V1;
-        load_dir(gp, n_iter > 0, D0, V0);
-        D1 = D0; V1 = false;
-        auto phase = [&](uint32_t p, const float3 &dcur, bool dvalid, float3 &dn, bool &vn) __attribute__((always_inline)) {
-            X4_T0();
-            asm volatile("" ::: "memory");
-            load_dir(gp + (p + 1) * G, p + 1 < n_iter, dn, vn);
-            // direction features of tile p first (their 32 floats are dead again before the operand fragments below are live)
-            frag_t dfr[SDIR];
-            if (p < n_iter) fb_dir_frags_from<H>(dcur.x, dcur.y, dcur.z, dvalid, hi, dfr);
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 16)) {
-                const uint32_t i = p - 2;
-                const unsigned char *bd = xch + X4_BD + (i & 1) * X4_BD_SIZE;
-                const unsigned char *fe = xch + X4_FEA + (i % 3) * 4 * X4_K;
-                cn_h8 zo[2], z[2][2], a[2][2], d[2];
-                x4_load_block(bd + X4_BD_BRO, lc, 0, zo);
-                x4_load_block(bd + X4_BD_HR, lc, 0, a[0]); x4_load_block(bd + X4_BD_HR, lc, 1, a[1]);
-                x4_dw(wro[0], zo, a[0]); x4_dw(wro[1], zo, a[1]);
-                x4_load_block(bd + X4_BD_ZR, lc, 0, z[0]); x4_load_block(bd + X4_BD_ZR, lc, 1, z[1]);
-                x4_load_block(bd + X4_BD_DIR, ln, 0, d);
-                x4_dw(wrd[0], z[0], d); x4_dw(wrd[1], z[1], d);
-                x4_load_block(fe, lc, 0, a[0]); x4_load_block(fe, lc, 1, a[1]);
-                x4_dw(wrf[0][0], z[0], a[0]); x4_dw(wrf[0][1], z[0], a[1]); x4_dw(wrf[1][0], z[1], a[0]); x4_dw(wrf[1][1], z[1], a[1]);
-                x4_load_block(bd + X4_BD_ZD, lc, 0, z[0]); x4_load_block(bd + X4_BD_ZD, lc, 1, z[1]);
-                x4_dw(wd0[0][0], z[0], a[0]); x4_dw(wd0[0][1], z[0], a[1]); x4_dw(wd0[1][0], z[1], a[0]); x4_dw(wd0[1][1], z[1], a[1]);
-            }
-            // publish them to the image wave B reads in phase p+1.  It is the slot whose direction image (tile p-2) was read just above: those
-            // reads are this wave's own and already issued — DS operations of one wave execute in order, and the fence keeps the compiler from
-            // moving the stores up
-            asm volatile("" ::: "memory");
-            if (p < n_iter) x4_publish<SDIR>(xch + X4_BD + (p & 1) * X4_BD_SIZE + X4_BD_DIR, lane, dfr);
-            X4_T1();
-        };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, D0, V0, D1, V1);
-            phase(p + 1, D1, V1, D0, V0);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; b++) x4_store(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, li, hi, wro[b]);
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            x4_store(part, po.r0, 96, 0, 64, FLD_NDIR, a, 0, li, hi, wrd[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                x4_store(part, po.r0, 96, FLD_NDIR, 64, 64, a, b, li, hi, wrf[a][b]);
-                x4_store(part, po.d0, 64, 0, 64, 64, a, b, li, hi, wd0[a][b]);
-            }
-        }
-    }
-    if ((ablate & 32) && lane == 0) {
-        unsigned long long *tt = reinterpret_cast<unsigned long long *>(partials + (size_t)300 * po.total) + ((size_t)gp * 4 + role) * 2;
-        tt[0] = tw_; tt[1] = tb_;
-    }
-}
-
-// ================================================================================================ two-pipeline form
-// The four-role kernel above keeps ONE tile in flight per CU and its chain waves are latency-bound (one wave per SIMD: every layer is an LDS
-// round trip plus a dependent conversion pass; measured 4.5 k cycles per tile on the critical wave against 1.5 k cycles of MFMA issue).
-// This form goes back to two producer/consumer pairs per workgroup — two tiles per phase — and keeps the weight gradients in the chain
-// waves themselves: with the 512-register budget their 24 persistent accumulator tiles live in accumulation registers, which only MFMAs
-// ever touch (no v_accvgpr traffic for them), and their operands come from WAVE-LOCAL images: each wave publishes its activation / gradient
-// fragments to its own LDS scratch and reads them back through ds_read_b64_tr_b16 (DS operations of one wave execute in order, so no
-// barrier and no double buffering).  Only fea and dz_3 cross between the two waves of a pair.  The independent dW MFMAs fill the issue
-// slots that the chain's dependent load -> MFMA -> convert sequence leaves empty.
+// ================================================================================================ the kernel
+// Two producer/consumer pairs per workgroup — two tiles per phase.  Wave A of a pair runs the geometry MLP (forward of tile p, then
+// dz_3 -> dz_1 and d(loss)/d(grid features) of tile p-2), wave B the density + colour heads of tile p-1, forward and backward; fea and
+// dz_3 cross between them through double-buffered 4 KiB LDS images, one workgroup barrier per phase.  Each wave also owns the weight
+// gradients of its layers: with the 512-register budget the 24 persistent accumulator tiles live in accumulation registers, which only
+// MFMAs ever touch, and their operands come from wave-local images: the wave publishes its activation / gradient fragments to its own LDS
+// scratch and reads them back through ds_read_b64_tr_b16 (DS operations of one wave execute in order: no barrier, no double buffering).
+// The independent dW MFMAs fill issue slots that the chain's dependent load -> MFMA -> convert sequence leaves empty.
 #define X2_FEA 0                              // 2 x 4 KiB, A -> B
 #define X2_Z3 (2 * 4 * X4_K)                  // 2 x 4 KiB, B -> A
 #define X2_A (X2_Z3 + 2 * 4 * X4_K)           // wave A's images: x0 2, h1 4, h2 4, z2 4, z1 4 KiB
@@ -831,6 +438,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
         };
         BIn I0 = load_in(gp), I1 = I0;
         unsigned char *my = xch + X2_B;
+        const bool dir_uniform = (dir_group % FLD_TILE) == 0;
         auto phase = [&](uint32_t p, const BIn &cur, BIn &nxt) __attribute__((always_inline)) {
             X4_T0();
             asm volatile("" ::: "memory");
@@ -842,7 +450,10 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                 const unsigned char *fe = xch + X2_FEA + (i & 1) * 4 * X4_K;
                 frag_t fea[4], dfr[SDIR];
                 x4_fetch<4>(fe, lane, fea);
-                fb_dir_frags_from<H>(cur.dx, cur.dy, cur.dz, valid, hi, dfr);
+                // one direction per tile (run() path): 27 lanes evaluate one feature each; the 64-byte scratch is the head of the dz_d image,
+                // which this wave rewrites later in the phase (its reads of the previous tile's image are already issued: in-order DS)
+                if (dir_uniform) fld_dir_frags_uniform(cur.dx, cur.dy, cur.dz, lane, hi, my + X2_B_ZD, dfr);
+                else fb_dir_frags_from<H>(cur.dx, cur.dy, cur.dz, valid, hi, dfr);
                 x4_publish<SDIR>(my + X2_B_DIR, lane, dfr);
                 // ---- forward of both heads
                 cn_f16v acc[2], out[1];
@@ -955,52 +566,45 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
 void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
                         hipStream_t st);
 
-static int x4_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("CNERF_FIELD_X4_BWD");            // 2 (default): two-pipeline kernel; 4: four-role kernel; 0: the round-1 kernels
-        v = e ? atoi(e) : 2;
+bool x2_eligible(const FieldDims &dm) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("CNERF_FIELD_X2_BWD");            // 0: the round-1 kernels (field_bwd_mma.hip / field_bwd_fused.hip)
+        on = e ? atoi(e) : 1;
     }
-    return v;
+    return on && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2);
 }
-bool x4_eligible(const FieldDims &dm) { return x4_variant() != 0 && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2); }
 
-int x4_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
+int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
               uint32_t max_partials, hipStream_t st) {
     const FieldLds lo = fld_lds_layout<true>(dm);
     if (lo.off[7] > FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID) return CNERF_EINVAL;
-    const bool two = x4_variant() == 2;
-    const uint32_t lds_bytes = two ? 2 * X2_PAIR_BYTES : X4_XCH_BYTES;          // dynamic part; the weight fragments are a 48 KiB static array
+    const uint32_t lds_bytes = 2 * X2_PAIR_BYTES;                               // dynamic part; the weight fragments are a 48 KiB static array
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
-    uint32_t blocks = two ? cn_div_up(n_tiles, 2) : n_tiles;
-    const uint32_t per_block = two ? 2 : 1;                                     // partial-gradient rows per workgroup
-    if (blocks > max_partials / per_block) blocks = max_partials / per_block;
+    uint32_t blocks = cn_div_up(n_tiles, 2);
+    if (blocks > max_partials / 2) blocks = max_partials / 2;                   // two partial-gradient rows per workgroup
     if (blocks > 256) blocks = 256;
     const MmOff po = x4_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
     // the partial rows are only written where a layer has rows / columns: zero the rows in use (padding entries stay 0)
-    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)blocks * per_block * po.total * sizeof(float), st);
+    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)blocks * 2 * po.total * sizeof(float), st);
     if (e0 != hipSuccess) return (int)e0;
     static int ablate = -1;
     if (ablate < 0) {
-        const char *e = getenv("CNERF_X4_ABLATE");             // measurement aid: bit 0 A-bwd, 1 A-fwd, 2 B, 3 C, 4 D switched off (results wrong), 5 timing
+        const char *e = getenv("CNERF_X2_ABLATE");             // measurement aid: bit 0 A-backward, 1 A-forward, 2 B switched off (results wrong), 5 role timing
         ablate = e ? atoi(e) : 0;
     }
-#define X4_LAUNCH(KERN)                                                                                                                    \
+#define X2_LAUNCH(KERN)                                                                                                                    \
     {                                                                                                                                      \
         auto kern = KERN;                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
                            grad_enc, partials, (uint32_t)ablate);                                                                          \
     }
-    if (two) {
-        if (dm.n_hidden_geo == 2) X4_LAUNCH(k_field_bwd_x2<2>) else X4_LAUNCH(k_field_bwd_x2<1>)
-    } else {
-        if (dm.n_hidden_geo == 2) X4_LAUNCH(k_field_bwd_x4<2>) else X4_LAUNCH(k_field_bwd_x4<1>)
-    }
+    if (dm.n_hidden_geo == 2) X2_LAUNCH(k_field_bwd_x2<2>) else X2_LAUNCH(k_field_bwd_x2<1>)
     int rc = cn_launch_status();
     if (rc) return rc;
-    ff_reduce_partials(partials, blocks * per_block, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
+    ff_reduce_partials(partials, blocks * 2, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
     return cn_launch_status();
 }

@@ -83,6 +83,22 @@ __host__ __device__ __forceinline__ FieldLds fld_lds_layout(const FieldDims &d) 
     return l;
 }
 
+// Direction features of a 32-sample tile whose samples share ONE direction (dir_group a multiple of the tile: the renderer's run() path,
+// one direction per ray).  Instead of every lane evaluating all 24 sines / cosines, lane q < 27 evaluates feature q, the 32 halves go
+// through a 64-byte LDS scratch of the wave and come back as the two natural-order B fragments (broadcast reads).  `scratch` must be
+// 16-byte aligned and private to the wave; DS operations of one wave execute in order, no barrier is involved.
+__device__ __forceinline__ void fld_dir_frags_uniform(float dx, float dy, float dz, uint32_t lane, uint32_t hi, unsigned char *scratch, cn_h8 *b) {
+    const uint32_t q = lane & 31;
+    const uint32_t qq = q >= 3 ? q - 3 : 0, k = qq / 6, r = qq % 6, c = q < 3 ? q : (r < 3 ? r : r - 3);
+    const float d = c == 0 ? dx : (c == 1 ? dy : dz);
+    const float a = d * (float)(1u << k);
+    const float sc = r < 3 ? __sinf(a) : __cosf(a);
+    const float v = q < 3 ? d : (q < FLD_NDIR ? sc : 0.0f);
+    if (lane < 32) reinterpret_cast<_Float16 *>(scratch)[q] = (_Float16)v;
+    b[0] = *reinterpret_cast<const cn_h8 *>(scratch + 16 * hi);
+    b[1] = *reinterpret_cast<const cn_h8 *>(scratch + 32 + 16 * hi);
+}
+
 // frequency encoding of a direction (nerf/base.py:42-60): [d, sin(2^k d), cos(2^k d)]_{k=0..3}, 27 values padded to 32
 template <bool FAST>
 __device__ __forceinline__ void fld_dir_features(float dx, float dy, float dz, float (&e)[FLD_DIR]) {

@@ -4,6 +4,8 @@
 #include <math.h>
 #include <type_traits>
 
+typedef _Float16 cn_gf_h2 __attribute__((ext_vector_type(2)));
+
 #define GE_MAX_LEVELS 32
 #define GE_BLOCK 256
 

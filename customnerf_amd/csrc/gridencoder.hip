@@ -180,6 +180,142 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ specialised forward gather
+// k_grid_fwd above is generic over table dtype / D / C / grid type / interpolation / dy_dx and pays for it in instructions: PMC passes of
+// round 2 (profiles/r02_*) show the gather busy ISSUING ~75 % of its time (202 vector + 152 scalar instructions per (sample, level) wave
+// item), not waiting on L2.  This kernel is the configuration CustomNeRF runs (fp16 table, D = 3, C = 2, linear interpolation, no input
+// gradient, align_corners = false) as straight-line code per level mode, chosen by one scalar branch per workgroup:
+//   * 32-bit byte offsets against a scalar table base (global_load ... , off-by-SGPR) instead of 64-bit address arithmetic;
+//   * the half x float products of the trilinear sum as v_fma_mix_f32 (the half operand is widened inside the FMA: bit-identical to
+//     convert-then-multiply, the conversion being exact; addend -0.0 keeps the sign of a zero product);
+//   * hashed levels: x + 1 differs from x in its trailing-ones run only, so the partner entry of an x-pair is entry k ^ 1 (x even) or
+//     k ^ 3 (x = 1 mod 4) of the same aligned 16-byte window; only x = 3 mod 4 needs a second, lane-masked load;
+//   * the weights in the reference's multiplication order ((wx wy) wz, gridencoder.cu:171-178) shared across the corner pairs.
+// Results are bit-identical to k_grid_fwd (same operations on the same values in the same order).
+__device__ __forceinline__ float gf_mix_lo(float w, uint32_t g2, float negzero) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(g2), "v"(negzero));
+    return r;
+}
+__device__ __forceinline__ float gf_mix_hi(float w, uint32_t g2, float negzero) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(g2), "v"(negzero));
+    return r;
+}
+// acc (half2) += half2(w * g.x, w * g.y), each product rounded to half, then the packed half add — ge_accum2's arithmetic
+__device__ __forceinline__ void gf_accum(cn_gf_h2 &acc, float w, uint32_t g2, float negzero) {
+    const float p0 = gf_mix_lo(w, g2, negzero), p1 = gf_mix_hi(w, g2, negzero);
+    const cn_gf_h2 p = {(_Float16)p0, (_Float16)p1};
+    acc = acc + p;
+}
+__device__ __forceinline__ uint32_t gf_ld1(const unsigned char *__restrict__ base, uint32_t byte_off) { return *reinterpret_cast<const uint32_t *>(base + byte_off); }
+struct alignas(8) gf_u2 { uint32_t x, y; };
+struct alignas(16) gf_u4 { uint32_t x, y, z, w; };
+
+__global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd_fast(const float *__restrict__ inputs, const __half *__restrict__ grid, const GridLevels lv,
+                                                            __half *__restrict__ outputs, uint32_t B, uint32_t n_levels, uint32_t nb, uint32_t gridtype,
+                                                            int swizzle, uint32_t ostride) {
+    uint32_t level, pb;
+    if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
+    const uint32_t b = pb * GE_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    uint32_t *out = reinterpret_cast<uint32_t *>(outputs) + ((size_t)level * ostride + b);
+    float in[3];
+    ge_load_coords<3>(inputs, b, in);
+    if (in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1 || in[2] < 0 || in[2] > 1) { *out = 0u; return; }
+
+    const uint32_t size = lv.size[level], resolution = lv.resolution[level];
+    const float scale = lv.scale[level];
+    const unsigned char *__restrict__ table = reinterpret_cast<const unsigned char *>(grid) + (size_t)lv.offset[level] * 4;   // 4 bytes per entry
+    float fr[3], om[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float pos = cn_fma(in[d], scale, 0.5f);
+        pg[d] = (uint32_t)floorf(pos);
+        fr[d] = pos - (float)pg[d];
+        om[d] = 1 - fr[d];
+    }
+    // weights of the four (y, z) rows for x and x + 1, reference order: x factor first, then y, then z
+    const float a00 = om[0] * om[1], a10 = fr[0] * om[1], a01 = om[0] * fr[1], a11 = fr[0] * fr[1];
+    const float w[8] = {a00 * om[2], a10 * om[2], a01 * om[2], a11 * om[2], a00 * fr[2], a10 * fr[2], a01 * fr[2], a11 * fr[2]};
+    uint32_t c[8];                                            // corner entries (half2 bit patterns), corner index = x + 2 y + 4 z
+    const int mode = ge_level_mode<3>(gridtype, false, size, resolution);         // workgroup-uniform
+    if (mode == GE_MODE_DENSE) {
+        // index = x + y s + z s^2 < size, x + 1 <= resolution: the two x corners are neighbours -> one 8-byte load per (y, z) row
+        const uint32_t s1 = resolution + 1, s2 = s1 * s1;
+        const uint32_t i00 = (pg[0] + pg[1] * s1 + pg[2] * s2) * 4u;
+        const gf_u2 r0 = *reinterpret_cast<const gf_u2 *>(table + i00);
+        const gf_u2 r1 = *reinterpret_cast<const gf_u2 *>(table + (i00 + s1 * 4u));
+        const gf_u2 r2 = *reinterpret_cast<const gf_u2 *>(table + (i00 + s2 * 4u));
+        const gf_u2 r3 = *reinterpret_cast<const gf_u2 *>(table + (i00 + (s1 + s2) * 4u));
+        c[0] = r0.x; c[1] = r0.y; c[2] = r1.x; c[3] = r1.y; c[4] = r2.x; c[5] = r2.y; c[6] = r3.x; c[7] = r3.y;
+    } else if (mode == GE_MODE_HASH2) {
+        const uint32_t mask = size - 1;
+        const uint32_t hy0 = pg[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = pg[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t x0 = pg[0], xm = x0 ^ (x0 + 1);                         // i1 = i0 ^ (xm & mask): the trailing-ones run of x0, plus one bit
+        const bool in_quad = (xm & mask) < 4u;                                  // x0 != 3 mod 4 (or a table of < 4 entries, which ge_levels rules out)
+        const bool odd = (x0 & 1u) != 0;                                        // partner = entry ^ 3 instead of entry ^ 1
+        const uint32_t hyz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        uint32_t i0[4];
+        gf_u4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                           // all four window loads first
+            i0[q] = (x0 ^ hyz[q]) & mask;
+            v[q] = *reinterpret_cast<const gf_u4 *>(table + ((i0[q] & ~3u) * 4u));
+        }
+        uint32_t far[4] = {0u, 0u, 0u, 0u};
+        if (!in_quad) {                                                         // one lane-masked block for the x = 3 mod 4 lanes
+#pragma unroll
+            for (int q = 0; q < 4; q++) far[q] = gf_ld1(table, ((i0[q] ^ xm) & mask) * 4u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool b0 = (i0[q] & 1u) != 0, b1 = (i0[q] & 2u) != 0;
+            const uint32_t plo = b1 ? v[q].z : v[q].x, phi = b1 ? v[q].w : v[q].y;      // the aligned pair holding entry i0
+            c[2 * q] = b0 ? phi : plo;
+            const uint32_t same = b0 ? plo : phi;                               // entry i0 ^ 1
+            const uint32_t olo = b1 ? v[q].x : v[q].z, ohi = b1 ? v[q].y : v[q].w;      // the other pair
+            const uint32_t cross = b0 ? olo : ohi;                              // entry i0 ^ 3
+            const uint32_t near = odd ? cross : same;
+            c[2 * q + 1] = in_quad ? near : far[q];
+        }
+    } else {
+        // GE_MODE_TILED2: index = (x + y s + z s^2) & mask; the x + 1 corner is the next entry modulo the table size
+        // (a dimension enters the strided sum only while the running stride still fits the table: ge_index / gridencoder.cu:66-84)
+        const uint32_t mask = size - 1, step = resolution + 1;
+        const uint32_t s1 = step <= size ? step : 0u;
+        const uint32_t s2 = (s1 && step * step <= size) ? step * step : 0u;
+        const uint32_t lin = pg[0] + pg[1] * s1 + pg[2] * s2;
+        const uint32_t row[4] = {lin, lin + s1, lin + s2, lin + s1 + s2};
+        // unaligned 8-byte load of (i0, i0 + 1) except at the wrap (i0 = size - 1: the pair would leave the level): there the window starts
+        // one entry earlier and the partner, entry 0 of the level, comes from a lane-masked load
+        gf_u2 r[4];
+        uint32_t i0[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            i0[q] = row[q] & mask;
+            r[q] = *reinterpret_cast<const gf_u2 *>(table + (i0[q] == mask ? i0[q] - 1 : i0[q]) * 4u);
+        }
+        bool any_wrap = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) any_wrap = any_wrap || i0[q] == mask;
+        uint32_t first = 0u;
+        if (any_wrap) first = gf_ld1(table, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool wrap = i0[q] == mask;
+            c[2 * q] = wrap ? r[q].y : r[q].x;
+            c[2 * q + 1] = wrap ? first : r[q].y;
+        }
+    }
+    const float negzero = -0.0f;
+    cn_gf_h2 acc = {(_Float16)0, (_Float16)0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) gf_accum(acc, w[k], c[k], negzero);
+    *out = __builtin_bit_cast(uint32_t, acc);
+}
+
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(GE_BLOCK) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                        float *__restrict__ grad_grid, uint32_t B, uint32_t n_levels, uint32_t nb,
@@ -333,6 +469,26 @@ static double ge_dense_weight() {
     return w;
 }
 
+// every level in use must be one of the three modes k_grid_fwd_fast implements (hashed levels additionally 4-entry aligned)
+static bool ge_fast_eligible(const GridLevels &lv, uint32_t nl, uint32_t gridtype) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("CNERF_GRID_FAST");
+        on = e ? atoi(e) : 1;
+    }
+    if (!on) return false;
+    for (uint32_t l = 0; l < nl; l++) {
+        const uint64_t step = (uint64_t)lv.resolution[l] + 1, cells = step * step * step;
+        const uint32_t size = lv.size[l];
+        const bool pow2 = (size & (size - 1)) == 0;
+        if (size >= (1u << 24)) return false;                                   // 32-bit byte offsets
+        if (cells <= size) continue;                                           // GE_MODE_DENSE
+        if (!pow2 || size < 8) return false;
+        if (gridtype == 0 && ((lv.offset[l] | size) & 3u)) return false;        // GE_MODE_HASH2 with aligned 16-byte windows
+    }
+    return true;
+}
+
 template <typename T, int D>
 static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *out, uint32_t B, uint32_t C, uint32_t L, uint32_t nl, T *dy_dx,
                     uint32_t gridtype, int ac, uint32_t interp, hipStream_t st, uint32_t ostride) {
@@ -343,6 +499,12 @@ static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *
     GridLevels lvb = lv;
     if (sw == 2) grid = dim3(CN_NXCD * ge_balance(lvb, nl, nb, D, gridtype, ac != 0, ge_dense_weight()));
     const GridLevels &lv_ = lvb;
+    if constexpr (std::is_same<T, __half>::value && D == 3) {
+        if (C == 2 && !dy_dx && interp == 0 && !ac && ge_fast_eligible(lv_, nl, gridtype)) {
+            hipLaunchKernelGGL(k_grid_fwd_fast, grid, block, 0, st, inputs, emb, lv_, out, B, nl, nb, gridtype, sw, ostride);
+            return cn_launch_status();
+        }
+    }
     switch (C) {
         case 1: hipLaunchKernelGGL((k_grid_fwd<T, D, 1>), grid, block, 0, st, inputs, emb, lv_, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;
         case 2: hipLaunchKernelGGL((k_grid_fwd<T, D, 2>), grid, block, 0, st, inputs, emb, lv_, out, B, L, nl, nb, dy_dx, gridtype, ac, interp, sw, ostride); break;

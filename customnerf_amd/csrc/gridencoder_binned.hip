@@ -599,12 +599,22 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
     for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) slab[gdelta[s_bin[sl]] + sl] = s_rec[sl];
 }
 
+// llrint(a) as a two's-complement 64-bit pattern, a = (value * 2^24) already in float32, |a| < 2^41.  The library's float -> int64
+// conversion is a dozen vector instructions (no such conversion in hardware) and there are four of them per record: they were most of this
+// kernel's instruction stream, and the kernel is issue-bound.  In double precision the classic "add 1.5 * 2^52" trick does it in one add:
+// the sum's mantissa holds the integer, rounded to nearest-even by the add itself; the low word of the constant's bit pattern is zero, so
+// only the high word needs the constant subtracted.  The 2^24 scale rides on the weight (a power of two commutes with the float32
+// rounding of the product), so the values are those of __float2ll_rn((w * f) * 16777216.0f), bit for bit.
+__device__ __forceinline__ unsigned long long b2_fix(float a) {
+    const double y = (double)a + 6755399441055744.0;                                // 1.5 * 2^52
+    return __builtin_bit_cast(unsigned long long, y) - 0x4338000000000000ull;
+}
 // the LDS image keeps the two channels in separate halves (acc[e], acc[BN_CHUNK + e]): random 8-byte atomics at a 16-byte stride reach
 // only half of the bank pairs (scratch/lds_atomic_peak.hip: 2.6 T ds_add_u64/s interleaved, 3.8 T/s split)
 __device__ __forceinline__ void b2_add(long long *acc, uint32_t e, float a, float b) {
-    // |a| <= 65504: a * 2^24 < 2^41, rounded to the fixed-point grid
-    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), (unsigned long long)__float2ll_rn(a * 16777216.0f));
-    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), (unsigned long long)__float2ll_rn(b * 16777216.0f));
+    // |value| <= 65504: value * 2^24 < 2^41, rounded to the fixed-point grid
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), b2_fix(a));
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), b2_fix(b));
 }
 
 __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
@@ -613,11 +623,12 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
     const float2 f = __half22float2(v.h);
     const uint32_t e = r.x & (BN_CHUNK - 1), t = (r.x >> 12) & 15u;
     if (t == B2_SINGLE) {
-        b2_add(acc, e, f.x, f.y);
+        b2_add(acc, e, f.x * 16777216.0f, f.y * 16777216.0f);
     } else {
         const float w1 = (float)(r.x >> 16) * (1.0f / 65536.0f), w0 = 1.0f - w1;
-        b2_add(acc, e, w0 * f.x, w0 * f.y);
-        b2_add(acc, e ^ ((2u << t) - 1u), w1 * f.x, w1 * f.y);
+        const float w1s = w1 * 16777216.0f, w0s = w0 * 16777216.0f;
+        b2_add(acc, e, w0s * f.x, w0s * f.y);
+        b2_add(acc, e ^ ((2u << t) - 1u), w1s * f.x, w1s * f.y);
     }
 }
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# time of k_field_bwd_x4 under CNERF_X4_ABLATE masks
+# time of k_field_bwd_x2 under CNERF_X2_ABLATE masks
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for m in "$@"; do
   mkdir -p gpurun_out/abx4_$m
-  CNERF_X4_ABLATE=$m rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abx4_$m -o b -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+  CNERF_X2_ABLATE=$m rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abx4_$m -o b -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
   python3 - <<E
 import csv
 rows=list(csv.DictReader(open('gpurun_out/abx4_$m/b_kernel_stats.csv')))

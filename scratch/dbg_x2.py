@@ -1,4 +1,4 @@
-"""per-layer error of the fused field backward against the oracle (debug aid for field_bwd_x4.hip)"""
+"""per-layer error of the fused field backward against the oracle (debug aid for field_bwd_x2.hip)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

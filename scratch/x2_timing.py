@@ -1,7 +1,7 @@
-"""per-role work / barrier-wait cycles of k_field_bwd_x4 (CNERF_X4_ABLATE |= 32)"""
+"""per-role work / barrier-wait cycles of k_field_bwd_x4 (CNERF_X2_ABLATE |= 32)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CNERF_X4_ABLATE"] = str(int(os.environ.get("CNERF_X4_ABLATE", "0")) | 32)
+os.environ["CNERF_X2_ABLATE"] = str(int(os.environ.get("CNERF_X2_ABLATE", "0")) | 32)
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from test_gpu_field import make_case, cuda
@@ -26,7 +26,7 @@ for it in range(3):
 print("backward ms", t0.elapsed_time(t1))
 ws = fmod._WS[xs.device]
 total = 64 * 32 + 4096 * 3 + 1024 + 64 * 96 + 1024
-two = os.environ.get("CNERF_FIELD_X4_BWD", "2") == "2"
+two = True
 row = 530 if two else 300
 tt = ws[row * total * 4: row * total * 4 + 256 * 4 * 2 * 8].view(torch.int64).view(256, 4, 2).cpu().numpy()
 n_phase = ((P // 32 // 512 + 3) & ~1) if two else ((P // 32 // 256 + 4) & ~1)

@@ -101,3 +101,58 @@ def test_field_backward(L, n_geo, half):
     # padded parameter rows/columns (tcnn pads 1 -> 16 outputs, 91 -> 96 inputs) must get exactly zero gradient
     assert torch.all(pd.grad[4096 + 64:] == 0)
     assert torch.all(pr.grad[:64 * 96].view(64, 96)[:, 91:] == 0)
+
+
+@pytest.mark.parametrize("n_geo,P,dir_group", [(2, 70003, 1), (1, 4099, 1), (2, 64 * 700, 64), (1, 32 * 3 + 5, 32), (2, 17, 1)])
+def test_field_backward_pipeline_shapes(n_geo, P, dir_group):
+    """k_field_bwd_x2 (fp16, 16 levels): several tiles per wave pair (the software pipeline really cycles), a ragged last tile, tile
+    counts below the pipeline depth, one / two hidden layers, and one direction per group of samples (the per-tile direction path when the
+    group is a multiple of the 32-sample tile) — against autograd on the oracle field."""
+    from customnerf_amd.field import field
+    L = 16
+    ref, enc, x, d = make_case(L, n_geo, P, seed=11)
+    ref.half = True
+    ref.pos_en.half = True
+    n_dir = (P + dir_group - 1) // dir_group
+    d_grp = d[:n_dir]
+    d_full = np.repeat(d_grp, dir_group, axis=0)[:P]
+    rng = np.random.default_rng(13)
+    gs = (rng.standard_normal(P) * 0.05).astype(np.float32)
+    gc = rng.standard_normal((P, 4)).astype(np.float32)
+    s_ref, c_ref, _ = ref(torch.from_numpy(x), torch.from_numpy(d_full))
+    torch.autograd.backward([s_ref, c_ref], [torch.from_numpy(gs), torch.from_numpy(gc)])
+    pn, pd, pr = (t.detach().clone().cuda().requires_grad_(True) for t in (ref.network, ref.density_network, ref.rgb_network))
+    e = enc.encode(cuda(x), bound=2.0, half=True)
+    s, c = field(e, cuda(x), cuda(d_grp), dir_group, 2 * L, n_geo, 4, pn, pd, pr)
+    torch.autograd.backward([s, c], [cuda(gs), cuda(gc)])
+    np.testing.assert_allclose(c.detach().cpu().numpy(), c_ref.detach().numpy(), rtol=0, atol=4e-3)
+    for name, a, b in (("net", pn.grad, ref.network.grad), ("den", pd.grad, ref.density_network.grad), ("rgb", pr.grad, ref.rgb_network.grad),
+                       ("grid", enc.embeddings.grad, ref.pos_en.embeddings.grad)):
+        a, b = a.cpu().numpy(), b.numpy()
+        scale = float(np.abs(b).max())
+        assert scale > 0, name
+        # the sums run over up to 70 k samples of half-precision products: the budget grows with sqrt(P) from the 3e-2 of the 2 k-sample case
+        assert np.abs(a - b).max() / scale < 3e-2 * (2 if name == "grid" else 1), f"{name}: max|diff|/max|ref| = {np.abs(a - b).max() / scale:.3e}"
+    assert torch.all(pd.grad[4096 + 64:] == 0)
+    assert torch.all(pr.grad[:64 * 96].view(64, 96)[:, 91:] == 0)
+
+
+def test_field_backward_is_reproducible():
+    """the per-pair partial sums and their reduction have a fixed order: two runs give the same bits"""
+    from customnerf_amd.field import field
+    L, n_geo, P = 16, 2, 40000
+    ref, enc, x, d = make_case(L, n_geo, P, seed=2)
+    pn0, pd0, pr0 = ref.network, ref.density_network, ref.rgb_network
+    g = torch.Generator().manual_seed(0)
+    gs, gc = torch.randn(P, generator=g).cuda() * 0.05, torch.randn(P, 4, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        pn, pd, pr = (t.detach().clone().cuda().requires_grad_(True) for t in (pn0, pd0, pr0))
+        with torch.no_grad():
+            e = enc.encode(cuda(x), bound=2.0, half=True)
+        e.requires_grad_(True)
+        s, c = field(e, cuda(x), cuda(d), 1, 2 * L, n_geo, 4, pn, pd, pr)
+        torch.autograd.backward([s, c], [gs, gc])
+        outs.append((pn.grad.clone(), pd.grad.clone(), pr.grad.clone(), e.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
