@@ -176,8 +176,8 @@ def main_edit(args, world, rank, dev):
         step(args.warmup + args.steps)
         sdops.set_profile(None)
         torch.cuda.synchronize()
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-        fl = sum(f for _, _, f in prof)
+        ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+        fl = sum(r[2] for r in prof)
         ach = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"kernel": "k_sd_gemm (implicit-GEMM conv / linear / attention GEMMs of the UNet + VAE)", "bound": "mfma", "achieved": ach,
                               "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(prof),

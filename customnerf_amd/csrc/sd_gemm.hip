@@ -33,6 +33,11 @@ __host__ __device__ constexpr uint32_t sg_lds_bytes(int bn) {
     const uint32_t stages = 2 * sg_stage_halfs(bn) * 2, ctile = SG_BM * (bn + 4) * 4;
     return stages > ctile ? stages : ctile;
 }
+// LDS-DMA loop: two unpadded stages
+__host__ __device__ constexpr uint32_t sg_lds_bytes_glds(int bn) {
+    const uint32_t stages = 2 * (SG_BM + bn) * SG_BK * 2, ctile = SG_BM * (bn + 4) * 4;
+    return stages > ctile ? stages : ctile;
+}
 
 __device__ __forceinline__ float sg_act(float v, int act) {
     if (act == 1) return v / (1.0f + __expf(-v));
@@ -54,7 +59,15 @@ __device__ __forceinline__ bool sg_coord(int32_t num, uint32_t tstride, uint32_t
 }
 
 // AMODE 0: dense A.  1: implicit conv, tap resolved per 16-byte chunk.  2: implicit conv with Cin % 64 == 0 (tap uniform per K step).
-template <int AMODE, int NT, bool SPLIT>
+// Source of a tap that falls into the zero padding (or of a row / K chunk beyond the problem): LDS-DMA loads cannot be predicated into
+// "write zeros", so those lanes read from this page instead.
+__device__ __attribute__((aligned(16))) unsigned char sg_zero_page[256];
+
+// row r of a [rows][64 halfs] LDS stage, 16-byte chunk c: XOR swizzle keyed on (row >> 1) & 7 — every ds_read_b128 lane group (16 lanes,
+// consecutive-ish rows, one chunk column) then covers all sixteen 16-byte slots of the 256-byte bank row: conflict-free.
+__device__ __forceinline__ uint32_t sg_swz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 7u); }
+
+template <int AMODE, int NT, bool SPLIT, bool GLDS = false>
 __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, float *__restrict__ partial, uint32_t k_tiles_per_split) {
     constexpr int BN = 64 * NT;
     constexpr int CB = BN * 8 / SG_THREADS;             // 16-byte chunks of B per thread per K step (4 | 2)
@@ -113,70 +126,179 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    uint4 sa[4], sb[CB];
-    auto fetch = [&](uint32_t kt) __attribute__((always_inline)) {
-        const uint32_t k = kt * SG_BK;
-        if (AMODE == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) sa[c] = (a_valid && k + ak + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(abase + k + ak + 8 * c) : make_uint4(0, 0, 0, 0);
-        } else if (AMODE == 2) {
-            uint32_t ih = 0, iw = 0;
-            const bool ok = a_valid && sg_coord(oh_s + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
-            const _Float16 *p = abase + ((size_t)ih * g.W_in + iw) * g.Cin + t_c0 + ak;
-#pragma unroll
-            for (int c = 0; c < 4; c++) sa[c] = ok ? *reinterpret_cast<const uint4 *>(p + 8 * c) : make_uint4(0, 0, 0, 0);
-            t_c0 += SG_BK;                                   // next K step (uniform)
-            if (t_c0 >= g.Cin) {
-                t_c0 = 0;
-                if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint32_t kk = k + ak + 8 * c;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (a_valid && kk < g.K) {
-                    const uint32_t tap = kk / g.Cin, ch = kk - tap * g.Cin, kh = tap / g.KW, kw = tap - kh * g.KW;
-                    uint32_t ih = 0, iw = 0;
-                    if (sg_coord(oh_s + (int32_t)kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)kw, g.tstride, g.ups, g.W_in, iw))
-                        v = *reinterpret_cast<const uint4 *>(abase + ((size_t)ih * g.W_in + iw) * g.Cin + ch);
+    if constexpr (!GLDS) {
+        uint4 sa[4], sb[CB];
+        auto fetch = [&](uint32_t kt) __attribute__((always_inline)) {
+            const uint32_t k = kt * SG_BK;
+            if (AMODE == 0) {
+    #pragma unroll
+                for (int c = 0; c < 4; c++) sa[c] = (a_valid && k + ak + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(abase + k + ak + 8 * c) : make_uint4(0, 0, 0, 0);
+            } else if (AMODE == 2) {
+                uint32_t ih = 0, iw = 0;
+                const bool ok = a_valid && sg_coord(oh_s + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
+                const _Float16 *p = abase + ((size_t)ih * g.W_in + iw) * g.Cin + t_c0 + ak;
+    #pragma unroll
+                for (int c = 0; c < 4; c++) sa[c] = ok ? *reinterpret_cast<const uint4 *>(p + 8 * c) : make_uint4(0, 0, 0, 0);
+                t_c0 += SG_BK;                                   // next K step (uniform)
+                if (t_c0 >= g.Cin) {
+                    t_c0 = 0;
+                    if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
                 }
-                sa[c] = v;
+            } else {
+    #pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t kk = k + ak + 8 * c;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (a_valid && kk < g.K) {
+                        const uint32_t tap = kk / g.Cin, ch = kk - tap * g.Cin, kh = tap / g.KW, kw = tap - kh * g.KW;
+                        uint32_t ih = 0, iw = 0;
+                        if (sg_coord(oh_s + (int32_t)kh, g.tstride, g.ups, g.H_in, ih) && sg_coord(ow_s + (int32_t)kw, g.tstride, g.ups, g.W_in, iw))
+                            v = *reinterpret_cast<const uint4 *>(abase + ((size_t)ih * g.W_in + iw) * g.Cin + ch);
+                    }
+                    sa[c] = v;
+                }
+            }
+    #pragma unroll
+            for (int c = 0; c < CB; c++) sb[c] = (b_valid && k + bk + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(bbase + k + bk + 8 * c) : make_uint4(0, 0, 0, 0);
+        };
+        auto commit = [&](uint32_t stage) __attribute__((always_inline)) {
+            _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
+    #pragma unroll
+            for (int c = 0; c < 4; c++) *reinterpret_cast<uint4 *>(sA + arow * SG_LDK + ak + 8 * c) = sa[c];
+    #pragma unroll
+            for (int c = 0; c < CB; c++) *reinterpret_cast<uint4 *>(sB + brow * SG_LDK + bk + 8 * c) = sb[c];
+        };
+        if (kt0 < kt1) {
+            fetch(kt0);
+            commit(0);
+        }
+        __syncthreads();
+        for (uint32_t kt = kt0; kt < kt1; kt++) {
+            const uint32_t stage = (kt - kt0) & 1;
+            if (kt + 1 < kt1) fetch(kt + 1);
+            const _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
+    #pragma unroll
+            for (int s = 0; s < SG_BK / 16; s++) {
+                sd_h8 a[2], b[NT];
+    #pragma unroll
+                for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const sd_h8 *>(sA + (wm * 64 + i * 32 + li) * SG_LDK + s * 16 + 8 * hi);
+    #pragma unroll
+                for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + (wn * 32 * NT + j * 32 + li) * SG_LDK + s * 16 + 8 * hi);
+    #pragma unroll
+                for (int i = 0; i < 2; i++)
+    #pragma unroll
+                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < kt1) commit(stage ^ 1);
+            __syncthreads();
+        }
+
+
+    } else {
+        // ---- LDS-DMA staging (global_load_lds_dwordx4): no staging registers, no ds_write pass.  Stage = A [128][64] + B [BN][64] halfs,
+        // unpadded 128-byte rows.  Round r of an operand covers rows 32 r .. 32 r + 31: a wave-instruction fills 8 rows x 8 chunks
+        // (lane-linear destination, as the instruction requires; 8 full 128-byte lines on the global side), thread t fills LDS slot
+        // (row 32 r + t / 8, chunk t % 8) from global chunk sg_swz(row, t % 8): the XOR swizzle lives on the SOURCE address and on the
+        // fragment reads.  (Measured and dropped: a chunk-major stage — one row per thread, no swizzle — touches 64 lines per
+        // wave-instruction on the global side and ran 1.4-1.6x slower.)
+        constexpr uint32_t GSTAGE = (SG_BM + BN) * SG_BK * 2;                   // bytes per stage
+        constexpr int RB = BN / 32;                                             // rounds of B per K step
+        const uint32_t grow = tid >> 3, gch = tid & 7u;                         // this thread's row inside a round, LDS chunk column
+        const unsigned char *zero = sg_zero_page;
+        const bool simple = AMODE == 2 && g.tstride == 1 && g.ups == 1;         // plain (strided) convolution: tap = pixel offset + bounds test
+        const _Float16 *arow_p[4];
+        int32_t a_oh[4], a_ow[4];
+        bool a_ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t row = 32 * r + grow, m = m0 + row;
+            a_ok[r] = m < g.M;
+            const uint32_t sc = sg_swz(row, gch) * 8;                            // source chunk (halfs) of this thread in round r
+            a_oh[r] = a_ow[r] = 0;
+            if (AMODE == 0) arow_p[r] = A + (size_t)(a_ok[r] ? m : 0) * g.lda + sc;
+            else {
+                const uint32_t hw = g.H_out * g.W_out, mm = a_ok[r] ? m : 0;
+                const uint32_t img = mm / hw, rem = mm - img * hw, oh = rem / g.W_out, ow = rem - oh * g.W_out;
+                a_oh[r] = (int32_t)(oh * g.stride) - (int32_t)g.pad_t;
+                a_ow[r] = (int32_t)(ow * g.stride) - (int32_t)g.pad_l;
+                arow_p[r] = A + (size_t)img * g.H_in * g.W_in * g.Cin + sc;
+                if (simple) arow_p[r] += ((ptrdiff_t)a_oh[r] * (ptrdiff_t)g.W_in + a_ow[r]) * (ptrdiff_t)g.Cin;   // tap (0, 0); may point before the image
             }
         }
+        const uint32_t a_sc0 = sg_swz(grow, gch) * 8;                            // (row >> 1) & 7 is the same for rows 32 r + grow: one source chunk
+        const _Float16 *brow_p[RB];
+        bool b_ok[RB];
 #pragma unroll
-        for (int c = 0; c < CB; c++) sb[c] = (b_valid && k + bk + 8 * c < g.K) ? *reinterpret_cast<const uint4 *>(bbase + k + bk + 8 * c) : make_uint4(0, 0, 0, 0);
-    };
-    auto commit = [&](uint32_t stage) __attribute__((always_inline)) {
-        _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
-#pragma unroll
-        for (int c = 0; c < 4; c++) *reinterpret_cast<uint4 *>(sA + arow * SG_LDK + ak + 8 * c) = sa[c];
-#pragma unroll
-        for (int c = 0; c < CB; c++) *reinterpret_cast<uint4 *>(sB + brow * SG_LDK + bk + 8 * c) = sb[c];
-    };
-    if (kt0 < kt1) {
-        fetch(kt0);
-        commit(0);
-    }
-    __syncthreads();
-    for (uint32_t kt = kt0; kt < kt1; kt++) {
-        const uint32_t stage = (kt - kt0) & 1;
-        if (kt + 1 < kt1) fetch(kt + 1);
-        const _Float16 *sA = lds + stage * STAGE, *sB = sA + SG_BM * SG_LDK;
-#pragma unroll
-        for (int s = 0; s < SG_BK / 16; s++) {
-            sd_h8 a[2], b[NT];
-#pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const sd_h8 *>(sA + (wm * 64 + i * 32 + li) * SG_LDK + s * 16 + 8 * hi);
-#pragma unroll
-            for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + (wn * 32 * NT + j * 32 + li) * SG_LDK + s * 16 + 8 * hi);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int r = 0; r < RB; r++) {
+            const uint32_t row = 32 * r + grow, n = n0 + row;
+            b_ok[r] = n < g.N;
+            brow_p[r] = B + (size_t)(b_ok[r] ? n : 0) * g.ldb + sg_swz(row, gch) * 8;
         }
-        if (kt + 1 < kt1) commit(stage ^ 1);
-        __syncthreads();
+        auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+            const uint32_t k = kt * SG_BK;
+            unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + SG_BM * SG_BK * 2;
+            const bool k_in = k + a_sc0 < g.K;
+            const ptrdiff_t tap_off = AMODE == 2 ? ((ptrdiff_t)t_kh * g.W_in + t_kw) * (ptrdiff_t)g.Cin + t_c0 : 0;     // uniform
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const void *src;
+                if (AMODE == 0) {
+                    src = (a_ok[r] && k_in) ? (const void *)(arow_p[r] + k) : (const void *)zero;
+                } else if (simple) {
+                    const bool ok = a_ok[r] && (uint32_t)(a_oh[r] + (int32_t)t_kh) < g.H_in && (uint32_t)(a_ow[r] + (int32_t)t_kw) < g.W_in;
+                    src = ok ? (const void *)(arow_p[r] + tap_off) : (const void *)zero;
+                } else {
+                    uint32_t ih = 0, iw = 0;
+                    const bool ok = a_ok[r] && sg_coord(a_oh[r] + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) &&
+                                    sg_coord(a_ow[r] + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
+                    src = ok ? (const void *)(arow_p[r] + ((size_t)ih * g.W_in + iw) * g.Cin + t_c0) : (const void *)zero;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sA + (32 * r + 8 * wave) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const void *src = (b_ok[r] && k_in) ? (const void *)(brow_p[r] + k) : (const void *)zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sB + (32 * r + 8 * wave) * 128), 16, 0, 0);
+            }
+            if (AMODE == 2) {
+                t_c0 += SG_BK;                                   // next K step (uniform)
+                if (t_c0 >= g.Cin) {
+                    t_c0 = 0;
+                    if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
+                }
+            }
+        };
+        // Two stages, one K step in flight.  (Measured and dropped: three stages with a counted vmcnt and a bare s_barrier — two steps in
+        // flight — cost the 128-wide tile its second resident workgroup (96 KiB of stages) and ran 1.2-1.4x slower there; no change for
+        // the 64-wide tile.)
+        if (kt0 < kt1) issue(kt0, 0);
+        __syncthreads();                                         // (drains the LDS-DMA: vmcnt(0) is part of the barrier's release)
+        for (uint32_t kt = kt0; kt < kt1; kt++) {
+            const uint32_t stage = (kt - kt0) & 1;
+            if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+            const unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + SG_BM * SG_BK * 2;
+#pragma unroll
+            for (int s2 = 0; s2 < SG_BK / 16; s2++) {
+                sd_h8 a[2], b[NT];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t row = wm * 64 + i * 32 + li;
+                    a[i] = *reinterpret_cast<const sd_h8 *>(sA + row * 128 + sg_swz(row, 2 * s2 + hi) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const uint32_t row = wn * 32 * NT + j * 32 + li;
+                    b[j] = *reinterpret_cast<const sd_h8 *>(sB + row * 128 + sg_swz(row, 2 * s2 + hi) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue phase 1: fp32 tile -> LDS [128][BN + 4] (lane owns column li of its MFMA tile, rows rho(r, hi))
@@ -413,10 +535,34 @@ static uint32_t sg_splits(const CnerfSdGemm *g, int nt, uint32_t &k_tiles_per_sp
     return p.splits;
 }
 
+static bool sg_use_glds() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CNERF_SG_GLDS");                 // 0: register-staged loop (round 1)
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+template <int AMODE, int NT, bool SPLIT, bool GLDS>
+static void sg_launch_g(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
+    static bool attr_set = false;
+    auto kern = k_sd_gemm<AMODE, NT, SPLIT, GLDS>;
+    const uint32_t lds_bytes = GLDS ? sg_lds_bytes_glds(64 * NT) : sg_lds_bytes(64 * NT);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(SG_THREADS), lds_bytes, st, *g, partial, kps);
+}
+
 template <int AMODE, int NT, bool SPLIT>
 static void sg_launch(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
+    if constexpr (AMODE != 1) {
+        if (sg_use_glds()) { sg_launch_g<AMODE, NT, SPLIT, true>(g, grid, st, partial, kps); return; }
+    }
     static bool attr_set = false;
-    auto kern = k_sd_gemm<AMODE, NT, SPLIT>;
+    auto kern = k_sd_gemm<AMODE, NT, SPLIT, false>;
     const uint32_t lds_bytes = sg_lds_bytes(64 * NT);
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -47,7 +47,7 @@ def _launch(d, device):
     check(lib.cnerf_sd_gemm(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0, stream()), "sd_gemm")
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch_outer * d.batch_inner))
+        _PROFILE.append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch_outer * d.batch_inner, (int(d.M), int(d.N), int(d.K), int(d.mode), int(d.batch_outer * d.batch_inner), int(d.H_in), int(d.Cin), int(d.tstride), int(d.ups))))
     return need.value > 0
 
 
