@@ -59,10 +59,6 @@ __device__ __forceinline__ bool sg_coord(int32_t num, uint32_t tstride, uint32_t
 }
 
 // AMODE 0: dense A.  1: implicit conv, tap resolved per 16-byte chunk.  2: implicit conv with Cin % 64 == 0 (tap uniform per K step).
-// Source of a tap that falls into the zero padding (or of a row / K chunk beyond the problem): LDS-DMA loads cannot be predicated into
-// "write zeros", so those lanes read from this page instead.
-__device__ __attribute__((aligned(16))) unsigned char sg_zero_page[256];
-
 // row r of a [rows][64 halfs] LDS stage, 16-byte chunk c: XOR swizzle keyed on (row >> 1) & 7 — every ds_read_b128 lane group (16 lanes,
 // consecutive-ish rows, one chunk column) then covers all sixteen 16-byte slots of the 256-byte bank row: conflict-free.
 __device__ __forceinline__ uint32_t sg_swz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 7u); }
@@ -204,63 +200,68 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         constexpr uint32_t GSTAGE = (SG_BM + BN) * SG_BK * 2;                   // bytes per stage
         constexpr int RB = BN / 32;                                             // rounds of B per K step
         const uint32_t grow = tid >> 3, gch = tid & 7u;                         // this thread's row inside a round, LDS chunk column
-        const unsigned char *zero = sg_zero_page;
+        // Both operands go through buffer descriptors: 32-bit per-lane byte offsets instead of 64-bit pointer arithmetic, and a lane whose
+        // offset lies beyond the buffer (set on purpose: a tap in the zero padding, a row or K chunk beyond the problem) gets ZEROS written
+        // to its LDS slot by the hardware range check (scratch/buffer_lds_oob_test.hip) — no predication, no zero page.
+        constexpr uint32_t OOB = 0xFFFFFF00u;
+        const uint32_t a_batch = AMODE == 0 ? 1u : g.M / (g.H_out * g.W_out);
+        const uint32_t a_bytes = AMODE == 0 ? (uint32_t)(((size_t)(g.M - 1) * g.lda + g.K) * 2) : (uint32_t)((size_t)a_batch * g.H_in * g.W_in * g.Cin * 2);
+        const uint32_t b_bytes = (uint32_t)(((size_t)(g.N - 1) * g.ldb + g.K) * 2);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(A), 0, a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(B), 0, b_bytes, 0x00020000);
         const bool simple = AMODE == 2 && g.tstride == 1 && g.ups == 1;         // plain (strided) convolution: tap = pixel offset + bounds test
-        const _Float16 *arow_p[4];
+        uint32_t a_off[4];                                                      // byte offset of this thread's source chunk in round r (tap (0, 0))
         int32_t a_oh[4], a_ow[4];
         bool a_ok[4];
+        const uint32_t a_sc0 = sg_swz(grow, gch) * 8;                            // source chunk (halfs): (row >> 1) & 7 is the same for rows 32 r + grow
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t row = 32 * r + grow, m = m0 + row;
             a_ok[r] = m < g.M;
-            const uint32_t sc = sg_swz(row, gch) * 8;                            // source chunk (halfs) of this thread in round r
             a_oh[r] = a_ow[r] = 0;
-            if (AMODE == 0) arow_p[r] = A + (size_t)(a_ok[r] ? m : 0) * g.lda + sc;
+            const uint32_t mm = a_ok[r] ? m : 0;
+            if (AMODE == 0) a_off[r] = (mm * g.lda + a_sc0) * 2;
             else {
-                const uint32_t hw = g.H_out * g.W_out, mm = a_ok[r] ? m : 0;
+                const uint32_t hw = g.H_out * g.W_out;
                 const uint32_t img = mm / hw, rem = mm - img * hw, oh = rem / g.W_out, ow = rem - oh * g.W_out;
                 a_oh[r] = (int32_t)(oh * g.stride) - (int32_t)g.pad_t;
                 a_ow[r] = (int32_t)(ow * g.stride) - (int32_t)g.pad_l;
-                arow_p[r] = A + (size_t)img * g.H_in * g.W_in * g.Cin + sc;
-                if (simple) arow_p[r] += ((ptrdiff_t)a_oh[r] * (ptrdiff_t)g.W_in + a_ow[r]) * (ptrdiff_t)g.Cin;   // tap (0, 0); may point before the image
+                // wrapping 32-bit arithmetic: for a tap inside the image the sum with the tap offset is the true byte offset
+                a_off[r] = ((img * g.H_in + (uint32_t)a_oh[r]) * g.W_in + (uint32_t)a_ow[r]) * g.Cin * 2 + a_sc0 * 2;
+                if (!simple) a_off[r] = img * g.H_in * g.W_in * g.Cin * 2 + a_sc0 * 2;
             }
         }
-        const uint32_t a_sc0 = sg_swz(grow, gch) * 8;                            // (row >> 1) & 7 is the same for rows 32 r + grow: one source chunk
-        const _Float16 *brow_p[RB];
-        bool b_ok[RB];
+        uint32_t b_off[RB];
 #pragma unroll
         for (int r = 0; r < RB; r++) {
             const uint32_t row = 32 * r + grow, n = n0 + row;
-            b_ok[r] = n < g.N;
-            brow_p[r] = B + (size_t)(b_ok[r] ? n : 0) * g.ldb + sg_swz(row, gch) * 8;
+            b_off[r] = n < g.N ? (n * g.ldb + sg_swz(row, gch) * 8) * 2 : OOB;
         }
         auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
             const uint32_t k = kt * SG_BK;
             unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + SG_BM * SG_BK * 2;
-            const bool k_in = k + a_sc0 < g.K;
-            const ptrdiff_t tap_off = AMODE == 2 ? ((ptrdiff_t)t_kh * g.W_in + t_kw) * (ptrdiff_t)g.Cin + t_c0 : 0;     // uniform
+            const bool k_in = k + a_sc0 < g.K;                                   // (lane-dependent only in a ragged last K step of a dense problem)
+            const uint32_t tap_off = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : k * 2;      // uniform
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const void *src;
+                uint32_t voff;
                 if (AMODE == 0) {
-                    src = (a_ok[r] && k_in) ? (const void *)(arow_p[r] + k) : (const void *)zero;
+                    voff = (a_ok[r] && k_in) ? a_off[r] + tap_off : OOB;
                 } else if (simple) {
                     const bool ok = a_ok[r] && (uint32_t)(a_oh[r] + (int32_t)t_kh) < g.H_in && (uint32_t)(a_ow[r] + (int32_t)t_kw) < g.W_in;
-                    src = ok ? (const void *)(arow_p[r] + tap_off) : (const void *)zero;
+                    voff = ok ? a_off[r] + tap_off : OOB;
                 } else {
                     uint32_t ih = 0, iw = 0;
                     const bool ok = a_ok[r] && sg_coord(a_oh[r] + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) &&
                                     sg_coord(a_ow[r] + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
-                    src = ok ? (const void *)(arow_p[r] + ((size_t)ih * g.W_in + iw) * g.Cin + t_c0) : (const void *)zero;
+                    voff = ok ? a_off[r] + ((ih * g.W_in + iw) * g.Cin + t_c0) * 2 : OOB;
                 }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sA + (32 * r + 8 * wave) * 128), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(sA + (32 * r + 8 * wave) * 128), 16, voff, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < RB; r++) {
-                const void *src = (b_ok[r] && k_in) ? (const void *)(brow_p[r] + k) : (const void *)zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sB + (32 * r + 8 * wave) * 128), 16, 0, 0);
+                const uint32_t voff = k_in ? b_off[r] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(sB + (32 * r + 8 * wave) * 128), 16, voff, k * 2, 0, 0);
             }
             if (AMODE == 2) {
                 t_c0 += SG_BK;                                   // next K step (uniform)
@@ -270,6 +271,21 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                 }
             }
         };
+        // fragment read offsets: the swizzled chunk position depends on the K sub-step only through its two high bits — four offsets per row set
+        uint32_t a_rd[2][4], b_rd[NT][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t row = wm * 64 + i * 32 + li;
+                a_rd[i][s2] = row * 128 + sg_swz(row, 2 * s2 + hi) * 16;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const uint32_t row = wn * 32 * NT + j * 32 + li;
+                b_rd[j][s2] = row * 128 + sg_swz(row, 2 * s2 + hi) * 16;
+            }
+        }
         // Two stages, one K step in flight.  (Measured and dropped: three stages with a counted vmcnt and a bare s_barrier — two steps in
         // flight — cost the 128-wide tile its second resident workgroup (96 KiB of stages) and ran 1.2-1.4x slower there; no change for
         // the 64-wide tile.)
@@ -283,15 +299,9 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             for (int s2 = 0; s2 < SG_BK / 16; s2++) {
                 sd_h8 a[2], b[NT];
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const uint32_t row = wm * 64 + i * 32 + li;
-                    a[i] = *reinterpret_cast<const sd_h8 *>(sA + row * 128 + sg_swz(row, 2 * s2 + hi) * 16);
-                }
+                for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][s2]);
 #pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    const uint32_t row = wn * 32 * NT + j * 32 + li;
-                    b[j] = *reinterpret_cast<const sd_h8 *>(sB + row * 128 + sg_swz(row, 2 * s2 + hi) * 16);
-                }
+                for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][s2]);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
