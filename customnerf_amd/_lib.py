@@ -148,3 +148,30 @@ def dtype_id(t):
     if t.dtype == torch.float16:
         return F16
     raise ValueError(f"unsupported dtype {t.dtype}")
+
+
+def scratch_key(device):
+    """Key of a per-device scratch buffer that must not be shared between concurrently running streams (the micro-batch pipeline of
+    trainer.ReconTrainer runs two half-batches on two streams): (device, stream handle)."""
+    import torch
+    return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
+_GRAD_CHAIN = {}
+
+
+def grad_chain_wait(device):
+    """Kernels that read-modify-write the trainers' shared persistent .grad buffers (grid scatter, field partial reduction) must not
+    overlap each other across streams: wait for the previous one ..."""
+    import torch
+    ev = _GRAD_CHAIN.get(device)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
+def grad_chain_record(device):
+    """... and leave an event behind for the next."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _GRAD_CHAIN[device] = ev

@@ -3,7 +3,7 @@ cnerf_field_forward / cnerf_field_backward.  Mirrors NeRFNetwork.forward/.densit
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, check, ptr, stream, F16, F32, require_cuda
+from ._lib import lib, check, ptr, stream, F16, F32, require_cuda, scratch_key, grad_chain_wait, grad_chain_record
 
 
 def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, with_rgb=True):
@@ -28,10 +28,11 @@ def _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, device):
     import ctypes
     need = ctypes.c_uint64(0)
     check(lib.cnerf_field_backward_workspace_bytes(P, enc_dim, n_hidden_geo, n_rgb_out, dt, ctypes.addressof(need)), "field_backward_workspace_bytes")
-    buf = _WS.get(device)
+    key = scratch_key(device)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < need.value:
         buf = torch.empty(int(need.value * 1.1) + 256, dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 
@@ -68,10 +69,13 @@ class FieldFunction(Function):
             g_all = torch.zeros(p_net.numel() + p_den.numel() + p_rgb.numel(), dtype=torch.float32, device=p_net.device)  # one fill, three views
             g_net, g_den, g_rgb = (t.view_as(p) for t, p in zip(g_all.split([p_net.numel(), p_den.numel(), p_rgb.numel()]), (p_net, p_den, p_rgb)))
         ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
+        if in_place:
+            grad_chain_wait(xyz.device)                                # the partial reduction adds into the shared .grad buffers
         check(lib.cnerf_field_backward(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
                                        ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
                                        ptr(ws), ws.numel(), dt, stream()), "field_backward")
         if in_place:
+            grad_chain_record(xyz.device)
             return g_enc, None, None, None, None, None, None, None, None, None, None
         return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb, None
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .._lib import lib, check, ptr, stream, dtype_id, require_cuda
+from .._lib import lib, check, ptr, stream, dtype_id, require_cuda, scratch_key, grad_chain_wait, grad_chain_record
 
 # Optional in-stream timing of the gather kernel (bench.py's roofline leg): when a list is installed with
 # set_profile(), every forward launch is bracketed by a pair of events recorded on the launch stream.
@@ -59,10 +59,11 @@ def _bwd_workspace(offsets_host, B, D, C, L, max_level, S, H, dt, device):
           "grid_encode_backward_workspace_bytes")
     if need.value == 0:
         return None, 0
-    buf = _WS_CACHE.get(device)
+    key = scratch_key(device)
+    buf = _WS_CACHE.get(key)
     if buf is None or buf.numel() < need.value:
         buf = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
-        _WS_CACHE[device] = buf
+        _WS_CACHE[key] = buf
     return buf, buf.numel()
 
 
@@ -132,9 +133,10 @@ class _Plan:
 
 
 def _side(device):
-    st = _SIDE.get(device)
+    key = scratch_key(device)                                # one side stream + plan slot per compute stream (micro-batch pipeline)
+    st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[device] = {'stream': torch.cuda.Stream(device=device), 'ws': None, 'owner': None}
+        st = _SIDE[key] = {'stream': torch.cuda.Stream(device=device), 'ws': None, 'owner': None}
     return st
 
 
@@ -193,6 +195,8 @@ class _grid_attach(Function):
         in_place = (tgt is not None and tgt.dtype == torch.float32 and tgt.is_contiguous() and tuple(tgt.shape) == tuple(eshape)
                     and tgt.device == grad.device)
         grad_embeddings = tgt if in_place else torch.zeros(eshape, device=grad.device, dtype=torch.float32)
+        if in_place:
+            grad_chain_wait(grad.device)                                        # read-modify-write of the shared .grad: one scatter at a time
         if ctx.plan is not None:
             ws, ev = ctx.plan.ws, ctx.plan.event
             torch.cuda.current_stream().wait_event(ev)
@@ -206,6 +210,8 @@ class _grid_attach(Function):
             ws, ws_bytes = _bwd_workspace(offsets_host, B, D, C, L, L, S, H, dtype_id(grad), grad.device)
             check(lib.cnerf_grid_encode_backward(ptr(grad), ptr(inputs), offsets_host.ctypes.data, ptr(grad_embeddings), B, D, C, L, L, S, H, None, None,
                                                  gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
+        if in_place:
+            grad_chain_record(grad.device)
         return None, None, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None
 
 
