@@ -92,6 +92,13 @@ class NeRFNetwork(NeRFRenderer):
         return cfg
 
     def _half(self):
+        """Precision of the fused field (grid gather + the three MLPs as ONE unit): the tcnn compute dtype, NOT the autocast state.
+        Deliberate deviation from the reference: there the grid encoder casts its table to half only under autocast (grid.py:45) while
+        tinycudann always computes in half, so outside autocast (evaluation loops that forget the context manager) float32 grid features
+        are rounded to half at the MLP input.  Here the gather feeds the fused kernel in the MLP's own precision — half features from the
+        fp16 shadow table when the networks are half, exact float32 end to end when `tcnn.set_default_dtype(torch.float32)` — and the
+        result does not depend on whether a caller wrapped the call in autocast.  (`GridEncoder.forward` / `grid_encode`, the drop-in
+        surface, keep the reference's autocast rule.)"""
         return self.network.compute_dtype == torch.float16
 
     def _geo(self, x):
