@@ -384,16 +384,35 @@ __device__ __forceinline__ void b2_pairs(const float (&in)[3], const GridLevels 
         if (interp == 1) pos[d] = ge_smoothstep(pos[d]);
     }
     fx = pos[0];
-    ge_dispatch_mode(ge_level_mode<3>(gridtype, align_corners, hashmap_size, resolution), [&](auto mode_c) {
+    const float oy = 1 - pos[1], oz = 1 - pos[2];
+    wyz[0] = oy * oz; wyz[1] = pos[1] * oz; wyz[2] = oy * pos[2]; wyz[3] = pos[1] * pos[2];
+    // Level-uniform index arithmetic, shared between the corners (ge_index_m called once per corner recomputes the y / z hash products
+    // — sixteen 32-bit multiplies, each a quarter-rate instruction — and the strided sums eight times):
+    const int mode = ge_level_mode<3>(gridtype, align_corners, hashmap_size, resolution);
+    if (mode == GE_MODE_HASH2) {
+        const uint32_t mask = hashmap_size - 1;
+        const uint32_t hy0 = pos_grid[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = pos_grid[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t hyz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        const uint32_t x0 = pos_grid[0], x1 = x0 + 1;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t pgl[3] = {pos_grid[0], pos_grid[1] + (q & 1), pos_grid[2] + (q >> 1)};
-        wyz[q] = ((q & 1) ? pos[1] : 1 - pos[1]) * ((q >> 1) ? pos[2] : 1 - pos[2]);
-        i0[q] = ge_index_m<3, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
-        pgl[0] += 1;
-        i1[q] = ge_index_m<3, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        for (int q = 0; q < 4; q++) { i0[q] = (x0 ^ hyz[q]) & mask; i1[q] = (x1 ^ hyz[q]) & mask; }
+    } else if (mode == GE_MODE_DENSE) {
+        const uint32_t s1 = align_corners ? resolution : resolution + 1, s2 = s1 * s1;
+        const uint32_t lin = pos_grid[0] + pos_grid[1] * s1 + pos_grid[2] * s2;
+        i0[0] = lin; i0[1] = lin + s1; i0[2] = lin + s2; i0[3] = lin + s1 + s2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) i1[q] = i0[q] + 1;
+    } else {
+        ge_dispatch_mode(mode, [&](auto mode_c) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t pgl[3] = {pos_grid[0], pos_grid[1] + (q & 1), pos_grid[2] + (q >> 1)};
+            i0[q] = ge_index_m<3, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            pgl[0] += 1;
+            i1[q] = ge_index_m<3, decltype(mode_c)::value>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        }
+        });
     }
-    });
 }
 
 // can the pair travel as one record?  (same chunk, and the two entries differ by a run of low ones)
@@ -425,6 +444,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restric
     const uint32_t level = lv.order[slot];
     const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
     if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    const bool dense = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PTS / B2_THREADS; i++) {
@@ -436,7 +456,8 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restric
         b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            (void)b2_ticket(cnt, i0[q] >> BN_CHUNK_LOG2);
+            if (dense) (void)b2_ticket(cnt, i0[q] >> BN_CHUNK_LOG2);              // a wave's samples share the chunk: one aggregated update
+            else atomicAdd(&cnt[i0[q] >> BN_CHUNK_LOG2], 1u);                      // hashed: the chunks are unrelated, skip the uniformity test
             if (!b2_paired(i0[q], i1[q])) atomicAdd(&cnt[i1[q] >> BN_CHUNK_LOG2], 1u);
         }
     }
@@ -565,7 +586,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
         const uint32_t fxq = min((uint32_t)(fx[i] * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t word, uint32_t val) {
-            uint32_t sl = b2_ticket(cursor, c);
+            uint32_t sl = spread ? b2_ticket(cursor, c) : atomicAdd(&cursor[c], 1u);   // (hashed levels: no wave-uniform chunks to aggregate)
             if (spread) {
                 // dense level: neighbouring tickets are neighbouring samples of one ray, i.e. the same table entries.  Scatter them over the
                 // bin's run (odd multiplier on the largest power-of-two prefix) so that an accumulate wave holds 64 unrelated records
