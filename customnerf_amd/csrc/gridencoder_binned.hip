@@ -518,7 +518,9 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
 // ticket IS its staging slot.  After one barrier the staging area is copied out slot by slot — consecutive lanes hold consecutive
 // records of one (block, bin) run, i.e. whole cache lines per store instruction.  Records beyond the staging capacity (blocks with
 // many chunk-straddling pairs) take the direct store; slot -> position is the same map either way.
+#ifndef B2S_PTS
 #define B2S_PTS 2048
+#endif
 #define B2S_MAX_CHUNKS 128                        // bins per level the staging area's tables (and its one-byte bin ids) cover
 #define B2S_CAP (B2S_PTS * 4 + 256)
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
@@ -792,7 +794,7 @@ static bool b2_enabled(int dtype) {
 // points per block and level in the hist / emit sweeps
 static uint32_t b2_pts() {
     static int p = -1;
-    if (p < 0) { p = b2_env("CNERF_B2_PTS", 2048); if (p != 1024 && p != 2048 && p != 4096 && p != 8192) p = 2048; }
+    if (p < 0) { p = b2_env("CNERF_B2_PTS", B2S_PTS); if (p != 1024 && p != 2048 && p != 4096 && p != 8192) p = 2048; }
     return (uint32_t)p;
 }
 
