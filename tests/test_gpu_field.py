@@ -103,13 +103,13 @@ def test_field_backward(L, n_geo, half):
     assert torch.all(pr.grad[:64 * 96].view(64, 96)[:, 91:] == 0)
 
 
-@pytest.mark.parametrize("n_geo,P,dir_group", [(2, 70003, 1), (1, 4099, 1), (2, 64 * 700, 64), (1, 32 * 3 + 5, 32), (2, 17, 1)])
-def test_field_backward_pipeline_shapes(n_geo, P, dir_group):
-    """k_field_bwd_x2 (fp16, 16 levels): several tiles per wave pair (the software pipeline really cycles), a ragged last tile, tile
+@pytest.mark.parametrize("n_geo,P,dir_group,L", [(2, 70003, 1, 16), (1, 4099, 1, 16), (2, 64 * 700, 64, 16), (1, 32 * 3 + 5, 32, 16), (2, 17, 1, 16),
+                                                 (2, 5000, 1, 12), (1, 2500, 128, 9)])
+def test_field_backward_pipeline_shapes(n_geo, P, dir_group, L):
+    """k_field_bwd_x2 (fp16, 9..16 levels = feature width padded to 32): several tiles per wave pair (the software pipeline really cycles), a ragged last tile, tile
     counts below the pipeline depth, one / two hidden layers, and one direction per group of samples (the per-tile direction path when the
     group is a multiple of the 32-sample tile) — against autograd on the oracle field."""
     from customnerf_amd.field import field
-    L = 16
     ref, enc, x, d = make_case(L, n_geo, P, seed=11)
     ref.half = True
     ref.pos_en.half = True
