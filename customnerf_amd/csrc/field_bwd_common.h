@@ -36,8 +36,9 @@ __device__ __forceinline__ void fb_gemm(const typename Prec<H>::elem_t *wf, uint
     }
 }
 
-// forward-order staging (same as field.hip)
-template <bool H, int KIND>
+// forward-order staging (same as field.hip).  SWZ: 16-byte fragment slots bank-swizzled for the transposing reads of field_bwd_x2.hip
+// (slot bits 2..3 ^= (K-step parity, half) — halves index i, i.e. byte offset 2 i; needs an even S)
+template <bool H, int KIND, bool SWZ = false>
 __device__ __forceinline__ void fb_stage_layer(typename Prec<H>::elem_t *dst, const float *__restrict__ W, uint32_t rows, uint32_t in_stride,
                                                uint32_t T, uint32_t S, uint32_t n_valid_cols) {
     using P = Prec<H>;
@@ -59,7 +60,7 @@ __device__ __forceinline__ void fb_stage_layer(typename Prec<H>::elem_t *dst, co
         }
         float v = 0.0f;
         if (row < rows && col >= 0 && (uint32_t)col < n_valid_cols) v = W[(size_t)row * in_stride + col];
-        dst[i] = (typename P::elem_t)v;
+        dst[SWZ ? (i ^ (((i >> 8) & 3u) << 5)) : i] = (typename P::elem_t)v;
     }
 }
 

@@ -36,12 +36,6 @@ __host__ __device__ __forceinline__ MmOff x4_offsets(const FieldDims &dm) {
 }
 
 #define X4_K 1024                            // one K-step image: 64 lanes x 16 B (16 features x 32 samples)
-__device__ __forceinline__ cn_h8 x4_tr_pair(const unsigned char *lds, uint32_t off0, uint32_t off1) {
-    union { cn_h8 h; x4_s4 s[2]; } f;
-    f.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(lds + off0));
-    f.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(lds + off1));
-    return f.h;
-}
 
 // A fragment of W^T for the data-gradient chain, read out of the FORWARD fragment store of the layer (dst[((t S + s) 64 + lane) 8 + j] =
 // W[32 t + (lane & 31)][col(s, lane >> 5, j)], field.hip) by two transposing reads.  Wanted: lane l = input feature 32 t' + (l & 31)
@@ -51,26 +45,50 @@ __device__ __forceinline__ cn_h8 x4_tr_pair(const unsigned char *lds, uint32_t o
 // chunks (address role of lane i = l & 15: row i >> 2, chunk q = i & 3), which for C-ordered columns sit at K-step 2 t' + (G & 1),
 // half q & 1, element offset 4 (q >> 1) and for natural columns (first layer) at half q >> 1, offset 4 (q & 1).
 // `lane_off` is that lane-dependent part (x4_lane_off_w), everything else is a compile-time immediate.
+// The store is bank-swizzled like the images below (fb_stage_layer<.., SWZ = true>, x4_img_swz): one lane offset per read.
+struct X4Img { uint32_t c0, c1; };
+__device__ __forceinline__ uint32_t x4_img_swz(uint32_t byte_off) { return byte_off ^ (((byte_off >> 9) & 3u) << 6); }
 template <int S>
-__device__ __forceinline__ cn_h8 x4_frag_T(const unsigned char *layer, uint32_t lane_off, int tp, int sp) {
-    const uint32_t c0 = ((sp >> 1) * S + 2 * tp) * 1024 + (16 * (sp & 1)) * 16;
-    return x4_tr_pair(layer + lane_off, c0, c0 + 8 * 16);
+__device__ __forceinline__ cn_h8 x4_frag_T(const unsigned char *layer, X4Img lane_off, int tp, int sp) {
+    const uint32_t c = ((sp >> 1) * S + 2 * tp) * 1024 + (16 * (sp & 1)) * 16;
+    union { cn_h8 h; x4_s4 s[2]; } f;
+    f.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(layer + lane_off.c0 + c));
+    f.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(layer + lane_off.c1 + c));
+    return f.h;
 }
-__device__ __forceinline__ uint32_t x4_lane_off_w(uint32_t l, bool natural_cols) {
+__device__ __forceinline__ X4Img x4_lane_off_w(uint32_t l, bool natural_cols) {
     const uint32_t G = l >> 4, i = l & 15, rho = i >> 2, q = i & 3;
     const uint32_t hi = natural_cols ? (q >> 1) : (q & 1), j0 = natural_cols ? 4 * (q & 1) : 4 * (q >> 1);
-    return (G & 1) * 1024 + hi * 512 + (4 * (l >> 5) + rho) * 16 + j0 * 2;
+    const uint32_t base = (G & 1) * 1024 + hi * 512 + (4 * (l >> 5) + rho) * 16;
+    X4Img o;
+    o.c0 = x4_img_swz(base) + j0 * 2;
+    o.c1 = x4_img_swz(base + 8 * 16) + j0 * 2;
+    return o;
+}
+// forward-order A fragment out of the swizzled store
+__device__ __forceinline__ cn_h8 x4_load_frag(const _Float16 *base, uint32_t t, uint32_t S, uint32_t s, uint32_t lane) {
+    return *reinterpret_cast<const cn_h8 *>(reinterpret_cast<const unsigned char *>(base) + (t * S + s) * 1024 + ((lane * 16) ^ ((((s & 1) * 2 + (lane >> 5)) << 6))));
 }
 // Operand fragment of a weight-gradient product out of a published image ([K-step][lane][8 halves], the B-fragment order of the chain):
 // lane l = feature 32 u + (l & 31) of the image (natural numbering), K-slots = samples 16 kk + 8 (l >> 5) + j'.
-__device__ __forceinline__ uint32_t x4_lane_off_img(uint32_t l, bool natural_slots) {
+// Bank swizzle of the images: the 32 lanes one transposing read serves together differ in K-step parity (1024 B) and half (512 B), both
+// multiples of the 256-byte bank period — four lanes per bank.  The 16-byte slot index therefore carries (K-step parity, half) XORed into
+// its bits 2..3 (x4_img_slot); the sample bit 2 of the second read then no longer adds as an immediate, so a lane holds one offset per read.
+__device__ __forceinline__ X4Img x4_lane_off_img(uint32_t l, bool natural_slots) {
     const uint32_t G = l >> 4, i = l & 15, rho = i >> 2, q = i & 3;
     const uint32_t hi = natural_slots ? (q >> 1) : (q & 1), j0 = natural_slots ? 4 * (q & 1) : 4 * (q >> 1);
-    return (G & 1) * 1024 + hi * 512 + (8 * (l >> 5) + rho) * 16 + j0 * 2;
+    const uint32_t base = (G & 1) * 1024 + hi * 512 + (8 * (l >> 5) + rho) * 16;
+    X4Img o;
+    o.c0 = x4_img_swz(base) + j0 * 2;
+    o.c1 = x4_img_swz(base + 4 * 16) + j0 * 2;
+    return o;
 }
-__device__ __forceinline__ cn_h8 x4_frag_img(const unsigned char *img, uint32_t lane_off, int u, int kk) {
-    const uint32_t c0 = 2 * u * 1024 + 16 * kk * 16;
-    return x4_tr_pair(img + lane_off, c0, c0 + 4 * 16);
+__device__ __forceinline__ cn_h8 x4_frag_img(const unsigned char *img, X4Img lane_off, int u, int kk) {
+    const uint32_t c = 2 * u * 1024 + 16 * kk * 16;
+    union { cn_h8 h; x4_s4 s[2]; } f;
+    f.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(img + lane_off.c0 + c));
+    f.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x4_s4 __attribute__((address_space(3))) *)(img + lane_off.c1 + c));
+    return f.h;
 }
 
 // da[t] += W^T(t, s) dz[s] with the W^T fragments read out of the forward store
@@ -81,12 +99,12 @@ __device__ __forceinline__ void x4_gemm(const _Float16 *wf, uint32_t S, uint32_t
 #pragma unroll
     for (int s = 0; s < NS; s++) {
 #pragma unroll
-        for (int t = 0; t < T; t++) acc[t] = Prec<true>::mfma(fb_load_frag<true>(wf, t, S, s0 + s, lane), b[s], acc[t]);
+        for (int t = 0; t < T; t++) acc[t] = Prec<true>::mfma(x4_load_frag(wf, t, S, s0 + s, lane), b[s], acc[t]);
     }
 }
 
 template <int T, int NS, int S>
-__device__ __forceinline__ void x4_gemm_T(const unsigned char *layer, uint32_t lane_off, const cn_h8 *b, cn_f16v (&acc)[T]) {
+__device__ __forceinline__ void x4_gemm_T(const unsigned char *layer, X4Img lane_off, const cn_h8 *b, cn_f16v (&acc)[T]) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
 #pragma unroll
@@ -182,12 +200,12 @@ __device__ __forceinline__ void x4_enc_mask(const cn_h8 (&raw)[SENC], uint32_t L
 template <int NS>
 __device__ __forceinline__ void x4_publish(unsigned char *img, uint32_t lane, const cn_h8 *x) {
 #pragma unroll
-    for (int s = 0; s < NS; s++) *reinterpret_cast<cn_h8 *>(img + (s * 64 + lane) * 16) = x[s];
+    for (int s = 0; s < NS; s++) *reinterpret_cast<cn_h8 *>(img + s * 1024 + ((lane * 16) ^ ((((s & 1) * 2 + (lane >> 5)) << 6)))) = x[s];
 }
 template <int NS>
 __device__ __forceinline__ void x4_fetch(const unsigned char *img, uint32_t lane, cn_h8 *x) {
 #pragma unroll
-    for (int s = 0; s < NS; s++) x[s] = *reinterpret_cast<const cn_h8 *>(img + (s * 64 + lane) * 16);
+    for (int s = 0; s < NS; s++) x[s] = *reinterpret_cast<const cn_h8 *>(img + s * 1024 + ((lane * 16) ^ ((((s & 1) * 2 + (lane >> 5)) << 6))));
 }
 
 // one 32 x 32 weight-gradient tile: acc += Z(out block) . A(in block)^T over the 32 samples of the tile (two K = 16 MFMAs)
@@ -195,7 +213,7 @@ __device__ __forceinline__ void x4_dw(cn_f16v &acc, const cn_h8 (&z)[2], const c
     acc = Prec<true>::mfma(z[0], a[0], acc);
     acc = Prec<true>::mfma(z[1], a[1], acc);
 }
-__device__ __forceinline__ void x4_load_block(const unsigned char *img, uint32_t lane_off, int u, cn_h8 (&f)[2]) {
+__device__ __forceinline__ void x4_load_block(const unsigned char *img, X4Img lane_off, int u, cn_h8 (&f)[2]) {
     f[0] = x4_frag_img(img, lane_off, u, 0);
     f[1] = x4_frag_img(img, lane_off, u, 1);
 }
@@ -268,13 +286,13 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     const float *d0 = pden, *dO = pden + FLD_HID * FLD_HID;
     const float *r0 = prgb, *rO = prgb + FLD_HID * in_r0;
 
-    fb_stage_layer<H, 0>(wl + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, SENC, dm.enc_pad);
-    if (NGEO == 2) fb_stage_layer<H, 1>(wl + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[3], d0, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fb_stage_layer<H, 1>(wl + lo.off[4], dO, 16, FLD_HID, 1, S64, FLD_HID);
-    fb_stage_layer<H, 2>(wl + lo.off[5], r0, FLD_HID, in_r0, 2, SR0, in_r0);
-    fb_stage_layer<H, 1>(wl + lo.off[6], rO, 16, FLD_HID, 1, S64, FLD_HID);
+    fb_stage_layer<H, 0, true>(wl + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, SENC, dm.enc_pad);
+    if (NGEO == 2) fb_stage_layer<H, 1, true>(wl + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1, true>(wl + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1, true>(wl + lo.off[3], d0, FLD_HID, FLD_HID, 2, S64, FLD_HID);
+    fb_stage_layer<H, 1, true>(wl + lo.off[4], dO, 16, FLD_HID, 1, S64, FLD_HID);
+    fb_stage_layer<H, 2, true>(wl + lo.off[5], r0, FLD_HID, in_r0, 2, SR0, in_r0);
+    fb_stage_layer<H, 1, true>(wl + lo.off[6], rO, 16, FLD_HID, 1, S64, FLD_HID);
     // the second K-step of the output-gradient images (features 16..31 of their padded 32-row tile) is never written: zero it once
     for (uint32_t i = threadIdx.x; i < 2 * 2 * (X4_K / 4); i += FLD_THREADS) {
         const uint32_t pr_ = i / (2 * (X4_K / 4)), w = i % (2 * (X4_K / 4));
@@ -296,8 +314,8 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     float *part = partials + (size_t)gp * po.total;
     const uint32_t off_n0 = lo.off[0] * 2, off_n1 = lo.off[1] * 2, off_n2 = lo.off[2] * 2, off_d0 = lo.off[3] * 2, off_dO = lo.off[4] * 2,
                    off_r0 = lo.off[5] * 2, off_rO = lo.off[6] * 2;
-    const uint32_t lw = x4_lane_off_w(lane, false), lwn = x4_lane_off_w(lane, true);
-    const uint32_t lc = x4_lane_off_img(lane, false), ln = x4_lane_off_img(lane, true);
+    const X4Img lw = x4_lane_off_w(lane, false), lwn = x4_lane_off_w(lane, true);
+    const X4Img lc = x4_lane_off_img(lane, false), ln = x4_lane_off_img(lane, true);
 
     if (role == 0) {
         // ======================================================================== wave A: geometry network + dW_n2 / n1 / n0
