@@ -63,16 +63,21 @@ __device__ __forceinline__ bool sg_coord(int32_t num, uint32_t tstride, uint32_t
 // consecutive-ish rows, one chunk column) then covers all sixteen 16-byte slots of the 256-byte bank row: conflict-free.
 __device__ __forceinline__ uint32_t sg_swz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 7u); }
 
-template <int AMODE, int NT, bool SPLIT, bool GLDS = false>
+// Measured and dropped: a 256 x 128 workgroup tile (each wave 128 x 64: 24 fragment reads per 32 MFMAs instead of 16 per 16) — 96..144 KiB of
+// stages leave one workgroup = one wave per SIMD on a CU, and even with three stages, double-buffered fragments and the DMA rounds slotted
+// between the MFMA groups it ran 480 / 607 / 655 TFLOP/s on the three large VAE convolutions against 608 / 727 / 797 for this tile.
+// SIMPLE (LDS-DMA loop, AMODE 2): plain strided convolution — no transposed stride, no upsampling; the tap is a pixel offset + bounds test.
+template <int AMODE, int NT, bool SPLIT, bool GLDS = false, bool SIMPLE = false>
 __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, float *__restrict__ partial, uint32_t k_tiles_per_split) {
     constexpr int BN = 64 * NT;
+    constexpr int MT = 2, BM = SG_BM;                   // 32-row MFMA tiles per wave along M
     constexpr int CB = BN * 8 / SG_THREADS;             // 16-byte chunks of B per thread per K step (4 | 2)
     constexpr uint32_t STAGE = sg_stage_halfs(BN);
     extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
     _Float16 *lds = reinterpret_cast<_Float16 *>(sg_lds);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
     const uint32_t wm = wave >> 1, wn = wave & 1;
-    const uint32_t m0 = blockIdx.x * SG_BM, n0 = blockIdx.y * BN;
+    const uint32_t m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     uint32_t z = 0, split = 0;
     if (SPLIT) split = blockIdx.z; else z = blockIdx.z;
     const uint32_t zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
@@ -114,9 +119,9 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         t_kw = tap - t_kh * g.KW;
     }
 
-    sd_f16v acc[2][NT];
+    sd_f16v acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
@@ -197,7 +202,8 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         // (row 32 r + t / 8, chunk t % 8) from global chunk sg_swz(row, t % 8): the XOR swizzle lives on the SOURCE address and on the
         // fragment reads.  (Measured and dropped: a chunk-major stage — one row per thread, no swizzle — touches 64 lines per
         // wave-instruction on the global side and ran 1.4-1.6x slower.)
-        constexpr uint32_t GSTAGE = (SG_BM + BN) * SG_BK * 2;                   // bytes per stage
+        constexpr uint32_t GSTAGE = (BM + BN) * SG_BK * 2;                      // bytes per stage
+        constexpr int RA = BM / 32;                                             // rounds of A per K step
         constexpr int RB = BN / 32;                                             // rounds of B per K step
         const uint32_t grow = tid >> 3, gch = tid & 7u;                         // this thread's row inside a round, LDS chunk column
         // Both operands go through buffer descriptors: 32-bit per-lane byte offsets instead of 64-bit pointer arithmetic, and a lane whose
@@ -209,13 +215,14 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         const uint32_t b_bytes = (uint32_t)(((size_t)(g.N - 1) * g.ldb + g.K) * 2);
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(A), 0, a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(B), 0, b_bytes, 0x00020000);
-        const bool simple = AMODE == 2 && g.tstride == 1 && g.ups == 1;         // plain (strided) convolution: tap = pixel offset + bounds test
-        uint32_t a_off[4];                                                      // byte offset of this thread's source chunk in round r (tap (0, 0))
-        int32_t a_oh[4], a_ow[4];
-        bool a_ok[4];
+        constexpr bool simple = SIMPLE;
+        const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);           // LDS destinations (M0) stay scalar arithmetic
+        uint32_t a_off[RA];                                                     // byte offset of this thread's source chunk in round r (tap (0, 0))
+        int32_t a_oh[RA], a_ow[RA];
+        bool a_ok[RA];
         const uint32_t a_sc0 = sg_swz(grow, gch) * 8;                            // source chunk (halfs): (row >> 1) & 7 is the same for rows 32 r + grow
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < RA; r++) {
             const uint32_t row = 32 * r + grow, m = m0 + row;
             a_ok[r] = m < g.M;
             a_oh[r] = a_ow[r] = 0;
@@ -237,32 +244,41 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             const uint32_t row = 32 * r + grow, n = n0 + row;
             b_off[r] = n < g.N ? (n * g.ldb + sg_swz(row, gch) * 8) * 2 : OOB;
         }
-        auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
-            const uint32_t k = kt * SG_BK;
-            unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + SG_BM * SG_BK * 2;
-            const bool k_in = k + a_sc0 < g.K;                                   // (lane-dependent only in a ragged last K step of a dense problem)
-            const uint32_t tap_off = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : k * 2;      // uniform
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
+        // One K step's DMA: uniform state, then RA + RB rounds (one wave-instruction each), then the tap advance.  Offsets are built without
+        // branches (bounds test -> OR with OOB): a `cond ? off : OOB` in front of the load turned into two exec-masked copies of the load.
+        uint32_t i_k = 0, i_tap = 0;
+        unsigned char *i_sA = sg_lds, *i_sB = sg_lds;
+        bool i_kin = true;
+        auto issue_begin = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+            i_k = kt * SG_BK;
+            i_sA = sg_lds + (size_t)stage * GSTAGE;
+            i_sB = i_sA + BM * SG_BK * 2;
+            i_kin = i_k + a_sc0 < g.K;                                           // (lane-dependent only in a ragged last K step of a dense problem)
+            i_tap = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : i_k * 2;      // uniform
+        };
+        auto issue_round = [&](int q) __attribute__((always_inline)) {
+            if (q < RA) {
+                const int r = q;
                 uint32_t voff;
                 if (AMODE == 0) {
-                    voff = (a_ok[r] && k_in) ? a_off[r] + tap_off : OOB;
+                    voff = (a_off[r] + i_tap) | ((a_ok[r] && i_kin) ? 0u : OOB);
                 } else if (simple) {
                     const bool ok = a_ok[r] && (uint32_t)(a_oh[r] + (int32_t)t_kh) < g.H_in && (uint32_t)(a_ow[r] + (int32_t)t_kw) < g.W_in;
-                    voff = ok ? a_off[r] + tap_off : OOB;
+                    voff = (a_off[r] + i_tap) | (ok ? 0u : OOB);
                 } else {
                     uint32_t ih = 0, iw = 0;
                     const bool ok = a_ok[r] && sg_coord(a_oh[r] + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) &&
                                     sg_coord(a_ow[r] + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
                     voff = ok ? a_off[r] + ((ih * g.W_in + iw) * g.Cin + t_c0) * 2 : OOB;
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(sA + (32 * r + 8 * wave) * 128), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(i_sA + (32 * r + 8 * wave_u) * 128), 16, voff, 0, 0, 0);
+            } else {
+                const int r = q - RA;
+                const uint32_t voff = b_off[r] | (i_kin ? 0u : OOB);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(i_sB + (32 * r + 8 * wave_u) * 128), 16, voff, i_k * 2, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < RB; r++) {
-                const uint32_t voff = k_in ? b_off[r] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(sB + (32 * r + 8 * wave) * 128), 16, voff, k * 2, 0, 0);
-            }
+        };
+        auto issue_end = [&]() __attribute__((always_inline)) {
             if (AMODE == 2) {
                 t_c0 += SG_BK;                                   // next K step (uniform)
                 if (t_c0 >= g.Cin) {
@@ -271,13 +287,19 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                 }
             }
         };
+        auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+            issue_begin(kt, stage);
+#pragma unroll
+            for (int q = 0; q < RA + RB; q++) issue_round(q);
+            issue_end();
+        };
         // fragment read offsets: the swizzled chunk position depends on the K sub-step only through its two high bits — four offsets per row set
-        uint32_t a_rd[2][4], b_rd[NT][4];
+        uint32_t a_rd[MT][4], b_rd[NT][4];
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const uint32_t row = wm * 64 + i * 32 + li;
+            for (int i = 0; i < MT; i++) {
+                const uint32_t row = wm * 32 * MT + i * 32 + li;
                 a_rd[i][s2] = row * 128 + sg_swz(row, 2 * s2 + hi) * 16;
             }
 #pragma unroll
@@ -294,18 +316,29 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         for (uint32_t kt = kt0; kt < kt1; kt++) {
             const uint32_t stage = (kt - kt0) & 1;
             if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
-            const unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + SG_BM * SG_BK * 2;
+            const unsigned char *sA = sg_lds + (size_t)stage * GSTAGE, *sB = sA + BM * SG_BK * 2;
+            // fragments of K sub-step s2 + 1 are requested before the MFMAs of s2 are issued (two register sets; the reads issue in the shadow of
+            // the previous sub-step's MFMAs).  Left alone the compiler keeps four fragment registers and waits on every read.
+            sd_h8 a[2][MT], b[2][NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][0]);
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[0][j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][0]);
 #pragma unroll
             for (int s2 = 0; s2 < SG_BK / 16; s2++) {
-                sd_h8 a[2], b[NT];
+                const int cur = s2 & 1, nxt = cur ^ 1;
+                if (s2 + 1 < SG_BK / 16) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][s2]);
+                    for (int i = 0; i < MT; i++) a[nxt][i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][s2 + 1]);
 #pragma unroll
-                for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][s2]);
+                    for (int j = 0; j < NT; j++) b[nxt][j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][s2 + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
@@ -315,21 +348,22 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     constexpr uint32_t LDC = BN + 4;
     float *ct = reinterpret_cast<float *>(sg_lds);
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) ct[(wm * 64 + i * 32 + sg_rho(r, hi)) * LDC + wn * 32 * NT + j * 32 + li] = acc[i][j][r];
+            for (int r = 0; r < 16; r++) ct[(wm * 32 * MT + i * 32 + sg_rho(r, hi)) * LDC + wn * 32 * NT + j * 32 + li] = acc[i][j][r];
     __syncthreads();
     // ---- phase 2: 8 consecutive columns per lane
     // optional: GroupNorm statistics of the output for the norm that reads it next.  A thread's column chunk is fixed over its rows, so
     // the (<= 2) groups' sums live in registers; flushed per image into a small LDS table, then one global atomic per (image, group) and tile.
     const bool do_gn = !SPLIT && g.gn_sums != nullptr;
-    __shared__ float gn_lds[4][36][2];
+    constexpr int GI = 4;                                // images a tile can touch (gn_rows >= 64)
+    __shared__ float gn_lds[GI][36][2];
     const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u;
     const uint32_t gn_g0 = n0 / gn_cg, gn_i0 = do_gn ? m0 / g.gn_rows : 0u;
     if (do_gn) {
-        for (uint32_t i = tid; i < 4 * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0.0f;
+        for (uint32_t i = tid; i < GI * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0.0f;
         __syncthreads();
     }
     float gs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
@@ -339,7 +373,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
     const uint32_t ldc32 = SPLIT ? g.N : g.ldc;
     constexpr uint32_t CPR = BN / 8;                    // column chunks per row
-    for (uint32_t c = tid; c < SG_BM * CPR; c += SG_THREADS) {
+    for (uint32_t c = tid; c < BM * CPR; c += SG_THREADS) {
         const uint32_t row = c / CPR, cc = (c % CPR) * 8;
         const uint32_t m = m0 + row, n = n0 + cc;
         if (m >= g.M || n >= g.N) continue;
@@ -436,7 +470,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         }
         __syncthreads();
         const uint32_t n_img = g.M / g.gn_rows;
-        for (uint32_t i = tid; i < 4 * 36; i += SG_THREADS) {
+        for (uint32_t i = tid; i < GI * 36; i += SG_THREADS) {
             const uint32_t im = i / 36, gl = i % 36, img = gn_i0 + im, grp = gn_g0 + gl;
             const float a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
             if (img < n_img && grp < g.gn_groups && (a != 0.0f || b2 != 0.0f)) {
@@ -554,10 +588,13 @@ static bool sg_use_glds() {
     return v != 0;
 }
 
-template <int AMODE, int NT, bool SPLIT, bool GLDS>
+template <int AMODE, int NT, bool SPLIT, bool GLDS, bool SIMPLE = false>
 static void sg_launch_g(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
+    if constexpr (GLDS && AMODE == 2 && !SIMPLE) {
+        if (g->tstride == 1 && g->ups == 1) { sg_launch_g<AMODE, NT, SPLIT, GLDS, true>(g, grid, st, partial, kps); return; }
+    }
     static bool attr_set = false;
-    auto kern = k_sd_gemm<AMODE, NT, SPLIT, GLDS>;
+    auto kern = k_sd_gemm<AMODE, NT, SPLIT, GLDS, SIMPLE>;
     const uint32_t lds_bytes = GLDS ? sg_lds_bytes_glds(64 * NT) : sg_lds_bytes(64 * NT);
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -606,9 +643,10 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
     int rc = sg_check(g);
     if (rc) return rc;
     hipStream_t st = CN_STREAM(stream);
-    const int nt = sg_pick_nt(g);
-    uint32_t kps;
-    uint32_t splits = sg_splits(g, nt, kps);
+    const SgPlan plan = sg_plan(g);
+    const int nt = plan.nt;
+    uint32_t kps = plan.kps;
+    uint32_t splits = plan.splits;
     if (splits > 1 && (!workspace || workspace_bytes < (uint64_t)splits * g->M * g->N * sizeof(float))) {
         splits = 1;
         kps = cn_div_up(g->K, SG_BK);
