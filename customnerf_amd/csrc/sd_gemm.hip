@@ -67,6 +67,12 @@ __device__ __forceinline__ uint32_t sg_swz(uint32_t row, uint32_t chunk) { retur
 // stages leave one workgroup = one wave per SIMD on a CU, and even with three stages, double-buffered fragments and the DMA rounds slotted
 // between the MFMA groups it ran 480 / 607 / 655 TFLOP/s on the three large VAE convolutions against 608 / 727 / 797 for this tile.
 // SIMPLE (LDS-DMA loop, AMODE 2): plain strided convolution — no transposed stride, no upsampling; the tap is a pixel offset + bounds test.
+// Measured and dropped: four stages (three K steps in flight, counted vmcnt + bare s_barrier) for launches of at most one workgroup per CU.
+// A lone workgroup's K step costs 0.35 us whatever the prefetch depth and whether the tile is 64 or 128 wide (scratch/gemm_kslope.py): the
+// 24-32 KiB of a stage pass the CU's 64 B/clk vector-memory path in 380-510 cycles — the step is bound by that fill rate, not by latency.
+// (The same rate bounds the chip: 32 KiB per 2.1 MFLOP tile step x 256 CUs x 64 B/clk = 2.5 PFLOP/s, i.e. the fill path and the matrix cores
+// would both have to be busy all the time; the kernel's 0.6-0.8 PFLOP/s on the large convolutions is where the two pipelines overlap today.)
+// A launch's fixed cost is 5.9 us (graph node 1.6 + kernel-argument load, first stage, epilogue's LDS round trip and stores).
 template <int AMODE, int NT, bool SPLIT, bool GLDS = false, bool SIMPLE = false>
 __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, float *__restrict__ partial, uint32_t k_tiles_per_split) {
     constexpr int BN = 64 * NT;
