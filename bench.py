@@ -302,7 +302,7 @@ def main():
             bpp = gather_bytes_per_point(L, opt.level_dim, isz)
             tot_ms, tot_b = sum(ms), sum(p * bpp for p in pts)
             achieved = tot_b / (tot_ms * 1e-3) / 1e9
-            result["roofline"] = {"kernel": "k_grid_fwd (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            result["roofline"] = {"kernel": "k_grid_fwd_fast (hash-grid gather forward)" if fp16 else "k_grid_fwd (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": measured_traffic(args.dtype, sum(pts) / len(pts)),
                                   "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
