@@ -35,6 +35,12 @@ CONFIGS = [
     ("hash_D3_C1_align", dict(input_dim=3, num_levels=6, level_dim=1, base_resolution=4, log2_hashmap_size=12, per_level_scale=2, gridtype='hash', align_corners=True)),
     ("tiled_D3_C8_smooth", dict(input_dim=3, num_levels=5, level_dim=8, base_resolution=8, log2_hashmap_size=15, per_level_scale=1.7, gridtype='tiled', interpolation='smoothstep')),
     ("hash_D4_C2", dict(input_dim=4, num_levels=4, level_dim=2, base_resolution=4, log2_hashmap_size=13, per_level_scale=2, gridtype='hash')),
+    # tiny tables: the tiled index drops a dimension once its running stride exceeds the table (gridencoder.cu:66-84) — 256 entries keep x, y;
+    # 16 entries keep x only — and the hashed x-pair window of the specialised fp16 gather meets a table of 4 / 64 entries
+    ("tiled_tiny_T8", dict(input_dim=3, num_levels=6, level_dim=2, base_resolution=8, log2_hashmap_size=8, per_level_scale=1.6, gridtype='tiled')),
+    ("tiled_tiny_T4", dict(input_dim=3, num_levels=5, level_dim=2, base_resolution=8, log2_hashmap_size=4, per_level_scale=1.6, gridtype='tiled')),
+    ("hash_tiny_T6", dict(input_dim=3, num_levels=6, level_dim=2, base_resolution=8, log2_hashmap_size=6, per_level_scale=1.6, gridtype='hash')),
+    ("hash_tiny_T2", dict(input_dim=3, num_levels=4, level_dim=2, base_resolution=8, log2_hashmap_size=2, per_level_scale=1.6, gridtype='hash')),
 ]
 
 
