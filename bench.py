@@ -143,6 +143,9 @@ def main_edit(args, world, rank, dev):
         v = (i * world + rank) % V
         return trainer.train_step((rgb[v], mask[v], rays_o[v], rays_d[v], H, W, f"view{v}"))
 
+    with torch.no_grad():                                               # both prompts' UNet graphs are captured before the timed region, whichever
+        for tz in (trainer.text_z, trainer.text_z_fg):                  # branch (global / local) the warm-up steps happen to draw
+            guidance.eps_pred(torch.zeros(2, 64, 64, 8, device=dev, dtype=torch.float16), 500, tz)     # NHWC CFG pair, channels padded to 8 (ops.add_noise)
     for i in range(max(args.warmup, V // world + 1)):                   # warm-up also fills the per-view cache of the pretrained render
         step(i)
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region

@@ -17,7 +17,7 @@ except Exception as e:
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     acc[r['Kernel_Name'][:44]][r['Counter_Name']].append(float(r['Counter_Value']))
-sel = ("k_bin2", "k_grid_fwd", "k_field_bwd_mma", "k_field_fwd", "k_sd_gemm", "k_sd_attention", "k_composite", "k_adam")
+sel = ("k_bin2", "k_grid_fwd", "k_field_bwd", "k_field_fwd", "k_sd_gemm", "k_sd_attention", "k_composite", "k_adam")
 for k in acc:
     if any(s in k for s in sel):
         print(k, {c: round(sum(v) / len(v), 1) for c, v in acc[k].items()}, 'n=%d' % len(next(iter(acc[k].values()))))
