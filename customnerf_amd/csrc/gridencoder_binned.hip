@@ -200,7 +200,7 @@ template <typename T>
 __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                          const BinPlan plan, const uint32_t *__restrict__ hist,
                                                          const uint32_t *__restrict__ bin_base, BinRec<T> *__restrict__ records, uint32_t B,
-                                                         uint32_t gridtype, int align_corners, uint32_t interp) {
+                                                         uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
     __shared__ uint32_t cursor[BN_MAX_CHUNKS];
     const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
@@ -220,6 +220,9 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ g
         using Vec = FeatVec<T, 2>;
         const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
         const float g0 = ge_to_float(g.v[0]), g1 = ge_to_float(g.v[1]);
+        if constexpr (sizeof(T) == 2) {                      // fixed-point sums: see b2_poison below
+            if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) grad_grid[((size_t)lv.offset[level] + index[0]) * 2] = __builtin_nanf("");
+        }
         // one cursor update and one double-width store per x-pair of corners (see k_bin_hist); record order inside a bin is
         // irrelevant: fp16 sums are exact fixed point, fp32 sums are order-dependent at rounding level only
         struct alignas(8) RecPair { BinRec<T> a, b; };
@@ -465,11 +468,18 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restric
     if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[slot] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
 }
 
+// The fixed-point sums cannot carry an infinity or a NaN (llrint of one is an arbitrary finite pattern), but the loss scaler finds overflow by
+// looking for exactly those in the gradients (the reference's half2 atomics propagate them: gridencoder.cu:324-337).  A non-finite incoming
+// gradient therefore poisons one of its destination entries directly; the accumulate's read-modify-write keeps it non-finite.
+__device__ __forceinline__ void b2_poison(float g0, float g1, float *__restrict__ grad_grid, const GridLevels &lv, uint32_t level, uint32_t entry) {
+    if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) grad_grid[((size_t)lv.offset[level] + entry) * 2] = __builtin_nanf("");
+}
+
 template <int PTS>
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                           const Bin2Plan plan, const uint32_t *__restrict__ hist,
                                                           const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0) {
+                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0, float *__restrict__ grad_grid) {
     __shared__ uint32_t cursor[BN_MAX_CHUNKS];
     const uint32_t slot = slot0 + blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t level = lv.order[slot];
@@ -489,6 +499,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
         b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
         const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
         const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
+        b2_poison(g0, g1, grad_grid, lv, level, i0[0]);
         const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
 #pragma unroll
@@ -526,7 +537,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                                  const Bin2Plan plan, const uint32_t *__restrict__ hist,
                                                                  const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                                 uint32_t gridtype, int align_corners, uint32_t interp) {
+                                                                 uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char b2s_lds[];       // one LDS object: records, bin ids, cursors, displacements
     uint2 *s_rec = reinterpret_cast<uint2 *>(b2s_lds);
     uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
@@ -579,6 +590,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
             b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
             const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
             g0[i] = __half2float(g.v[0]); g1[i] = __half2float(g.v[1]);
+            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
         }
     }
     __syncthreads();
@@ -890,9 +902,9 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     const uint32_t max_chunks = b2_max_chunks(plan, nl);
     if (staged && b2_pts() == B2S_PTS && max_chunks <= B2S_MAX_CHUNKS)          // larger tables (T = 2^20, 2^21): direct emit below
         hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 16 + 16, st, grad, inputs, lv, plan, ws.hist,
-                           ws.bin_base, ws.slab, B, gridtype, ac, interp);
+                           ws.bin_base, ws.slab, B, gridtype, ac, interp, gemb);
     else switch (b2_pts()) {
-#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u); break;
+#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u, gemb); break;
         B2_EMIT(1024) B2_EMIT(2048) B2_EMIT(4096) B2_EMIT(8192)
 #undef B2_EMIT
     }
@@ -946,7 +958,7 @@ static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, f
     bn_layout(plan, B, nl, dtype, &ws, workspace);
     const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL((k_bin_emit<T>), grid1, dim3(BN_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, (BinRec<T> *)ws.records, B,
-                       gridtype, ac, interp);
+                       gridtype, ac, interp, gemb);
     // upper bound of accumulate workgroups: every bin may add one partial segment
     const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64((uint64_t)B * nl * 8, BN_SEG);
     const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(typename BinAcc<T>::type) + 16;

@@ -239,3 +239,29 @@ def test_rejects_bad_arguments():
     enc = build(CONFIGS[2][1])
     with pytest.raises(RuntimeError):
         enc(torch.rand(8, 3))           # CPU tensor: no CPU path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_backward_propagates_non_finite_gradients(bad):
+    """The loss scaler detects overflow by looking for inf / NaN in the gradients (GradScaler; the reference's half2 atomics propagate them,
+    gridencoder.cu:324-337).  The binned fp16 backward sums in fixed point, which cannot carry them: a non-finite incoming gradient must still
+    leave a non-finite entry in the table gradient."""
+    kw = CONFIGS[0][1]
+    enc = build(kw)
+    B = 70001                                                 # B x levels >= 2^20: the binned (fixed-point) path, not the atomic kernel
+    x = torch.from_numpy(make_inputs(B, 3)).cuda()
+    with torch.autocast('cuda', dtype=torch.float16):
+        out = enc(x * 2 - 1, bound=1.0)
+    assert out.dtype == torch.float16
+    g = torch.randn(out.shape, device='cuda').half() * 1e-3
+    g[1234, 17] = bad
+    out.backward(g)
+    grad = enc.embeddings.grad
+    assert not bool(torch.isfinite(grad).all()), "a non-finite output gradient vanished in the scatter"
+    # and a clean gradient stays clean
+    enc.embeddings.grad = None
+    with torch.autocast('cuda', dtype=torch.float16):
+        out = enc(x * 2 - 1, bound=1.0)
+    out.backward(torch.randn(out.shape, device='cuda').half() * 1e-3)
+    assert bool(torch.isfinite(enc.embeddings.grad).all())
