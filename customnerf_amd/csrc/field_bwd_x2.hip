@@ -564,6 +564,15 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             x4_store(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, li, hi, wro[b]);
             x4_store(part, po.dO, 64, 0, 1, 64, 0, b, li, hi, wdo[b]);
         }
+        // the padding of this pipeline's partial row (output-layer rows beyond the real outputs, the colour layer's columns 91..95): the row is
+        // summed entry by entry into the parameter gradients, so it is written in full here instead of being zero-filled before the launch
+        // (50 MB of memset per backward)
+        for (uint32_t i = dm.n_rgb_out * 64 + lane; i < 16 * 64; i += 64) part[po.rO + i] = 0.0f;
+        for (uint32_t i = 64 + lane; i < 16 * 64; i += 64) part[po.dO + i] = 0.0f;
+        for (uint32_t i = lane; i < 64 * (96 - FLD_NDIR - 64); i += 64) {
+            const uint32_t row = i / (96 - FLD_NDIR - 64), col = FLD_NDIR + 64 + i % (96 - FLD_NDIR - 64);
+            part[po.r0 + row * 96 + col] = 0.0f;
+        }
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             x4_store(part, po.r0, 96, 0, 64, FLD_NDIR, a, 0, li, hi, wrd[a]);
@@ -605,9 +614,7 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     if (blocks > 256) blocks = 256;
     const MmOff po = x4_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
-    // the partial rows are only written where a layer has rows / columns: zero the rows in use (padding entries stay 0)
-    hipError_t e0 = hipMemsetAsync(partials, 0, (size_t)blocks * 2 * po.total * sizeof(float), st);
-    if (e0 != hipSuccess) return (int)e0;
+    // (every pipeline writes its whole partial row, padding included: no zero fill)
     static int ablate = -1;
     if (ablate < 0) {
         const char *e = getenv("CNERF_X2_ABLATE");             // measurement aid: bit 0 A-backward, 1 A-forward, 2 B switched off (results wrong), 5 role timing
