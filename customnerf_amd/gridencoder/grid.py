@@ -126,7 +126,7 @@ _SIDE = {}          # device -> {'stream': side stream, 'ws': workspace of the p
 
 class _Plan:
     """a prepared scatter plan (lives on the autograd node: dropped with the graph if the backward never runs)"""
-    __slots__ = ('ws', 'event', '__weakref__')
+    __slots__ = ('ws', 'event', 'inputs_ptr', 'rows', '__weakref__')
 
     def __init__(self, ws, event):
         self.ws, self.event = ws, event
@@ -144,6 +144,37 @@ def _side_busy(side):
     return side['owner'] is not None and side['owner']() is not None
 
 
+def _prepare_plan(inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corners, interpolation, dt, device):
+    """Issue the coordinate-only half of the binned backward scatter (histogram + scans) for `inputs` [B, D] on the side stream of the
+    current compute stream -> _Plan, or None when the side stream still holds an earlier plan / the problem takes the atomic kernel."""
+    import ctypes
+    side = _side(device)
+    if _side_busy(side):
+        return None
+    need = ctypes.c_uint64(0)
+    check(lib.cnerf_grid_encode_backward_workspace_bytes(offsets_host.ctypes.data, B, D, C, L, L, S, H, dt, ctypes.addressof(need)),
+          "grid_encode_backward_workspace_bytes")
+    if not need.value:
+        return None
+    if side['ws'] is None or side['ws'].numel() < need.value:
+        side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
+    ws = side['ws']
+    cur = torch.cuda.current_stream()
+    side['stream'].wait_stream(cur)                              # the coordinates were produced on the current stream
+    ok = ctypes.c_int(0)
+    check(lib.cnerf_grid_encode_backward_prepare(ptr(inputs), offsets_host.ctypes.data, B, D, C, L, L, S, H, gridtype, int(align_corners),
+                                                 interpolation, dt, ptr(ws), ws.numel(), ctypes.addressof(ok), side['stream'].cuda_stream),
+          "grid_encode_backward_prepare")
+    if not ok.value:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(side['stream'])
+    plan = _Plan(ws, ev)
+    plan.inputs_ptr, plan.rows = inputs.data_ptr(), B
+    side['owner'] = weakref.ref(plan)
+    return plan
+
+
 class _grid_attach(Function):
     """Backward half of _grid_encode for a feature buffer that was filled by GridEncoder.encode_into calls: forward hands the buffer
     on unchanged, backward scatters d(loss)/d(features) [L,B,C] into the table gradient for ALL B rows of `inputs`.
@@ -152,8 +183,7 @@ class _grid_attach(Function):
 
     @staticmethod
     def forward(ctx, enc, inputs, embeddings, offsets_host, per_level_scale, base_resolution, gridtype, align_corners, interpolation, overlap,
-                grad_in_place=False):
-        import ctypes
+                grad_in_place=False, plan=None):
         ctx.param = embeddings if grad_in_place else None
         L, B, C = enc.shape
         D = inputs.shape[1]
@@ -161,27 +191,11 @@ class _grid_attach(Function):
         dt = dtype_id(enc)
         ctx.save_for_backward(inputs)
         ctx.cfg = (offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, tuple(embeddings.shape))
-        ctx.plan = None
-        side = _side(enc.device) if overlap else None
-        if side is not None and not _side_busy(side):
-            need = ctypes.c_uint64(0)
-            check(lib.cnerf_grid_encode_backward_workspace_bytes(offsets_host.ctypes.data, B, D, C, L, L, S, H, dt, ctypes.addressof(need)),
-                  "grid_encode_backward_workspace_bytes")
-            if need.value:
-                if side['ws'] is None or side['ws'].numel() < need.value:
-                    side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=enc.device)
-                ws = side['ws']
-                cur = torch.cuda.current_stream()
-                side['stream'].wait_stream(cur)                              # the coordinates were produced on the current stream
-                ok = ctypes.c_int(0)
-                check(lib.cnerf_grid_encode_backward_prepare(ptr(inputs), offsets_host.ctypes.data, B, D, C, L, L, S, H, gridtype, int(align_corners),
-                                                             interpolation, dt, ptr(ws), ws.numel(), ctypes.addressof(ok), side['stream'].cuda_stream),
-                      "grid_encode_backward_prepare")
-                if ok.value:
-                    ev = torch.cuda.Event()
-                    ev.record(side['stream'])
-                    ctx.plan = _Plan(ws, ev)
-                    side['owner'] = weakref.ref(ctx.plan)
+        if plan is not None and (plan.inputs_ptr != inputs.data_ptr() or plan.rows != B):
+            plan = None                                                          # prepared for other coordinates: not ours
+        if plan is None and overlap:
+            plan = _prepare_plan(inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corners, interpolation, dt, enc.device)
+        ctx.plan = plan
         return enc.detach()
 
     @staticmethod
@@ -212,7 +226,7 @@ class _grid_attach(Function):
                                                  gridtype, int(align_corners), interpolation, dtype_id(grad), ptr(ws), ws_bytes, stream()), "grid_encode_backward")
         if in_place:
             grad_chain_record(grad.device)
-        return None, None, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None
+        return None, None, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None, None
 
 
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
@@ -338,11 +352,22 @@ class GridEncoder(nn.Module):
             e1.record()
             prof.append((e0, e1, B, L, table.element_size()))
 
-    def attach_backward(self, enc, inputs_unit, overlap=True):
+    def prepare_backward(self, inputs_unit, half):
+        """Issue the coordinate-only half of the backward scatter for inputs_unit [P, D] (float32, contiguous, [0, 1] grid coordinates) NOW, on
+        the side stream — as soon as the coordinates exist, e.g. before the last encode_into, whose gather it then overlaps — and return the
+        plan for attach_backward(..., plan=).  None when nothing was issued (attach_backward then does it itself)."""
+        assert inputs_unit.is_contiguous() and inputs_unit.dtype == torch.float32
+        P, D = inputs_unit.shape
+        dt = dtype_id(torch.empty(0, dtype=torch.float16 if half else torch.float32))
+        return _prepare_plan(inputs_unit, self._offsets_host, P, D, self.level_dim, self.num_levels, float(np.log2(self.per_level_scale)),
+                             int(self.base_resolution), self.gridtype_id, self.align_corners, self.interp_id, dt, inputs_unit.device)
+
+    def attach_backward(self, enc, inputs_unit, overlap=True, plan=None):
         """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table.
-        overlap: issue the coordinate-only half of the backward scatter now, on a second stream (see _grid_attach)."""
+        overlap: issue the coordinate-only half of the backward scatter now, on a second stream (see _grid_attach); plan: it was issued
+        earlier by prepare_backward on these coordinates."""
         return _grid_attach.apply(enc, inputs_unit.contiguous().float(), self.embeddings, self._offsets_host, self.per_level_scale, self.base_resolution,
-                                  self.gridtype_id, self.align_corners, self.interp_id, bool(overlap), bool(getattr(self, 'grad_in_place', False)))
+                                  self.gridtype_id, self.align_corners, self.interp_id, bool(overlap), bool(getattr(self, 'grad_in_place', False)), plan)
 
     def forward(self, inputs, bound=1, max_level=None, return_kernel_layout=False):
         """grid.py:151-168: [..., D] -> [..., L*C]."""

@@ -170,12 +170,23 @@ class NeRFNetwork(NeRFRenderer):
         sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None, with_rgb=False)
         return sigma
 
-    def split_forward(self, enc, unit, x, d, dir_group):
+    def _overlap_plan(self):
+        return getattr(self.opt, 'overlap_scatter_plan', True) and os.environ.get('CNERF_GRID_OVERLAP', '1') != '0'
+
+    def split_prepare(self, unit, grad_enabled):
+        """As soon as every row of `unit` is written (i.e. before the last split_encode): start the coordinate-only half of the backward
+        scatter on the side stream, where it overlaps that gather instead of the field kernels.  -> plan for split_forward, or None."""
+        if not (grad_enabled and self.pos_en.embeddings.requires_grad and self._overlap_plan()):
+            return None
+        if os.environ.get('CNERF_GRID_EARLY_PLAN', '1') == '0':
+            return None
+        return self.pos_en.prepare_backward(unit, self._half())
+
+    def split_forward(self, enc, unit, x, d, dir_group, plan=None):
         """forward() on a complete feature buffer: (sigma [P], rgbc [P, 4]); gradients reach the table through attach_backward"""
         enc_dim, n_geo, n_rgb = self._fused_cfg()
         if torch.is_grad_enabled() and self.pos_en.embeddings.requires_grad:
-            overlap = getattr(self.opt, 'overlap_scatter_plan', True) and os.environ.get('CNERF_GRID_OVERLAP', '1') != '0'
-            enc = self.pos_en.attach_backward(enc, unit, overlap=overlap)
+            enc = self.pos_en.attach_backward(enc, unit, overlap=self._overlap_plan(), plan=plan)
         sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
                             self.rgb_network.params, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
         return sigma, rgbc

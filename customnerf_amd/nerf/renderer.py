@@ -223,6 +223,8 @@ class NeRFRenderer(nn.Module):
         dbg, dmask = bool(getattr(self.opt, 'detach_bg', False)), bool(getattr(self.opt, 'detach_mask_from_field', False))
         split = (num_steps == upsample_steps and getattr(self.opt, 'split_eval', True) and getattr(self, 'supports_split_eval', False)
                  and not getattr(self.opt, 'eval_fine_density', False))
+        grad_on = torch.is_grad_enabled()
+        plan = None
         with torch.no_grad():
             noise = None
             both = None
@@ -251,6 +253,7 @@ class NeRFRenderer(nn.Module):
                 z_all, xyz_f, src = render_ops.sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw(),
                                                                         xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3),
                                                                         unit_fine_out=unit[Pc:].view(N, upsample_steps, 3), bound=bnd)
+                plan = self.split_prepare(unit, grad_on)                     # all coordinates exist: the scatter's histogram runs beside the gather below
                 self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True)
             else:
                 z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
@@ -260,7 +263,7 @@ class NeRFRenderer(nn.Module):
                     self.density(xyz_all.view(-1, 3))
         if split:
             # both blocks hold num_steps samples per ray, so "one direction per num_steps consecutive samples" covers the list with [d | d]
-            sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, torch.cat([rays_d, rays_d], 0), num_steps)
+            sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, torch.cat([rays_d, rays_d], 0), num_steps, plan=plan)
             out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
             # per-sample by-products (weights, sorted-order sigma / rgbc copies, detached): a second launch, only if somebody reads them
             aux = _Lazy(lambda: render_ops.composite_run_indexed_aux(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr))
