@@ -94,6 +94,7 @@ __device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corne
 // Level-uniform shortcuts of ge_index (same results, bit for bit).  The generic form costs a 32-bit remainder per corner (~30 VALU
 // instructions, eight times per sample and level); which branch it takes depends on the level only:
 //   GE_MODE_DENSE   every dimension enters the stride product and the product fits the table: index = sum p[d] * step^d < size, no wrap
+//                   (align_corners: the boundary corner wraps once, see ge_index_m)
 //   GE_MODE_HASH2   hashed level whose table size is a power of two: index = hash & (size - 1)
 //   GE_MODE_GENERIC anything else (tiled levels that wrap, odd table sizes)
 #define GE_MODE_GENERIC 0
@@ -129,6 +130,10 @@ __device__ __forceinline__ uint32_t ge_index_m(uint32_t gridtype, bool align_cor
             index += p[d] * stride;
             stride *= step;
         }
+        // align_corners: a point on the upper boundary has corner coordinate `resolution`, one past the last grid line, so the strided sum
+        // can pass the level (by less than its size: step (step^D - 1) / (step - 1) < 2 step^D); the reference wraps it (`% hashmap_size`,
+        // gridencoder.cu:66-84) — the corner's weight is zero there, but the entry must stay inside the level
+        if (align_corners && index >= hashmap_size) index -= hashmap_size;
         return index;
     } else if constexpr (MODE == GE_MODE_TILED2) {
         uint32_t stride = 1, index = 0;

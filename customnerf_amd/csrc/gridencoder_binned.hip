@@ -405,6 +405,13 @@ __device__ __forceinline__ void b2_pairs(const float (&in)[3], const GridLevels 
         i0[0] = lin; i0[1] = lin + s1; i0[2] = lin + s2; i0[3] = lin + s1 + s2;
 #pragma unroll
         for (int q = 0; q < 4; q++) i1[q] = i0[q] + 1;
+        if (align_corners) {                                    // boundary corners wrap into the level (ge_index_m<GE_MODE_DENSE>)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (i0[q] >= hashmap_size) i0[q] -= hashmap_size;
+                if (i1[q] >= hashmap_size) i1[q] -= hashmap_size;
+            }
+        }
     } else {
         ge_dispatch_mode(mode, [&](auto mode_c) {
 #pragma unroll
