@@ -200,3 +200,29 @@ def test_in_place_gradient_accumulation_matches_autograd_accumulation():
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
     finally:
         tcnn.set_default_dtype(torch.float32)
+
+
+def test_training_is_bit_reproducible():
+    """Two identical fp16 trainings (same seed, full-size 128x128 views so that the binned fixed-point scatter, the wave-specialised field
+    backward and the split-bin reduction all run) end in bit-identical parameters: every reduction on the path has a fixed order or is
+    exact (the reference's half2 atomic scatter is not reproducible)."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+
+    def train():
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True)
+        model = NeRFNetwork(opt).cuda()
+        H = W = 128
+        V = 2
+        o, d, rgb, mask = _target_scene(H, W, V)
+        tr = ReconTrainer(model, opt, fp16=True)
+        for i in range(3):
+            tr.train_step(o[i % V], d[i % V], rgb[i % V], mask[i % V], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+        return [p.detach().clone() for p in model.parameters()]
+
+    a, b = train(), train()
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
