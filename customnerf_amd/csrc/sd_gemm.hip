@@ -379,23 +379,49 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
     const uint32_t ldc32 = SPLIT ? g.N : g.ldc;
     constexpr uint32_t CPR = BN / 8;                    // column chunks per row
+    // The epilogue of a tile used to take 9.4 k cycles — 4 us, two thirds of a single-K-step launch and ~13 % of a large convolution's tile
+    // time (cycle stamps) — almost all of it instruction issue: every element of every item went through its own `n + e < N` exec-mask
+    // branch (three times), the activation switch and, for SiLU, an IEEE division.  Tiles that lie inside the problem (tile-uniform test)
+    // take a guard-free instantiation; the bias of a thread's column chunk (the same for all its items) is read once; the activation is
+    // selected once per item; the sigmoid forms use the hardware reciprocal (their result is rounded to half right after).
+    float bias8[8];
+    {
+        const uint32_t nb_ = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) bias8[e] = (!SPLIT && g.bias && nb_ + e < g.N) ? g.bias[nb_ + e] : 0.0f;
+    }
+    auto phase2 = [&](auto inside_c) __attribute__((always_inline)) {
+    constexpr bool INSIDE = decltype(inside_c)::value;   // the whole tile is inside [M, N]
     for (uint32_t c = tid; c < BM * CPR; c += SG_THREADS) {
         const uint32_t row = c / CPR, cc = (c % CPR) * 8;
         const uint32_t m = m0 + row, n = n0 + cc;
-        if (m >= g.M || n >= g.N) continue;
+        if (!INSIDE && (m >= g.M || n >= g.N)) continue;
         const sd_f4 v0 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc), v1 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const bool full = n + 8 <= g.N;
+        const bool full = INSIDE || n + 8 <= g.N;
         if (!SPLIT) {
-            const float *brow_ = g.bias_rows ? g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) : nullptr;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                if (n + e < g.N) {
-                    float x = v[e] * g.alpha;
-                    if (g.bias) x += g.bias[n + e];
-                    if (brow_) x += brow_[n + e];
-                    v[e] = sg_act(x, g.act);
+            for (int e = 0; e < 8; e++) v[e] = v[e] * g.alpha + bias8[e];            // (columns beyond N are never stored)
+            if (g.bias_rows) {
+                const float *brow_ = g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N);
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] += brow_[n + e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        if (INSIDE || n + e < g.N) v[e] += brow_[n + e];
                 }
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            } else if (g.act == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[e]));
             }
             if (R) {
                 const _Float16 *rp = R + (size_t)m * g.ldr + n;
@@ -406,7 +432,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; e++)
-                        if (n + e < g.N) v[e] += (float)rp[e];
+                        if (INSIDE || n + e < g.N) v[e] += (float)rp[e];
                 }
             }
         }
@@ -415,7 +441,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             _Float16 *cp = C + (size_t)m * g.ldc + n / 2;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if (n + 2 * e + 1 < g.N) {
+                if (INSIDE || n + 2 * e + 1 < g.N) {
                     const float gt = v[2 * e + 1];
                     cp[e] = (_Float16)(v[2 * e] * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752f))));
                 }
@@ -438,7 +464,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             }
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                if (n + e < g.N) {
+                if (INSIDE || n + e < g.N) {
                     const float xf = (float)(_Float16)v[e];                         // what the consumer will read
                     const int k = ((uint32_t)e < split_c) ? 0 : 1;
                     gs[k][0] += xf;
@@ -456,16 +482,19 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    if (n + e < g.N) cp[e] = (_Float16)v[e];
+                    if (INSIDE || n + e < g.N) cp[e] = (_Float16)v[e];
             }
         }
         if (C32) {
             float *cp = C32 + (size_t)m * ldc32 + n;
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                if (n + e < g.N) cp[e] = v[e];
+                if (INSIDE || n + e < g.N) cp[e] = v[e];
         }
     }
+    };
+    if (m0 + BM <= g.M && n0 + BN <= g.N) phase2(std::true_type{});
+    else phase2(std::false_type{});
     if (do_gn) {
         if (gn_img != 0xFFFFFFFFu) {
             const uint32_t gl = (n0 + (tid % CPR) * 8) / gn_cg - gn_g0;
