@@ -392,7 +392,10 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     }
     auto phase2 = [&](auto inside_c) __attribute__((always_inline)) {
     constexpr bool INSIDE = decltype(inside_c)::value;   // the whole tile is inside [M, N]
-    for (uint32_t c = tid; c < BM * CPR; c += SG_THREADS) {
+    constexpr int NIT = BM * CPR / SG_THREADS;            // items per thread (8 | 4): fixed trip count, unrolled — the LDS reads of all items
+#pragma unroll                                           // are in flight together instead of one read -> convert -> store chain per item
+    for (int k = 0; k < NIT; k++) {
+        const uint32_t c = tid + k * SG_THREADS;
         const uint32_t row = c / CPR, cc = (c % CPR) * 8;
         const uint32_t m = m0 + row, n = n0 + cc;
         if (!INSIDE && (m >= g.M || n >= g.N)) continue;
