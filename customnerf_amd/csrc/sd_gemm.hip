@@ -39,10 +39,11 @@ __host__ __device__ constexpr uint32_t sg_lds_bytes_glds(int bn) {
     return stages > ctile ? stages : ctile;
 }
 
+// (the sigmoid forms use the hardware reciprocal, as the GEMM kernel's own epilogue does: the result is rounded to half right after)
 __device__ __forceinline__ float sg_act(float v, int act) {
-    if (act == 1) return v / (1.0f + __expf(-v));
+    if (act == 1) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-    if (act == 3) return v / (1.0f + __expf(-1.702f * v));
+    if (act == 3) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
     return v;                                            // 0, and 4 (GEGLU pairs are combined by the caller)
 }
 
@@ -534,6 +535,55 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
             a = a * g.alpha + (g.bias ? g.bias[n] : 0.0f);
             b = b * g.alpha + (g.bias ? g.bias[n + 1] : 0.0f);
             reinterpret_cast<_Float16 *>(g.C)[(size_t)m * g.ldc + c] = (_Float16)(a * (0.5f * b * (1.0f + erff(b * 0.70710678118654752f))));
+        }
+        return;
+    }
+    // four consecutive columns per thread (16-byte partial loads, 8-byte stores, 32-bit index arithmetic) when the row pitches allow it;
+    // the element-wise loop below is the general form
+    if ((g.N & 3u) == 0 && (g.ldc & 3u) == 0 && (!g.residual || (g.ldr & 3u) == 0) && total < 0xFFFFFFFFull) {
+        const uint32_t total4 = (uint32_t)(total / 4), n4 = g.N / 4;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+            const uint32_t m = i / n4, n = (i - m * n4) * 4;
+            sd_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t s = 0; s < splits; s++) a += *reinterpret_cast<const sd_f4 *>(partial + (size_t)s * total + (size_t)i * 4);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = a[e] * g.alpha + (g.bias ? g.bias[n + e] : 0.0f);
+            if (g.bias_rows) {
+                const float *br = g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) + n;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += br[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = sg_act(v[e], g.act);
+            if (g.residual) {
+                typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));
+                const _Float16 *rp = reinterpret_cast<const _Float16 *>(g.residual) + (size_t)m * g.ldr + n;
+                if ((((uintptr_t)rp) & 7) == 0) {
+                    const sd_h4 r = *reinterpret_cast<const sd_h4 *>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)r[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)rp[e];
+                }
+            }
+            if (g.C) {
+                typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));
+                sd_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                _Float16 *cp = reinterpret_cast<_Float16 *>(g.C) + (size_t)m * g.ldc + n;
+                if ((((uintptr_t)cp) & 7) == 0) *reinterpret_cast<sd_h4 *>(cp) = o;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cp[e] = o[e];
+                }
+            }
+            if (g.C32) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) g.C32[(size_t)m * g.ldc + n + e] = v[e];
+            }
         }
         return;
     }
