@@ -1,12 +1,18 @@
 #!/usr/bin/env python
-"""bench.py — training rays/s of the CustomNeRF hot path on MI355X (contract: see the task statement / DESIGN.md §measurement).
+"""bench.py — training rays/s + SDS edit-steps/s of the CustomNeRF hot path on MI355X (contract: see the task statement / DESIGN.md §5).
 
-One step = one full reconstruction step of the reference's loop body (utils_init_nerf.py:194-241, 599-629) on one
-128x128 synthetic view per GPU: ray batch -> NeRFRenderer.render (the `run()` path the reference's -O2 recipe uses, 64+64
-samples; or --path march for the occupancy-march `run_cuda()` path) -> loss -> backward -> [RCCL all-reduce of the
-gradients when N>1] -> Adam.  Inputs (rays, targets, tables) are resident in HBM before the timed region.
+BASELINE.json's metric has two halves and the default invocation (`python bench.py --gpus N --steps K --warmup W`) times BOTH, one
+after the other, with the same K / W, and prints them in ONE JSON line:
 
-Prints ONE JSON line from rank 0.
+  * top level = training rays/s.  One step = one full reconstruction step of the reference's loop body (utils_init_nerf.py:194-241,
+    599-629) on one 128x128 synthetic view per GPU: ray batch -> NeRFRenderer.render (the `run()` path the reference's -O2 recipe uses,
+    64+64 samples; or --path march for the occupancy-march `run_cuda()` path) -> loss -> backward -> [RCCL all-reduce of the gradients
+    when N>1] -> Adam.  `roofline` = the hash-grid gather against HBM, `cpu_baseline` = the oracle renderer on the host cores.
+  * "secondary" = SDS edit-steps/s (utils_init_nerf.py:353-394, sd.py:115-155), same keys (value / ms_per_step / steps / warmup /
+    roofline{bound: mfma} / cpu_baseline / config).
+
+`--task recon` / `--task edit` time one half only (profiling runs).  Inputs (rays, targets, tables, weights) are resident in HBM before
+either timed region.  Prints ONE JSON line from rank 0.
 """
 import argparse
 import json
@@ -31,15 +37,15 @@ def measured_traffic(dtype, points_per_launch):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gather_pmc.json")))
     if not files:
-        return None
+        return None, None
     try:
         rec = json.load(open(files[-1]))
         e = rec.get(dtype)
         if not e:
-            return None
-        return (2.0 * e["fetch_size_kb"] + e["write_size_kb"]) * 1024.0 * points_per_launch / e["points"]
+            return None, None
+        return (2.0 * e["fetch_size_kb"] + e["write_size_kb"]) * 1024.0 * points_per_launch / e["points"], os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def gather_bytes_per_point(L, C, itemsize, D=3):
@@ -47,39 +53,45 @@ def gather_bytes_per_point(L, C, itemsize, D=3):
     return L * (2 ** D) * C * itemsize + 4 * D + L * C * itemsize
 
 
-def cpu_baseline(opt, n_rays_side=40, steps=3):
+def cpu_baseline(opt, n_rays_side=40, warm=2, steps=5):
     """The oracle (CPU restatement of the reference's pure-PyTorch renderer + C grid encoder) timed on this box's host
     cores on a BOUNDED sample of the same workload: a (side x side)-ray view of the same scene/field, same 64+64 samples,
-    forward + backward + Adam.  Reported beside the GPU number, never as the thing measured."""
-    import numpy as np
+    forward + backward + Adam.  Protocol of BASELINE.md §2: torch on ALL host cores, 2 warm-up steps, median of 5; the same
+    protocol is repeated on 32 threads (the renderer's small matmuls do not scale past that) and the FASTER of the two is the
+    reported baseline — both figures and os.cpu_count() are in the record.  Reported beside the GPU number, never as the thing measured."""
     from oracle import torch_oracle as to
     from customnerf_amd import scene as sc
-    threads = min(32, os.cpu_count() or 1)          # more threads only slow the small matmuls down
-    torch.set_num_threads(threads)
-    ref = to.FieldRef(bound=opt.bound, num_levels=opt.num_levels, level_dim=opt.level_dim, base_resolution=opt.base_resolution,
-                      log2_hashmap_size=opt.log2_hashmap_size, desired_resolution=opt.desired_resolution, gridtype='hash',
-                      n_hidden_geo=opt.n_hidden_geo, seed=0)
-    params = [ref.pos_en.embeddings, ref.network, ref.density_network, ref.rgb_network]
-    optim = torch.optim.Adam([{'params': params[:1], 'lr': opt.lr * 10}, {'params': params[1:], 'lr': opt.lr}], betas=(0.9, 0.99), eps=1e-15)
+    ncpu = os.cpu_count() or 1
     H = W = n_rays_side
     o, d = to.generate_rays(torch.from_numpy(sc.poses(8))[:1], *sc.intrinsics(H, W), H, W)
     o, d = o.reshape(1, -1, 3), d.reshape(1, -1, 3)
     rgb, mask = sc.targets(1, H, W)
     aabb = torch.tensor([-opt.bound] * 3 + [opt.bound] * 3)
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
-        res = to.run(ref, o, d, aabb, opt.min_near, num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, perturb=True, training=True)
-        loss = ((res['image'].reshape(-1, 3) - rgb[0]) ** 2).mean() + opt.train_conf * ((res['render_mask'].reshape(-1) - mask[0].reshape(-1)) ** 2).mean()
-        optim.zero_grad()
-        loss.backward()
-        optim.step()
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
-    return {"value": H * W / t, "unit": "rays/s", "cores": threads, "kind": "port",
+    runs = {}
+    for threads in sorted({ncpu, min(32, ncpu)}, reverse=True):
+        torch.set_num_threads(threads)
+        ref = to.FieldRef(bound=opt.bound, num_levels=opt.num_levels, level_dim=opt.level_dim, base_resolution=opt.base_resolution,
+                          log2_hashmap_size=opt.log2_hashmap_size, desired_resolution=opt.desired_resolution, gridtype='hash',
+                          n_hidden_geo=opt.n_hidden_geo, seed=0)
+        params = [ref.pos_en.embeddings, ref.network, ref.density_network, ref.rgb_network]
+        optim = torch.optim.Adam([{'params': params[:1], 'lr': opt.lr * 10}, {'params': params[1:], 'lr': opt.lr}], betas=(0.9, 0.99), eps=1e-15)
+        times = []
+        for it in range(warm + steps):
+            t0 = time.perf_counter()
+            res = to.run(ref, o, d, aabb, opt.min_near, num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, perturb=True, training=True)
+            loss = ((res['image'].reshape(-1, 3) - rgb[0]) ** 2).mean() + opt.train_conf * ((res['render_mask'].reshape(-1) - mask[0].reshape(-1)) ** 2).mean()
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+            if it >= warm:
+                times.append(time.perf_counter() - t0)
+        runs[threads] = H * W / sorted(times)[len(times) // 2]
+    best = max(runs, key=runs.get)
+    return {"value": runs[best], "unit": "rays/s", "cores": best, "host_cpu_count": ncpu, "kind": "port",
+            "rays_per_s_by_threads": {str(k): v for k, v in runs.items()},
             "sample": f"{H}x{W}-ray view of the same scene/field ({opt.num_steps}+{opt.upsample_steps} samples, L{opt.num_levels} T2^{opt.log2_hashmap_size} grid), "
-                      f"fwd+bwd+Adam, median of {steps} steps after 1 warm-up; grid encode/scatter = single-thread C oracle, MLP/renderer = torch CPU on {threads} threads"}
+                      f"fwd+bwd+Adam, median of {steps} steps after {warm} warm-ups (BASELINE.md §2), run on {' and '.join(str(k) for k in runs)} torch threads, faster one reported; "
+                      f"grid encode/scatter = C oracle (OpenMP over points / levels), MLP/renderer = torch CPU"}
 
 
 def cpu_baseline_edit(steps=1):
@@ -89,7 +101,8 @@ def cpu_baseline_edit(steps=1):
     linearly in pixels; the self-attention share, quadratic, is undercounted — the baseline is therefore optimistic for the CPU)."""
     from oracle import sd_oracle as so
     from customnerf_amd.sd import arch
-    threads = min(64, os.cpu_count() or 1)
+    ncpu = os.cpu_count() or 1
+    threads = ncpu
     torch.set_num_threads(threads)
     usd = arch.random_state_dict(arch.unet_params(arch.UNET_SD15), 1)
     vsd = arch.random_state_dict(arch.vae_encoder_params(arch.VAE_SD15), 2)
@@ -98,22 +111,44 @@ def cpu_baseline_edit(steps=1):
     text = torch.randn(2, 77, 768, generator=g)
     alphas = arch.alphas_cumprod()
     times = []
-    for it in range(steps):
+    for it in range(steps + 1):                                          # one warm-up (thread pool, allocator), then the timed step(s)
         t0 = time.perf_counter()
         loss, _, _ = so.train_step_sd(vsd, arch.VAE_SD15, usd, arch.UNET_SD15, img, text, 500, torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 4, 32, 32, generator=g),
                                       alphas, 100.0, 0.01, size=(256, 256))
         loss.backward()
-        times.append(time.perf_counter() - t0)
+        if it > 0:
+            times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / (4.0 * t), "unit": "edit-steps/s", "cores": threads, "kind": "port",
-            "sample": f"SDS half only (VAE encode fwd+input-grad, UNet CFG pair) of one step at 256x256 / 32x32 latents = 1/4 of the pixels, {t:.1f} s measured, "
-                      f"rate divided by 4; torch CPU float32 on {threads} threads; NeRF render excluded"}
+    return {"value": 1.0 / (4.0 * t), "unit": "edit-steps/s", "cores": threads, "host_cpu_count": ncpu, "kind": "port",
+            "sample": f"SDS half only (VAE encode fwd+input-grad, UNet CFG pair) of one step at 256x256 / 32x32 latents = 1/4 of the pixels, {t:.1f} s measured after one warm-up, "
+                      f"rate divided by 4; torch CPU float32 on {threads} threads (all host cores); NeRF render excluded"}
 
 
-def main_edit(args, world, rank, dev):
-    """--task edit: SDS edit-steps/s.  One step = EditTrainer.train_step: render one 128x128 view of the edited field (run() path, fg/bg split),
-    global/local SDS term (512x512 VAE encode fwd + input gradient, SD-1.5 UNet on the CFG pair), background-preservation L1 against the cached
-    pretrained render, backward through the renderer, [RCCL grad all-reduce], Adam.  View-parallel over ranks."""
+def _timed(step, args, world, dist):
+    """EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, last step's return value)"""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
+
+
+def run_edit(args, world, rank, dev):
+    """SDS edit-steps/s.  One step = EditTrainer.train_step: render one 128x128 view of the edited field (run() path, fg/bg split),
+    global/local SDS term (512x512 VAE encode fwd + input gradient, SD-1.5 UNet on the CFG pair; --sds-views V: V views per step through ONE
+    UNet batch of 2V — BASELINE.json north_star "optionally SDS camera views"), background-preservation L1 against the cached pretrained
+    render, backward through the renderer, [RCCL grad all-reduce], Adam.  View-parallel over ranks.  -> result dict on rank 0, None elsewhere."""
     import copy
     import torch.distributed as dist
     from customnerf_amd import scene as sc, tcnn
@@ -132,6 +167,7 @@ def main_edit(args, world, rank, dev):
     guidance = StableDiffusion(dev, '1.5', opt, seed=0)                 # SD-1.5 shapes, seeded random weights (no checkpoint offline)
     H = W = args.res
     V = 8
+    nv = max(1, int(getattr(args, 'sds_views', 1)))
     c2w = torch.from_numpy(sc.poses(V)).to(dev)
     rays_o, rays_d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
     rays_o, rays_d = rays_o.view(V, 1, H * W, 3), rays_d.view(V, 1, H * W, 3)
@@ -139,95 +175,63 @@ def main_edit(args, world, rank, dev):
     rgb, mask = rgb.to(dev), mask.to(dev)
     trainer = EditTrainer(model, pretrained, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, world_size=world)
 
+    def view(j):
+        v = j % V
+        return (rgb[v], mask[v], rays_o[v], rays_d[v], H, W, f"view{v}")
+
     def step(i):
-        v = (i * world + rank) % V
-        return trainer.train_step((rgb[v], mask[v], rays_o[v], rays_d[v], H, W, f"view{v}"))
+        base = (i * world + rank) * nv
+        if nv == 1:
+            return trainer.train_step(view(base))
+        return trainer.train_step_multi([view(base + k) for k in range(nv)])
 
     with torch.no_grad():                                               # both prompts' UNet graphs are captured before the timed region, whichever
         for tz in (trainer.text_z, trainer.text_z_fg):                  # branch (global / local) the warm-up steps happen to draw
-            guidance.eps_pred(torch.zeros(2, 64, 64, 8, device=dev, dtype=torch.float16), 500, tz)     # NHWC CFG pair, channels padded to 8 (ops.add_noise)
-    for i in range(max(args.warmup, V // world + 1)):                   # warm-up also fills the per-view cache of the pretrained render
+            guidance.eps_pred(torch.zeros(2 * nv, 64, 64, 8, device=dev, dtype=torch.float16), 500, tz)   # NHWC CFG pair(s), channels padded to 8 (ops.add_noise)
+    for i in range(max(args.warmup, V // (world * nv) + 1)):            # warm-up also fills the per-view cache of the pretrained render
         step(i)
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, ld = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, (loss, ld) = _timed(step, args, world, dist)
     skipped = args.steps - (trainer.scaler.good_steps() - good0) if trainer.scaler is not None else 0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     if rank != 0:
-        return
+        return None
     result = {"metric": "SDS edit-steps/s", "value": world * args.steps / dt, "unit": "edit-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-              "config": {"workload": f"cfg3 synthetic: {H}x{W} view/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on the CFG pair "
-                                     "at 64x64 latents + VAE encoder fwd/input-grad at 512x512, lambda_sd=0.01, keep_bg=1000, LGIE global/local alternation, fwd+bwd+Adam",
+              "config": {"workload": f"cfg3 synthetic: {nv} {H}x{W} view(s)/step/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on "
+                                     f"{nv} CFG pair(s) at 64x64 latents + VAE encoder fwd/input-grad at 512x512, lambda_sd=0.01, keep_bg=1000, LGIE global/local alternation, fwd+bwd+Adam",
+                         "sds_views_per_step": nv, "views_per_s": world * nv * args.steps / dt,
                          "parallelism": f"dp{world} (view-parallel SDS, RCCL grad all-reduce)" if world > 1 else "single GPU", "final_loss": float(loss),
                          "loss_scale": f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}", "steps_skipped_on_overflow": skipped}}
     if not args.no_roofline:
         prof = []
+        use_graph = guidance.use_graph
         guidance.use_graph = False                                       # eager launches so that each GEMM can be bracketed by events
         sdops.set_profile(prof)
         step(args.warmup + args.steps)
         sdops.set_profile(None)
+        guidance.use_graph = use_graph
         torch.cuda.synchronize()
         ms = sum(r[0].elapsed_time(r[1]) for r in prof)
         fl = sum(r[2] for r in prof)
         ach = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"kernel": "k_sd_gemm (implicit-GEMM conv / linear / attention GEMMs of the UNet + VAE)", "bound": "mfma", "achieved": ach,
                               "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(prof),
-                              "gemm_ms_per_step": ms, "algorithmic_tflop_per_step": fl / 1e12}
+                              "gemm_ms_per_step": ms, "algorithmic_tflop_per_step": fl / 1e12,
+                              "timing": "per-launch HIP event pairs on the launch stream over one eager step (the timed region replays the UNet as a hipGraph)"}
     if not args.no_cpu_baseline and world == 1:
         try:
             result["cpu_baseline"] = cpu_baseline_edit()
         except Exception as e:
             result["cpu_baseline"] = {"value": None, "unit": "edit-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-    print(json.dumps(result), flush=True)
+    del trainer, guidance, model, pretrained
+    torch.cuda.empty_cache()
+    return result
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--task", choices=["recon", "edit"], default="recon", help="recon: training rays/s (headline); edit: SDS edit-steps/s")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--path", choices=["run", "march"], default="run")
-    ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
-    ap.add_argument("--res", type=int, default=128)
-    ap.add_argument("--grid", choices=["synthetic", "bear"], default="synthetic",
-                    help="synthetic = the benchmark scene of SURVEY.md 8d (hash, T=2^19, desired 2048; the headline number); "
-                         "bear = the reference field's own table (tiledgrid, T=2^21, desired 8192; network_grid.py:89-96)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def run_recon(args, world, rank, dev):
+    """training rays/s -> result dict on rank 0, None elsewhere.  --scaling weak: every rank renders its own 128x128 view (view-parallel);
+    --scaling strong: the ranks split ONE view's rays into contiguous chunks (2048 rays per GPU at 8 GPUs)."""
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    if args.task == "edit":
-        main_edit(args, world, rank, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
     from customnerf_amd import scene as sc, tcnn
     from customnerf_amd.gridencoder import grid as ge
     from customnerf_amd.nerf.network_grid import NeRFNetwork
@@ -252,12 +256,21 @@ def main():
         grid = torch.from_numpy(sc.sphere_density_grid(model.cascade, 128, opt.bound, 1.0, 100.0)).to(dev)
         model.density_grid.copy_(grid)
         model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
-    trainer = ReconTrainer(model, opt, fp16=fp16, world_size=world)
+    trainer = ReconTrainer(model, opt, fp16=fp16, world_size=world, dp_mode=args.dp)
     render_kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=0, max_steps=opt.max_steps)
-    n_rays = H * W
+    strong = args.scaling == "strong"
+    if strong:                                           # contiguous ray chunk per rank, resident before the timed region
+        n_rays = (H * W + world - 1) // world
+        lo, hi = rank * n_rays, min((rank + 1) * n_rays, H * W)
+        rays_o, rays_d = rays_o[:, :, lo:hi].contiguous(), rays_d[:, :, lo:hi].contiguous()
+        rgb, mask = rgb[:, lo:hi].contiguous(), mask[:, lo:hi].contiguous()
+        rays_per_step = H * W
+    else:
+        n_rays = H * W
+        rays_per_step = n_rays * world
 
     def step(i):
-        v = (i * world + rank) % V                       # each rank renders its own view (view-parallel data parallelism)
+        v = (i % V) if strong else (i * world + rank) % V      # weak: each rank renders its own view (view-parallel data parallelism)
         return trainer.train_step(rays_o[v], rays_d[v], rgb[v], mask[v], **render_kw)
 
     for i in range(args.warmup):
@@ -265,33 +278,22 @@ def main():
     prof = [] if not args.no_roofline else None
     ge.set_profile(prof)
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, out = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, (loss, out) = _timed(step, args, world, dist)
     ge.set_profile(None)
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     result = None
     if rank == 0:
-        value = n_rays * world * args.steps / dt
+        value = rays_per_step * args.steps / dt
         result = {
             "metric": "training rays/s", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"cfg2 synthetic {H}x{W} view/GPU, " + ("tiled grid L16 T2^21 desired 8192 (23.97M entries, the reference field's own table), "
-                                                                         if args.grid == "bear" else "hash grid L16 T2^19 (6.12M entries), ")
+            "config": {"workload": f"cfg2 synthetic {H}x{W} view" + ("/GPU, " if not strong else f" split over {world} GPU(s), ")
+                                   + ("tiled grid L16 T2^21 desired 8192 (23.97M entries, the reference field's own table), "
+                                      if args.grid == "bear" else "hash grid L16 T2^19 (6.12M entries), ")
                                    + ("run() path 64+64 samples/ray" if args.path == "run" else "run_cuda() occupancy-march path, unit-sphere occupancy")
-                                   + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays, "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single GPU",
+                                   + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays,
+                       "parallelism": (f"dp{world} ({'ray-chunk' if strong else 'view-parallel'}, RCCL {trainer.dp_describe()})" if world > 1 else "single GPU"),
                        "path": args.path, "final_loss": float(loss),
                        "loss_scale": (f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}" if trainer.scaler is not None else "none (fp32)"),
                        "steps_skipped_on_overflow": (args.steps - (trainer.scaler.good_steps() - good0)) if trainer.scaler is not None else 0},
@@ -305,9 +307,10 @@ def main():
             bpp = gather_bytes_per_point(L, opt.level_dim, isz)
             tot_ms, tot_b = sum(ms), sum(p * bpp for p in pts)
             achieved = tot_b / (tot_ms * 1e-3) / 1e9
-            result["roofline"] = {"kernel": "k_grid_fwd_fast (hash-grid gather forward)" if fp16 else "k_grid_fwd (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            traffic, traffic_src = measured_traffic(args.dtype, sum(pts) / len(pts))
+            result["roofline"] = {"kernel": ge.forward_kernel_name(fp16) + " (hash-grid gather forward)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": measured_traffic(args.dtype, sum(pts) / len(pts)),
+                                  "traffic": traffic, "traffic_source": (traffic_src + " (committed rocprofv3 --pmc passes of this command; not re-measured in this run)") if traffic_src else None,
                                   "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
                                   "algorithmic_bytes_per_point": bpp}
         if not args.no_cpu_baseline and world == 1:
@@ -315,6 +318,60 @@ def main():
                 result["cpu_baseline"] = cpu_baseline(opt)
             except Exception as e:                                    # the baseline leg must never take the GPU number down
                 result["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", choices=["both", "recon", "edit"], default="both",
+                    help="both (default): training rays/s at the top level + SDS edit-steps/s under \"secondary\", in one JSON line; recon / edit: one half only")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--path", choices=["run", "march"], default="run")
+    ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--grid", choices=["synthetic", "bear"], default="synthetic",
+                    help="synthetic = the benchmark scene of SURVEY.md 8d (hash, T=2^19, desired 2048; the headline number); "
+                         "bear = the reference field's own table (tiledgrid, T=2^21, desired 8192; network_grid.py:89-96)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="recon leg at N>1: weak = one 128x128 view per GPU (default), strong = one view's rays split over the GPUs")
+    ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded",
+                    help="N>1 gradient exchange: sharded = fp16 reduce-scatter + sharded Adam + all-gather of the fp16 shadow; allreduce = one fp32 all-reduce")
+    ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    result = None
+    if args.task in ("both", "recon"):
+        result = run_recon(args, world, rank, dev)
+    if args.task in ("both", "edit"):
+        try:
+            edit = run_edit(args, world, rank, dev)
+        except Exception as e:                                            # in the combined line a failing edit leg must not take the rays/s half down
+            if args.task == "edit":
+                raise
+            edit = {"metric": "SDS edit-steps/s", "value": None, "unit": "edit-steps/s", "error": repr(e)} if rank == 0 else None
+        if args.task == "edit":
+            result = edit
+        elif rank == 0:
+            result["secondary"] = edit
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

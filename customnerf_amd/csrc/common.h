@@ -18,6 +18,29 @@ static inline uint64_t cn_div_up64(uint64_t a, uint64_t b) { return (a + b - 1) 
 
 #define CN_STREAM(s) ((hipStream_t)(s))
 
+// Measurement / tuning switches (kernel-generation selectors, sweep overrides, ablation masks) are read from the environment ONLY in builds
+// made with `make TUNING=1` (-DCNERF_TUNING, used by the scratch/ scripts).  The release library always takes the default: nothing in the
+// shipped .so changes behaviour with an environment variable.
+#include <stdlib.h>
+static inline int cn_tune_env(const char *name, int dflt) {
+#ifdef CNERF_TUNING
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+static inline double cn_tune_env_f(const char *name, double dflt) {
+#ifdef CNERF_TUNING
+    const char *e = getenv(name);
+    return e ? atof(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 // All float arithmetic in these kernels is compiled with -ffp-contract=off; fused multiply-adds are spelled out
 // with cn_fma so that index-producing arithmetic is bit-identical to the oracle (oracle/raymarching_ref.c).
 __device__ __forceinline__ float cn_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

@@ -296,8 +296,7 @@ int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
               float *g_rgb, void *workspace, hipStream_t st);
 static bool fb_use_fused(const FieldDims &dm, int dtype) {
-    static int env = -1;
-    if (env < 0) { const char *e = getenv("CNERF_FIELD_FUSED_BWD"); env = e ? atoi(e) : 1; }
+    static const int env = cn_tune_env("CNERF_FIELD_FUSED_BWD", 1);
     return env && dtype == CNERF_F16 && dm.enc_pad <= 32;           // 92 KiB weight fragments + 64 KiB staging must fit the 160 KiB LDS
 }
 

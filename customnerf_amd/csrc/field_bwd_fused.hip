@@ -380,13 +380,9 @@ __global__ void __launch_bounds__(256) k_field_reduce_partials(const float *__re
 #define FF_MAX_BLOCKS 512              // partial-gradient rows in the workspace (the wave-specialised kernel uses two per workgroup)
 uint64_t ff_workspace_bytes(const FieldDims &dm) { return (uint64_t)FF_MAX_BLOCKS * ff_offsets(dm).total * sizeof(float) + 256; }
 
-// field_bwd_x2.hip (the default) and field_bwd_mma.hip (round-1 kernel, CNERF_FIELD_X2_BWD=0)
+// field_bwd_x2.hip: the two-pipeline kernel for 32-wide encodings (9..16 levels); the four-wave kernel of this file serves the narrower ones
 bool x2_eligible(const FieldDims &dm);
 int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
-              const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
-              uint32_t max_partials, hipStream_t st);
-bool mm_eligible(const FieldDims &dm);
-int mm_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
               uint32_t max_partials, hipStream_t st);
 
@@ -400,9 +396,6 @@ int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
               float *g_rgb, void *workspace, hipStream_t st) {
     if (x2_eligible(dm)) {
         return x2_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
-    }
-    if (mm_eligible(dm)) {
-        return mm_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
     }
     const FieldLds lo = fld_lds_layout<true>(dm);
     const FieldLdsT lt = fb_ldsT_layout<true>(dm);

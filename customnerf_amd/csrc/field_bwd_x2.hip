@@ -267,7 +267,13 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                                                               uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                               const float *__restrict__ pden, const float *__restrict__ prgb,
                                                               const float *__restrict__ g_sigma, const float *__restrict__ g_rgbc,
-                                                              void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate) {
+                                                              void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate_arg) {
+#ifdef CNERF_TUNING
+    const uint32_t ablate = ablate_arg;                       // measurement aid, tuning builds only
+#else
+    constexpr uint32_t ablate = 0;                            // release build: the ablation / role-timing branches fold away
+    (void)ablate_arg;
+#endif
     constexpr bool H = true;
     constexpr int SENC = 2;                                   // enc_pad == 32
     using PR = Prec<H>;
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     const uint32_t pair = wave >> 1, role = wave & 1;
     unsigned char *xch = fld_lds + pair * X2_PAIR_BYTES;
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(x2_w);
-    unsigned long long tw_ = 0, tb_ = 0;
+    [[maybe_unused]] unsigned long long tw_ = 0, tb_ = 0;
     const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
     const uint32_t G = gridDim.x * 2, gp = blockIdx.x * 2 + pair;                   // tile pipelines of the whole launch / this one
     const uint32_t n_iter = (n_tiles + G - 1) / G;                                  // workgroup-uniform: same barrier count for every wave
@@ -583,10 +589,12 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             }
         }
     }
-    if ((ablate & 32) && lane == 0) {
-        unsigned long long *tt = reinterpret_cast<unsigned long long *>(partials + (size_t)530 * po.total) + ((size_t)blockIdx.x * 4 + wave) * 2;
+#ifdef CNERF_TUNING
+    if ((ablate & 32) && lane == 0) {                         // role-timing dump: the last two rows of the FF_MAX_BLOCKS-row workspace (blocks <= 255 then)
+        unsigned long long *tt = reinterpret_cast<unsigned long long *>(partials + (size_t)510 * po.total) + ((size_t)blockIdx.x * 4 + wave) * 2;
         tt[0] = tw_; tt[1] = tb_;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host entry (called from field_bwd_fused.hip)
@@ -594,11 +602,7 @@ void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t tot
                         hipStream_t st);
 
 bool x2_eligible(const FieldDims &dm) {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("CNERF_FIELD_X2_BWD");            // 0: the round-1 kernels (field_bwd_mma.hip / field_bwd_fused.hip)
-        on = e ? atoi(e) : 1;
-    }
+    static const int on = cn_tune_env("CNERF_FIELD_X2_BWD", 1);   // 0 (tuning builds): the four-wave kernel of field_bwd_fused.hip
     return on && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2);
 }
 
@@ -615,11 +619,10 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     const MmOff po = x4_offsets(dm);
     float *partials = reinterpret_cast<float *>(workspace);
     // (every pipeline writes its whole partial row, padding included: no zero fill)
-    static int ablate = -1;
-    if (ablate < 0) {
-        const char *e = getenv("CNERF_X2_ABLATE");             // measurement aid: bit 0 A-backward, 1 A-forward, 2 B switched off (results wrong), 5 role timing
-        ablate = e ? atoi(e) : 0;
-    }
+    // measurement aid of tuning builds only (bit 0 A-backward, 1 A-forward, 2 B switched off — results wrong —, 5 role timing); the release
+    // kernel is compiled with the mask fixed at 0 (X2_ABLATE below)
+    static const int ablate = cn_tune_env("CNERF_X2_ABLATE", 0);
+    if ((ablate & 32) && blocks > 255) blocks = 255;                          // rows 510 / 511 of the workspace hold the timing dump
 #define X2_LAUNCH(KERN)                                                                                                                    \
     {                                                                                                                                      \
         auto kern = KERN;                                                                                                                  \

@@ -453,29 +453,17 @@ __global__ void __launch_bounds__(256) k_cast_f32_f16(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------ host side
 static int ge_swizzle_default() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("CNERF_GRID_SWIZZLE");
-        v = e ? atoi(e) : 2;
-    }
+    static const int v = cn_tune_env("CNERF_GRID_SWIZZLE", 2);
     return v;
 }
 static double ge_dense_weight() {
-    static double w = -1;
-    if (w < 0) {
-        const char *e = getenv("CNERF_GRID_DENSE_W");
-        w = e ? atof(e) : 0.7;               // measured: 0.2 / 0.3 / 0.5 / 0.7 -> 274 / 260 / 243 / 239 us per launch (uniform slices: 247)
-    }
+    static const double w = cn_tune_env_f("CNERF_GRID_DENSE_W", 0.7);   // measured: 0.2 / 0.3 / 0.5 / 0.7 -> 274 / 260 / 243 / 239 us per launch (uniform slices: 247)
     return w;
 }
 
 // every level in use must be one of the three modes k_grid_fwd_fast implements (hashed levels additionally 4-entry aligned)
 static bool ge_fast_eligible(const GridLevels &lv, uint32_t nl, uint32_t gridtype) {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("CNERF_GRID_FAST");
-        on = e ? atoi(e) : 1;
-    }
+    static const int on = cn_tune_env("CNERF_GRID_FAST", 1);
     if (!on) return false;
     for (uint32_t l = 0; l < nl; l++) {
         const uint64_t step = (uint64_t)lv.resolution[l] + 1, cells = step * step * step;

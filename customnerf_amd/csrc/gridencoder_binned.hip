@@ -806,10 +806,7 @@ static uint64_t bn_layout(const BinPlan &plan, uint32_t B, uint32_t nl, int dtyp
 
 
 // ---- second form, host side
-static int b2_env(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+static int b2_env(const char *name, int dflt) { return cn_tune_env(name, dflt); }
 static bool b2_enabled(int dtype) {
     static int v1 = -1;
     if (v1 < 0) v1 = b2_env("CNERF_BIN_V1", 0);

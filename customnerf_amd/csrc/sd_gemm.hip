@@ -318,8 +318,11 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
         // Two stages, one K step in flight.  (Measured and dropped: three stages with a counted vmcnt and a bare s_barrier — two steps in
         // flight — cost the 128-wide tile its second resident workgroup (96 KiB of stages) and ran 1.2-1.4x slower there; no change for
         // the 64-wide tile.)
+        // The LDS-DMA data of OTHER waves is read after each barrier: every wave drains its own DMA (vmcnt(0)) before it arrives.  The wait is
+        // spelled out — a workgroup-scope barrier does not promise it (hipcc happens to emit one today; Composable Kernel writes it too).
         if (kt0 < kt1) issue(kt0, 0);
-        __syncthreads();                                         // (drains the LDS-DMA: vmcnt(0) is part of the barrier's release)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         for (uint32_t kt = kt0; kt < kt1; kt++) {
             const uint32_t stage = (kt - kt0) & 1;
             if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
@@ -347,6 +350,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
                     for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of stage ^ 1 has landed before anybody reads it
             __syncthreads();
         }
     }
@@ -630,10 +634,7 @@ static int sg_check(const CnerfSdGemm *g) {
 // partial round trip and one launch.  The old rule (ceil(512 / tiles) splits, only below 256 tiles) overshot 512 workgroups and paid a
 // second, nearly empty round on the 32x32 / 16x16 UNet levels: 1.3-1.4x slower there.
 struct SgPlan { int nt; uint32_t splits, kps; };
-static int sg_env(const char *name) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : 0;
-}
+static int sg_env(const char *name) { return cn_tune_env(name, 0); }     // release build: always 0 (common.h)
 static SgPlan sg_plan(const CnerfSdGemm *g) {
     const uint32_t n_ktiles = cn_div_up(g->K, SG_BK);
     const uint32_t batch = g->batch_outer * g->batch_inner;
@@ -667,13 +668,19 @@ static uint32_t sg_splits(const CnerfSdGemm *g, int nt, uint32_t &k_tiles_per_sp
     return p.splits;
 }
 
-static bool sg_use_glds() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("CNERF_SG_GLDS");                 // 0: register-staged loop (round 1)
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
+// The LDS-DMA loader addresses A and B through buffer descriptors: 32-bit byte offsets, a 32-bit num_records and 0xFFFFFF00 as the
+// "out of range" offset.  An operand whose extent (per batch entry for A) does not fit below that sentinel takes the register-staged
+// loader, which uses 64-bit pointers.
+static bool sg_glds_fits(const CnerfSdGemm *g) {
+    const uint64_t lim = 0xFFFFFF00ull - 4096;
+    const uint64_t a_bytes = g->mode == 0 ? ((uint64_t)(g->M - 1) * g->lda + g->K) * 2
+                                          : (uint64_t)(g->M / (g->H_out * g->W_out)) * g->H_in * g->W_in * g->Cin * 2;
+    const uint64_t b_bytes = ((uint64_t)(g->N - 1) * g->ldb + g->K) * 2;
+    return a_bytes < lim && b_bytes < lim;
+}
+static bool sg_use_glds(const CnerfSdGemm *g) {
+    static const int v = cn_tune_env("CNERF_SG_GLDS", 1);        // 0: register-staged loop (round 1)
+    return v != 0 && sg_glds_fits(g);
 }
 
 template <int AMODE, int NT, bool SPLIT, bool GLDS, bool SIMPLE = false>
@@ -694,7 +701,7 @@ static void sg_launch_g(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *
 template <int AMODE, int NT, bool SPLIT>
 static void sg_launch(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
     if constexpr (AMODE != 1) {
-        if (sg_use_glds()) { sg_launch_g<AMODE, NT, SPLIT, true>(g, grid, st, partial, kps); return; }
+        if (sg_use_glds(g)) { sg_launch_g<AMODE, NT, SPLIT, true>(g, grid, st, partial, kps); return; }
     }
     static bool attr_set = false;
     auto kern = k_sd_gemm<AMODE, NT, SPLIT, false>;

@@ -30,6 +30,11 @@ def set_profile(sink):
     _PROFILE = sink
 
 
+def forward_kernel_name(half):
+    """name of the gather kernel the CustomNeRF configuration launches (bench.py's roofline record)"""
+    return "k_grid_fwd_fast" if half else "k_grid_fwd"
+
+
 _gridtype_to_id = {'hash': 0, 'tiled': 1}
 _interp_to_id = {'linear': 0, 'smoothstep': 1}
 

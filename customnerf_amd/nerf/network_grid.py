@@ -5,8 +5,6 @@ Same module tree and parameter names as the reference so its state dicts line up
 Grid geometry defaults to the reference's hard-coded values (tiled, log2 T = 21, finest 8192; network_grid.py:89-96)
 and can be overridden through `opt.grid_type / opt.log2_hashmap_size / opt.desired_resolution / opt.num_levels`.
 """
-import os
-
 import torch
 from torch import nn
 
@@ -171,14 +169,14 @@ class NeRFNetwork(NeRFRenderer):
         return sigma
 
     def _overlap_plan(self):
-        return getattr(self.opt, 'overlap_scatter_plan', True) and os.environ.get('CNERF_GRID_OVERLAP', '1') != '0'
+        return getattr(self.opt, 'overlap_scatter_plan', True)
 
     def split_prepare(self, unit, grad_enabled):
         """As soon as every row of `unit` is written (i.e. before the last split_encode): start the coordinate-only half of the backward
         scatter on the side stream, where it overlaps that gather instead of the field kernels.  -> plan for split_forward, or None."""
         if not (grad_enabled and self.pos_en.embeddings.requires_grad and self._overlap_plan()):
             return None
-        if os.environ.get('CNERF_GRID_EARLY_PLAN', '1') == '0':
+        if not getattr(self.opt, 'early_scatter_plan', True):
             return None
         return self.pos_en.prepare_backward(unit, self._half())
 

@@ -15,7 +15,7 @@ Differences that are deliberate:
 import torch
 from torch.autograd import Function
 
-from .._lib import lib, check, ptr, stream
+from .._lib import lib, check, ptr, stream, scratch_key
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "composite_rays_train_sdf", "march_rays", "composite_rays", "compact_rays_alive"]
@@ -90,18 +90,20 @@ _HITS_MAX_BYTES = 512 << 20          # above this the write pass re-marches (cne
 
 
 def _hits_scratch(N, max_steps, device):
-    """Per-device scratch for the occupied-probe list of march_rays_train: N * max_steps (t, dt) pairs, uninitialised.  Grown on demand,
+    """Per-(device, stream) scratch (scratch_key: concurrent calls on two streams must not share it, nor have it freed under them) for the
+    occupied-probe list of march_rays_train: N * max_steps (t, dt) pairs, uninitialised.  Grown on demand,
     released when a request needs less than a quarter of what is held (one full-image call must not pin its worst case for the life of
     the process), and never larger than _HITS_MAX_BYTES: returns None beyond that and the caller takes the re-marching writer."""
     need = N * max_steps * 2
+    key = scratch_key(device)
     if need * 4 > _HITS_MAX_BYTES:
-        _HITS.pop(device, None)
+        _HITS.pop(key, None)
         return None
-    buf = _HITS.get(device)
+    buf = _HITS.get(key)
     if buf is None or buf.numel() < need or buf.numel() > 4 * need:
-        _HITS.pop(device, None)
+        _HITS.pop(key, None)
         buf = None                                                  # drop the old block before asking for the new one
-        buf = _HITS[device] = torch.empty(need, dtype=torch.float32, device=device)
+        buf = _HITS[key] = torch.empty(need, dtype=torch.float32, device=device)
     return buf
 
 

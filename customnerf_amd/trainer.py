@@ -90,13 +90,16 @@ def check_grads_finite(scaler, parameters, flat):
 
 
 class ReconTrainer:
-    def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic'):
-        """loss_scale: 'dynamic' = the reference's GradScaler policy (utils_init_nerf.py `self.scaler = GradScaler(enabled=self.fp16)`:
+    def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic', dp_mode='allreduce'):
+        """dp_mode (world_size > 1): 'allreduce' = one in-place fp32 all-reduce of the flat gradient buffer; 'sharded' = customnerf_amd.dp.ShardedExchange
+        (fp16 all-to-all payload summed in fp32 on arrival, sharded Adam, all-gather of the fp16 shadow; MLP groups all-reduced while the grid scatter runs).
+        loss_scale: 'dynamic' = the reference's GradScaler policy (utils_init_nerf.py `self.scaler = GradScaler(enabled=self.fp16)`:
         init 65536, x2 / 2000 clean steps, x0.5 + skipped step on inf) kept on the device (optim.DynamicLossScaler, fused Adam only);
         a float = static scale."""
         self.model, self.opt = model, opt
         self.fp16 = fp16
         self.world_size = world_size
+        self.dp_mode = dp_mode if world_size > 1 else 'none'
         if loss_scale == 'dynamic' and not (fp16 and fused_adam):
             loss_scale = 128.0
         self.scaler = DynamicLossScaler(next(model.parameters()).device) if loss_scale == 'dynamic' else None
@@ -118,6 +121,12 @@ class ReconTrainer:
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)      # main.py:189
+
+    def dp_describe(self):
+        """one-line description of the gradient exchange (bench.py's config.parallelism)"""
+        if self.dp_mode == 'sharded' and getattr(self, '_dp', None) is not None:
+            return self._dp.describe()
+        return "fp32 grad all-reduce, in place on the flat buffer"
 
     def loss(self, outputs, rgbs, mask):
         """utils_init_nerf.py:220-234"""

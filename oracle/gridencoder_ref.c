@@ -104,6 +104,9 @@ static inline float ldg(const void *grid, int dtype, size_t i) {
 void orc_grid_encode_forward(const float *inputs, const void *embeddings, const int *offsets, void *outputs,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                              void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype) {
+    /* levels are independent (disjoint output rows): one OpenMP task per level — bench.py's cpu_baseline leg uses the host's cores;
+     * within a level the points are visited in order, so the results do not depend on the thread count */
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t level = 0; level < max_level; level++) {
         const size_t goff = (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
@@ -189,6 +192,9 @@ void orc_grid_encode_backward(const void *grad, const float *inputs, const int *
                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                               const void *dy_dx, float *grad_inputs,
                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype) {
+    /* one OpenMP task per level: a level's updates land in its own slice of grad_embeddings and are applied in point order (the
+     * sequential sum order of this restatement is kept whatever the thread count) */
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t level = 0; level < max_level; level++) {
         const size_t goff = (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);

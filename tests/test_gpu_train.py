@@ -223,6 +223,9 @@ def test_training_is_bit_reproducible():
             tr.train_step(o[i % V], d[i % V], rgb[i % V], mask[i % V], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
         return [p.detach().clone() for p in model.parameters()]
 
-    a, b = train(), train()
+    try:
+        a, b = train(), train()
+    finally:
+        tcnn.set_default_dtype(torch.float32)                 # the fp16 default must not leak into later tests
     for pa, pb in zip(a, b):
         assert torch.equal(pa, pb)
