@@ -49,6 +49,11 @@ SIGNATURES = {
     "cnerf_mlp_backward": [vp, u32, vp, vp, u32, u32, u32, u32, u32, u32, i32, vp, u32, vp, vp, u64, i32, vp],
     "cnerf_mlp_backward_workspace_bytes": [u32, u32, u32, u32, u32, i32, vp],
     "cnerf_generate_rays": [vp, u32, u32, u32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "cnerf_generate_rays_fisheye": [vp, u32, u32, u32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
+    "cnerf_occupancy_points": [vp, u32, f32, f32, vp, vp],
+    "cnerf_occupancy_update": [vp, u32, f32, vp, vp, vp],
+    "cnerf_occupancy_finalize_pack": [vp, u32, f32, vp, u32, vp, vp, vp],
+    "cnerf_sample_pdf": [vp, vp, vp, u32, u32, u32, vp, vp],
     "cnerf_sample_coarse": [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp],
     "cnerf_sample_fine_merge_split": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp],

@@ -4,23 +4,57 @@
 // ------------------------------------------------------------------------------------------------ ray generation
 // One thread per pixel of one view.  convention 0: nerfstudio / OpenGL pinhole (reference nerf/provider.py:402-464,
 // output already in [H,W] order, i.e. the [W,H]->[H,W] permute of :460-464 is folded into the index);
-// convention 1: torch-ngp get_rays (reference nerf/provider_utils.py:239-302).
+// convention 1: torch-ngp get_rays (reference nerf/provider_utils.py:239-302);
+// convention 2: nerfstudio OPENCV_FISHEYE (provider.py:421-433): the normalised pixel coordinate is un-distorted by ten Newton steps on the
+// OpenCV radial + tangential model (provider_utils.py:128-234, operation for operation), then theta = |coord| (clipped to [0, pi]) gives
+// dir = (x sin(theta)/theta, y sin(theta)/theta, -cos(theta)) before the rotation.
+struct RayDistortion { float k1, k2, k3, k4, p1, p2; };
+
+// provider_utils.py:128-194 (_compute_residual_and_jacobian) + :221-232 (one Newton step), float32, the reference's operation order
+__device__ __forceinline__ void rg_undistort_step(float &x, float &y, float xd, float yd, const RayDistortion &k, float eps) {
+    const float r = x * x + y * y;
+    const float d = 1.0f + r * (k.k1 + r * (k.k2 + r * (k.k3 + r * k.k4)));
+    const float fx = d * x + 2 * k.p1 * x * y + k.p2 * (r + 2 * x * x) - xd;
+    const float fy = d * y + 2 * k.p2 * x * y + k.p1 * (r + 2 * y * y) - yd;
+    const float d_r = k.k1 + r * (2.0f * k.k2 + r * (3.0f * k.k3 + r * 4.0f * k.k4));
+    const float d_x = 2.0f * x * d_r, d_y = 2.0f * y * d_r;
+    const float fx_x = d + d_x * x + 2.0f * k.p1 * y + 6.0f * k.p2 * x;
+    const float fx_y = d_y * x + 2.0f * k.p1 * x + 2.0f * k.p2 * y;
+    const float fy_x = d_x * y + 2.0f * k.p2 * y + 2.0f * k.p1 * x;
+    const float fy_y = d + d_y * y + 2.0f * k.p2 * x + 6.0f * k.p1 * y;
+    const float den = fy_x * fx_y - fx_x * fy_y;
+    const float xn = fx * fy_y - fy * fx_y, yn = fy * fx_x - fx * fy_x;
+    const bool ok = fabsf(den) > eps;
+    x = x + (ok ? xn / den : 0.0f);
+    y = y + (ok ? yn / den : 0.0f);
+}
+
 __global__ void __launch_bounds__(256) k_generate_rays(const float *__restrict__ c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy,
-                                                       float cx, float cy, float level, int convention, float *__restrict__ origins,
-                                                       float *__restrict__ directions) {
+                                                       float cx, float cy, float level, int convention, RayDistortion dist,
+                                                       float *__restrict__ origins, float *__restrict__ directions) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t v = blockIdx.y;
     if (pix >= H * W) return;
     const uint32_t iy = pix / W, ix = pix - iy * W;
     const float *m = c2w + (size_t)v * 12;   // row-major [3,4]
     float dx, dy, dz;
-    if (convention == 0) {
+    if (convention == 0 || convention == 2) {
         // torch.linspace(0, W*l-1, W)[ix]: start + ix*step for the lower half, end - (W-1-ix)*step for the upper half
         const float endx = W * level - 1.0f, endy = H * level - 1.0f;
         const float stepx = W > 1 ? endx / (float)(W - 1) : 0.0f, stepy = H > 1 ? endy / (float)(H - 1) : 0.0f;
         const float x = ((ix < W / 2) ? (float)ix * stepx : endx - (float)(W - 1 - ix) * stepx) + 0.5f;
         const float y = ((iy < H / 2) ? (float)iy * stepy : endy - (float)(H - 1 - iy) * stepy) + 0.5f;
-        const float px = (x - cx) / fx, py = -(y - cy) / fy, pz = -1.0f;
+        float px = (x - cx) / fx, py = -(y - cy) / fy, pz = -1.0f;
+        if (convention == 2) {
+            const float xd = px, yd = py;
+            for (int it = 0; it < 10; it++) rg_undistort_step(px, py, xd, yd, dist, 1e-3f);      // max_iterations = 10, eps = 1e-3 (provider_utils.py:200-201)
+            float theta = sqrtf(px * px + py * py);
+            theta = fminf(fmaxf(theta, 0.0f), 3.14159265358979323846f);                      // torch.clip(theta, 0, math.pi)
+            const float st = sinf(theta);
+            px = px * st / theta;                                                               // (0/0 at the exact principal point, as in the reference)
+            py = py * st / theta;
+            pz = -cosf(theta);
+        }
         dx = m[0] * px + m[1] * py + m[2] * pz;
         dy = m[4] * px + m[5] * py + m[6] * pz;
         dz = m[8] * px + m[9] * py + m[10] * pz;
@@ -168,8 +202,20 @@ int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, fl
     if (!c2w || !origins || !directions) return CNERF_ENULL;
     if (convention < 0 || convention > 1 || fx == 0.0f || fy == 0.0f) return CNERF_EINVAL;
     if (V == 0 || H == 0 || W == 0) return CNERF_OK;
+    const RayDistortion none = {0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_generate_rays, dim3(cn_div_up(H * W, 256), V), dim3(256), 0, CN_STREAM(stream), c2w, V, H, W, fx, fy, cx, cy, level,
-                       convention, origins, directions);
+                       convention, none, origins, directions);
+    return cn_launch_status();
+}
+
+int cnerf_generate_rays_fisheye(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy, float level,
+                                const float *distortion_host, float *origins, float *directions, void *stream) {
+    if (!c2w || !origins || !directions || !distortion_host) return CNERF_ENULL;
+    if (fx == 0.0f || fy == 0.0f) return CNERF_EINVAL;
+    if (V == 0 || H == 0 || W == 0) return CNERF_OK;
+    const RayDistortion k = {distortion_host[0], distortion_host[1], distortion_host[2], distortion_host[3], distortion_host[4], distortion_host[5]};
+    hipLaunchKernelGGL(k_generate_rays, dim3(cn_div_up(H * W, 256), V), dim3(256), 0, CN_STREAM(stream), c2w, V, H, W, fx, fy, cx, cy, level, 2, k,
+                       origins, directions);
     return cn_launch_status();
 }
 

@@ -221,6 +221,57 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sample_pdf as its own entry point
+// `sample_pdf(bins, weights, n_samples, det)` (renderer.py:21-55) for arbitrary bins / weights (run() itself goes through the fused
+// k_sample_fine_merge above): one wave per row, pdf / cdf as a wave scan, inverse-CDF search in LDS.  bins [B, n_bins], weights [B, n_bins - 1]
+// -> samples [B, n_samples]; u [B, n_samples] replays the draw of :37, NULL = det (the midpoint linspace of :33-35).
+#define RN_PDF_MAXB 256
+__global__ void __launch_bounds__(RN_THREADS) k_sample_pdf(const float *__restrict__ bins, const float *__restrict__ weights, const float *__restrict__ u_rand,
+                                                           uint32_t B, uint32_t n_bins, uint32_t n_samples, float *__restrict__ samples) {
+    __shared__ float s_cdf[RN_WAVES][RN_PDF_MAXB], s_bin[RN_WAVES][RN_PDF_MAXB];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * RN_WAVES + wave;
+    if (n >= B) return;                                   // whole wave exits together; no workgroup barrier below
+    float *cdf = s_cdf[wave], *bn = s_bin[wave];
+    const uint32_t nw = n_bins - 1;
+    const float *wr = weights + (size_t)n * nw, *br = bins + (size_t)n * n_bins;
+    for (uint32_t i = lane; i < n_bins; i += 64) bn[i] = br[i];
+    float tot = 0.0f;
+    for (uint32_t k = lane; k < nw; k += 64) tot += wr[k] + 1e-5f;
+    tot = rn_wave_sum(tot);
+    float csum = 0.0f;
+    for (uint32_t base = 0; base < nw; base += 64) {
+        const uint32_t k = base + lane;
+        const float pdf = (k < nw) ? (wr[k] + 1e-5f) / tot : 0.0f;
+        const float c = rn_incl_sum_scan(pdf, csum, lane);
+        if (k < nw) cdf[k + 1] = c;
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ncdf = n_bins;
+    for (uint32_t m = lane; m < n_samples; m += 64) {
+        float u;
+        if (u_rand) u = u_rand[(size_t)n * n_samples + m];
+        else {                                            // torch.linspace(0.5/t, 1 - 0.5/t, t)[m]
+            const float a = 0.0f + 0.5f / (float)n_samples, b = 1.0f - 0.5f / (float)n_samples;
+            const float step = n_samples > 1 ? (b - a) / (float)(n_samples - 1) : 0.0f;
+            u = (m < n_samples / 2) ? a + step * (float)m : b - step * (float)(n_samples - 1 - m);
+        }
+        uint32_t lo = 0, hi = ncdf;                       // searchsorted(right=True): first index with cdf > u
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t below = lo > 0 ? lo - 1 : 0, above = lo < ncdf - 1 ? lo : ncdf - 1;
+        const float cb = cdf[below], ca = cdf[above];
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float tt = (u - cb) / denom;
+        samples[(size_t)n * n_samples + m] = bn[below] + tt * (bn[above] - bn[below]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ composites
 // per-sample quantities of one variant (0 all, 1 fg, 2 bg)
 __device__ __forceinline__ float rn_edit(float conf, int soft, float thr) {
@@ -529,5 +580,14 @@ int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mas
     hipLaunchKernelGGL(k_recon_loss_sum, dim3(1), dim3(64), 0, CN_STREAM(stream), loss + 1, blocks, loss);
     return cn_launch_status();
 }
+
+int cnerf_sample_pdf(const float *bins, const float *weights, const float *u, uint32_t B, uint32_t n_bins, uint32_t n_samples, float *samples, void *stream) {
+    if (n_bins < 2 || n_bins > RN_PDF_MAXB) return CNERF_EINVAL;
+    if (B == 0 || n_samples == 0) return CNERF_OK;
+    if (!bins || !weights || !samples) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_pdf, dim3(cn_div_up(B, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), bins, weights, u, B, n_bins, n_samples, samples);
+    return cn_launch_status();
+}
+
 
 }  // extern "C"

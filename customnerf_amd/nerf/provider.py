@@ -82,8 +82,9 @@ class NerfstudioScene:
             jf = os.path.join(data_dir, "transforms_train.json")
         with open(jf, encoding="UTF-8") as fh:
             meta = json.load(fh)
-        if meta.get("camera_model") == "OPENCV_FISHEYE":
-            raise NotImplementedError("OPENCV_FISHEYE undistortion (provider.py:421-433) is not built: pinhole scenes only")
+        # provider.py:254 + :354-359: OPENCV_FISHEYE scenes go through the un-distortion branch of the ray generator
+        self.distortion = ([float(meta.get(k, 0.0)) for k in ("k1", "k2", "k3", "k4", "p1", "p2")]
+                           if meta.get("camera_model") == "OPENCV_FISHEYE" else None)
         self.meta = meta
         frames = sorted(meta["frames"], key=lambda x: x["file_path"])                                  # provider.py:218
         poses = np.array([np.array(f["transform_matrix"]) for f in frames]).astype(np.float32)
@@ -117,7 +118,8 @@ class NerfstudioScene:
         else:
             self.H, self.W = int(meta["h"] / resolution_level), int(meta["w"] / resolution_level)
             self.images = self.masks = None
-        o, d = generate_rays(self.camera_to_world.to(device), self.fx, self.fy, self.cx, self.cy, self.H, self.W, float(resolution_level), "nerfstudio")
+        o, d = generate_rays(self.camera_to_world.to(device), self.fx, self.fy, self.cx, self.cy, self.H, self.W, float(resolution_level), "nerfstudio",
+                             distortion=self.distortion)
         self.rays_o, self.rays_d = o.view(self.n_images, 1, -1, 3), d.view(self.n_images, 1, -1, 3)
 
     def __len__(self):

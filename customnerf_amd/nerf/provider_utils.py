@@ -33,8 +33,9 @@ def custom_meshgrid(*args):
     return torch.meshgrid(*args, indexing='ij')
 
 
-def generate_rays(c2w, fx, fy, cx, cy, H, W, level=1.0, convention='nerfstudio'):
+def generate_rays(c2w, fx, fy, cx, cy, H, W, level=1.0, convention='nerfstudio', distortion=None):
     """Per-pixel rays for V cameras on the device (HIP kernel k_generate_rays).
+    distortion = [k1, k2, k3, k4, p1, p2] selects the OPENCV_FISHEYE branch of the nerfstudio convention (provider.py:421-433).
 
     convention 'nerfstudio': reference nerf/provider.py:402-464 pinhole branch (x = linspace(0, W*level-1, W) + .5,
     dir = normalize(R [ (x-cx)/fx, -(y-cy)/fy, -1 ]), origin = c2w[:, 3], output [V, H, W, 3]);
@@ -45,6 +46,14 @@ def generate_rays(c2w, fx, fy, cx, cy, H, W, level=1.0, convention='nerfstudio')
     V = c2w.shape[0]
     origins = torch.empty(V, H, W, 3, dtype=torch.float32, device=c2w.device)
     directions = torch.empty_like(origins)
+    if distortion is not None:
+        import ctypes
+        if convention != 'nerfstudio' or len(distortion) != 6:
+            raise ValueError("distortion = [k1, k2, k3, k4, p1, p2] goes with the nerfstudio convention")
+        k = (ctypes.c_float * 6)(*[float(v) for v in distortion])
+        check(lib.cnerf_generate_rays_fisheye(ptr(c2w), V, int(H), int(W), float(fx), float(fy), float(cx), float(cy), float(level),
+                                              ctypes.cast(k, ctypes.c_void_p), ptr(origins), ptr(directions), stream()), "generate_rays_fisheye")
+        return origins, directions
     conv = {'nerfstudio': 0, 'ngp': 1}[convention]
     check(lib.cnerf_generate_rays(ptr(c2w), V, int(H), int(W), float(fx), float(fy), float(cx), float(cy), float(level), conv,
                                   ptr(origins), ptr(directions), stream()), "generate_rays")

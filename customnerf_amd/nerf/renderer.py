@@ -3,6 +3,8 @@
 Implemented (reference lines): sample_pdf (21-55), NeRFRenderer.__init__ (199-243), reset_extra_state (266-276),
 run (278-405), weights_sum_i (407-474), run_cuda (597-718), update_extra_state (1658-1715), render (1719-1733).
 Out of scope: the SDF/NeuS paths, mesh export, the unused run_cuda2 / render_cuda duplicates.
+Every function here ends in HIP kernels (render.hip, raymarching.hip, occupancy.hip): there is no torch restatement of the
+reference's bodies in the product — that lives in oracle/torch_oracle.py, for the tests.
 
 Reference defects handled deliberately (SURVEY.md "Known reference defects"):
   * run_cuda reads `opt.bg_color` which argparse never defines -> read with getattr(..., None);
@@ -18,31 +20,24 @@ import torch
 import torch.nn as nn
 
 from .. import raymarching
-from .provider_utils import custom_meshgrid, safe_normalize
+from .._lib import lib, check, ptr, stream, require_cuda
 from . import render_ops
 
 
 def sample_pdf(bins, weights, n_samples, det=False, u=None):
-    """renderer.py:21-55.  bins [B,T], weights [B,T-1] -> [B,n_samples].  `u` replays the random draw of :37."""
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    if det:
-        u = torch.linspace(0. + 0.5 / n_samples, 1. - 0.5 / n_samples, steps=n_samples, device=weights.device)
-        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
-    elif u is None:
-        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=weights.device)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below = torch.clamp(inds - 1, min=0)
-    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
-    cdf_b, cdf_a = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
-    bins_b, bins_a = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
-    denom = cdf_a - cdf_b
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    t = (u - cdf_b) / denom
-    return bins_b + t * (bins_a - bins_b)
+    """The reference's `sample_pdf(bins, weights, n_samples, det)` (renderer.py:21-55) on the HIP kernel k_sample_pdf: bins [B, T],
+    weights [B, T-1] -> [B, n_samples].  `u` [B, n_samples] replays the random draw of :37 (drawn here with torch.rand when training).
+    run() does not come through here — its resampling is fused with the merge (render_ops.sample_fine_merge)."""
+    require_cuda(bins, weights, u)
+    bins, weights = bins.contiguous().float(), weights.contiguous().float()
+    B, T = bins.shape
+    if weights.shape != (B, T - 1):
+        raise ValueError(f"sample_pdf: weights must be [B, {T - 1}] for bins [B, {T}]")
+    if not det and u is None:
+        u = torch.rand(B, n_samples, device=bins.device)
+    out = torch.empty(B, n_samples, dtype=torch.float32, device=bins.device)
+    check(lib.cnerf_sample_pdf(ptr(bins), ptr(weights), None if det else ptr(u.contiguous().float()), B, T, int(n_samples), ptr(out), stream()), "sample_pdf")
+    return out
 
 
 class _Lazy:
@@ -120,92 +115,29 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
-    # ------------------------------------------------------------------------------------------ run (pure-torch path)
+    # ------------------------------------------------------------------------------------------ run (the path `-O2` takes)
     def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, light_d=None, ambient_ratio=1.0, shading='albedo',
             bg_color=None, perturb=False, _draws=None, **kwargs):
-        """renderer.py:278-405.  rays_o, rays_d [B,N,3] (B == 1) -> result dict.
-        `_draws` = dict(light, z, u) replays the RNG draws of :305, :317 and sample_pdf:37 (tests)."""
-        if (getattr(self.opt, 'fused_render', True) and rays_o.is_cuda and getattr(self.opt, 'train_conf', 0) and upsample_steps >= 2
-                and 3 <= num_steps <= 128 and upsample_steps <= 128 and getattr(self, 'supports_dir_group', False)):
-            return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-        draws = _draws or {}
-        results = {}
-        aabb = self.aabb_train if self.training else self.aabb_infer
+        """renderer.py:278-405.  rays_o, rays_d [B,N,3] (B == 1) -> result dict, on the fused HIP kernels (no torch fallback: CPU
+        tensors raise).  `_draws` = dict(light, z, u) replays the RNG draws of :305, :317 and sample_pdf:37 (tests).
+        The reference fills its result dict only under `opt.train_conf` (:383-405): without it the dict is empty here too."""
+        require_cuda(rays_o, rays_d)
+        if not getattr(self.opt, 'train_conf', 0):
+            return {}
+        if not (3 <= num_steps <= 128 and 2 <= upsample_steps <= 128):
+            raise ValueError(f"run(): the sampling kernels take 3..128 coarse and 2..128 importance samples per ray (got {num_steps} + {upsample_steps}; "
+                             "the reference's recipe is 64 + 64)")
+        return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
 
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
-        nears = nears.unsqueeze(-1)
-        fars = fars.unsqueeze(-1)
-
-        if light_d is None:                                                       # :303-306 (consumes RNG; value unused)
-            light_d = rays_o[0] + (draws['light'].to(device) if 'light' in draws else torch.randn(3, device=device, dtype=torch.float))
-            light_d = safe_normalize(light_d)
-
-        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
-        z_vals = nears + (fars - nears) * z_vals
-        sample_dist = (fars - nears) / num_steps
-        if perturb:
-            zr = draws['z'].to(device) if 'z' in draws else torch.rand(z_vals.shape, device=device)
-            z_vals = z_vals + (zr - 0.5) * sample_dist
-
-        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
-        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
-
-        if upsample_steps > 0:
-            with torch.no_grad():
-                sig_c = self.density(xyzs.reshape(-1, 3))['sigma'].view(N, num_steps).float()
-                deltas = z_vals[..., 1:] - z_vals[..., :-1]
-                deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
-                alphas = 1 - torch.exp(-deltas * sig_c)
-                alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
-                weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
-                z_vals_mid = (z_vals[..., :-1] + 0.5 * deltas[..., :-1])
-                u = draws['u'].to(device) if 'u' in draws else None
-                new_z_vals = sample_pdf(z_vals_mid, weights[:, 1:-1], upsample_steps, det=not self.training, u=u).detach()
-                new_xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * new_z_vals.unsqueeze(-1)
-                new_xyzs = torch.min(torch.max(new_xyzs, aabb[:3]), aabb[3:])
-                if getattr(self.opt, 'eval_fine_density', False):               # :353, output-dead in the reference
-                    self.density(new_xyzs.reshape(-1, 3))
-            z_vals = torch.cat([z_vals, new_z_vals], dim=1)
-            z_vals, z_index = torch.sort(z_vals, dim=1)
-            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
-            xyzs = torch.gather(xyzs, dim=1, index=z_index.unsqueeze(-1).expand_as(xyzs))
-
-        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+    def _field_all(self, xyz, rays_d, S):
+        """sigma [P], rgb+confidence [P, 4] of P = N*S samples (S consecutive samples share a ray direction) from a subclass forward()"""
         if getattr(self, 'supports_dir_group', False):
-            # the fused field reads one direction per ray (samples of a ray share rays_d): no [N*S,3] expansion copy
-            sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), rays_d, dir_group=xyzs.shape[1])
+            sigmas, rgbc, _ = self(xyz, rays_d, dir_group=S)
         else:
-            sigmas, rgbs, normals = self(xyzs.reshape(-1, 3), dirs.reshape(-1, 3))
-        if rgbs.shape[-1] > 3:
-            n_dim = rgbs.shape[-1] - 3
-            rgbs, masks = rgbs.split([3, n_dim], dim=-1)
-            masks = masks.reshape(N, -1, n_dim).float()
-        else:
-            masks = None
-        sigmas = sigmas.view(N, -1, 1)
-        rgbs = rgbs.reshape(N, -1, 3).float()
-
-        if getattr(self.opt, 'train_conf', 0):
-            results = self.weights_sum_i(sample_dist, sigmas, None, dirs, None, z_vals, nears, fars, rgbs, prefix, masks=masks, is_all=True)
-            if getattr(self.opt, 'soft_mask', False):                             # :386-389
-                edit_mask = torch.sigmoid((masks - self.opt.conf_thr) * 100)
-                sigmas_fg = sigmas * edit_mask
-                sigmas_bg = sigmas * (1 - edit_mask)
-            else:                                                                 # :391-395
-                edit_mask = masks > 0.5
-                sigmas_bg = torch.where(edit_mask, torch.zeros_like(sigmas), sigmas)
-                sigmas_fg = torch.where(edit_mask, sigmas, torch.zeros_like(sigmas))
-            results['sigma'] = sigmas
-            results['rgbs'] = rgbs
-            results['edit_mask'] = edit_mask
-            results['fg'] = self.weights_sum_i(sample_dist, sigmas_fg, None, dirs, None, z_vals, nears, fars, rgbs, prefix, masks=masks, if_fg=True)
-            results['bg'] = self.weights_sum_i(sample_dist, sigmas_bg, None, dirs, None, z_vals, nears, fars, rgbs, prefix, masks=masks)
-        return results
+            sigmas, rgbc, _ = self(xyz, rays_d.repeat_interleave(S, dim=0))
+        if rgbc.shape[-1] != 4:
+            raise ValueError("run() with opt.train_conf needs forward() to return rgb + 1 confidence channel (network_grid.py:126-129)")
+        return sigmas.reshape(-1), rgbc.reshape(-1, 4)
 
     def _run_fused(self, rays_o, rays_d, num_steps, upsample_steps, perturb, _draws=None):
         """run() on the fused kernels: 2 sampling launches + 2 field launches (+1 gather each) + 1 composite launch.
@@ -272,7 +204,7 @@ class NeRFRenderer(nn.Module):
             rgbs_e = _Lazy(lambda: aux.get()[2].view(N, S, 4)[..., :3])
             conf_of = lambda: aux.get()[2].view(N, S, 4)[..., 3:4]
         else:
-            sigmas, rgbc, _ = self(xyz_all.view(-1, 3), rays_d, dir_group=S)
+            sigmas, rgbc = self._field_all(xyz_all.view(-1, 3), rays_d, S)
             out_ray, out_w = render_ops.composite_run(sigmas.view(N, S), rgbc.view(N, S, 4), z_all, nears, fars, num_steps, soft, thr, dbg, dmask)
             weights_of = lambda v: out_w[v]
             sigma_e, rgbs_e = sigmas.view(N, S, 1), rgbc.view(N, S, 4)[..., :3]
@@ -298,137 +230,148 @@ class NeRFRenderer(nn.Module):
         return results
 
     def weights_sum_i(self, sample_dist, sigmas, normals, dirs, weights, z_vals, nears, fars, rgbs, prefix, masks=None,
-                      bg_color=None, if_fg=False, is_all=False):
-        """renderer.py:407-474 (normals are None on the grid backbone)."""
-        if is_all and getattr(self.opt, 'detach_bg', False):                      # :409-418
-            edit_points = masks.mean(-1, keepdims=True) >= 0.5
-            sigmas = torch.where(edit_points, sigmas, sigmas.detach())
-            rgbs = torch.where(edit_points, rgbs, rgbs.detach())
-        deltas = z_vals[..., 1:] - z_vals[..., :-1]
-        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
-        alphas = 1 - torch.exp(-deltas * sigmas.squeeze(-1))
-        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
-        weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+                      bg_color=None, if_fg=False, is_all=False, num_steps=None):
+        """One alpha composite with the reference's signature (renderer.py:407-474) on the compositing kernel of run() (its "all" variant
+        takes sigma as given): sigmas [N,S(,1)], rgbs [N,S,3], masks [N,S,1] | None, z_vals [N,S], nears / fars / sample_dist [N,1].
+        Differentiable in sigmas / rgbs / masks.  `num_steps` = (far - near) / sample_dist, the kernel's form of the last interval; when it is
+        not passed it is recovered from the first ray (one host read)."""
+        N, S = z_vals.shape
+        nears, fars = nears.reshape(N).contiguous().float(), fars.reshape(N).contiguous().float()
+        if num_steps is None:
+            num_steps = int(torch.round((fars[0] - nears[0]) / sample_dist.reshape(-1)[0]).item())
+        conf = masks.reshape(N, S, 1).float() if masks is not None else torch.zeros(N, S, 1, device=z_vals.device)
+        rgbc = torch.cat([rgbs.reshape(N, S, 3).float(), conf], dim=-1)
+        detach_bg = bool(is_all and getattr(self.opt, 'detach_bg', False))                           # :409-418
+        out_ray, out_w = render_ops.composite_run(sigmas.reshape(N, S).float(), rgbc, z_vals.contiguous().float(), nears, fars, num_steps,
+                                                  True, float(getattr(self.opt, 'conf_thr', 0.5)), detach_bg,
+                                                  bool(getattr(self.opt, 'detach_mask_from_field', False)))
+        r = out_ray[0]
         results = {}
-        weights_sum = weights.sum(dim=-1)
-        ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
-        depth = torch.sum(weights * ori_z_vals, dim=-1)
-        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
-        image = image.view(*prefix, 3)
-        depth = depth.view(*prefix)
-        if if_fg and bg_color is not None:
+        image = r[:, 0:3].reshape(*prefix, 3)
+        if if_fg and bg_color is not None:                                                            # :451-453
             results['black_image'] = image
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        mask = (nears < fars).reshape(*prefix)
+            image = image + (1 - r[:, 4]).unsqueeze(-1).reshape(*prefix, 1) * bg_color
         results['image'] = image
-        if getattr(self.opt, 'train_conf', 0):
-            w = weights.unsqueeze(-1).detach() if getattr(self.opt, 'detach_mask_from_field', False) else weights.unsqueeze(-1)
-            results['render_mask'] = torch.sum(w * masks, dim=-2).view(*prefix, -1)
-        results['depth'] = depth
-        results['weights_sum'] = weights_sum
-        results['weights'] = weights
-        results['mask'] = mask
+        if getattr(self.opt, 'train_conf', 0) and masks is not None:
+            results['render_mask'] = r[:, 5].reshape(*prefix, 1)
+        results['depth'] = r[:, 3].reshape(*prefix)
+        results['weights_sum'] = r[:, 4]
+        results['weights'] = out_w[0]
+        results['mask'] = (nears < fars).reshape(*prefix)
         return results
 
     # ------------------------------------------------------------------------------------------ run_cuda (occupancy march)
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, light_d=None, ambient_ratio=1.0, shading='albedo', bg_color=None,
                  perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, _noises=None, **kwargs):
-        """renderer.py:597-718."""
+        """renderer.py:597-718: occupancy-grid march.  Training: one compacted sample list per batch (march_rays_train ->
+        field -> composite_rays_train); inference: the alive-ray loop of :661-688 with device-side compaction."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.cuda().contiguous().view(-1, 3)
         rays_d = rays_d.cuda().contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-        # NB: the reference does not pass min_near here, so the wrapper default 0.2 applies (renderer.py:612-613)
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        # the reference passes no min_near here: the wrapper's default 0.2 applies (:612-613)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb)
         results = {}
-        normals = None
-
         if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb,
-                                                                    128, force_all_rays, dt_gamma, max_steps, noises=_noises)
-            sigmas, rgbs, normals = self(xyzs, dirs)
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs.float(), deltas, rays, T_thresh)
-            results['rays'] = rays
-            results['num_points'] = xyzs.shape[0]
+            weights_sum, depth, image = self._march_train(rays_o, rays_d, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, _noises, results)
         else:
-            dtype = torch.float32
-            weights_sum = torch.zeros(N, dtype=dtype, device=device)
-            depth = torch.zeros(N, dtype=dtype, device=device)
-            image = torch.zeros(N, 3, dtype=dtype, device=device)
-            n_alive = N
-            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
-            rays_alive_next = torch.empty_like(rays_alive)
-            count = torch.zeros(1, dtype=torch.int32, device=device)
-            rays_t = nears.clone()
-            step = 0
-            while step < max_steps:                                               # :667-688
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
-                                                            self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
-                                                            perturb if step == 0 else False, dt_gamma, max_steps)
-                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
-                raymarching.compact_rays_alive(rays_alive, n_alive, rays_alive_next, count)     # device-side `[rays_alive >= 0]`
-                rays_alive, rays_alive_next = rays_alive_next, rays_alive
-                n_alive = int(count.item())
-                step += n_step
-
-        opt_bg = getattr(self.opt, 'bg_color', None)
-        if opt_bg:
-            bg = torch.tensor([np.array(opt_bg)], dtype=torch.float32, device=device)
+            weights_sum, depth, image = self._march_infer(rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, light_d, ambient_ratio, shading)
+        bg = getattr(self.opt, 'bg_color', None)                    # read by the reference (:694) but never defined by its argparse
+        if bg:
+            bg = torch.as_tensor(np.asarray(bg, dtype=np.float32), device=image.device).reshape(1, -1)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg
-        image = image.view(*prefix, 3)
-        depth = depth.view(*prefix)
-        weights_sum = weights_sum.reshape(*prefix)
-        mask = (nears < fars).reshape(*prefix)
-        results['image'] = image
-        results['depth'] = depth
-        results['weights_sum'] = weights_sum
-        results['mask'] = mask
+        results.update(image=image.view(*prefix, 3), depth=depth.view(*prefix), weights_sum=weights_sum.reshape(*prefix),
+                       mask=(nears < fars).reshape(*prefix))
         return results
 
+    def _march_train(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, noises, results):
+        """:617-635.  The per-call sample counter is one slot of the 16-entry ring `step_counter` (mean_count is their average, update_extra_state)."""
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
+                                                                max_steps, noises=noises)
+        sigmas, rgbs, _ = self(xyzs, dirs)
+        results['rays'] = rays
+        results['num_points'] = xyzs.shape[0]
+        return raymarching.composite_rays_train(sigmas, rgbs.float(), deltas, rays, T_thresh)
+
+    def _march_infer(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, light_d, ambient_ratio, shading):
+        """:637-688.  Every round advances each alive ray by n_step occupied samples, accumulates in place and compacts the alive list on the
+        device (`rays_alive[rays_alive >= 0]` of :684 as a ballot + scan kernel); the only host read per round is the alive count that sizes
+        the next round's launches."""
+        N, device = rays_o.shape[0], rays_o.device
+        acc = torch.zeros(5 * N, dtype=torch.float32, device=device)                # weights_sum | depth | rgb: one zero-fill, three views
+        weights_sum, depth, image = acc[:N], acc[N:2 * N], acc[2 * N:].view(N, 3)
+        alive = torch.arange(N, dtype=torch.int32, device=device)
+        alive_next = torch.empty_like(alive)
+        count = torch.zeros(1, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        n_alive, done = N, 0
+        while done < max_steps and n_alive > 0:
+            n_step = max(min(N // n_alive, 8), 1)                                   # :671
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
+                                                        self.cascade, self.grid_size, nears, fars, 128, perturb and done == 0, dt_gamma, max_steps)
+            sigmas, rgbs, _ = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+            raymarching.composite_rays(n_alive, n_step, alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+            raymarching.compact_rays_alive(alive, n_alive, alive_next, count)
+            alive, alive_next = alive_next, alive
+            n_alive = int(count.item())
+            done += n_step
+        return weights_sum, depth, image
+
     # ------------------------------------------------------------------------------------------ occupancy grid refresh
+    @property
+    def mean_density(self):
+        """mean of the valid cells after the last refresh (renderer.py:1710); kept on the device by update_extra_state, read on demand"""
+        md = self.__dict__.get('_mean_density', 0)
+        return float(md[0]) if torch.is_tensor(md) else md
+
+    @mean_density.setter
+    def mean_density(self, v):
+        self.__dict__['_mean_density'] = v
+
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        """renderer.py:1658-1715."""
+    def update_extra_state(self, decay=0.95, S=128, _rand=None):
+        """renderer.py:1658-1715 as kernels (csrc/occupancy.hip): per cascade, jittered cell-centre queries -> density -> EMA-max into
+        `density_grid` (Morton order); then mean density, threshold min(mean, density_thresh) and packbits in one go, all on the device.
+        `S` (the reference's chunk size) is accepted and ignored: a cascade's 128^3 queries are one batch.  `_rand` = list of [H^3, 3] U[0,1)
+        tensors, one per cascade, replaying the `torch.rand_like` draws of :1695 (tests).  The only host read is the 16-slot sample-count
+        ring that sizes the next march_rays_train calls (:1714-1716)."""
         if not self.cuda_ray:
             return
-        tmp_grid = - torch.ones_like(self.density_grid)
-        dev = self.density_bitfield.device
-        X = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        Y = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        Z = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        for xs in X:
-            for ys in Y:
-                for zs in Z:
-                    xx, yy, zz = custom_meshgrid(xs, ys, zs)
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / self.grid_size
-                        cas_xyzs = xyzs * (bound - half_grid_size)
-                        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-                        sigmas = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
-                        tmp_grid[cas, indices] = sigmas.float()
-        valid_mask = self.density_grid >= 0
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid[valid_mask]).item()
+        H, dev = self.grid_size, self.density_bitfield.device
+        n = H ** 3
+        nblk = (n + 255) // 256
+        partials = torch.empty(self.cascade * nblk, 2, dtype=torch.float64, device=dev)
+        xyzs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            half = bound / H
+            rnd = (_rand[cas].to(dev) if _rand is not None else torch.rand(n, 3, device=dev)).contiguous().float()
+            check(lib.cnerf_occupancy_points(ptr(rnd), H, float(bound), float(half), ptr(xyzs), stream()), "occupancy_points")
+            sigmas = self.density(xyzs)['sigma'].reshape(-1).float().contiguous()
+            check(lib.cnerf_occupancy_update(ptr(sigmas), H, float(decay), ptr(self.density_grid[cas]), ptr(partials[cas * nblk:]), stream()), "occupancy_update")
+        state = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib.cnerf_occupancy_finalize_pack(ptr(partials), self.cascade * nblk, float(self.density_thresh), ptr(self.density_grid),
+                                                self.density_bitfield.numel(), ptr(state), ptr(self.density_bitfield), stream()), "occupancy_finalize_pack")
+        self.mean_density = state
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
         total_step = min(16, self.local_step)
         if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            self.mean_count = self._mean_sample_count(total_step)
         self.local_step = 0
+
+    def _mean_sample_count(self, total_step):
+        """average samples per march_rays_train call over the last `total_step` calls (:1714-1716); data-parallel ranks average it too, so
+        that every rank sizes its sample budget alike"""
+        tot = self.step_counter[:total_step, 0].sum().float()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(tot)
+            tot = tot / dist.get_world_size()
+        return int(tot.item() / total_step)
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=2048, **kwargs):
         """renderer.py:1719-1733."""

@@ -43,6 +43,8 @@ class EditTrainer:
         self._flat = flat_grad_buffer(self.model.parameters())          # .grad views of one flat buffer: the all-reduce runs in place
         enable_grad_in_place(model)
         self._rng = np.random.RandomState(seed)
+        self.replay = None            # tests: dict(branch='global'|'local', t=<timestep draw before t_ratio>, sample_noise=, noise=) replaces the step's SDS draws
+        self.sds_resolution = int(getattr(opt, 'sds_resolution', 512))       # utils_init_nerf.py:303 resizes to 512 x 512
         guidance.set_system(self)
         self._render_kw = {k: v for k, v in vars(opt).items() if k != 'bg_color'}       # bg_color is passed explicitly (utils_init_nerf.py:365)
 
@@ -88,17 +90,24 @@ class EditTrainer:
         """utils_init_nerf.py:283-309: global (whole image, global prompt) or local (fg image, local prompt, scaled t) SDS term"""
         opt = self.opt
         text_z, text_z_fg = self.get_textz(pred_rgb.shape[0], match_probs)
+        rp = self.replay or {}
         t_ratio = 1
         if getattr(opt, 'g_only', False):
-            text_emb, img_rgb = text_z, pred_rgb
+            is_global = True
         elif getattr(opt, 'l_only', False):
-            text_emb, img_rgb, t_ratio = text_z_fg, pred_rgb_fg, opt.local_t_ratio
-        elif self._rng.random_sample() < opt.global_ratio:
+            is_global = False
+        elif 'branch' in rp:
+            is_global = rp['branch'] == 'global'
+        else:
+            is_global = self._rng.random_sample() < opt.global_ratio
+        if is_global:
             text_emb, img_rgb = text_z, pred_rgb
         else:
             text_emb, img_rgb, t_ratio = text_z_fg, pred_rgb_fg, opt.local_t_ratio
-        latents = self.guidance.encode_imgs(img_rgb.float(), resize=(512, 512))            # F.interpolate(..., (512, 512)) folded into the VAE front-end
-        return self.guidance.train_step(latents, text_emb, system=self, t_ratio=t_ratio)
+        r = self.sds_resolution
+        latents = self.guidance.encode_imgs(img_rgb.float(), sample_noise=rp.get('sample_noise'), resize=(r, r))    # F.interpolate(..., (512, 512)) folded into the VAE front-end
+        t_val = int(rp['t'] * t_ratio) if 't' in rp else None                                                     # sd.py:132
+        return self.guidance.train_step(latents, text_emb, system=self, t_ratio=t_ratio, t_val=t_val, noise=rp.get('noise'))
 
     def train_step_editing(self, data):
         """utils_init_nerf.py:353-394.  data = (rgbs, mask, rays_o, rays_d, H, W, img_path)"""

@@ -55,6 +55,20 @@ int cnerf_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, v
 /* packbits — raymarching.h:11, kernel raymarching.cu:267-289.  grid [N*8] floats -> bitfield [N] bytes. */
 int cnerf_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream);
 
+/* Occupancy-grid refresh — NeRFRenderer.update_extra_state (nerf/renderer.py:1658-1715) without its Python loops, temporary grid and
+ * host synchronisations.  Per cascade: cnerf_occupancy_points -> the caller's density query -> cnerf_occupancy_update; then once
+ * cnerf_occupancy_finalize_pack.
+ *   points:   rand [H^3, 3] U[0,1) (the `torch.rand_like` draw of :1695) -> xyzs [H^3, 3], cell i = (x, y, z) in meshgrid('ij') order
+ *             (:1679-1684): xyzs = (2 c / (H-1) - 1) * (cas_bound - half_grid) + (2 rand - 1) * half_grid  (:1690-1695);
+ *   update:   sigmas [H^3] in the same order; density_grid_cascade [H^3] (Morton order, :1688 + :1697) gets max(old * decay, sigma) where
+ *             old >= 0 (:1707-1709); partials [ceil(H^3 / 256)][2] doubles receive (sum, count) of the valid cells of this cascade;
+ *   finalize: partials of ALL cascades [n_partials][2] -> state[0] = mean density of the valid cells (:1710), state[1] = min(mean,
+ *             density_thresh) (:1712); bitfield [n_bytes] = packbits(density_grid [n_bytes * 8], state[1]) (:1713, raymarching.cu:267-289). */
+int cnerf_occupancy_points(const float *rand, uint32_t H, float cas_bound, float half_grid, float *xyzs, void *stream);
+int cnerf_occupancy_update(const float *sigmas, uint32_t H, float decay, float *density_grid_cascade, double *partials, void *stream);
+int cnerf_occupancy_finalize_pack(const double *partials, uint32_t n_partials, float density_thresh, const float *density_grid,
+                                  uint32_t n_bytes, float *state, uint8_t *bitfield, void *stream);
+
 /* march_rays_train — raymarching.h:13, kernel raymarching.cu:311-480.
  * Same arguments as the reference binding.  Unlike the reference (atomics-ordered, nondeterministic slots) the
  * sample segments are laid out in RAY ORDER by an exclusive scan: rays[n] = (n, offset_n, num_steps_n).
@@ -237,10 +251,21 @@ int cnerf_mlp_backward_workspace_bytes(uint32_t P, uint32_t n_in, uint32_t n_out
  * ---------------------------------------------------------------------------------------------- */
 int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy,
                         float level, int convention, float *origins, float *directions, void *stream);
+/* The OPENCV_FISHEYE branch of NerfstudioData._generate_rays (nerf/provider.py:421-433): the nerfstudio pixel grid of convention 0, each
+ * normalised coordinate un-distorted by radial_and_tangential_undistort (nerf/provider_utils.py:197-234: ten Newton steps on the residual /
+ * Jacobian of :128-194, eps 1e-3), theta = clip(|coord|, 0, pi), dir = normalize(R [x sin(theta)/theta, y sin(theta)/theta, -cos(theta)]).
+ * distortion_host: [k1, k2, k3, k4, p1, p2] (host array, as the reference's `distortion_params`, provider.py:359). */
+int cnerf_generate_rays_fisheye(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy,
+                                float level, const float *distortion_host, float *origins, float *directions, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pure-PyTorch renderer `NeRFRenderer.run` (nerf/renderer.py:278-405) as fused kernels.
  * ---------------------------------------------------------------------------------------------- */
+/* sample_pdf — nerf/renderer.py:21-55 for arbitrary bins / weights (run() itself uses the fused cnerf_sample_fine_merge): bins [B, n_bins],
+ * weights [B, n_bins - 1] -> samples [B, n_samples]; pdf = (w + 1e-5) / sum, cdf = [0, cumsum(pdf)], searchsorted(right=True), lerp with
+ * denom < 1e-5 -> 1.  u [B, n_samples] replays the torch.rand draw of :37; NULL = det (the midpoint linspace of :33-35).  n_bins <= 256. */
+int cnerf_sample_pdf(const float *bins, const float *weights, const float *u, uint32_t B, uint32_t n_bins, uint32_t n_samples,
+                     float *samples, void *stream);
 /* Stratified sampling: z = near + (far-near) * linspace(0,1,T)[i] + (noise-0.5)*sample_dist (noise NULL = no
  * perturbation), xyz = clip(o + d z, aabb)  (renderer.py:310-322).  z_vals [N,T], xyzs [N,T,3]. */
 int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb,

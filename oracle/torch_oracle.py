@@ -371,6 +371,80 @@ def generate_rays(c2w, fx, fy, cx, cy, H, W, level=1):
     return torch.stack(origins), torch.stack(directions)
 
 
+def undistort(coords, dist, eps=1e-3, max_iterations=10):
+    """provider_utils.py:197-234 (radial_and_tangential_undistort) with its residual / Jacobian (:128-194): coords [..., 2],
+    dist = [k1, k2, k3, k4, p1, p2] -> undistorted coords.  Pinned by tests/golden/rays_fisheye.npz, which the reference's own function produced."""
+    k1, k2, k3, k4, p1, p2 = [torch.tensor(float(v)) for v in dist]
+    xd, yd = coords[..., 0], coords[..., 1]
+    x, y = xd, yd
+    for _ in range(max_iterations):
+        r = x * x + y * y
+        d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+        fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+        fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+        d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+        d_x = 2.0 * x * d_r
+        d_y = 2.0 * y * d_r
+        fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+        fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+        fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+        fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+        den = fy_x * fx_y - fx_x * fy_y
+        xn = fx * fy_y - fy * fx_y
+        yn = fy * fx_x - fx * fy_x
+        x = x + torch.where(torch.abs(den) > eps, xn / den, torch.zeros_like(den))
+        y = y + torch.where(torch.abs(den) > eps, yn / den, torch.zeros_like(den))
+    return torch.stack([x, y], dim=-1)
+
+
+def generate_rays_fisheye(c2w, fx, fy, cx, cy, H, W, level, dist):
+    """provider.py:402-464, OPENCV_FISHEYE branch (:421-433): c2w [V,3,4] -> origins, directions [V, H, W, 3]."""
+    tx = torch.linspace(0, W * level - 1, W)
+    ty = torch.linspace(0, H * level - 1, H)
+    x, y = torch.meshgrid(tx, ty, indexing='ij')
+    x = (x + 0.5).reshape(-1)
+    y = (y + 0.5).reshape(-1)
+    coord = undistort(torch.stack([(x - cx) / fx, -(y - cy) / fy], -1), dist)
+    theta = torch.clip(torch.sqrt(torch.sum(coord ** 2, dim=-1)), 0.0, math.pi)
+    d = torch.stack([coord[..., 0] * torch.sin(theta) / theta, coord[..., 1] * torch.sin(theta) / theta, -torch.cos(theta)], -1)
+    origins, directions = [], []
+    for v in range(c2w.shape[0]):
+        R = c2w[v, :3, :3]
+        dv = torch.nn.functional.normalize(torch.sum(d[:, None, :] * R[None], dim=-1), dim=-1)
+        origins.append(c2w[v, :3, 3].expand_as(dv).reshape(W, H, 3).permute(1, 0, 2))
+        directions.append(dv.reshape(W, H, 3).permute(1, 0, 2))
+    return torch.stack(origins), torch.stack(directions)
+
+
+def update_extra_state(field, density_grid, bound, cascade, grid_size=128, decay=0.95, density_thresh=10.0, rand=None):
+    """renderer.py:1658-1715 with S = grid_size (one chunk): density_grid [cascade, H^3] (Morton order, numpy float32, updated copy returned),
+    `rand` = list of the [H^3, 3] `torch.rand_like` draws of :1695 per cascade.  -> (density_grid, mean_density, bitfield).
+    `2 * coords / (H - 1)` is written as a multiplication by the float reciprocal: that is what torch computes on the GPU the reference
+    runs on (a tensor divided by a host scalar), and the HIP kernel does the same."""
+    H = grid_size
+    ar = torch.arange(H, dtype=torch.int32)
+    xx, yy, zz = torch.meshgrid(ar, ar, ar, indexing='ij')
+    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+    indices = torch.from_numpy(co.morton3D(coords.numpy())).long()
+    xyzs = (2 * coords.float()) * torch.tensor(1.0 / (H - 1), dtype=torch.float32) - 1
+    grid = torch.from_numpy(np.array(density_grid, dtype=np.float32, copy=True))
+    tmp = -torch.ones_like(grid)
+    for cas in range(cascade):
+        b = min(2 ** cas, bound)
+        half = b / H
+        cas_xyzs = xyzs * (b - half)
+        r = rand[cas] if rand is not None else torch.rand_like(cas_xyzs)
+        cas_xyzs = cas_xyzs + (r * 2 - 1) * half
+        with torch.no_grad():
+            sig = field.density(cas_xyzs)['sigma'].reshape(-1).float()
+        tmp[cas, indices] = sig
+    valid = grid >= 0
+    grid[valid] = torch.maximum(grid[valid] * decay, tmp[valid])
+    mean_density = torch.mean(grid[valid]).item()
+    thresh = min(mean_density, density_thresh)
+    return grid.numpy(), mean_density, co.packbits(grid.numpy(), thresh)
+
+
 # ------------------------------------------------------------------ run_cuda (renderer.py:597-718) and the occupancy grid
 def run_cuda_train(field, rays_o, rays_d, aabb, bound, density_bitfield, cascade, grid_size=128, noises=None, dt_gamma=0,
                    max_steps=1024, T_thresh=1e-4, mean_count=-1, force_all_rays=True):

@@ -209,6 +209,45 @@ def main():
             rays[f"gen_rays_{tag}_l{level}__d"] = dirs.reshape(W, H, 3).permute(1, 0, 2).numpy()
     np.savez(os.path.join(args.out, "rays.npz"), **rays)
 
+    # ---- (7b) the OPENCV_FISHEYE branch of _generate_rays (provider.py:415-433): the reference's own radial_and_tangential_undistort
+    # (provider_utils.py:197-234) is CALLED here; the lines around it (pixel grid, coord stack, theta mapping, rotation, normalise, permute)
+    # are executed on the same inputs as for the pinhole branch above.
+    import math
+    fish = {}
+    for tag, (H, W), level, dist in (("24x40", (24, 40), 1, [-0.05, 0.02, -0.004, 0.0007, 1e-3, -2e-3]),
+                                     ("32", (32, 32), 2, [0.11, -0.03, 0.0, 0.0, 0.0, 0.0])):
+        c2w, fx, fy, cx, cy = scene_rays(H, W, view=5, fovy_deg=140.0)
+        cx, cy = cx * level + 0.3, cy * level - 0.2                  # principal point in full-resolution pixels, off the pixel centres
+        fx, fy = fx * level, fy * level
+        distortion_params = torch.Tensor(dist)
+        tx = torch.linspace(0, W * level - 1, W)
+        ty = torch.linspace(0, H * level - 1, H)
+        x, y = torch.meshgrid(tx, ty)
+        x = (x + 0.5).reshape(-1)
+        y = (y + 0.5).reshape(-1)
+        coord = torch.stack([(x - cx) / fx, -(y - cy) / fy], -1)
+        coord_x_offset = torch.stack([(x - cx + 1) / fx, -(y - cy) / fy], -1)
+        coord_y_offset = torch.stack([(x - cx) / fx, -(y - cy + 1) / fy], -1)
+        coord_stack = torch.stack([coord, coord_x_offset, coord_y_offset], dim=0)
+        directions_stack = torch.empty((3,) + (coord_stack.shape[1],) + (3,))
+        coord_stack = ref_pu.radial_and_tangential_undistort(coord_stack, distortion_params.squeeze().unsqueeze(0).repeat(coord_stack.shape[1], 1))
+        theta = torch.sqrt(torch.sum(coord_stack ** 2, dim=-1))
+        theta = torch.clip(theta, 0.0, math.pi)
+        sin_theta = torch.sin(theta)
+        directions_stack[..., 0] = coord_stack[..., 0] * sin_theta / theta
+        directions_stack[..., 1] = coord_stack[..., 1] * sin_theta / theta
+        directions_stack[..., 2] = -torch.cos(theta)
+        c = torch.from_numpy(c2w).unsqueeze(0).repeat(coord_stack.shape[1], 1, 1)
+        directions_stack = torch.sum(directions_stack[..., None, :] * c[..., :3, :3], dim=-1)
+        directions_stack = torch.nn.functional.normalize(directions_stack, dim=-1)
+        fish[f"{tag}__c2w"] = c2w
+        fish[f"{tag}__intr"] = np.array([fx, fy, cx, cy, H, W, level], np.float64)
+        fish[f"{tag}__dist"] = np.array(dist, np.float32)
+        fish[f"{tag}__undist"] = coord_stack[0].numpy()
+        fish[f"{tag}__o"] = c[..., :3, 3].reshape(W, H, 3).permute(1, 0, 2).numpy()
+        fish[f"{tag}__d"] = directions_stack[0].reshape(W, H, 3).permute(1, 0, 2).numpy()
+    np.savez(os.path.join(args.out, "rays_fisheye.npz"), **fish)
+
     # ---- (2)+(3) weights_sum_i and the full run() dict with a closed-form field plugged in (renderer.py:278-474)
     class ToyRenderer(ref_renderer.NeRFRenderer):
         def __init__(self, opt):

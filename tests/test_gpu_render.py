@@ -38,6 +38,110 @@ def test_generate_rays_against_reference_golden(golden):
             np.testing.assert_allclose(d[0].cpu().numpy(), g[f"gen_rays_{tag}_l{level}__d"], rtol=0, atol=1e-6)
 
 
+def test_fisheye_rays_against_reference_golden(golden):
+    """OPENCV_FISHEYE branch of _generate_rays (provider.py:421-433): k_generate_rays convention 2 against directions the reference's own
+    radial_and_tangential_undistort produced (tests/golden/make_golden.py section 7b), and against the oracle restatement."""
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    g = golden("rays_fisheye")
+    for tag in ("24x40", "32"):
+        fx, fy, cx, cy, H, W, level = g[f"{tag}__intr"]
+        H, W = int(H), int(W)
+        c2w = T(g[f"{tag}__c2w"])[None]
+        dist = [float(v) for v in g[f"{tag}__dist"]]
+        o, d = generate_rays(c2w.cuda(), fx, fy, cx, cy, H, W, level, 'nerfstudio', distortion=dist)
+        np.testing.assert_array_equal(o[0].cpu().numpy(), g[f"{tag}__o"])
+        # ten Newton steps + sin / cos of the device's libm vs glibc: a few float32 ulps on unit vectors
+        np.testing.assert_allclose(d[0].cpu().numpy(), g[f"{tag}__d"], rtol=0, atol=2e-6)
+        o_ref, d_ref = to.generate_rays_fisheye(c2w, fx, fy, cx, cy, H, W, level, dist)
+        np.testing.assert_allclose(d[0].cpu().numpy(), d_ref[0].numpy(), rtol=0, atol=2e-6)
+    # zero distortion: the un-distortion is the identity, only the theta mapping remains (|coord| -> angle from the optical axis)
+    o, d = generate_rays(T(g["32__c2w"])[None].cuda(), 20.0, 20.0, 16.3, 15.8, 32, 32, 1.0, 'nerfstudio', distortion=[0.0] * 6)
+    assert torch.isfinite(d).all() and torch.allclose(d.norm(dim=-1), torch.ones(1, 32, 32, device='cuda'), atol=1e-5)
+
+
+def test_fisheye_scene_loader(tmp_path):
+    """NerfstudioScene on an OPENCV_FISHEYE transforms.json: the distortion parameters reach the ray kernel (the loader used to raise)."""
+    import json
+    from customnerf_amd.nerf.provider import NerfstudioScene
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    frames = []
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        m = np.eye(4)
+        a = 2 * np.pi * i / 4
+        m[:3, 3] = [2 * np.cos(a), 0.3, 2 * np.sin(a)]
+        frames.append({"file_path": f"images/{i:03d}.png", "transform_matrix": m.tolist()})
+    meta = dict(camera_model="OPENCV_FISHEYE", fl_x=30.0, fl_y=30.0, cx=16.0, cy=12.0, w=32, h=24, k1=0.05, k2=-0.01, k3=0.002, k4=0.0, frames=frames)
+    (tmp_path / "transforms.json").write_text(json.dumps(meta))
+    sc = NerfstudioScene(str(tmp_path), load_images=False)
+    assert sc.distortion == [0.05, -0.01, 0.002, 0.0, 0.0, 0.0]
+    o, d = generate_rays(sc.camera_to_world.cuda(), 30.0, 30.0, 16.0, 12.0, 24, 32, 1.0, 'nerfstudio', distortion=sc.distortion)
+    assert torch.equal(sc.rays_d.view(-1, 3), d.view(-1, 3))
+    o2, d2 = generate_rays(sc.camera_to_world.cuda(), 30.0, 30.0, 16.0, 12.0, 24, 32, 1.0, 'nerfstudio')
+    assert not torch.allclose(d, d2, atol=1e-3)                     # and they differ from the pinhole rays
+
+
+def test_sample_pdf_kernel_against_reference_golden(golden):
+    """renderer.sample_pdf (k_sample_pdf) against outputs of the reference's own sample_pdf (renderer.py:21-55)."""
+    from customnerf_amd.nerf.renderer import sample_pdf
+    g = golden("sample_pdf")
+    bins, w = cuda(g["bins"]), cuda(g["weights"])
+    out = sample_pdf(bins, w, 16, det=True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out_det"], rtol=0, atol=2e-6)
+    out = sample_pdf(bins, w, 16, det=False, u=cuda(g["u"]))
+    ref = g["out_rnd"]
+    err = np.abs(out.cpu().numpy() - ref)
+    # the CDF is a wave scan here and a sequential cumsum there: a draw that lands within float rounding of a CDF step may pick the neighbouring bin
+    assert (err > 2e-6).mean() < 0.01, float((err > 2e-6).mean())
+    # a ragged n_samples (not a multiple of the wave) and the wave-strided bins loop
+    gen = torch.Generator().manual_seed(3)
+    bins = torch.sort(torch.rand(37, 130, generator=gen), dim=-1).values
+    w = torch.rand(37, 129, generator=gen)
+    u = torch.rand(37, 75, generator=gen)
+    ref = to.sample_pdf(bins, w, 75, det=False, u=u)
+    out = sample_pdf(bins.cuda(), w.cuda(), 75, det=False, u=u.cuda())
+    err = (out.cpu() - ref).abs()
+    assert float((err > 2e-6).float().mean()) < 0.01
+    with pytest.raises(RuntimeError):
+        sample_pdf(bins, w, 8, det=True)                             # CPU tensors: there is no CPU path
+
+
+def test_weights_sum_i_method_against_reference_golden(golden):
+    """NeRFRenderer.weights_sum_i (the compositing kernel behind the reference's signature) against outputs and gradients of the reference's
+    own weights_sum_i (renderer.py:407-474), plain and with detach_bg / detach_mask_from_field."""
+    g = golden("weights_sum_i")
+    N = g["sigmas"].shape[0]
+    for tag, kw in (("plain", {}), ("detach", dict(detach_bg=True, detach_mask_from_field=True))):
+        model = _toy_renderer(**kw)
+        s, c = cuda(g["sigmas"]).requires_grad_(True), cuda(g["rgbs"]).requires_grad_(True)
+        res = model.weights_sum_i(cuda(g["sample_dist"]), s, None, None, None, cuda(g["z"]), cuda(g["nears"]), cuda(g["fars"]), c, (1, N),
+                                  masks=cuda(g["masks"]), is_all=True)
+        loss = (res['image'] ** 2).sum() + res['weights_sum'].sum() + (res['render_mask'] * 0.3).sum() + res['depth'].sum()
+        loss.backward()
+        for k in ("image", "depth", "render_mask", "weights_sum", "weights"):
+            np.testing.assert_allclose(res[k].detach().cpu().numpy(), g[f"{tag}__{k}"], rtol=1e-5, atol=2e-6, err_msg=f"{tag}:{k}")
+        np.testing.assert_array_equal(res["mask"].cpu().numpy(), g[f"{tag}__mask"])
+        gs, gc = g[f"{tag}__grad_sigmas"], g[f"{tag}__grad_rgbs"]
+        np.testing.assert_allclose(s.grad.cpu().numpy(), gs, rtol=2e-4, atol=2e-5 * float(np.abs(gs).max()), err_msg=tag + ":grad_sigmas")
+        np.testing.assert_allclose(c.grad.cpu().numpy(), gc, rtol=2e-4, atol=2e-6, err_msg=tag + ":grad_rgbs")
+
+
+def test_run_without_train_conf_and_unsupported_counts():
+    """the reference's run() leaves its result dict empty without opt.train_conf (renderer.py:383-405); sample counts outside the kernels'
+    range are rejected loudly (there is no torch slow path behind run())"""
+    model = _toy_renderer(train_conf=0)
+    o = torch.zeros(1, 4, 3, device='cuda'); o[..., 2] = 3.0
+    d = torch.zeros(1, 4, 3, device='cuda'); d[..., 2] = -1.0
+    assert model.run(o, d, num_steps=8, upsample_steps=8) == {}
+    model = _toy_renderer()
+    with pytest.raises(ValueError):
+        model.run(o, d, num_steps=8, upsample_steps=0)
+    with pytest.raises(ValueError):
+        model.run(o, d, num_steps=256, upsample_steps=8)
+    with pytest.raises(RuntimeError):
+        model.run(o.cpu(), d.cpu(), num_steps=8, upsample_steps=8)
+
+
 def test_adam_step_matches_torch():
     from customnerf_amd.optim import adam_step
     torch.manual_seed(0)
@@ -237,11 +341,38 @@ def test_update_extra_state_builds_occupancy():
     model.update_extra_state()
     dg = model.density_grid.cpu().numpy()
     assert dg.min() >= 0 and model.mean_density > 0
+    np.testing.assert_allclose(model.mean_density, float(dg.astype(np.float64).mean()), rtol=1e-6)
     thr = min(model.mean_density, model.density_thresh)
     np.testing.assert_array_equal(model.density_bitfield.cpu().numpy(), co.packbits(dg, thr))
     # the gaussian blob (network_grid.py:150-156) makes the centre dense: the centre cell must be occupied in cascade 0
     centre = co.morton3D(np.array([[64, 64, 64]], np.int32))[0]
     assert dg[0, centre] > thr
+
+
+def test_update_extra_state_kernels_vs_oracle():
+    """The occupancy refresh kernels (csrc/occupancy.hip) against the restatement of renderer.py:1658-1715 with the same jitter draws: two
+    refreshes on a 32^3 grid (the second one exercises the 0.95 decay against the first one's densities), with a cell marked invalid (< 0)."""
+    model, ref, opt = _fields(cuda_ray=True)
+    Hs = 32
+    model.grid_size = Hs
+    model.density_grid = torch.zeros(model.cascade, Hs ** 3, device='cuda')
+    model.density_bitfield = torch.zeros(model.cascade * Hs ** 3 // 8, dtype=torch.uint8, device='cuda')
+    model.density_grid[1, 77] = -1.0                                  # an invalid cell stays untouched and out of the mean
+    grid_ref = model.density_grid.cpu().numpy()
+    gen = torch.Generator().manual_seed(4)
+    for it in range(2):
+        rand = [torch.rand(Hs ** 3, 3, generator=gen) for _ in range(model.cascade)]
+        model.local_step = 0
+        model.update_extra_state(_rand=rand)
+        grid_ref, mean_ref, bits_ref = to.update_extra_state(ref, grid_ref, opt.bound, model.cascade, Hs, 0.95, opt.density_thresh, rand)
+        dg = model.density_grid.cpu().numpy()
+        assert dg[1, 77] == -1.0
+        np.testing.assert_allclose(dg, grid_ref, rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(model.mean_density, mean_ref, rtol=1e-4)
+        bits = model.density_bitfield.cpu().numpy()
+        assert np.unpackbits(bits ^ bits_ref).sum() <= 4              # cells within rounding of the threshold may differ
+        np.testing.assert_array_equal(bits, co.packbits(dg, min(model.mean_density, model.density_thresh)))
+    assert model.iter_density == 2
 
 
 def _rand_composite_inputs(N=200, S=128, seed=0):

@@ -71,3 +71,83 @@ def test_editing_global_and_local_terms():
     tr3, model3, pre3, data3 = _setup(keep_bg=1000.0, lambda_sd=0.0)
     loss3, ld3 = tr3.train_step(data3(0))
     assert set(ld3) == {"loss_bg"} and float(loss3) < 50.0
+
+
+# ------------------------------------------------------------------------------------------------ the composed step against the oracle
+def _paired_field(opt, seed):
+    """a NeRFNetwork (HIP) and a FieldRef (CPU oracle) holding the same parameters"""
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from oracle import torch_oracle as to
+    model = NeRFNetwork(opt).cuda()
+    ref = to.FieldRef(bound=opt.bound, num_levels=opt.num_levels, level_dim=2, base_resolution=16, log2_hashmap_size=opt.log2_hashmap_size,
+                      desired_resolution=opt.desired_resolution, gridtype='hash', n_hidden_geo=opt.n_hidden_geo, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():
+        ref.pos_en.embeddings.copy_((torch.rand(ref.pos_en.embeddings.shape, generator=g) * 2 - 1) * 0.5)
+        model.pos_en.embeddings.copy_(ref.pos_en.embeddings.cuda())
+        model.network.params.copy_(ref.network.cuda())
+        model.density_network.params.copy_(ref.density_network.cuda())
+        model.rgb_network.params.copy_(ref.rgb_network.cuda())
+    return model, ref
+
+
+@pytest.mark.parametrize("variant", ["g_only", "l_only", "ori_bg"])
+def test_editing_step_matches_composed_oracle(variant):
+    """EditTrainer.train_step_editing (render -> global / local SDS term with local_t_ratio -> keep_bg L1, ori_bg substitution) against
+    oracle/edit_oracle.py (to.run + so.train_step_sd + the L1 of utils_init_nerf.py:282-308, 353-394) on the same draws: loss terms and
+    the gradient that reaches the grid table and the MLPs."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd.guidance import StableDiffusion
+    from customnerf_amd.sd.editing import EditTrainer
+    from oracle import edit_oracle as eo
+    tcnn.set_default_dtype(torch.float32)
+    kw = dict(g_only=dict(g_only=True, keep_bg=0.0), l_only=dict(l_only=True, keep_bg=1000.0, local_t_ratio=0.5),
+              ori_bg=dict(ori_bg=True, keep_bg=1000.0))[variant]
+    opt = sc.make_opt(num_levels=4, n_hidden_geo=1, num_steps=8, upsample_steps=8, cfg=7.5, lambda_sd=0.01, log_loss_item=False, sds_resolution=128, **kw)
+    model, ref = _paired_field(opt, 0)
+    pre, ref_pre = _paired_field(opt, 7)
+    pre.eval()
+    half = lambda sd: {k: (v.half().float() if v.dim() > 1 else v) for k, v in sd.items()}
+    usd = half(arch.random_state_dict(arch.unet_params(arch.UNET_TINY), 1))
+    vsd = half(arch.random_state_dict(arch.vae_encoder_params(arch.VAE_TINY), 2))
+    guide = StableDiffusion("cuda", "1.5", opt, unet_state=usd, vae_state=vsd, unet_cfg=arch.UNET_TINY, vae_cfg=arch.VAE_TINY)
+    H = W = 16
+    N = H * W
+    c2w = torch.from_numpy(sc.poses(4)[1:2]).cuda()
+    o, d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+    o, d = o.view(1, N, 3), d.view(1, N, 3)
+    g = torch.Generator().manual_seed(3)
+    rgbs = torch.rand(1, N, 3, generator=g)
+    draws = dict(light=torch.randn(3, generator=g), z=torch.rand(N, 8, generator=g), u=torch.rand(N, 8, generator=g))
+    sample_noise, noise = torch.randn(1, 4, 16, 16, generator=g), torch.randn(1, 4, 16, 16, generator=g)
+    text_z = guide.synthetic_text_embeds(0).half().float()
+    text_z_fg = guide.synthetic_text_embeds(1).half().float()
+    t_draw = 613
+    branch = dict(g_only='global', l_only='local', ori_bg='global')[variant]
+
+    tr = EditTrainer(model, pre, guide, opt, text_z, text_z_fg, fp16=False)
+    tr._render_kw['_draws'] = draws
+    tr.replay = dict(branch=branch, t=t_draw, sample_noise=sample_noise.cuda(), noise=noise.cuda())
+    model.train()
+    _, _, loss, ld = tr.train_step_editing((rgbs.cuda(), None, o, d, H, W, "v0"))
+    loss.backward()
+
+    aabb = torch.tensor([-opt.bound] * 3 + [opt.bound] * 3)
+    loss_ref, ld_ref, _ = eo.train_step_editing(ref, ref_pre, o.cpu(), d.cpu(), rgbs, H, W, aabb, opt, vsd, arch.VAE_TINY, usd, arch.UNET_TINY,
+                                                text_z.cpu(), text_z_fg.cpu(), guide.alphas_host, draws, draws, branch, t_draw, sample_noise, noise,
+                                                size=(128, 128))
+    loss_ref.backward()
+    assert ld_ref['t'] == (306 if variant == 'l_only' else 613)                       # local_t_ratio reached the timestep (sd.py:132)
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    assert rel(ld['loss_sds'], ld_ref['loss_sds']) < 5e-2, (float(ld['loss_sds']), float(ld_ref['loss_sds']))
+    if opt.keep_bg:
+        assert rel(ld['loss_bg'], ld_ref['loss_bg']) < (2e-2 if variant == 'ori_bg' else 1e-3), (float(ld['loss_bg']), float(ld_ref['loss_bg']))
+    assert rel(loss, loss_ref) < 5e-2
+    l2 = lambda a, b: float((a.detach().cpu().float() - b.detach().float()).norm() / (b.detach().float().norm() + 1e-20))
+    errs = dict(grid=l2(model.pos_en.embeddings.grad, ref.pos_en.embeddings.grad), net=l2(model.network.params.grad, ref.network.grad),
+                den=l2(model.density_network.params.grad, ref.density_network.grad), rgb=l2(model.rgb_network.params.grad, ref.rgb_network.grad))
+    assert float(ref.pos_en.embeddings.grad.abs().max()) > 0
+    # the SDS gradient passes a float16 UNet and the float16 VAE backward before it reaches the (float32) renderer
+    assert all(e < 6e-2 for e in errs.values()), errs

@@ -31,7 +31,8 @@ def to_nhwc8(x):
     return out.cuda()
 
 
-@pytest.mark.parametrize("cfg_name,hw", [("tiny", 32), ("tiny", 24), ("sd15", 16)])
+# ("sd15", 64) is the size the reference runs the UNet at: latents [2, 4, 64, 64] (nerf/sd.py:140)
+@pytest.mark.parametrize("cfg_name,hw", [("tiny", 32), ("tiny", 24), ("sd15", 16), ("sd15", 64)])
 def test_unet_forward(cfg_name, hw):
     from customnerf_amd.sd import arch
     from customnerf_amd.sd.unet import UNet
@@ -56,7 +57,8 @@ def test_unet_forward(cfg_name, hw):
         assert rel_err(out_g2.permute(0, 3, 1, 2), ref2)[1] < 1e-2
 
 
-@pytest.mark.parametrize("cfg_name,size", [("tiny", 64), ("sd15", 128)])
+# ("sd15", 512) is the size the reference encodes at (utils_init_nerf.py:303: F.interpolate(..., (512, 512)))
+@pytest.mark.parametrize("cfg_name,size", [("tiny", 64), ("sd15", 128), ("sd15", 512)])
 def test_vae_encode_forward_backward(cfg_name, size):
     from customnerf_amd.sd import arch
     from customnerf_amd.sd.vae import VAEEncoder

@@ -20,6 +20,23 @@ def test_sample_pdf(golden):
     np.testing.assert_allclose(out.numpy(), g["out_rnd"], rtol=0, atol=1e-6)
 
 
+def test_fisheye_rays(golden):
+    """oracle restatement of the OPENCV_FISHEYE ray branch (provider.py:421-433, provider_utils.py:128-234) against what the reference's
+    own radial_and_tangential_undistort produced"""
+    g = golden("rays_fisheye")
+    for tag in ("24x40", "32"):
+        fx, fy, cx, cy, H, W, level = g[f"{tag}__intr"]
+        H, W = int(H), int(W)
+        xs = torch.linspace(0, W * level - 1, W)
+        ys = torch.linspace(0, H * level - 1, H)
+        x, y = torch.meshgrid(xs, ys, indexing='ij')
+        coord = torch.stack([((x + 0.5).reshape(-1) - cx) / fx, -((y + 0.5).reshape(-1) - cy) / fy], -1)
+        np.testing.assert_allclose(to.undistort(coord, g[f"{tag}__dist"]).numpy(), g[f"{tag}__undist"], rtol=0, atol=1e-6)
+        o, d = to.generate_rays_fisheye(T(g[f"{tag}__c2w"])[None], fx, fy, cx, cy, H, W, level, g[f"{tag}__dist"])
+        np.testing.assert_array_equal(o[0].numpy(), g[f"{tag}__o"])
+        np.testing.assert_allclose(d[0].numpy(), g[f"{tag}__d"], rtol=0, atol=1e-6)
+
+
 def test_trunc_exp(golden):
     g = golden("trunc_exp")
     x = T(g["x"]).requires_grad_(True)
