@@ -208,16 +208,17 @@ def test_march_rays_train_probe_list_cap_takes_the_remarching_writer(rm, scene, 
     counter = torch.zeros(2, dtype=torch.int32).cuda()
     x, dd, l, r = rm.march_rays_train(cuda(o), cuda(d), 2.0, cuda(bitfield), 2, 128, cuda(nears), cuda(fars), counter, -1, True, 128, True, 0, 1024,
                                       noises=cuda(noises))
-    assert torch.device("cuda", torch.cuda.current_device()) not in rmod._HITS
+    key = rmod.scratch_key(x.device)                                  # the probe scratch is held per (device, stream)
+    assert key not in rmod._HITS
     np.testing.assert_array_equal(r.cpu().numpy(), rr)
     np.testing.assert_array_equal(x.cpu().numpy(), xr)
     np.testing.assert_array_equal(l.cpu().numpy(), lr)
     # and the scratch is released when requests shrink a lot
     monkeypatch.setattr(rmod, "_HITS_MAX_BYTES", 512 << 20)
     rmod._hits_scratch(4096, 1024, x.device)
-    big = rmod._HITS[x.device].numel()
+    big = rmod._HITS[key].numel()
     rmod._hits_scratch(64, 1024, x.device)
-    assert rmod._HITS[x.device].numel() < big // 4 + 1
+    assert rmod._HITS[key].numel() < big // 4 + 1
 
 
 @pytest.mark.parametrize("stride", [3, 4])
