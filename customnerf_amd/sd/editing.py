@@ -134,13 +134,53 @@ class EditTrainer:
             loss_dict['loss_bg'] = loss_bg.detach()
         return pred_rgb, pred_ws, loss, loss_dict
 
+    def train_step_editing_multi(self, views):
+        """V camera views in one step (BASELINE.json north_star: the per-iteration batch shards "rays (and optionally SDS camera views)"): every
+        view is rendered and gets its own background term exactly as in train_step_editing; the V images (or fg images — the global / local
+        draw of utils_init_nerf.py:296 is made once per step) go through ONE VAE batch and ONE UNet batch of 2V, each with its own timestep
+        and noise.  loss = mean over the views of the single-view loss."""
+        opt = self.opt
+        V = len(views)
+        preds, preds_fg, losses_bg, match = [], [], [], None
+        pred_rgb = pred_ws = None
+        for data in views:
+            rgbs, mask, rays_o, rays_d, H, W, img_path = data
+            B, N = rays_o.shape[:2]
+            bg_color = self._bg_color(rays_o, B, N)
+            with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+                outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **self._render_kw)
+            img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+            pred_rgb, pred_rgb_fg, pred_rgb_bg = img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
+            pred_ws = outputs['weights_sum'].reshape(B, H, W)
+            pt_rgb_fg, pt_rgb_bg, pt_mask, pt_depth_fg, match = self.get_pt(rays_o, rays_d, img_path, bg_color, B, H, W)
+            if getattr(opt, 'ori_bg', False):
+                non_edit = ((pt_mask + outputs['render_mask'].reshape(B, H, W, -1)) < 0.5).permute(0, 3, 1, 2)
+                pt_rgb_bg = rgbs.reshape(B, H, W, 3).permute(0, 3, 1, 2) * non_edit + (~non_edit) * pt_rgb_bg
+            preds.append(pred_rgb)
+            preds_fg.append(pred_rgb_fg)
+            if opt.keep_bg:
+                losses_bg.append(opt.keep_bg * F.l1_loss(pt_rgb_bg, pred_rgb_bg.float()))
+        loss, loss_dict = 0.0, {}
+        if opt.lambda_sd:
+            loss, loss_dict = self.train_step_sd(torch.cat(preds, 0), torch.cat(preds_fg, 0), None if self.clip_view is False else match)
+            loss = loss / V
+        if opt.keep_bg:
+            loss_bg = torch.stack(losses_bg).mean()
+            loss = loss + loss_bg
+            loss_dict['loss_bg'] = loss_bg.detach()
+        return pred_rgb, pred_ws, loss, loss_dict
+
     def allreduce_grads(self):
         self._flat = allreduce_grads_flat(list(self.model.parameters()), self._flat, self.world_size)     # same path the gloo test exercises
 
-    def train_step(self, data):
+    def train_step_multi(self, views):
+        """one optimiser step on several camera views at once (train_step_editing_multi)"""
+        return self.train_step(views, multi=True)
+
+    def train_step(self, data, multi=False):
         """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""
         self.model.train()
-        pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing(data)
+        pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing_multi(data) if multi else self.train_step_editing(data)
         if self.scaler is not None:
             self.scaler.backward(loss)
         else:

@@ -94,37 +94,68 @@ class StableDiffusion(nn.Module):
         t = int(torch.randint(min_step, max_step + 1, [1], generator=self._gen))
         return int(t * t_ratio)
 
-    def _ctx_half(self, text_embeddings):
-        """float16 copy of a text embedding, cached per source tensor (storage + version): the UNet keeps one captured graph and one
-        set of cross-attention K / V^T per context tensor, so the same prompt must arrive as the same tensor every step."""
-        key = (text_embeddings.data_ptr(), text_embeddings._version, tuple(text_embeddings.shape), text_embeddings.dtype)
+    def _ctx_half(self, text_embeddings, pairs=1):
+        """float16 copy of a text embedding (repeated `pairs` times for a multi-view batch), cached per source tensor (storage + version):
+        the UNet keeps one captured graph and one set of cross-attention K / V^T per context tensor, so the same prompt must arrive as the
+        same tensor every step."""
+        key = (text_embeddings.data_ptr(), text_embeddings._version, tuple(text_embeddings.shape), text_embeddings.dtype, pairs)
         ent = self._ctx_cache.get(key)
         if ent is None:
             if len(self._ctx_cache) >= 8:
                 self._ctx_cache.pop(next(iter(self._ctx_cache)))
-            ent = (text_embeddings, text_embeddings.to(self.device, torch.float16).contiguous())      # the source reference pins the key
+            ctx = text_embeddings.to(self.device, torch.float16)
+            if pairs > 1:
+                ctx = ctx.repeat(pairs, 1, 1)                                                          # (uncond, text) x pairs
+            ent = (text_embeddings, ctx.contiguous())                                                  # the source reference pins the key
             self._ctx_cache[key] = ent
         return ent[1]
 
     def eps_pred(self, unet_in, t, text_embeddings):
-        tt = torch.full((unet_in.shape[0],), float(t), dtype=torch.float32, device=self.device)
-        ctx = self._ctx_half(text_embeddings)
+        """unet_in [2V, h, w, 8]; t: one timestep, or V of them (one per (uncond, text) pair); text_embeddings [2, 77, D] is shared by the pairs"""
+        B = unet_in.shape[0]
+        if isinstance(t, (list, tuple)):
+            tt = torch.tensor([float(x) for x in t for _ in (0, 1)], dtype=torch.float32).to(self.device, non_blocking=True)
+        else:
+            tt = torch.full((B,), float(t), dtype=torch.float32, device=self.device)
+        ctx = self._ctx_half(text_embeddings, B // 2)
         return self.unet.graphed(unet_in, tt, ctx) if self.use_graph else self.unet(unet_in, tt, ctx)
 
     def sds_grad(self, latents, text_embeddings, t, noise):
-        """sd.py:133-148 on device: add_noise, UNet on the CFG pair, `text + g (text - uncond)`, (1 - abar_t) weighting, nan_to_num."""
-        ab = float(self.alphas_host[t])
-        unet_in = ops.add_noise(latents.contiguous(), noise, ab)
-        eps = self.eps_pred(unet_in, t, text_embeddings)
-        return ops.sds_grad(eps, noise, ab, float(self.opt.cfg), float(self.opt.lambda_sd))
+        """sd.py:133-148 on device: add_noise, UNet on the CFG pair, `text + g (text - uncond)`, (1 - abar_t) weighting, nan_to_num.
+        latents / noise [V, 4, h, w]: V views go through ONE UNet call of batch 2V (pairs laid out (uncond, text) per view); `t` is then an
+        int (shared) or a list of V timesteps (BASELINE.json north_star: "optionally SDS camera views")."""
+        V = latents.shape[0]
+        if V == 1 and not isinstance(t, (list, tuple)):
+            ab = float(self.alphas_host[t])
+            unet_in = ops.add_noise(latents.contiguous(), noise, ab)
+            eps = self.eps_pred(unet_in, t, text_embeddings)
+            return ops.sds_grad(eps, noise, ab, float(self.opt.cfg), float(self.opt.lambda_sd))
+        ts = list(t) if isinstance(t, (list, tuple)) else [int(t)] * V
+        latents, noise = latents.contiguous(), noise.contiguous()
+        _, _, h, w = latents.shape
+        unet_in = torch.empty(2 * V, h, w, 8, dtype=torch.float16, device=latents.device)
+        for v in range(V):
+            ops.add_noise(latents[v:v + 1], noise[v:v + 1], float(self.alphas_host[ts[v]]), out=unet_in[2 * v:2 * v + 2])
+        eps = self.eps_pred(unet_in, ts, text_embeddings)
+        grad = torch.empty_like(noise)
+        for v in range(V):
+            ops.sds_grad(eps[2 * v:2 * v + 2], noise[v:v + 1], float(self.alphas_host[ts[v]]), float(self.opt.cfg), float(self.opt.lambda_sd), out=grad[v:v + 1])
+        return grad
 
     def train_step(self, latents, text_embeddings, mask=None, img_path=None, tuning=False, gt_rgb=None, t_val=None, system=None, is_all=False,
                    camera=None, tuning_cls=False, t_ratio=1, noise=None):
-        t = self.draw_timestep(system, t_ratio) if t_val is None else int(t_val)
+        V = latents.shape[0]
+        if t_val is not None:
+            t = t_val if isinstance(t_val, (list, tuple)) else int(t_val)
+        elif V == 1:
+            t = self.draw_timestep(system, t_ratio)
+        else:
+            t = [self.draw_timestep(system, t_ratio) for _ in range(V)]              # every view of a multi-view step gets its own timestep
         with torch.no_grad():
-            lat = latents.detach().float()
+            lat = latents.detach().float().contiguous()                          # NCHW, dense: the kernels below index it as raw memory
             if noise is None:
-                noise = torch.randn_like(lat)
+                noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
+            noise = noise.contiguous()
             grad = self.sds_grad(lat, text_embeddings, t, noise)
         target = (latents - grad).detach()
         loss = 0.5 * F.mse_loss(latents, target, reduction="sum")                     # d loss / d latents = grad (sd.py:150-152)

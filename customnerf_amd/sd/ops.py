@@ -336,17 +336,23 @@ def timestep_embedding(t, dim):
     return out
 
 
-def add_noise(latents, noise, alpha_bar):
-    """latents, noise [1, 4, h, w] float32 -> UNet input [2, h, w, 8] half (the CFG pair)."""
+def add_noise(latents, noise, alpha_bar, out=None):
+    """latents, noise [1, 4, h, w] float32 -> UNet input [2, h, w, 8] half (the CFG pair); `out`: a contiguous [2, h, w, 8] half destination
+    (one pair of a multi-view batch)."""
     _, _, h, w = latents.shape
-    out = torch.empty(2, h, w, 8, dtype=torch.float16, device=latents.device)
+    assert latents.shape[0] == 1 and latents.is_contiguous() and noise.is_contiguous()
+    if out is None:
+        out = torch.empty(2, h, w, 8, dtype=torch.float16, device=latents.device)
+    assert out.is_contiguous() and out.dtype == torch.float16 and out.numel() == 2 * h * w * 8
     check(lib.cnerf_sd_add_noise(ptr(latents), ptr(noise), float(alpha_bar), h * w, ptr(out), stream()), "sd_add_noise")
     return out
 
 
-def sds_grad(eps, noise, alpha_bar, guidance, lambda_sd):
-    """eps [2, h, w, ld] half (uncond, text), noise [1, 4, h, w] float32 -> grad [1, 4, h, w] float32."""
+def sds_grad(eps, noise, alpha_bar, guidance, lambda_sd, out=None):
+    """eps [2, h, w, ld] half (uncond, text), noise [1, 4, h, w] float32 -> grad [1, 4, h, w] float32 (`out`: contiguous destination)."""
     _, h, w, ld = eps.shape
-    grad = torch.empty_like(noise)
+    assert eps.is_contiguous() and noise.is_contiguous() and noise.shape[0] == 1
+    grad = torch.empty_like(noise) if out is None else out
+    assert grad.is_contiguous() and grad.dtype == torch.float32 and grad.numel() == noise.numel()
     check(lib.cnerf_sd_sds_grad(ptr(eps), ld, ptr(noise), float(alpha_bar), float(guidance), float(lambda_sd), h * w, ptr(grad), stream()), "sd_sds_grad")
     return grad

@@ -140,10 +140,11 @@ def test_editing_step_matches_composed_oracle(variant):
                                                 size=(128, 128))
     loss_ref.backward()
     assert ld_ref['t'] == (306 if variant == 'l_only' else 613)                       # local_t_ratio reached the timestep (sd.py:132)
-    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    rel = lambda a, b: abs(float(a.detach()) - float(b.detach())) / max(abs(float(b.detach())), 1e-12)
     assert rel(ld['loss_sds'], ld_ref['loss_sds']) < 5e-2, (float(ld['loss_sds']), float(ld_ref['loss_sds']))
     if opt.keep_bg:
-        assert rel(ld['loss_bg'], ld_ref['loss_bg']) < (2e-2 if variant == 'ori_bg' else 1e-3), (float(ld['loss_bg']), float(ld_ref['loss_bg']))
+        # the fg / bg split is sigmoid(100 (conf - thr)): it amplifies float32 rounding differences of the confidence a hundredfold
+        assert rel(ld['loss_bg'], ld_ref['loss_bg']) < (2e-2 if variant == 'ori_bg' else 5e-3), (float(ld['loss_bg']), float(ld_ref['loss_bg']))
     assert rel(loss, loss_ref) < 5e-2
     l2 = lambda a, b: float((a.detach().cpu().float() - b.detach().float()).norm() / (b.detach().float().norm() + 1e-20))
     errs = dict(grid=l2(model.pos_en.embeddings.grad, ref.pos_en.embeddings.grad), net=l2(model.network.params.grad, ref.network.grad),
@@ -151,3 +152,44 @@ def test_editing_step_matches_composed_oracle(variant):
     assert float(ref.pos_en.embeddings.grad.abs().max()) > 0
     # the SDS gradient passes a float16 UNet and the float16 VAE backward before it reaches the (float32) renderer
     assert all(e < 6e-2 for e in errs.values()), errs
+
+
+def test_multi_view_step_is_the_mean_of_single_view_steps():
+    """EditTrainer.train_step_editing_multi (V views through one VAE batch and one UNet batch of 2V) against the same views taken one at a
+    time with the same draws: loss = mean of the single-view losses, gradient = mean of the single-view gradients."""
+    tr, model, pre, data = _setup(keep_bg=1000.0, lambda_sd=0.01, g_only=True, sds_resolution=128)
+    g = torch.Generator().manual_seed(9)
+    N = 32 * 32
+    draws = dict(light=torch.randn(3, generator=g), z=torch.rand(N, 16, generator=g), u=torch.rand(N, 16, generator=g))
+    tr._render_kw['_draws'] = draws
+    sample_noise, noise = torch.randn(2, 4, 16, 16, generator=g).cuda(), torch.randn(2, 4, 16, 16, generator=g).cuda()
+    views = [data(0), data(1)]
+    model.train()
+
+    def grads():
+        out = [p.grad.detach().clone() for p in model.parameters()]
+        for p in model.parameters():
+            p.grad.zero_()
+        return out
+
+    tr.replay = dict(t=500, sample_noise=sample_noise, noise=noise)
+    _, _, loss_m, ld_m = tr.train_step_editing_multi(views)
+    tr.scaler.backward(loss_m)
+    g_multi = grads()
+    singles, g_single = [], None
+    for v in range(2):
+        tr.replay = dict(t=500, sample_noise=sample_noise[v:v + 1], noise=noise[v:v + 1])
+        _, _, loss_v, _ = tr.train_step_editing(views[v])
+        tr.scaler.backward(loss_v)
+        gv = grads()
+        singles.append(float(loss_v))
+        g_single = gv if g_single is None else [a + b for a, b in zip(g_single, gv)]
+    assert abs(float(loss_m) - 0.5 * sum(singles)) / (0.5 * sum(singles)) < 2e-3, (float(loss_m), singles)
+    for a, b in zip(g_multi, g_single):
+        b = 0.5 * b
+        assert float((a - b).norm() / (b.norm() + 1e-20)) < 2e-2
+    assert len(tr.pt_dict) == 2
+    # and one optimiser step through the public entry point
+    tr.replay = None
+    loss, ld = tr.train_step_multi(views)
+    assert np.isfinite(float(loss)) and set(ld) == {"loss_sds", "loss_bg"} and tr.global_step == 1
