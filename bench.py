@@ -171,7 +171,7 @@ def run_edit(args, world, rank, dev):
     rays_o, rays_d = rays_o.view(V, 1, H * W, 3), rays_d.view(V, 1, H * W, 3)
     rgb, mask = sc.targets(V, H, W)
     rgb, mask = rgb.to(dev), mask.to(dev)
-    trainer = EditTrainer(model, pretrained, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, world_size=world)
+    trainer = EditTrainer(model, pretrained, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, world_size=world, dp_mode=args.dp)
 
     def view(j):
         v = j % V

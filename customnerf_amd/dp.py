@@ -1,0 +1,163 @@
+"""Data-parallel gradient exchange for the NeRF parameters — the layer the reference lacks (its DDP scaffolding is dead code:
+nerf/utils_init_nerf.py:76-78, 709-726), designed for the xGMI topology of an 8 x MI355X node rather than for NCCL
+habits: xGMI is point to point (7 links per GPU), so the exchange is an ALL-TO-ALL — every link carries its 1/world slice at the same
+time — instead of a ring that is bound by one link.
+
+Per step, for the big parameter (the hash-grid table: 12.2 M floats here, 47.9 M for the reference's bear field):
+
+  1. pack      local float32 gradient * (1 / world) -> float16 payload (half the bytes; the same precision the reference's own fp16 training
+               gives the table gradient: `__half2` atomics under the same GradScaler — gridencoder.cu:324-330), the float32 source is zeroed;
+  2. exchange  `all_to_all_single`: rank j receives slice j of every rank's payload (world x shard halves);
+  3. reduce    the `world` slices are summed in FLOAT32 on arrival (no half-precision accumulation across ranks);
+  4. update    Adam on the owned shard only (moments exist for the shard only: 1/world of the optimiser state per GPU), writing the
+               float32 master shard and the float16 shadow shard in the same pass;
+  5. publish   `all_gather_into_tensor` of the float16 SHADOW shards, in place in the shadow table — the forward pass reads the shadow,
+               so 2 bytes per parameter come back instead of the 4 of an all-reduce.
+
+The small parameters (the three MLPs: 22.5 k floats) are all-reduced in float32 and updated on every rank; their all-reduce is issued
+from a hook that fires between the field backward and the grid scatter (`start_small`), so it overlaps the scatter kernels.
+With a dynamic loss scaler every rank checks its reduced shard (+ the MLP gradients) and the found-inf flags are OR-ed with one 4-byte
+all-reduce(MAX), on the device: all ranks skip or step together, no host read.
+
+Bytes per GPU and step (S = table floats): out 2 S (7/8 of it over the links), in 2 S (shadow) — against 8 S for a float32 all-reduce.
+
+Works on any `torch.distributed` backend ("nccl" = RCCL on the GPUs; the world-2 gloo test in tests/test_dropin_and_dp.py runs the same
+code on host tensors, where the Adam arithmetic is spelled out in torch — CUDA tensors always take the HIP kernel)."""
+import torch
+import torch.distributed as dist
+
+BIG_PARAM_MIN = 1 << 20
+ALIGN = 64                      # shard boundaries in elements (float4 / half8 vector accesses of the Adam kernel, 128-byte lines)
+
+
+def _adam_host(p, g, m, v, half_out, lr, betas, eps, step, inv_scale):
+    """torch.optim.Adam's update on host tensors (gloo test only)"""
+    g = g * inv_scale
+    m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+    p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+    if half_out is not None:
+        half_out.copy_(p)
+
+
+class ShardedExchange:
+    def __init__(self, params, flat, lr_of, world_size, rank, betas=(0.9, 0.99), eps=1e-15, scaler=None, half_shadow=False, group=None):
+        """params: the trainable parameters in the order their .grad views sit in `flat` (trainer.flat_grad_buffer); lr_of(p) -> base lr."""
+        self.world, self.rank, self.group = world_size, rank, group
+        self.betas, self.eps, self.scaler = betas, eps, scaler
+        self.flat = flat
+        self.lr_of = lr_of
+        off, self.big, self.small = 0, [], []
+        for p in params:
+            n = p.numel()
+            (self.big if n >= BIG_PARAM_MIN else self.small).append((p, off, n))
+            off += (n + 3) // 4 * 4
+        if self.small:
+            lo, hi = self.small[0][1], self.small[-1][1] + self.small[-1][2]
+            assert all(o >= lo for _, o, _ in self.small) and not any(lo <= o < hi for _, o, _ in self.big), "small parameters must be contiguous in the flat buffer"
+            self.small_seg = flat[lo:hi]
+        else:
+            self.small_seg = None
+        self.state = []
+        for p, o, n in self.big:
+            s = ((n + world_size - 1) // world_size + ALIGN - 1) // ALIGN * ALIGN
+            dev = p.device
+            st = dict(p=p, off=o, n=n, shard=s,
+                      send=torch.zeros(world_size * s, dtype=torch.float16, device=dev),      # pad stays zero
+                      recv=torch.empty(world_size, s, dtype=torch.float16, device=dev),
+                      g32=torch.empty(s, dtype=torch.float32, device=dev),
+                      m=torch.zeros(s, dtype=torch.float32, device=dev), v=torch.zeros(s, dtype=torch.float32, device=dev),
+                      # the float32 master of the OWNED shard (a padded private copy: the parameter's own storage stays the full table so that
+                      # checkpoints / evaluation code see the usual tensor — consolidate() refreshes it)
+                      master=torch.zeros(s, dtype=torch.float32, device=dev), step=0)
+            lo, hi = rank * s, min((rank + 1) * s, n)
+            if hi > lo:
+                st['master'][:hi - lo].copy_(p.detach().reshape(-1)[lo:hi])
+            if half_shadow:
+                st['shadow'] = torch.zeros(world_size * s, dtype=torch.float16, device=dev)
+                st['shadow'][:n].copy_(p.detach().reshape(-1))
+            else:
+                st['gather32'] = torch.zeros(world_size * s, dtype=torch.float32, device=dev)
+            self.state.append(st)
+        self._small_work = None
+
+    def describe(self):
+        return (f"fp16 all-to-all of the table gradient (1/{self.world} pre-scaled, fp32 sum on arrival) + sharded Adam + all-gather of the "
+                f"{'fp16 shadow' if 'shadow' in self.state[0] else 'fp32 master'} shards; MLP gradients fp32 all-reduce overlapped with the grid scatter")
+
+    def shadow_table(self, p):
+        """the full float16 shadow of big parameter p (what the forward gather reads), kept current by step()"""
+        for st in self.state:
+            if st['p'] is p and 'shadow' in st:
+                return st['shadow'][:st['n']].view(p.shape)
+        return None
+
+    # ---- called from the backward pass, between the field backward and the grid scatter
+    def start_small(self):
+        if self.small_seg is not None and self._small_work is None:
+            self._small_work = dist.all_reduce(self.small_seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # ---- after the backward pass
+    def exchange(self):
+        """steps 1-3 for every big parameter; the small parameters' all-reduce is completed (started here if no hook did)"""
+        inv_world = 1.0 / self.world
+        works = []
+        for st in self.state:
+            src = self.flat[st['off']:st['off'] + st['n']]
+            torch.mul(src, inv_world, out=st['send'][:st['n']])          # float32 -> float16 payload, pre-scaled so that the sum stays in range
+            src.zero_()                                                  # the scatter of the next step accumulates into it
+            works.append(dist.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=True))
+        self.start_small()
+        for st, w in zip(self.state, works):
+            w.wait()
+            torch.sum(st['recv'], dim=0, dtype=torch.float32, out=st['g32'])          # float32 accumulation on arrival
+        self._small_work.wait() if self._small_work is not None else None
+        self._small_work = None
+
+    def check(self):
+        """found_inf over the owned shards and the reduced small gradients, OR-ed across ranks on the device"""
+        if self.scaler is None:
+            return
+        for st in self.state:
+            self.scaler.check(st['g32'])
+        if self.small_seg is not None:
+            self.scaler.check(self.small_seg)
+        dist.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=self.group)
+
+    def step(self, lr_factor, loss_scale=1.0):
+        """steps 4-5 for the big parameters.  The gradients in g32 are MEANS over ranks of loss_scale-scaled gradients (the 1/world factor went
+        into the payload); the small parameters are left to the caller's optimiser (their reduced gradient is a SUM: un-scale by 1/(scale*world))."""
+        for st in self.state:
+            p, s, n = st['p'], st['shard'], st['n']
+            lo = self.rank * s
+            half_out = st['shadow'][lo:lo + s] if 'shadow' in st else None
+            lr = self.lr_of(p) * lr_factor
+            st['step'] += 1
+            if p.is_cuda:
+                from ._lib import lib, check, ptr, stream
+                if self.scaler is not None:
+                    check(lib.cnerf_adam_step_scaled(ptr(st['master']), ptr(st['g32']), ptr(st['m']), ptr(st['v']), ptr(half_out), s, float(lr),
+                                                     float(self.betas[0]), float(self.betas[1]), float(self.eps), ptr(self.scaler.state), 1.0, 0, stream()),
+                          "adam_step_scaled")
+                else:
+                    check(lib.cnerf_adam_step(ptr(st['master']), ptr(st['g32']), ptr(st['m']), ptr(st['v']), ptr(half_out), s, float(lr),
+                                              float(self.betas[0]), float(self.betas[1]), float(self.eps), st['step'], 1.0 / loss_scale, 0, stream()), "adam_step")
+            else:
+                _adam_host(st['master'], st['g32'], st['m'], st['v'], half_out, lr, self.betas, self.eps, st['step'], 1.0 / loss_scale)
+            if 'shadow' in st:
+                dist.all_gather_into_tensor(st['shadow'], st['shadow'][lo:lo + s], group=self.group)          # in place: 2 bytes per parameter
+            else:
+                dist.all_gather_into_tensor(st['gather32'], st['master'], group=self.group)
+                p.data.reshape(-1).copy_(st['gather32'][:n])
+            p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
+
+    @torch.no_grad()
+    def consolidate(self):
+        """refresh the full float32 parameters from the owners' master shards (before a checkpoint / an evaluation that reads float32)"""
+        for st in self.state:
+            if 'shadow' not in st:
+                continue                                                 # float32 mode keeps the parameter current in step()
+            full = torch.empty(self.world * st['shard'], dtype=torch.float32, device=st['p'].device)
+            dist.all_gather_into_tensor(full, st['master'], group=self.group)
+            st['p'].data.reshape(-1).copy_(full[:st['n']])

@@ -21,6 +21,22 @@ def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_ou
     return sigma, rgbc
 
 
+def field_forward_rows(enc, row0, xyz_rows, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma_out, rgbc_out):
+    """Full evaluation (sigma + rgb/confidence) of rows row0 .. row0 + len(xyz_rows) of the kernel-layout feature buffer enc [L, P, 2], written
+    into sigma_out [n] / rgbc_out [n, 4] (views into buffers that cover the whole sample list).  renderer._run_fused evaluates the coarse block
+    as soon as its features exist — its sigma feeds the importance sampling, so the separate density-only pass of the reference
+    (renderer.py:326) costs nothing extra — and the fine block after its gather."""
+    require_cuda(enc, xyz_rows, dirs, p_net, p_den, p_rgb, sigma_out, rgbc_out)
+    n = xyz_rows.shape[0]
+    assert enc.is_contiguous() and row0 + n <= enc.shape[1] and xyz_rows.is_contiguous() and dirs.is_contiguous()
+    assert sigma_out.is_contiguous() and rgbc_out.is_contiguous() and sigma_out.numel() == n and rgbc_out.numel() == 4 * n
+    dt = F16 if enc.dtype == torch.float16 else F32
+    src = enc.data_ptr() + row0 * enc.shape[2] * enc.element_size()
+    check(lib.cnerf_field_forward_strided(src, ptr(xyz_rows), ptr(dirs), int(dir_group), n, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
+                                          ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(sigma_out), ptr(rgbc_out), dt, int(enc.shape[1]), stream()),
+          "field_forward")
+
+
 _WS = {}
 
 
@@ -78,6 +94,26 @@ class FieldFunction(Function):
             grad_chain_record(xyz.device)
             return g_enc, None, None, None, None, None, None, None, None, None, None
         return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb, None
+
+
+class FieldAttach(Function):
+    """FieldFunction for outputs that were already computed block by block with field_forward_rows: forward hands (sigma, rgbc) on, backward is
+    FieldFunction's (it recomputes the forward from the saved inputs, so nothing else has to be kept)."""
+
+    @staticmethod
+    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc):
+        ctx.params = (p_net, p_den, p_rgb) if grad_in_place else None
+        ctx.save_for_backward(enc, xyz.contiguous().float(), dirs.contiguous().float(), p_net, p_den, p_rgb)
+        ctx.cfg = (dir_group, enc_dim, n_hidden_geo, n_rgb_out)
+        return sigma.detach(), rgbc.detach()
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgbc):
+        return FieldFunction.backward(ctx, g_sigma, g_rgbc) + (None, None)
+
+
+def field_attach(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma, rgbc, grad_in_place=False):
+    return FieldAttach.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc)
 
 
 def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False):

@@ -126,6 +126,16 @@ class _grid_encode(Function):
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 
+_PRE_SCATTER_HOOK = None
+
+
+def set_pre_scatter_hook(fn):
+    """fn() is called at the top of the grid scatter's backward, i.e. after the field backward has been enqueued and before the scatter
+    kernels are: the data-parallel layer starts the MLP gradients' all-reduce there so that it overlaps the scatter (customnerf_amd.dp)."""
+    global _PRE_SCATTER_HOOK
+    _PRE_SCATTER_HOOK = fn
+
+
 _SIDE = {}          # device -> {'stream': side stream, 'ws': workspace of the prepared plan, 'owner': weakref to the plan waiting for its backward}
 
 
@@ -208,6 +218,8 @@ class _grid_attach(Function):
         inputs, = ctx.saved_tensors
         offsets_host, B, D, C, L, S, H, gridtype, interpolation, align_corners, eshape = ctx.cfg
         grad = grad.contiguous()
+        if _PRE_SCATTER_HOOK is not None:
+            _PRE_SCATTER_HOOK()
         # grad_in_place (the trainers' persistent flat .grad buffer): the scatter is a read-modify-write of its destination anyway, so it
         # accumulates straight into embeddings.grad — no 49 MB zero-fill and no AccumulateGrad add pass (~45 us per step at T = 2^19)
         tgt = ctx.param.grad if ctx.param is not None else None

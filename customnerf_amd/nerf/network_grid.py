@@ -12,7 +12,7 @@ from .renderer import NeRFRenderer
 from .encoding import get_encoder, get_embedder
 from .provider_utils import trunc_exp
 from .. import tcnn
-from ..field import field, field_forward_raw
+from ..field import field, field_attach, field_forward_raw, field_forward_rows
 from ..gridencoder import GridEncoder
 
 
@@ -188,6 +188,29 @@ class NeRFNetwork(NeRFRenderer):
         sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
                             self.rgb_network.params, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
         return sigma, rgbc
+
+    # ---- block-wise full evaluation (renderer._run_fused): the coarse block is evaluated in full as soon as its features exist (its sigma is
+    # what the importance sampling needs, so the reference's separate density pass — renderer.py:326 — disappears), the fine block after its
+    # gather; split_attach then makes the pair differentiable.
+    def split_outputs(self, P, device):
+        return torch.empty(P, dtype=torch.float32, device=device), torch.empty(P, 4, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def split_forward_rows(self, enc, row0, x_rows, d, dir_group, sigma_all, rgbc_all):
+        enc_dim, n_geo, n_rgb = self._fused_cfg()
+        n = x_rows.shape[0]
+        field_forward_rows(enc, row0, x_rows, d.reshape(-1, 3).contiguous().float(), dir_group, enc_dim, n_geo, n_rgb, self.network.params,
+                           self.density_network.params, self.rgb_network.params, sigma_all[row0:row0 + n], rgbc_all[row0:row0 + n])
+
+    def split_attach(self, enc, unit, x, d, dir_group, sigma_all, rgbc_all, plan=None):
+        """(sigma [P], rgbc [P, 4]) computed by split_forward_rows -> the same values, differentiable in the table and the MLP parameters"""
+        if not torch.is_grad_enabled():
+            return sigma_all, rgbc_all
+        enc_dim, n_geo, n_rgb = self._fused_cfg()
+        if self.pos_en.embeddings.requires_grad:
+            enc = self.pos_en.attach_backward(enc, unit, overlap=self._overlap_plan(), plan=plan)
+        return field_attach(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
+                            self.rgb_network.params, sigma_all, rgbc_all, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
 
     def get_params(self, lr):
         """network_grid.py:196-206: grid lr x10."""

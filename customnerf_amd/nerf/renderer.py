@@ -160,6 +160,7 @@ class NeRFRenderer(nn.Module):
         with torch.no_grad():
             noise = None
             both = None
+            blockwise = False
             if perturb and self.training and 'z' not in draws and 'u' not in draws:
                 # rand(N,T) then rand(N,t) (renderer.py:317, :37) drawn by one generator launch: the first N*T values are the jitter
                 both = torch.rand(N * (num_steps + upsample_steps), device=device)
@@ -181,12 +182,22 @@ class NeRFRenderer(nn.Module):
                 z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3),
                                                          unit_out=unit[:Pc].view(N, num_steps, 3), bound=bnd)
                 self.split_encode(enc, unit, xyz_list[:Pc], 0, unit_ready=True)
-                sig_c = self.split_density(enc, xyz_list[:Pc])
+                blockwise = bool(getattr(self.opt, 'blockwise_field', True)) and self._fused_cfg()[2] == 4
+                if blockwise:
+                    # full evaluation of the coarse block right away: its sigma drives the importance sampling and its colours are the
+                    # coarse half of the final evaluation — no density-only pass, no second visit of these rows
+                    sig_all, rgbc_all = self.split_outputs(P, device)
+                    self.split_forward_rows(enc, 0, xyz_list[:Pc], rays_d, num_steps, sig_all, rgbc_all)
+                    sig_c = sig_all[:Pc]
+                else:
+                    sig_c = self.split_density(enc, xyz_list[:Pc])
                 z_all, xyz_f, src = render_ops.sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw(),
                                                                         xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3),
                                                                         unit_fine_out=unit[Pc:].view(N, upsample_steps, 3), bound=bnd)
                 plan = self.split_prepare(unit, grad_on)                     # all coordinates exist: the scatter's histogram runs beside the gather below
                 self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True)
+                if blockwise:
+                    self.split_forward_rows(enc, Pc, xyz_list[Pc:], rays_d, upsample_steps, sig_all, rgbc_all)
             else:
                 z_vals, xyzs = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise)
                 sig_c = self.density(xyzs.view(-1, 3))['sigma'].float().contiguous()
@@ -195,7 +206,11 @@ class NeRFRenderer(nn.Module):
                     self.density(xyz_all.view(-1, 3))
         if split:
             # both blocks hold num_steps samples per ray, so "one direction per num_steps consecutive samples" covers the list with [d | d]
-            sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, torch.cat([rays_d, rays_d], 0), num_steps, plan=plan)
+            dirs2 = torch.cat([rays_d, rays_d], 0)
+            if blockwise:
+                sig_l, rgbc_l = self.split_attach(enc, unit, xyz_list, dirs2, num_steps, sig_all, rgbc_all, plan=plan)
+            else:
+                sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, dirs2, num_steps, plan=plan)
             out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
             # per-sample by-products (weights, sorted-order sigma / rgbc copies, detached): a second launch, only if somebody reads them
             aux = _Lazy(lambda: render_ops.composite_run_indexed_aux(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr))

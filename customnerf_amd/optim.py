@@ -66,12 +66,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.half_shadows = {}
         self.grad_scale_inv = 1.0
         self.scaler = None              # DynamicLossScaler: gradient scale, skip decision and step count come from its device state
+        self.skip_params = set()        # id(p) of parameters some other owner updates (dp.ShardedExchange: the sharded grid table)
 
     @torch.no_grad()
     def step(self, closure=None):
         for group in self.param_groups:
             for p in group['params']:
-                if p.grad is None:
+                if p.grad is None or id(p) in self.skip_params:
                     continue
                 st = self.state[p]
                 if not st:

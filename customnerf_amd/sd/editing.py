@@ -10,12 +10,13 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
-from ..trainer import allreduce_grads_flat, check_grads_finite, enable_grad_in_place, flat_grad_buffer, refresh_half_shadow, register_half_shadow
+from ..trainer import (allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
+                       setup_sharded_dp)
 
 
 class EditTrainer:
     def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale='dynamic', seed=0,
-                 clip_guidance=None, clip_match_text=None):
+                 clip_guidance=None, clip_match_text=None, dp_mode='allreduce'):
         """text_z / text_z_fg: the [2, 77, 768] (uncond, cond) embeddings of the global / local prompt; with `opt.clip_view` they are
         LISTS of three such tensors for the ", front view" / ", side view" / ", back view" prompts (prepare_text_embeddings,
         utils_init_nerf.py:318-336), `clip_guidance` is a customnerf_amd.sd.clip_view.CLIP and `clip_match_text` the token ids [3, 77] of
@@ -42,6 +43,7 @@ class EditTrainer:
         self.pt_dict = {}
         self._flat = flat_grad_buffer(self.model.parameters())          # .grad views of one flat buffer: the all-reduce runs in place
         enable_grad_in_place(model)
+        self._dp = setup_sharded_dp(self, model, fp16) if (dp_mode == 'sharded' and world_size > 1) else None
         self._rng = np.random.RandomState(seed)
         self.replay = None            # tests: dict(branch='global'|'local', t=<timestep draw before t_ratio>, sample_noise=, noise=) replaces the step's SDS draws
         self.sds_resolution = int(getattr(opt, 'sds_resolution', 512))       # utils_init_nerf.py:303 resizes to 512 x 512
@@ -185,17 +187,6 @@ class EditTrainer:
             self.scaler.backward(loss)
         else:
             (loss * self.loss_scale).backward()
-        self.allreduce_grads()
-        f = self.lr_factor()
-        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
-            g['lr'] = base * f
-        self.optimizer.grad_scale_inv = 1.0 / (self.loss_scale * self.world_size)
-        if self.scaler is not None:
-            check_grads_finite(self.scaler, list(self.model.parameters()), self._flat)
-            self.optimizer.step()
-            self.scaler.update()
-        else:
-            self.optimizer.step()
-        refresh_half_shadow(self.optimizer, self.model)
+        apply_optimizer_step(self)                                       # gradient exchange (world > 1) + scaler check + Adam + shadow hand-over
         self.global_step += 1
         return loss.detach(), loss_dict

@@ -89,6 +89,56 @@ def check_grads_finite(scaler, parameters, flat):
             scaler.check(g.contiguous())
 
 
+def setup_sharded_dp(trainer, model, fp16, rank=None, group=None):
+    """dp_mode 'sharded' (customnerf_amd.dp.ShardedExchange): the big parameters (the grid table) leave the trainer's FusedAdam — their owner
+    shards are updated by the exchange — and the MLP all-reduce is hooked in front of the grid scatter."""
+    from .dp import ShardedExchange, BIG_PARAM_MIN
+    opt_ = trainer.optimizer
+    lr_by_id = {id(p): i for i, g in enumerate(opt_.param_groups) for p in g['params']}
+    params = [p for p in model.parameters() if p.requires_grad]
+    enc = getattr(model, 'pos_en', None)
+    half = bool(fp16 and enc is not None and hasattr(enc, 'half_table') and enc.level_dim % 2 == 0)
+    rank = dist.get_rank(group) if rank is None else rank
+    dp = ShardedExchange(params, trainer._flat, lambda p: trainer.base_lrs[lr_by_id[id(p)]], trainer.world_size, rank, betas=(0.9, 0.99), eps=1e-15,
+                         scaler=trainer.scaler, half_shadow=half, group=group)
+    opt_.skip_params = {id(st['p']) for st in dp.state}
+    if half and enc is not None:
+        sh = dp.shadow_table(enc.embeddings)
+        if sh is not None:
+            opt_.half_shadows[enc.embeddings] = sh                 # refresh_half_shadow hands it to the encoder after every step
+            enc.set_half_table(sh)
+    if enc is not None and hasattr(enc, 'attach_backward'):
+        from .gridencoder import grid as ge
+        ge.set_pre_scatter_hook(dp.start_small)                    # MLP gradients go out while the grid scatter still runs
+    return dp
+
+
+def apply_optimizer_step(trainer):
+    """gradient exchange + GradScaler check + Adam + scaler update + fp16 shadow hand-over, for ReconTrainer and EditTrainer (fused Adam path).
+    world_size 1: no exchange; dp_mode 'allreduce': one in-place fp32 all-reduce of the flat buffer; 'sharded': dp.ShardedExchange."""
+    f = trainer.lr_factor()
+    for g, base in zip(trainer.optimizer.param_groups, trainer.base_lrs):
+        g['lr'] = base * f
+    dp = getattr(trainer, '_dp', None)
+    trainer.optimizer.grad_scale_inv = 1.0 / (trainer.loss_scale * trainer.world_size)
+    if dp is not None:
+        dp.exchange()
+        dp.check()
+        dp.step(f, trainer.loss_scale)
+        trainer.optimizer.step()                                     # the small (replicated) parameters; the big ones are in skip_params
+        if trainer.scaler is not None:
+            trainer.scaler.update()
+    else:
+        trainer.allreduce_grads()
+        if trainer.scaler is not None:
+            check_grads_finite(trainer.scaler, list(trainer.model.parameters()), trainer._flat)      # on the all-reduced gradients: every rank takes the same skip decision
+            trainer.optimizer.step()
+            trainer.scaler.update()
+        else:
+            trainer.optimizer.step()
+    refresh_half_shadow(trainer.optimizer, trainer.model)
+
+
 class ReconTrainer:
     def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic', dp_mode='allreduce'):
         """dp_mode (world_size > 1): 'allreduce' = one in-place fp32 all-reduce of the flat gradient buffer; 'sharded' = customnerf_amd.dp.ShardedExchange
@@ -118,6 +168,7 @@ class ReconTrainer:
         self._flat = flat_grad_buffer(self.model.parameters())   # persistent, pre-zeroed .grad views of one flat buffer (zeroed by the fused step)
         if fused_adam:
             enable_grad_in_place(model)                          # (torch.optim.Adam + zero_grad keeps the views too, but stay on the plain path there)
+        self._dp = setup_sharded_dp(self, model, fp16) if (self.dp_mode == 'sharded' and fused_adam) else None
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)      # main.py:189
@@ -154,21 +205,14 @@ class ReconTrainer:
             self.scaler.backward(loss)
         else:
             (loss * self.loss_scale).backward()
-        self.allreduce_grads()
-        f = self.lr_factor()
-        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
-            g['lr'] = base * f
-        inv = 1.0 / (self.loss_scale * self.world_size)
         if self.fused_adam:
-            self.optimizer.grad_scale_inv = inv
-            if self.scaler is not None:
-                check_grads_finite(self.scaler, list(self.model.parameters()), self._flat)      # on the all-reduced gradients: every rank takes the same skip decision
-                self.optimizer.step()
-                self.scaler.update()
-            else:
-                self.optimizer.step()
-            refresh_half_shadow(self.optimizer, self.model)
+            apply_optimizer_step(self)
         else:
+            self.allreduce_grads()
+            f = self.lr_factor()
+            for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+                g['lr'] = base * f
+            inv = 1.0 / (self.loss_scale * self.world_size)
             if inv != 1.0:
                 torch._foreach_mul_([p.grad for p in self.model.parameters() if p.grad is not None], inv)
             self.optimizer.step()

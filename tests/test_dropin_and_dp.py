@@ -88,3 +88,78 @@ def test_dp_allreduce_gloo_world2(tmp_path):
                           "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert out.stdout.count("ok") == 2
+
+
+SHARDED_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from customnerf_amd.dp import ShardedExchange, BIG_PARAM_MIN
+from customnerf_amd.trainer import flat_grad_buffer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+for half_shadow in (True, False):
+    g0 = torch.Generator().manual_seed(0)
+    n_big = BIG_PARAM_MIN + 1234                                   # not a multiple of world * 64: the last shard is padded
+    big = torch.nn.Parameter(torch.randn(n_big // 2, 2, generator=g0) * 0.1)
+    s1 = torch.nn.Parameter(torch.randn(100, generator=g0)); s2 = torch.nn.Parameter(torch.randn(7, 3, generator=g0))
+    params = [big, s1, s2]
+    flat = flat_grad_buffer(params)
+    ref = [p.detach().clone() for p in params]                      # single-process reference: Adam on the MEAN gradient of all ranks
+    ref_opt = torch.optim.Adam([{'params': [torch.nn.Parameter(r) for r in ref]}], lr=1.0, betas=(0.9, 0.99), eps=1e-15)
+    rp = ref_opt.param_groups[0]['params']
+    lrs = {id(big): 5e-3, id(s1): 5e-4, id(s2): 5e-4}
+    dp = ShardedExchange(params, flat, lambda p: lrs[id(p)], world, rank, half_shadow=half_shadow)
+    small_opt = torch.optim.Adam([s1, s2], lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
+    assert len(dp.state) == 1 and dp.small_seg.numel() >= 100 + 21
+    for step in range(3):
+        grads = []
+        for r in range(world):                                     # what every rank "computes": deterministic per (rank, step)
+            gr = torch.Generator().manual_seed(1000 * step + r)
+            grads.append([torch.randn(p.shape, generator=gr) * (1 + r) for p in params])
+        for p, gl in zip(params, grads[rank]):
+            p.grad.add_(gl)                                        # accumulate into the persistent flat views, as autograd does
+        dp.exchange()
+        assert float(flat[:n_big].abs().max()) == 0.0              # the big gradient slot was packed and zeroed
+        dp.check()
+        dp.step(1.0)
+        for p in (s1, s2):
+            p.grad.mul_(1.0 / world)                               # the small gradients arrive as SUMS
+        small_opt.step(); small_opt.zero_grad(set_to_none=False)
+        # ---- reference
+        mean16 = sum((gl[0] * (1.0 / world)).half().float() for gl in grads)          # float16 payload, float32 sum on arrival
+        rp[0].grad = mean16.clone(); rp[1].grad = sum(gl[1] for gl in grads) / world; rp[2].grad = sum(gl[2] for gl in grads) / world
+        # per-parameter lr: three single-parameter Adams share the state layout of one; emulate with explicit lr scaling
+        for q, lr in zip(rp, (5e-3, 5e-4, 5e-4)):
+            st = ref_opt.state.setdefault(q, {})
+            if not st:
+                st['m'] = torch.zeros_like(q); st['v'] = torch.zeros_like(q); st['t'] = 0
+            st['t'] += 1
+            st['m'].mul_(0.9).add_(q.grad, alpha=0.1); st['v'].mul_(0.99).addcmul_(q.grad, q.grad, value=0.01)
+            q.data.addcdiv_(st['m'], (st['v'].sqrt() / (1 - 0.99 ** st['t']) ** 0.5).add_(1e-15), value=-lr / (1 - 0.9 ** st['t']))
+        dp.consolidate()
+        assert torch.allclose(big.detach(), rp[0].detach(), rtol=1e-5, atol=1e-6), (step, (big.detach() - rp[0]).abs().max())
+        assert torch.allclose(s1.detach(), rp[1].detach(), rtol=1e-5, atol=1e-6) and torch.allclose(s2.detach(), rp[2].detach(), rtol=1e-5, atol=1e-6)
+        if half_shadow:
+            sh = dp.shadow_table(big)
+            assert sh.dtype == torch.float16 and torch.equal(sh, big.detach().half())     # every rank holds the complete, current shadow
+        allp = [torch.empty_like(big.data) for _ in range(world)]
+        dist.all_gather(allp, big.data)
+        assert all(torch.equal(allp[0], x) for x in allp)          # replicas identical after consolidate
+    # the owner keeps 1/world of the moments
+    assert dp.state[0]['m'].numel() * world < n_big + world * 64 + 1
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_dp_sharded_exchange_gloo_world2(tmp_path):
+    """customnerf_amd.dp.ShardedExchange on two host processes: fp16 all-to-all payload summed in fp32, sharded Adam, all-gather of the
+    shadow / master shards, small parameters all-reduced — against a single-process Adam on the mean gradient."""
+    script = tmp_path / "dp_sharded_worker.py"
+    script.write_text(SHARDED_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.stdout.count("ok") == 2

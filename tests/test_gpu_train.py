@@ -229,3 +229,61 @@ def test_training_is_bit_reproducible():
         tcnn.set_default_dtype(torch.float32)                 # the fp16 default must not leak into later tests
     for pa, pb in zip(a, b):
         assert torch.equal(pa, pb)
+
+
+def test_half_batches_sum_to_the_full_batch():
+    """SURVEY.md §4's data-parallel contract on the real field, on one GPU: the gradient of a ray batch equals the sum of the gradients of its
+    two halves (each weighted by its share of the rays) — what two ranks of a ray-chunk split produce before the exchange.  Full-size view
+    (128 x 128, L16 T2^19, 64 + 64 samples, fp16) so that the binned fixed-point scatter, the x2 field backward and the fused loss all run.
+    The per-sample table updates are identical in both runs and each launch sums them exactly (64-bit fixed point); what differs is ONE float32
+    rounding per entry when a launch's sum is added to `.grad` (once for the full batch, twice for the halves): the table gradients agree to
+    float32 rounding, not bit for bit; the MLP gradients (float32 partial sums in a different order) to 1e-5 of their scale."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    try:
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True)
+        model = NeRFNetwork(opt).cuda()
+        with torch.no_grad():
+            model.pos_en.embeddings.uniform_(-0.3, 0.3)
+            model.pos_en.invalidate_half_table()
+        H = W = 128
+        o, d, rgb, mask = _target_scene(H, W, 1)
+        N = H * W
+        tr = ReconTrainer(model, opt, fp16=True)
+        g = torch.Generator().manual_seed(5)
+        draws = dict(z=torch.rand(N, 64, generator=g).cuda(), u=torch.rand(N, 64, generator=g).cuda())
+        model.train()
+
+        def grad_of(lo, hi, weight):
+            dr = dict(z=draws['z'][lo:hi].contiguous(), u=draws['u'][lo:hi].contiguous())
+            with torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(o[0][:, lo:hi].contiguous(), d[0][:, lo:hi].contiguous(), staged=False, perturb=True, force_all_rays=True,
+                                   num_steps=64, upsample_steps=64, _draws=dr)
+                loss = tr.loss(out, rgb[0][lo:hi].contiguous(), mask[0][lo:hi].contiguous())
+            tr.scaler.backward(loss * weight)                           # weight = this chunk's share of the rays (a power of two: exact)
+
+        def take():
+            gs = [p.grad.detach().clone() for p in model.parameters()]
+            for p in model.parameters():
+                p.grad.zero_()
+            return gs
+
+        grad_of(0, N, 1.0)
+        full = take()
+        grad_of(0, N // 2, 0.5)
+        grad_of(N // 2, N, 0.5)
+        halves = take()
+        names = [n for n, _ in model.named_parameters()]
+        for n, a, b in zip(names, full, halves):
+            scale = float(a.abs().max())
+            assert scale > 0, n
+            if n == "pos_en.embeddings":
+                assert float((a != 0).float().mean()) > 0.01
+                np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=3e-7, atol=2e-7 * scale, err_msg=n)
+            else:
+                np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-5 * scale, err_msg=n)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
