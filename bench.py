@@ -210,9 +210,11 @@ def run_edit(args, world, rank, dev):
         # queue the gap between `event.record()` and the launch call lands inside the bracket (small GEMMs read 17 us instead of the 8 us
         # rocprofv3 shows).  A device-side sleep in front keeps the queue full while the host enqueues the whole step: events and kernels
         # then execute back to back.
-        sleep_cycles = int(0.12 * torch.cuda.get_device_properties(dev).clock_rate * 1e3) if hasattr(torch.cuda, "_sleep") else 0
-        if sleep_cycles:
-            torch.cuda._sleep(sleep_cycles)
+        if hasattr(torch.cuda, "_sleep"):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(); torch.cuda._sleep(2000000); c1.record(); torch.cuda.synchronize()          # calibrate the spin counter's rate
+            per_ms = 2000000 / max(c0.elapsed_time(c1), 1e-3)
+            torch.cuda._sleep(int(min(120.0 * per_ms, 2e9)))                                         # ~120 ms head start for the host
         sdops.set_profile(prof)
         step(args.warmup + args.steps + 1)
         sdops.set_profile(None)
