@@ -578,6 +578,10 @@ int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, flo
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared);
 int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
                void *workspace, hipStream_t st);
+int bn_prepare_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
+                    void *workspace, hipStream_t st, uint32_t row0, uint32_t rows);
+int bn_prepare_finish(const GridLevels &lv, uint32_t B, uint32_t nl, int dtype, void *workspace, hipStream_t st);
+uint32_t bn_hist_block_points(int dtype);
 #define BN_MIN_UPDATES (1u << 20)        // below this many (point, level) pairs the plain atomic kernel is cheaper than five launches
 
 extern "C" {
@@ -669,6 +673,57 @@ int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offse
           !(((uintptr_t)workspace) & 255)))
         return CNERF_OK;
     rc = bn_prepare(inputs, lv, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream));
+    if (rc == 0) *prepared = 1;
+    return rc;
+}
+
+// cnerf_grid_encode_backward_prepare in pieces: the histogram of rows [row0, row0 + rows) of the B-sample list can be taken as soon as THOSE
+// coordinates exist (row0 a multiple of *block_points of cnerf_grid_encode_backward_prepare_block; the range ends on a block border or at B), each
+// piece on whatever stream suits the caller; ..._finish runs the scans once every row has been counted and leaves the plan that
+// cnerf_grid_encode_backward_prepared consumes.  *prepared = 0 (nothing launched): the shape takes the atomic kernel, or the records are float32.
+int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points) {
+    if (!block_points) return CNERF_ENULL;
+    *block_points = bn_hist_block_points(dtype);
+    return CNERF_OK;
+}
+
+static int ge_prepare_common(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                             uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes, GridLevels &lv, bool &go) {
+    go = false;
+    if (gridtype > 1 || interp > 1) return CNERF_EINVAL;
+    int rc = ge_levels(offsets_host, L, L, S, H, lv);
+    if (rc) return rc;
+    if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
+    go = dtype == CNERF_F16 && B && workspace && (uint64_t)B * L >= BN_MIN_UPDATES && bn_eligible(B, D, C, L, lv) &&
+         workspace_bytes >= bn_workspace_bytes(B, L, lv, dtype) && !(((uintptr_t)workspace) & 255) && bn_hist_block_points(dtype) != 0;
+    return CNERF_OK;
+}
+
+int cnerf_grid_encode_backward_prepare_rows(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                            uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, uint32_t row0, uint32_t rows,
+                                            void *workspace, uint64_t workspace_bytes, int *prepared, void *stream) {
+    if (!prepared) return CNERF_ENULL;
+    *prepared = 0;
+    GridLevels lv;
+    bool go;
+    int rc = ge_prepare_common(offsets_host, B, D, C, L, S, H, gridtype, interp, dtype, workspace, workspace_bytes, lv, go);
+    if (rc || !go) return rc;
+    if (!inputs) return CNERF_ENULL;
+    rc = bn_prepare_rows(inputs, lv, B, L, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream), row0, rows);
+    if (rc == 0) *prepared = 1;
+    return rc;
+}
+
+int cnerf_grid_encode_backward_prepare_finish(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                              uint32_t gridtype, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes, int *prepared,
+                                              void *stream) {
+    if (!prepared) return CNERF_ENULL;
+    *prepared = 0;
+    GridLevels lv;
+    bool go;
+    int rc = ge_prepare_common(offsets_host, B, D, C, L, S, H, gridtype, interp, dtype, workspace, workspace_bytes, lv, go);
+    if (rc || !go) return rc;
+    rc = bn_prepare_finish(lv, B, L, dtype, workspace, CN_STREAM(stream));
     if (rc == 0) *prepared = 1;
     return rc;
 }

@@ -445,12 +445,14 @@ __device__ __forceinline__ uint32_t b2_ticket(uint32_t *counters, uint32_t c) {
     return atomicAdd(&counters[c], 1u);
 }
 
+// (pb0, nbl): the launch covers point blocks pb0 .. pb0 + nbl - 1 of every level — the histogram of a sample list may be taken in several
+// launches, each as soon as its rows exist (cnerf_grid_encode_backward_prepare_rows)
 template <int PTS>
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restrict__ inputs, const GridLevels lv, const Bin2Plan plan,
                                                           uint32_t *__restrict__ hist, uint32_t B, uint32_t gridtype, int align_corners,
-                                                          uint32_t interp) {
+                                                          uint32_t interp, uint32_t pb0, uint32_t nbl) {
     __shared__ uint32_t cnt[BN_MAX_CHUNKS];
-    const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
+    const uint32_t slot = blockIdx.x / nbl, pb = pb0 + blockIdx.x % nbl;
     const uint32_t level = lv.order[slot];
     const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
     if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
@@ -870,20 +872,38 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
     return off;
 }
 
-static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
-                     hipStream_t st) {
+// histogram of the point blocks that cover rows [row0, row0 + rows) (row0 a multiple of the block size; the range ends on a block border or at B)
+static int b2_hist_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
+                        hipStream_t st, uint32_t row0, uint32_t rows) {
     Bin2Plan plan;
     b2_plan(lv, nl, B, plan);
     Bin2Ws ws;
     b2_layout(plan, B, nl, &ws, workspace);
-    switch (b2_pts()) {
-#define B2_HIST(P) case P: hipLaunchKernelGGL(k_bin2_hist<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp); break;
+    const uint32_t pts = b2_pts();
+    if (row0 % pts || row0 + rows > B || ((row0 + rows) % pts && row0 + rows != B) || rows == 0) return CNERF_EINVAL;
+    const uint32_t pb0 = row0 / pts, nbl = cn_div_up(rows, pts);
+    switch (pts) {
+#define B2_HIST(P) case P: hipLaunchKernelGGL(k_bin2_hist<P>, dim3(nbl * nl), dim3(B2_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp, pb0, nbl); break;
         B2_HIST(1024) B2_HIST(2048) B2_HIST(4096) B2_HIST(8192)
 #undef B2_HIST
     }
+    return cn_launch_status();
+}
+
+static int b2_scans(const GridLevels &lv, uint32_t B, uint32_t nl, void *workspace, hipStream_t st) {
+    Bin2Plan plan;
+    b2_plan(lv, nl, B, plan);
+    Bin2Ws ws;
+    b2_layout(plan, B, nl, &ws, workspace);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, b2_seg(B, b2_max_chunks(plan, nl)), ws.seg_bin);
     return cn_launch_status();
+}
+
+static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
+                     hipStream_t st) {
+    const int rc = b2_hist_rows(inputs, lv, B, nl, gridtype, ac, interp, workspace, st, 0, B);
+    return rc ? rc : b2_scans(lv, B, nl, workspace, st);
 }
 
 static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
@@ -975,6 +995,18 @@ static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, f
                        ws.bin_base, ws.seg_first, lv, plan, gemb);
     return cn_launch_status();
 }
+
+// the plan in pieces (float16 records only): histogram of a row range / the scans once every range is counted
+int bn_prepare_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
+                    void *workspace, hipStream_t st, uint32_t row0, uint32_t rows) {
+    if (!b2_enabled(dtype)) return CNERF_EINVAL;
+    return b2_hist_rows(inputs, lv, B, nl, gridtype, ac, interp, workspace, st, row0, rows);
+}
+int bn_prepare_finish(const GridLevels &lv, uint32_t B, uint32_t nl, int dtype, void *workspace, hipStream_t st) {
+    if (!b2_enabled(dtype)) return CNERF_EINVAL;
+    return b2_scans(lv, B, nl, workspace, st);
+}
+uint32_t bn_hist_block_points(int dtype) { return b2_enabled(dtype) ? b2_pts() : 0u; }
 
 int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
                void *workspace, hipStream_t st) {

@@ -190,6 +190,50 @@ def _prepare_plan(inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corner
     return plan
 
 
+def _plan_rows(state, inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corners, interpolation, dt, device, row0, rows, finish):
+    """The plan of _prepare_plan in pieces (cnerf_grid_encode_backward_prepare_rows / _finish): `state` is None for the first piece and the
+    value returned by the previous call afterwards; every piece is issued on the side stream after the current stream's work so far (the
+    coordinates of ITS rows must exist).  -> state (a dict) while pieces are pending, a _Plan once `finish`, or None when the shape takes the
+    atomic kernel / the side stream is busy (then nothing was issued and attach_backward plans by itself)."""
+    import ctypes
+    side = _side(device)
+    if state is None:
+        if _side_busy(side):
+            return None
+        need = ctypes.c_uint64(0)
+        check(lib.cnerf_grid_encode_backward_workspace_bytes(offsets_host.ctypes.data, B, D, C, L, L, S, H, dt, ctypes.addressof(need)),
+              "grid_encode_backward_workspace_bytes")
+        if not need.value:
+            return None
+        if side['ws'] is None or side['ws'].numel() < need.value:
+            side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
+        state = {'ws': side['ws'], 'token': _Plan(side['ws'], None)}
+        state['token'].inputs_ptr, state['token'].rows = inputs.data_ptr(), B
+        side['owner'] = weakref.ref(state['token'])                  # the side stream's workspace is taken from the first piece on
+    ws = state['ws']
+    cur = torch.cuda.current_stream()
+    side['stream'].wait_stream(cur)
+    ok = ctypes.c_int(0)
+    if rows:
+        check(lib.cnerf_grid_encode_backward_prepare_rows(ptr(inputs), offsets_host.ctypes.data, B, D, C, L, S, H, gridtype, int(align_corners),
+                                                          interpolation, dt, int(row0), int(rows), ptr(ws), ws.numel(), ctypes.addressof(ok),
+                                                          side['stream'].cuda_stream), "grid_encode_backward_prepare_rows")
+        if not ok.value:
+            side['owner'] = None
+            return None
+    if not finish:
+        return state
+    check(lib.cnerf_grid_encode_backward_prepare_finish(offsets_host.ctypes.data, B, D, C, L, S, H, gridtype, interpolation, dt, ptr(ws), ws.numel(),
+                                                        ctypes.addressof(ok), side['stream'].cuda_stream), "grid_encode_backward_prepare_finish")
+    if not ok.value:
+        side['owner'] = None
+        return None
+    plan = state['token']
+    plan.event = torch.cuda.Event()
+    plan.event.record(side['stream'])
+    return plan
+
+
 class _grid_attach(Function):
     """Backward half of _grid_encode for a feature buffer that was filled by GridEncoder.encode_into calls: forward hands the buffer
     on unchanged, backward scatters d(loss)/d(features) [L,B,C] into the table gradient for ALL B rows of `inputs`.
@@ -378,6 +422,23 @@ class GridEncoder(nn.Module):
         dt = dtype_id(torch.empty(0, dtype=torch.float16 if half else torch.float32))
         return _prepare_plan(inputs_unit, self._offsets_host, P, D, self.level_dim, self.num_levels, float(np.log2(self.per_level_scale)),
                              int(self.base_resolution), self.gridtype_id, self.align_corners, self.interp_id, dt, inputs_unit.device)
+
+    def hist_block_points(self, half):
+        """granularity (rows) of prepare_backward_rows for this precision; 0 = the piecewise plan is not available (float32 records)"""
+        import ctypes
+        n = ctypes.c_uint32(0)
+        check(lib.cnerf_grid_encode_backward_prepare_block(dtype_id(torch.empty(0, dtype=torch.float16 if half else torch.float32)), ctypes.addressof(n)),
+              "grid_encode_backward_prepare_block")
+        return int(n.value)
+
+    def prepare_backward_rows(self, state, inputs_unit, half, row0, rows, finish):
+        """prepare_backward in pieces: count rows [row0, row0 + rows) of inputs_unit [P, D] now (they must be written), `finish` on the last piece
+        -> state to pass to the next call, the plan after the last one, or None (nothing issued; attach_backward then plans by itself)."""
+        assert inputs_unit.is_contiguous() and inputs_unit.dtype == torch.float32
+        P, D = inputs_unit.shape
+        dt = dtype_id(torch.empty(0, dtype=torch.float16 if half else torch.float32))
+        return _plan_rows(state, inputs_unit, self._offsets_host, P, D, self.level_dim, self.num_levels, float(np.log2(self.per_level_scale)),
+                          int(self.base_resolution), self.gridtype_id, self.align_corners, self.interp_id, dt, inputs_unit.device, row0, rows, finish)
 
     def attach_backward(self, enc, inputs_unit, overlap=True, plan=None):
         """enc [L, P, C] filled by encode_into for the rows of inputs_unit [P, D] -> the same features, differentiable in the table.

@@ -180,6 +180,17 @@ class NeRFNetwork(NeRFRenderer):
             return None
         return self.pos_en.prepare_backward(unit, self._half())
 
+    def split_prepare_rows(self, state, unit, grad_enabled, row0, rows, finish):
+        """split_prepare in pieces: the histogram of rows [row0, row0 + rows) as soon as those coordinates exist (the coarse block right after the
+        coarse sampling, the fine block after the importance sampling), so that the whole plan is ready before the field backward starts.
+        -> (state | plan | None, piecewise): piecewise False = not available for this shape / precision: use split_prepare."""
+        if not (grad_enabled and self.pos_en.embeddings.requires_grad and self._overlap_plan() and getattr(self.opt, 'early_scatter_plan', True)):
+            return None, True
+        blk = self.pos_en.hist_block_points(self._half())
+        if not blk or row0 % blk or (rows % blk and row0 + rows != unit.shape[0]) or not getattr(self.opt, 'piecewise_scatter_plan', True):
+            return None, False
+        return self.pos_en.prepare_backward_rows(state, unit, self._half(), row0, rows, finish), True
+
     def split_forward(self, enc, unit, x, d, dir_group, plan=None):
         """forward() on a complete feature buffer: (sigma [P], rgbc [P, 4]); gradients reach the table through attach_backward"""
         enc_dim, n_geo, n_rgb = self._fused_cfg()

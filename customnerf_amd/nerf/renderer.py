@@ -181,6 +181,9 @@ class NeRFRenderer(nn.Module):
                 bnd = float(self.opt.bound)                                  # the samplers also write the grid's [0,1] coordinates (no elementwise pass)
                 z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3),
                                                          unit_out=unit[:Pc].view(N, num_steps, 3), bound=bnd)
+                # the scatter plan's histogram in two pieces: the coarse block's rows now (beside the coarse gather), the fine block's after the
+                # importance sampling — all of it is then done before the field backward starts
+                pstate, piecewise = self.split_prepare_rows(None, unit, grad_on, 0, Pc, False)
                 self.split_encode(enc, unit, xyz_list[:Pc], 0, unit_ready=True)
                 blockwise = bool(getattr(self.opt, 'blockwise_field', True)) and self._fused_cfg()[2] == 4
                 if blockwise:
@@ -194,7 +197,10 @@ class NeRFRenderer(nn.Module):
                 z_all, xyz_f, src = render_ops.sample_fine_merge_split(rays_o, rays_d, nears, fars, aabb, z_vals, sig_c, upsample_steps, u_draw(),
                                                                         xyz_fine_out=xyz_list[Pc:].view(N, upsample_steps, 3),
                                                                         unit_fine_out=unit[Pc:].view(N, upsample_steps, 3), bound=bnd)
-                plan = self.split_prepare(unit, grad_on)                     # all coordinates exist: the scatter's histogram runs beside the gather below
+                if piecewise and pstate is not None:
+                    plan, _ = self.split_prepare_rows(pstate, unit, grad_on, Pc, P - Pc, True)
+                elif not piecewise:
+                    plan = self.split_prepare(unit, grad_on)                 # all coordinates exist: the scatter's histogram runs beside the gather below
                 self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True)
                 if blockwise:
                     self.split_forward_rows(enc, Pc, xyz_list[Pc:], rays_d, upsample_steps, sig_all, rgbc_all)

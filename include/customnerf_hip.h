@@ -171,6 +171,18 @@ int cnerf_grid_encode_backward(const void *grad, const float *inputs, const int3
 int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                        uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                        int dtype, void *workspace, uint64_t workspace_bytes, int *prepared, void *stream);
+/* The plan in pieces (float16 records): the histogram of rows [row0, row0 + rows) of the B-sample list can be taken as soon as THOSE coordinates
+ * exist — run()'s coarse block at the very beginning of the forward, its fine block after the importance sampling — so that all of it is done
+ * before the field backward starts (a histogram that is still running then slows that kernel from 407 to 491 us: DESIGN.md §4 round 3).
+ * row0 must be a multiple of *block_points (cnerf_grid_encode_backward_prepare_block) and the range must end on a block border or at B;
+ * ..._finish runs the scans once every row has been counted.  *prepared = 0: nothing launched (the shape takes the atomic kernel / float32 records). */
+int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points);
+int cnerf_grid_encode_backward_prepare_rows(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                            float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, uint32_t row0,
+                                            uint32_t rows, void *workspace, uint64_t workspace_bytes, int *prepared, void *stream);
+int cnerf_grid_encode_backward_prepare_finish(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                              uint32_t gridtype, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                                              int *prepared, void *stream);
 int cnerf_grid_encode_backward_prepared(const void *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                         uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                         uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *workspace,
