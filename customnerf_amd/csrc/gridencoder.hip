@@ -209,7 +209,7 @@ __device__ __forceinline__ void gf_accum(cn_gf_h2 &acc, float w, uint32_t g2, fl
     acc = acc + p;
 }
 __device__ __forceinline__ uint32_t gf_ld1(const unsigned char *__restrict__ base, uint32_t byte_off) { return *reinterpret_cast<const uint32_t *>(base + byte_off); }
-struct alignas(8) gf_u2 { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) gf_u2 { uint32_t x, y; };        // read at 4-byte-aligned entry addresses (still one global_load_dwordx2)
 struct alignas(16) gf_u4 { uint32_t x, y, z, w; };
 
 __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd_fast(const float *__restrict__ inputs, const __half *__restrict__ grid, const GridLevels lv,
