@@ -70,6 +70,8 @@ SIGNATURES = {
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
     "cnerf_scaler_check": [vp, u64, vp, vp],
     "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],
+    "cnerf_dp_pack": [vp, vp, u64, f32, vp],
+    "cnerf_dp_reduce": [vp, u32, u64, vp, vp, vp],
     "cnerf_scaler_update": [vp, f32, f32, u32, vp],
     # ---- include/customnerf_sd.h (score-distillation primitives)
     "cnerf_sd_gemm": [vp, vp, u64, vp],

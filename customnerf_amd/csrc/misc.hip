@@ -141,6 +141,43 @@ __global__ void k_scaler_update(float *state, float growth, float backoff, float
     state[2] = 0.0f;
 }
 
+// ---- data-parallel exchange (customnerf_amd/dp.py).  pack: float32 gradient * scale -> float16 payload, the float32 source zeroed in the same pass
+// (the next step's scatter accumulates into it); reduce: the `world` float16 slices a rank received, summed in float32, + the scaler's found-inf flag.
+__global__ void __launch_bounds__(256) k_dp_pack(float *__restrict__ g, __half *__restrict__ out, uint64_t n, float scale) {
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(g)[i];
+        union { __half2 h[2]; uint2 u; } o;
+        o.h[0] = __floats2half2_rn(v.x * scale, v.y * scale);
+        o.h[1] = __floats2half2_rn(v.z * scale, v.w * scale);
+        reinterpret_cast<uint2 *>(out)[i] = o.u;
+        reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { out[i] = __float2half_rn(g[i] * scale); g[i] = 0.f; }
+}
+
+__global__ void __launch_bounds__(256) k_dp_reduce(const __half *__restrict__ recv, uint32_t world, uint64_t shard, float *__restrict__ out,
+                                                   float *__restrict__ state) {
+    const uint64_t n8 = shard / 8, stride = (uint64_t)gridDim.x * blockDim.x;          // shard is a multiple of 64 elements (dp.ALIGN)
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (uint32_t r = 0; r < world; ++r) {
+            union { uint4 u; __half2 h[4]; } v;
+            v.u = reinterpret_cast<const uint4 *>(recv + (uint64_t)r * shard)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float2 f = __half22float2(v.h[k]); acc[2 * k] += f.x; acc[2 * k + 1] += f.y; }
+        }
+        reinterpret_cast<float4 *>(out)[2 * i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += acc[k] - acc[k];
+        bad = bad || (t != 0.0f);
+    }
+    if (state && __any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;
+}
+
 // k_adam with the gradient scale, the skip decision and the step count taken from the scaler state (see cnerf_adam_step_scaled)
 __global__ void __launch_bounds__(256) k_adam_scaled(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                                                      __half *__restrict__ ph, uint64_t n, float lr, float beta1, float beta2, float eps,
@@ -263,6 +300,27 @@ int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half,
     const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
     hipLaunchKernelGGL(k_adam_scaled, dim3(blocks), dim3(256), 0, CN_STREAM(stream), p, g, m, v, (__half *)p_half, n, lr, beta1, beta2, eps, state,
                        extra_inv, zero_grad);
+    return cn_launch_status();
+}
+
+int cnerf_dp_pack(float *grad, void *payload_half, uint64_t n, float scale, void *stream) {
+    if (!grad || !payload_half) return CNERF_ENULL;
+    if (n == 0) return CNERF_OK;
+    if ((((uintptr_t)grad) & 15) || (((uintptr_t)payload_half) & 7)) return CNERF_EINVAL;
+    const uint64_t want = cn_div_up64(cn_div_up64(n, 4), 256);
+    const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(k_dp_pack, dim3(blocks), dim3(256), 0, CN_STREAM(stream), grad, (__half *)payload_half, n, scale);
+    return cn_launch_status();
+}
+
+int cnerf_dp_reduce(const void *recv_half, uint32_t world, uint64_t shard, float *out, float *scaler_state, void *stream) {
+    if (!recv_half || !out) return CNERF_ENULL;
+    if (world == 0 || (shard & 63)) return CNERF_EINVAL;
+    if (shard == 0) return CNERF_OK;
+    if ((((uintptr_t)recv_half) | ((uintptr_t)out)) & 15) return CNERF_EINVAL;
+    const uint64_t want = cn_div_up64(shard / 8, 256);
+    const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(k_dp_reduce, dim3(blocks), dim3(256), 0, CN_STREAM(stream), (const __half *)recv_half, world, shard, out, scaler_state);
     return cn_launch_status();
 }
 

@@ -105,13 +105,22 @@ class ShardedExchange:
         works = []
         for st in self.state:
             src = self.flat[st['off']:st['off'] + st['n']]
-            torch.mul(src, inv_world, out=st['send'][:st['n']])          # float32 -> float16 payload, pre-scaled so that the sum stays in range
-            src.zero_()                                                  # the scatter of the next step accumulates into it
+            if src.is_cuda:                                              # one pass: float32 -> pre-scaled float16 payload, source zeroed
+                from ._lib import lib, check, ptr, stream
+                check(lib.cnerf_dp_pack(ptr(src), ptr(st['send']), st['n'], inv_world, stream()), "dp_pack")
+            else:
+                torch.mul(src, inv_world, out=st['send'][:st['n']])      # pre-scaled so that the sum stays in range
+                src.zero_()                                              # the scatter of the next step accumulates into it
             works.append(dist.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=True))
         self.start_small()
         for st, w in zip(self.state, works):
             w.wait()
-            torch.sum(st['recv'], dim=0, dtype=torch.float32, out=st['g32'])          # float32 accumulation on arrival
+            if st['recv'].is_cuda:                                       # float32 accumulation on arrival (+ the scaler's found-inf test of the shard)
+                from ._lib import lib, check, ptr, stream
+                check(lib.cnerf_dp_reduce(ptr(st['recv']), self.world, st['shard'], ptr(st['g32']),
+                                          ptr(self.scaler.state) if self.scaler is not None else None, stream()), "dp_reduce")
+            else:
+                torch.sum(st['recv'], dim=0, dtype=torch.float32, out=st['g32'])
         self._small_work.wait() if self._small_work is not None else None
         self._small_work = None
 
@@ -120,7 +129,8 @@ class ShardedExchange:
         if self.scaler is None:
             return
         for st in self.state:
-            self.scaler.check(st['g32'])
+            if not st['g32'].is_cuda:                                    # on the device cnerf_dp_reduce already tested the shard
+                self.scaler.check(st['g32'])
         if self.small_seg is not None:
             self.scaler.check(self.small_seg)
         dist.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=self.group)

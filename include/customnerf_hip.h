@@ -368,6 +368,17 @@ int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half,
                            float eps, const float *state, float extra_inv, int zero_grad, void *stream);
 int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (customnerf_amd/dp.py; the reference has no working multi-GPU path: its DDP scaffolding
+ * is dead code, nerf/utils_init_nerf.py:76-78, 709-726 — SURVEY.md §8e).  The collectives themselves are RCCL's; these are
+ * the two passes either side of the all-to-all.
+ * cnerf_dp_pack   : payload[i] = half(grad[i] * scale), grad[i] = 0   (grad 16-byte aligned, payload 8-byte aligned)
+ * cnerf_dp_reduce : out[i] = sum_r float(recv[r * shard + i]), r < world, accumulated in float32; shard % 64 == 0;
+ *                   scaler_state (nullable): found_inf |= any non-finite sum — cnerf_scaler_check folded in.
+ * ---------------------------------------------------------------------------------------------- */
+int cnerf_dp_pack(float *grad, void *payload_half, uint64_t n, float scale, void *stream);
+int cnerf_dp_reduce(const void *recv_half, uint32_t world, uint64_t shard, float *out, float *scaler_state, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

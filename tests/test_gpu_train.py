@@ -287,3 +287,115 @@ def test_half_batches_sum_to_the_full_batch():
                 np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-5 * scale, err_msg=n)
     finally:
         tcnn.set_default_dtype(torch.float32)
+
+
+def test_sharded_exchange_on_the_gpu_single_rank():
+    """customnerf_amd.dp.ShardedExchange on the real device path (RCCL process group of ONE rank: the collectives are self-copies, everything else is the
+    code an 8-GPU run executes): float16 payload, float32 sum on arrival, `cnerf_adam_step_scaled` on the padded owner shard, in-place all-gather of the
+    float16 shadow, found-inf check + MAX all-reduce, the MLP all-reduce started from the pre-scatter hook.
+    Step 1 is checked exactly: the table after the step == Adam (spelled out in torch) on float(half(gradient)) — the payload's float16 rounding is the
+    only arithmetic difference from the plain trainer (with eps = 1e-15 Adam turns a flushed-to-zero gradient into a full-size step difference, which is
+    why the two trainers are not compared entry by entry).  Then the loss of a few steps is compared with the plain fused-Adam trainer."""
+    import os
+    import torch.distributed as dist
+    from customnerf_amd import scene as sc, tcnn, dp as dpm
+    from customnerf_amd.gridencoder import grid as ge
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer, setup_sharded_dp
+    tcnn.set_default_dtype(torch.float16)
+    created = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            created = True
+        H = W = 128
+        o, d, rgb, mask = _target_scene(H, W, 2)
+        losses = {}
+        for mode in ("plain", "sharded"):
+            torch.manual_seed(0)
+            opt = sc.make_opt(fp16=True)
+            model = NeRFNetwork(opt).cuda()
+            tr = ReconTrainer(model, opt, fp16=True)
+            table = model.pos_en.embeddings
+            fired, seen = [], {}
+            if mode == "sharded":
+                tr._dp = setup_sharded_dp(tr, model, True, rank=0)
+                st = tr._dp.state[0]
+                assert len(tr._dp.state) == 1 and st['shard'] % 64 == 0 and st['p'] is table
+                assert model.pos_en.half_table().data_ptr() == tr._dp.shadow_table(table).data_ptr()
+                start, exchange = tr._dp.start_small, tr._dp.exchange
+
+                def start_small():
+                    fired.append(1)
+                    start()
+
+                def exchange_and_keep():
+                    if 'g' not in seen:
+                        seen['g'] = tr._flat[st['off']:st['off'] + st['n']].clone()
+                        seen['p0'] = st['master'][:st['n']].clone()
+                        seen['scale'] = float(tr.scaler.state[0])
+                    exchange()
+                tr._dp.start_small, tr._dp.exchange = start_small, exchange_and_keep
+                ge.set_pre_scatter_hook(start_small)
+            ls = []
+            for i in range(4):
+                torch.manual_seed(100 + i)
+                out = tr.train_step(o[i % 2], d[i % 2], rgb[i % 2], mask[i % 2], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+                ls.append(float(out[0] if isinstance(out, (tuple, list)) else out))
+                if mode == "sharded" and i == 0:
+                    g16 = seen['g'].half().float()                         # the payload (world 1: pre-scale 1)
+                    assert float(seen['g'].abs().max()) > 0
+                    p, m, v = seen['p0'].clone(), torch.zeros_like(g16), torch.zeros_like(g16)
+                    lr = tr._dp.lr_of(table)                                # lr factor of step 0 is 1
+                    dpm._adam_host(p, g16, m, v, None, lr, (0.9, 0.99), 1e-15, 1, 1.0 / seen['scale'])
+                    got = st['master'][:st['n']]
+                    assert float((got - p).abs().max()) <= 2e-6 * lr + 1e-9, float((got - p).abs().max())
+                    assert float((got - seen['p0']).abs().max()) > 0.5 * lr          # it did step
+                    assert torch.equal(tr._dp.shadow_table(table).reshape(-1), got.half())      # shadow shard == half(master shard), gathered in place
+                    assert float(tr._flat[st['off']:st['off'] + st['n']].abs().max()) == 0        # the scatter target was re-zeroed
+            if mode == "sharded":
+                assert len(fired) >= 4                                    # the hook fired in every backward
+                tr._dp.consolidate()
+                assert torch.equal(tr._dp.shadow_table(table), table.detach().half())
+                assert tr.scaler.good_steps() == 4
+                assert all(bool(torch.isfinite(q).all()) for q in model.parameters())
+            losses[mode] = ls
+            ge.set_pre_scatter_hook(None)
+        assert abs(losses["plain"][0] - losses["sharded"][0]) <= 1e-6 * abs(losses["plain"][0])         # same start
+        for a, b in zip(losses["plain"], losses["sharded"]):
+            assert abs(a - b) <= 0.1 * abs(a), (losses)
+    finally:
+        ge.set_pre_scatter_hook(None)
+        if created:
+            dist.destroy_process_group()
+        tcnn.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("n,world", [(1000003, 8), (4096, 2), (65, 1)])
+def test_dp_pack_and_reduce_kernels(n, world):
+    """cnerf_dp_pack / cnerf_dp_reduce against the torch spelling dp.ShardedExchange uses on host tensors: half(g * 1/world) with the source zeroed;
+    float32 sum of the world float16 slices, found-inf raised for a non-finite sum only."""
+    from customnerf_amd._lib import lib, check, ptr, stream
+    g = torch.Generator(device="cuda"); g.manual_seed(n)
+    base = torch.randn(n + 4, device="cuda", generator=g) * 100.0
+    grad = base[4:]                                                       # 16-byte aligned view at an offset, ragged tail
+    want = (grad * (1.0 / world)).half()
+    payload = torch.full((n + 8,), 7.0, dtype=torch.float16, device="cuda")
+    check(lib.cnerf_dp_pack(ptr(grad), ptr(payload), n, 1.0 / world, stream()), "dp_pack")
+    assert torch.equal(payload[:n], want) and float(payload[n:].min()) == 7.0
+    assert float(grad.abs().max()) == 0 and float(base[:4].abs().min()) > 0
+    shard = (n // world + 63) // 64 * 64
+    recv = (torch.randn(world, shard, device="cuda", generator=g) * 50.0).half()
+    out = torch.empty(shard, device="cuda")
+    state = torch.tensor([65536.0, 0, 0, 0], device="cuda")
+    check(lib.cnerf_dp_reduce(ptr(recv), world, shard, ptr(out), ptr(state), stream()), "dp_reduce")
+    ref = torch.zeros(shard, device="cuda")
+    for r in range(world):
+        ref += recv[r].float()                                            # same order: sequential float32 adds
+    assert torch.equal(out, ref) and float(state[2]) == 0.0
+    recv[world - 1, shard - 1] = float("inf")
+    check(lib.cnerf_dp_reduce(ptr(recv), world, shard, ptr(out), ptr(state), stream()), "dp_reduce")
+    assert float(state[2]) == 1.0 and torch.isinf(out[-1])
+    assert lib.cnerf_dp_reduce(ptr(recv), world, shard + 8, ptr(out), None, stream()) < 0      # shard not a multiple of 64: rejected
