@@ -33,6 +33,10 @@ __device__ __forceinline__ GnGeom gn_geom(uint32_t C, uint32_t G) {
     return q;
 }
 
+// Measured and dropped (round 3): statistics + apply in ONE launch for the UNet's tensors — a workgroup per (image, lcm(8, C/G) channels) over all rows,
+// slab kept in registers, so the statistics never leave the workgroup.  With 16-64 workgroups the slab moves at one CU's pace: 55 us for 2 x 4096 x 320
+// against 2 x 8 us for the two launches; restricted to the tensors of at most 4 rows per thread (16 x 16 and 8 x 8 latents) the edit step gains 0.4 %.
+// (scratch/gn_bench.py times the shapes.)
 // MODE 0: forward statistics (sum x, sum x^2).  MODE 1: backward statistics (sum g, sum g xhat), g = dy * act'(z) * gamma.
 template <int MODE>
 __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,

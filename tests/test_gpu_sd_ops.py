@@ -107,7 +107,10 @@ def test_conv2d_vae_downsample_and_input_gradients():
 
 
 @pytest.mark.parametrize("B,HW,C,G,eps,silu", [(2, 256, 320, 32, 1e-5, True), (2, 64, 2560, 32, 1e-5, True), (1, 4096, 128, 32, 1e-6, True), (2, 100, 960, 32, 1e-6, False),
-                                               (1, 777, 512, 32, 1e-6, False)])
+                                               (1, 777, 512, 32, 1e-6, False),
+                                               # the UNet's shapes at 64 x 64 latents (and a ragged row count)
+                                               (2, 4096, 320, 32, 1e-5, True), (2, 1024, 1920, 32, 1e-5, True), (1, 256, 2560, 32, 1e-5, True),
+                                               (2, 4096, 960, 32, 1e-5, True), (1, 4096, 512, 32, 1e-6, False), (2, 4097, 640, 32, 1e-5, True)])
 def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
     from customnerf_amd.sd import ops
     g = torch.Generator().manual_seed(C + HW)
