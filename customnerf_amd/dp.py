@@ -162,6 +162,44 @@ class ShardedExchange:
                 p.data.reshape(-1).copy_(st['gather32'][:n])
             p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
 
+    # ---- checkpoints: the optimiser state of a sharded run in the UNSHARDED layout (a checkpoint then loads into any world size)
+    @torch.no_grad()
+    def export_optimizer_state(self, optimizer):
+        """gather the owners' Adam moments of the big parameters into `optimizer.state[p]` ({'step', 'exp_avg', 'exp_avg_sq'}: FusedAdam's /
+        torch.optim.Adam's entry for p) and refresh the float32 parameters: `optimizer.state_dict()` afterwards is what an unsharded run
+        would save (utils_init_nerf.py:793-794 stores the optimiser in 'full' checkpoints).  Collective: every rank calls it."""
+        self.consolidate()
+        for st in self.state:
+            p, n, dev = st['p'], st['n'], st['p'].device
+            full = torch.empty(self.world * st['shard'], dtype=torch.float32, device=dev)
+            entry = optimizer.state[p]
+            for key, src in (('exp_avg', st['m']), ('exp_avg_sq', st['v'])):
+                dist.all_gather_into_tensor(full, src, group=self.group)
+                entry[key] = full[:n].clone().view(p.shape)
+            entry['step'] = st['step']
+
+    @torch.no_grad()
+    def import_optimizer_state(self, optimizer, drop=True):
+        """the inverse, after `optimizer.load_state_dict(...)` and the model's `load_state_dict`: this rank's slice of the loaded moments,
+        the master shard and the shadow are taken from the full tensors; `drop` frees the full moments again."""
+        for st in self.state:
+            p, n, s = st['p'], st['n'], st['shard']
+            lo, hi = self.rank * s, min((self.rank + 1) * s, n)
+            entry = optimizer.state.get(p, {})
+            for key, dst in (('exp_avg', st['m']), ('exp_avg_sq', st['v'])):
+                dst.zero_()
+                if key in entry and hi > lo:
+                    dst[:hi - lo].copy_(entry[key].reshape(-1)[lo:hi])
+            st['step'] = int(entry.get('step', 0))
+            st['master'].zero_()
+            if hi > lo:
+                st['master'][:hi - lo].copy_(p.detach().reshape(-1)[lo:hi])
+            if 'shadow' in st:
+                st['shadow'][:n].copy_(p.detach().reshape(-1))
+            if drop and p in optimizer.state:
+                del optimizer.state[p]
+            p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
+
     @torch.no_grad()
     def consolidate(self):
         """refresh the full float32 parameters from the owners' master shards (before a checkpoint / an evaluation that reads float32)"""
