@@ -14,8 +14,9 @@ Per step, for the big parameter (the hash-grid table: 12.2 M floats here, 47.9 M
   5. publish   `all_gather_into_tensor` of the float16 SHADOW shards, in place in the shadow table — the forward pass reads the shadow,
                so 2 bytes per parameter come back instead of the 4 of an all-reduce.
 
-The small parameters (the three MLPs: 22.5 k floats) are all-reduced in float32 and updated on every rank; their all-reduce is issued
-from a hook that fires between the field backward and the grid scatter (`start_small`), so it overlaps the scatter kernels.
+The small parameters (the three MLPs: 22.5 k floats) are all-reduced in float32 and updated on every rank.  (`start_small` can be hooked between
+the field backward and the grid scatter — `gridencoder.grid.set_pre_scatter_hook` — so that this all-reduce runs under the scatter kernels; that
+needs `async_ops`, which is off: see __init__.)
 With a dynamic loss scaler every rank checks its reduced shard (+ the MLP gradients) and the found-inf flags are OR-ed with one 4-byte
 all-reduce(MAX), on the device: all ranks skip or step together, no host read.
 
@@ -81,10 +82,15 @@ class ShardedExchange:
                 st['gather32'] = torch.zeros(world_size * s, dtype=torch.float32, device=dev)
             self.state.append(st)
         self._small_work = None
+        # async_op=True collectives (handles waited on later) would let the MLP all-reduce run under the grid scatter, but with this torch / RCCL every
+        # step that issues one runs ~3.5 % slower END TO END (edit step 16.5 -> 17.2 ms on one rank, uniformly over all kernels, UNet graph replay
+        # included; the blocking form of the same collectives: 16.6 ms — scratch/edit_dp_world1.py).  Blocking collectives it is: "blocking" means
+        # the compute stream waits for the collective, never the host.
+        self.async_ops = False
 
     def describe(self):
         return (f"fp16 all-to-all of the table gradient (1/{self.world} pre-scaled, fp32 sum on arrival) + sharded Adam + all-gather of the "
-                f"{'fp16 shadow' if 'shadow' in self.state[0] else 'fp32 master'} shards; MLP gradients fp32 all-reduce overlapped with the grid scatter")
+                f"{'fp16 shadow' if 'shadow' in self.state[0] else 'fp32 master'} shards; MLP gradients fp32 all-reduce{' under the grid scatter' if self.async_ops else ''}")
 
     def shadow_table(self, p):
         """the full float16 shadow of big parameter p (what the forward gather reads), kept current by step()"""
@@ -96,7 +102,9 @@ class ShardedExchange:
     # ---- called from the backward pass, between the field backward and the grid scatter
     def start_small(self):
         if self.small_seg is not None and self._small_work is None:
-            self._small_work = dist.all_reduce(self.small_seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._small_work = dist.all_reduce(self.small_seg, op=dist.ReduceOp.SUM, group=self.group, async_op=self.async_ops)
+            if self._small_work is None:
+                self._small_work = True
 
     # ---- after the backward pass
     def exchange(self):
@@ -111,17 +119,19 @@ class ShardedExchange:
             else:
                 torch.mul(src, inv_world, out=st['send'][:st['n']])      # pre-scaled so that the sum stays in range
                 src.zero_()                                              # the scatter of the next step accumulates into it
-            works.append(dist.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=True))
+            works.append(dist.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=self.async_ops))
         self.start_small()
         for st, w in zip(self.state, works):
-            w.wait()
+            if w is not None:
+                w.wait()
             if st['recv'].is_cuda:                                       # float32 accumulation on arrival (+ the scaler's found-inf test of the shard)
                 from ._lib import lib, check, ptr, stream
                 check(lib.cnerf_dp_reduce(ptr(st['recv']), self.world, st['shard'], ptr(st['g32']),
                                           ptr(self.scaler.state) if self.scaler is not None else None, stream()), "dp_reduce")
             else:
                 torch.sum(st['recv'], dim=0, dtype=torch.float32, out=st['g32'])
-        self._small_work.wait() if self._small_work is not None else None
+        if self._small_work is not None and self._small_work is not True:
+            self._small_work.wait()
         self._small_work = None
 
     def check(self):

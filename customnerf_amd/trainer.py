@@ -91,7 +91,7 @@ def check_grads_finite(scaler, parameters, flat):
 
 def setup_sharded_dp(trainer, model, fp16, rank=None, group=None):
     """dp_mode 'sharded' (customnerf_amd.dp.ShardedExchange): the big parameters (the grid table) leave the trainer's FusedAdam — their owner
-    shards are updated by the exchange — and the MLP all-reduce is hooked in front of the grid scatter."""
+    shards are updated by the exchange (and, only with `dp.async_ops`, the MLP all-reduce is hooked in front of the grid scatter)."""
     from .dp import ShardedExchange, BIG_PARAM_MIN
     opt_ = trainer.optimizer
     lr_by_id = {id(p): i for i, g in enumerate(opt_.param_groups) for p in g['params']}
@@ -107,7 +107,7 @@ def setup_sharded_dp(trainer, model, fp16, rank=None, group=None):
         if sh is not None:
             opt_.half_shadows[enc.embeddings] = sh                 # refresh_half_shadow hands it to the encoder after every step
             enc.set_half_table(sh)
-    if enc is not None and hasattr(enc, 'attach_backward'):
+    if dp.async_ops and enc is not None and hasattr(enc, 'attach_backward'):
         from .gridencoder import grid as ge
         ge.set_pre_scatter_hook(dp.start_small)                    # MLP gradients go out while the grid scatter still runs
     return dp
@@ -142,7 +142,7 @@ def apply_optimizer_step(trainer):
 class ReconTrainer:
     def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic', dp_mode='allreduce'):
         """dp_mode (world_size > 1): 'allreduce' = one in-place fp32 all-reduce of the flat gradient buffer; 'sharded' = customnerf_amd.dp.ShardedExchange
-        (fp16 all-to-all payload summed in fp32 on arrival, sharded Adam, all-gather of the fp16 shadow; MLP groups all-reduced while the grid scatter runs).
+        (fp16 all-to-all payload summed in fp32 on arrival, sharded Adam, all-gather of the fp16 shadow; MLP groups all-reduced in fp32).
         loss_scale: 'dynamic' = the reference's GradScaler policy (utils_init_nerf.py `self.scaler = GradScaler(enabled=self.fp16)`:
         init 65536, x2 / 2000 clean steps, x0.5 + skipped step on inf) kept on the device (optim.DynamicLossScaler, fused Adam only);
         a float = static scale."""

@@ -110,6 +110,7 @@ for half_shadow in (True, False):
     rp = ref_opt.param_groups[0]['params']
     lrs = {id(big): 5e-3, id(s1): 5e-4, id(s2): 5e-4}
     dp = ShardedExchange(params, flat, lambda p: lrs[id(p)], world, rank, half_shadow=half_shadow)
+    dp.async_ops = not half_shadow                                  # both forms of the collectives (blocking is the default)
     small_opt = torch.optim.Adam([s1, s2], lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
     assert len(dp.state) == 1 and dp.small_seg.numel() >= 100 + 21
     for step in range(3):
