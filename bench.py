@@ -122,6 +122,14 @@ def cpu_baseline_edit(steps=1):
                       f"rate divided by 4; torch CPU float32 on {threads} threads of {ncpu} host cores (all cores: 70x slower); NeRF render excluded"}
 
 
+def _dp_selftest(args, trainer, model, fp16):
+    """--dp-selftest (one GPU): run the step with the multi-GPU gradient exchange switched on over a ONE-rank RCCL group — the collectives are
+    self-copies, every kernel and stream hop of the N > 1 path is real.  What an 8-GPU run adds to this is link time only."""
+    if getattr(args, "dp_selftest", False) and trainer.world_size == 1 and args.dp == "sharded":
+        from customnerf_amd.trainer import setup_sharded_dp
+        trainer._dp = setup_sharded_dp(trainer, model, fp16, rank=0)
+
+
 def _timed(step, args, world, dist):
     """EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, last step's return value)"""
     if world > 1:
@@ -172,6 +180,7 @@ def run_edit(args, world, rank, dev):
     rgb, mask = sc.targets(V, H, W)
     rgb, mask = rgb.to(dev), mask.to(dev)
     trainer = EditTrainer(model, pretrained, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, world_size=world, dp_mode=args.dp)
+    _dp_selftest(args, trainer, model, True)
 
     def view(j):
         v = j % V
@@ -267,6 +276,7 @@ def run_recon(args, world, rank, dev):
         model.density_grid.copy_(grid)
         model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
     trainer = ReconTrainer(model, opt, fp16=fp16, world_size=world, dp_mode=args.dp)
+    _dp_selftest(args, trainer, model, fp16)
     render_kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=0, max_steps=opt.max_steps)
     strong = args.scaling == "strong"
     if strong:                                           # contiguous ray chunk per rank, resident before the timed region
@@ -351,9 +361,16 @@ def main():
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded",
                     help="N>1 gradient exchange: sharded = fp16 reduce-scatter + sharded Adam + all-gather of the fp16 shadow; allreduce = one fp32 all-reduce")
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
+    ap.add_argument("--dp-selftest", action="store_true", help="one GPU: force the sharded gradient exchange on over a one-rank RCCL group (no link time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON record.  Native libraries write there too (RCCL prints a version banner at communicator creation and
+    # flushes it at exit): keep a private duplicate of the real stdout for the record and point fd 1 at stderr for everybody else.
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -363,8 +380,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     result = None
@@ -396,9 +414,11 @@ def main():
         elif rank == 0:
             result["secondary"] = edit
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(record_fd, (json.dumps(result) + "\n").encode())
+    os.close(record_fd)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
