@@ -552,12 +552,11 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
     uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(b2s_lds + (size_t)B2S_CAP * 9);
     uint32_t *gdelta = cursor + B2S_MAX_CHUNKS;                                     // staging slot -> slab position (wrapping uint32 arithmetic)
-    uint32_t *s_off = gdelta + B2S_MAX_CHUNKS, *s_cnt = s_off + B2S_MAX_CHUNKS;      // staging offset and record count of each bin
-    uint32_t *s_total = s_cnt + B2S_MAX_CHUNKS;
+    uint32_t *s_total = gdelta + B2S_MAX_CHUNKS;
     const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t level = lv.order[slot];
     const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
-    const bool spread = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
+    const bool dense_lvl = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
     if (threadIdx.x < 64) {
         // counts of this block per bin (difference of the scanned histogram), two bins per lane -> staging offsets
         const uint32_t lane = threadIdx.x;
@@ -579,8 +578,6 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
         const uint32_t ib = cn_wave_incl_scan(cnt[1]);
         const uint32_t oa = ia - cnt[0], ob = tot_a + ib - cnt[1];
         cursor[lane] = oa; cursor[lane + 64] = ob;
-        s_off[lane] = oa; s_off[lane + 64] = ob;
-        s_cnt[lane] = cnt[0]; s_cnt[lane + 64] = cnt[1];
         gdelta[lane] = gpos[0] - oa; gdelta[lane + 64] = gpos[1] - ob;
         if (lane == 63) *s_total = tot_a + ib;
     }
@@ -609,15 +606,10 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
         const uint32_t fxq = min((uint32_t)(fx[i] * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t word, uint32_t val) {
-            uint32_t sl = spread ? b2_ticket(cursor, c) : atomicAdd(&cursor[c], 1u);   // (hashed levels: no wave-uniform chunks to aggregate)
-            if (spread) {
-                // dense level: neighbouring tickets are neighbouring samples of one ray, i.e. the same table entries.  Scatter them over the
-                // bin's run (odd multiplier on the largest power-of-two prefix) so that an accumulate wave holds 64 unrelated records
-                // instead of ~7-way same-address LDS atomics.
-                const uint32_t o = s_off[c], n = s_cnt[c], rk = sl - o;
-                const uint32_t k = 31u - (uint32_t)__clz((int)(n | 1u));
-                if (rk < (1u << k)) sl = o + ((rk * ((0x9E3779B1u >> (32u - k)) | 1u)) & ((1u << k) - 1u));
-            }
+            // dense levels: a wave's samples share the chunk — one aggregated ticket; hashed levels: no wave-uniform chunks to aggregate.
+            // (Round 2 also scattered a dense bin's tickets over its run so that an accumulate wave would not hold runs of same-entry records;
+            // measured again in round 3 with the lane-chunked record order of the accumulate in place: 2.157 ms per step either way — removed.)
+            const uint32_t sl = dense_lvl ? b2_ticket(cursor, c) : atomicAdd(&cursor[c], 1u);
             if (sl < B2S_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
             else slab[gdelta[c] + sl] = make_uint2(word, val);
         };
@@ -921,11 +913,11 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     static int staged = -1;
     if (staged < 0) {
         staged = b2_env("CNERF_B2_STAGED", 1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + B2S_MAX_CHUNKS * 16 + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + B2S_MAX_CHUNKS * 8 + 16);
     }
     const uint32_t max_chunks = b2_max_chunks(plan, nl);
     if (staged && b2_pts() == B2S_PTS && max_chunks <= B2S_MAX_CHUNKS)          // larger tables (T = 2^20, 2^21): direct emit below
-        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 16 + 16, st, grad, inputs, lv, plan, ws.hist,
+        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 8 + 16, st, grad, inputs, lv, plan, ws.hist,
                            ws.bin_base, ws.slab, B, gridtype, ac, interp, gemb);
     else switch (b2_pts()) {
 #define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u, gemb); break;
