@@ -348,6 +348,63 @@ def main():
             orient[f"{method}_{int(center)}__poses"] = out.numpy()
             orient[f"{method}_{int(center)}__transform"] = tr.numpy()
     np.savez(os.path.join(args.out, "orient.npz"), **orient)
+
+    # ---- occupancy-grid refresh: the reference's own update_extra_state loop (renderer.py:1658-1715) on a 16^3 grid (grid_size is an attribute;
+    # the 128 of the constructor would need 50 MB of recorded jitter).  The two native calls of the loop are bit manipulation only and are
+    # stubbed in numpy: morton3D = 10-bit interleave (raymarching.cu:56-69), packbits = bit i of byte n is grid[8 n + i] > thresh (:267-289).
+    def _expand(v):
+        v = v.astype(np.uint32)
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+
+    def _morton3D(coords):
+        c = coords.numpy().astype(np.uint32)
+        return torch.from_numpy((_expand(c[:, 0]) | (_expand(c[:, 1]) << np.uint32(1)) | (_expand(c[:, 2]) << np.uint32(2))).astype(np.int32))
+
+    def _packbits(grid, thresh, bitfield=None):
+        bits = (grid.reshape(-1, 8).numpy() > np.float32(thresh)).astype(np.uint8)
+        return torch.from_numpy((bits << np.arange(8, dtype=np.uint8)).sum(-1).astype(np.uint8))
+
+    ref_renderer.raymarching.morton3D = _morton3D
+    ref_renderer.raymarching.packbits = _packbits
+    Hg = 16
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ = ToyRenderer(make_opt(cuda_ray=True, density_thresh=10))
+    occ.grid_size = Hg
+    g = torch.Generator().manual_seed(21)
+    grid0 = torch.rand(occ.cascade, Hg ** 3, generator=g) * 20.0
+    grid0[torch.rand(occ.cascade, Hg ** 3, generator=g) < 0.1] = -1.0           # invalid cells stay untouched (:1707)
+    grid0[torch.rand(occ.cascade, Hg ** 3, generator=g) < 0.3] = 0.0
+    occ.density_grid = grid0.clone()
+    occ.density_bitfield = torch.zeros(occ.cascade * Hg ** 3 // 8, dtype=torch.uint8)
+    occ_out = {"grid0": grid0.numpy(), "grid_size": np.int64(Hg), "cascade": np.int64(occ.cascade), "bound": np.float32(occ.bound), "decay": np.float32(0.95),
+               "density_thresh": np.float32(occ.density_thresh)}
+    rand_like = torch.rand_like
+    for rnd in range(2):                                                          # two refreshes: the second one sees the first one's grid
+        draws = []
+
+        def rec_rand_like(t, *a, **k):
+            r = rand_like(t, *a, **k)
+            draws.append(r.clone())
+            return r
+        torch.manual_seed(30 + rnd)
+        occ.local_step = 3 + rnd
+        occ.step_counter[:4, 0] = torch.tensor([100, 200, 301, 77], dtype=torch.int32)
+        torch.rand_like = rec_rand_like
+        try:
+            occ.update_extra_state(decay=0.95, S=Hg)
+        finally:
+            torch.rand_like = rand_like
+        assert len(draws) == occ.cascade
+        occ_out[f"r{rnd}__rand"] = torch.stack(draws).numpy()
+        occ_out[f"r{rnd}__grid"] = occ.density_grid.numpy().copy()
+        occ_out[f"r{rnd}__mean_density"] = np.float64(occ.mean_density)
+        occ_out[f"r{rnd}__bitfield"] = occ.density_bitfield.numpy().copy()
+        occ_out[f"r{rnd}__mean_count"] = np.int64(occ.mean_count)
+    np.savez_compressed(os.path.join(args.out, "occupancy.npz"), **occ_out)
     print("golden vectors written to", args.out)
 
 

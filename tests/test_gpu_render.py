@@ -377,6 +377,31 @@ def test_update_extra_state_kernels_vs_oracle():
     assert model.iter_density == 2
 
 
+def test_update_extra_state_matches_reference_golden(golden):
+    """NeRFRenderer.update_extra_state (occupancy kernels) replaying the jitter draws of the reference's own loop (renderer.py:1658-1715 run on a
+    16^3 grid with the toy density, tests/golden/occupancy.npz): density grid, mean density, bitfield and the sample-count ring, two refreshes."""
+    g = golden("occupancy")
+    H, cas = int(g["grid_size"]), int(g["cascade"])
+    model = _toy_renderer(cuda_ray=True, bound=float(g["bound"]), density_thresh=float(g["density_thresh"]))
+    assert model.cascade == cas
+    model.grid_size = H
+    model.density_grid = T(g["grid0"]).cuda().contiguous()
+    model.density_bitfield = torch.zeros(cas * H ** 3 // 8, dtype=torch.uint8, device="cuda")
+    for rnd in range(2):
+        model.local_step = 3 + rnd
+        model.step_counter[:4, 0] = torch.tensor([100, 200, 301, 77], dtype=torch.int32, device="cuda")
+        model.update_extra_state(decay=float(g["decay"]), S=H, _rand=[T(r) for r in g[f"r{rnd}__rand"]])
+        want = g[f"r{rnd}__grid"]
+        dg = model.density_grid.cpu().numpy()
+        assert np.array_equal(dg < 0, want < 0) and np.array_equal(dg[want < 0], want[want < 0])
+        np.testing.assert_allclose(dg, want, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(float(model.mean_density), float(g[f"r{rnd}__mean_density"]), rtol=1e-6)
+        thr = min(float(g[f"r{rnd}__mean_density"]), float(g["density_thresh"]))
+        diff = np.unpackbits(model.density_bitfield.cpu().numpy() ^ g[f"r{rnd}__bitfield"], bitorder="little").astype(bool)
+        assert not diff[np.abs(want.reshape(-1) - thr) > 1e-4].any() and diff.sum() <= 2
+        assert model.mean_count == int(g[f"r{rnd}__mean_count"]) and model.local_step == 0
+
+
 def _rand_composite_inputs(N=200, S=128, seed=0):
     g = torch.Generator().manual_seed(seed)
     sig = (torch.rand(N, S, generator=g) * 6) ** 2

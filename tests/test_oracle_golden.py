@@ -160,3 +160,29 @@ def test_near_far_c_oracle_matches_reference_path(golden):
     assert np.all(nears[hit] <= fars[hit]) and np.all(nears[hit] > 2.0)
     # the golden run() itself must be a non-degenerate scene: most rays hit the [-2,2]^3 box
     assert g["train_T8__mask"].mean() > 0.9 and g["train_T8__weights_sum"].max() > 0.5
+
+
+def _occupancy_rounds(g):
+    grid = g("occupancy")
+    H, cas = int(grid["grid_size"]), int(grid["cascade"])
+    return grid, H, cas
+
+
+def test_update_extra_state_against_reference(golden):
+    """The oracle's occupancy refresh against the reference's own update_extra_state loop (renderer.py:1658-1715, run on a 16^3 grid with the
+    toy density; tests/golden/make_golden.py records the jitter draws): two refreshes, the second on the first one's grid.  The one stated
+    difference — `2 * coords / (H - 1)` as a multiplication by the float reciprocal (what the GPU the reference runs on computes) against the
+    true division of the CPU run that made the vectors — moves a query position by at most one ulp."""
+    g, H, cas = _occupancy_rounds(golden)
+    grid = g["grid0"]
+    for rnd in range(2):
+        rand = [T(r) for r in g[f"r{rnd}__rand"]]
+        grid, mean, bits = to.update_extra_state(ToyField(), grid, float(g["bound"]), cas, H, float(g["decay"]), float(g["density_thresh"]), rand)
+        want = g[f"r{rnd}__grid"]
+        assert np.array_equal(grid < 0, want < 0) and np.array_equal(grid[want < 0], want[want < 0])       # invalid cells untouched
+        np.testing.assert_allclose(grid, want, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(mean, float(g[f"r{rnd}__mean_density"]), rtol=1e-6)
+        thr = min(float(g[f"r{rnd}__mean_density"]), float(g["density_thresh"]))
+        diff = np.unpackbits(bits ^ g[f"r{rnd}__bitfield"], bitorder="little").astype(bool)
+        assert not diff[np.abs(want.reshape(-1) - thr) > 1e-4].any()                 # bits may differ only for cells at the threshold
+        assert diff.sum() <= 2
