@@ -136,11 +136,13 @@ def encode_imgs(sd, cfg, imgs, sample_noise):
 
 
 # ------------------------------------------------------------------------------------------------ train_step (sd.py:115-155)
-def sds_grad(unet_sd, unet_cfg, latents, text_embeddings, t, noise, alphas, guidance_scale, lambda_sd):
-    """latents [1,4,h,w], text_embeddings [2,77,D] (uncond, text), integer t, noise ~ N(0,1) like latents."""
+def sds_grad(unet_sd, unet_cfg, latents, text_embeddings, t, noise, alphas, guidance_scale, lambda_sd, eps_fn=None):
+    """latents [1,4,h,w], text_embeddings [2,77,D] (uncond, text), integer t, noise ~ N(0,1) like latents.
+    eps_fn(x [2,4,h,w], t [2], ctx) replaces the UNet (tests/golden/sds.npz: the reference's own train_step was run with a closed-form one)."""
     ab = alphas[t]
     noisy = ab.sqrt() * latents + (1 - ab).sqrt() * noise                                  # scheduler.add_noise
-    eps = unet_forward(unet_sd, unet_cfg, torch.cat([noisy] * 2), torch.full((2,), float(t)), text_embeddings)
+    x2, t2 = torch.cat([noisy] * 2), torch.full((2,), float(t))
+    eps = eps_fn(x2, t2, text_embeddings) if eps_fn is not None else unet_forward(unet_sd, unet_cfg, x2, t2, text_embeddings)
     e_uncond, e_text = eps.chunk(2)
     e = e_text + guidance_scale * (e_text - e_uncond)                                      # sd.py:141 (the reference's form)
     return torch.nan_to_num((1 - ab) * (e - noise) * lambda_sd)

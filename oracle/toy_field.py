@@ -30,3 +30,12 @@ class ToyField:
 
     def __call__(self, x, d):
         return toy_sigma(x), toy_rgbc(x, d), None
+
+
+def toy_eps(x, t, ctx):
+    """A closed-form stand-in for the UNet's epsilon prediction (ours, like the rest of this file): x [B, 4, h, w], t a scalar or [B] tensor of
+    timesteps, ctx [B, 77, D] text embeddings -> [B, 4, h, w].  Depends on all three inputs, differs between the two halves of a CFG batch."""
+    t = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 1, 1, 1).to(x.device) * 1e-3
+    c = ctx.float()[:, :, :4].mean(1).reshape(-1, 4, 1, 1).to(x.device)
+    ch = torch.arange(4, dtype=torch.float32, device=x.device).reshape(1, 4, 1, 1)
+    return torch.tanh(0.7 * x.float() + 0.3 * t - 0.2 * ch) + 0.25 * c * torch.cos(x.float() * (1.0 + 0.5 * ch)) + 0.05 * x.float().roll(1, dims=-1)

@@ -405,6 +405,88 @@ def main():
         occ_out[f"r{rnd}__bitfield"] = occ.density_bitfield.numpy().copy()
         occ_out[f"r{rnd}__mean_count"] = np.int64(occ.mean_count)
     np.savez_compressed(os.path.join(args.out, "occupancy.npz"), **occ_out)
+
+    # ---- SDS guidance: the reference's own StableDiffusion.train_step (nerf/sd.py:115-155).  The class is built without its __init__ (which
+    # downloads the pipeline); third-party pieces are stand-ins with the PUBLISHED definitions: the scheduler's scaled-linear betas and
+    # add_noise(x, n, t) = sqrt(abar_t) x + sqrt(1 - abar_t) n; the UNet is the closed-form toy_eps of oracle/toy_field.py.
+    for name in ("transformers", "diffusers", "torchvision"):
+        _stub(name)
+    sys.modules["transformers"].logging = types.SimpleNamespace(set_verbosity_error=lambda: None)
+    sys.modules["diffusers"].DiffusionPipeline = object
+    sys.modules["torchvision"].transforms = types.SimpleNamespace()
+    from nerf import sd as ref_sd
+    from oracle.toy_field import toy_eps
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    abar = torch.cumprod(1.0 - betas, dim=0)
+
+    class _Sched:
+        alphas_cumprod = abar
+
+        def add_noise(self, x, n, t):
+            a = abar[t].reshape(-1, 1, 1, 1)
+            return a.sqrt() * x + (1 - a).sqrt() * n
+
+    poison = {}
+
+    class _UNet:
+        def __call__(self, x, t, encoder_hidden_states=None, class_labels=None):
+            e = toy_eps(x, t.float(), encoder_hidden_states)
+            if poison:
+                e = e.clone()
+                e[1, 0, 0, 0], e[1, 1, 2, 3], e[0, 2, 1, 1] = float("nan"), float("inf"), float("-inf")
+            return types.SimpleNamespace(sample=e)
+
+    sds_out = {"alphas_cumprod": abar.numpy()}
+    g = torch.Generator().manual_seed(44)
+    text = torch.randn(2, 77, 16, generator=g)
+    sds_out["text"] = text.numpy()
+    cases = {"plain": dict(t_ratio=1), "local": dict(t_ratio=0.4), "stage_late": dict(t_ratio=1, stage_time=True, step=900),
+             "stage_early": dict(t_ratio=1, stage_time=True, step=100), "nonfinite": dict(t_ratio=1, poison=True)}
+    for tag, c in cases.items():
+        guide = ref_sd.StableDiffusion.__new__(ref_sd.StableDiffusion)
+        torch.nn.Module.__init__(guide)
+        guide.device = "cpu"
+        guide.opt = argparse.Namespace(cfg=100.0, stage_time=bool(c.get("stage_time")), iters=1000, lambda_sd=0.01, max_ratio=0.98)
+        guide.scheduler, guide.unet = _Sched(), _UNet()
+        guide.num_train_timesteps = 1000
+        guide.min_step, guide.max_step = int(1000 * 0.02), int(1000 * 0.98)                 # sd.py:69-70
+        guide.alphas = abar
+        poison.clear()
+        if c.get("poison"):
+            poison["on"] = True
+        lat = (torch.randn(1, 4, 8, 8, generator=g) * 0.8).requires_grad_(True)
+        torch.manual_seed(70 + len(sds_out))
+        drawn = []
+        randint, randn_like = torch.randint, torch.randn_like
+
+        def rec_randint(*a, **k):
+            k.pop("device", None)
+            r = randint(*a, **k)
+            drawn.append(("randint", a[0], a[1], r.clone()))
+            return r
+
+        def rec_randn_like(t_, *a, **k):
+            r = randn_like(t_, *a, **k)
+            drawn.append(("randn_like", r.clone()))
+            return r
+        torch.randint, torch.randn_like = rec_randint, rec_randn_like
+        try:
+            loss, ld = guide.train_step(lat, text, system=types.SimpleNamespace(global_step=c.get("step", 0)), t_ratio=c["t_ratio"])
+        finally:
+            torch.randint, torch.randn_like = randint, randn_like
+        loss.backward()
+        assert [d[0] for d in drawn] == ["randint", "randn_like"]
+        sds_out[f"{tag}__latents"] = lat.detach().numpy()
+        sds_out[f"{tag}__t_ratio"] = np.float64(c["t_ratio"])
+        sds_out[f"{tag}__stage_time"] = np.int64(bool(c.get("stage_time")))
+        sds_out[f"{tag}__global_step"] = np.int64(c.get("step", 0))
+        sds_out[f"{tag}__randint_lo_hi"] = np.array([drawn[0][1], drawn[0][2]], np.int64)   # the range the reference drew from (hi exclusive)
+        sds_out[f"{tag}__t_draw"] = drawn[0][3].numpy()
+        sds_out[f"{tag}__noise"] = drawn[1][1].numpy()
+        sds_out[f"{tag}__loss"] = np.float64(loss.item())
+        sds_out[f"{tag}__loss_sds"] = np.float64(ld["loss_sds"])
+        sds_out[f"{tag}__grad_latents"] = lat.grad.numpy()
+    np.savez_compressed(os.path.join(args.out, "sds.npz"), **sds_out)
     print("golden vectors written to", args.out)
 
 

@@ -193,3 +193,55 @@ def test_multi_view_step_is_the_mean_of_single_view_steps():
     tr.replay = None
     loss, ld = tr.train_step_multi(views)
     assert np.isfinite(float(loss)) and set(ld) == {"loss_sds", "loss_bg"} and tr.global_step == 1
+
+
+def test_sds_train_step_matches_reference_golden(golden):
+    """StableDiffusion.train_step of this package (draw_timestep, cnerf_sd_add_noise, the CFG / weighting / nan_to_num kernel cnerf_sd_sds_grad, the
+    loss) against the reference's own train_step (nerf/sd.py:115-155; tests/golden/sds.npz), with the UNet replaced on both sides by the closed-form
+    toy_eps.  The product pipeline carries the UNet's input and output in float16, and cfg = 100 multiplies that rounding by 100."""
+    import types
+    from customnerf_amd import scene as sc
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd.guidance import StableDiffusion
+    from oracle.toy_field import toy_eps
+    g = golden("sds")
+    opt = sc.make_opt(fp16=True, cfg=100.0, lambda_sd=0.01, log_loss_item=False)
+    usd = arch.random_state_dict(arch.unet_params(arch.UNET_TINY), 1)
+    vsd = arch.random_state_dict(arch.vae_encoder_params(arch.VAE_TINY), 2)
+    guide = StableDiffusion("cuda", "1.5", opt, unet_state=usd, vae_state=vsd, unet_cfg=arch.UNET_TINY, vae_cfg=arch.VAE_TINY)
+    text = torch.from_numpy(g["text"]).cuda()
+    state = {}
+
+    def eps_pred(unet_in, t, text_embeddings):                           # [2, h, w, 8] half in, [2, h, w, 4] half out, like the UNet
+        x = unet_in[..., :4].permute(0, 3, 1, 2).float()
+        e = toy_eps(x, torch.full((2,), float(t)), text_embeddings)
+        if state.get("poison"):
+            e[1, 0, 0, 0], e[1, 1, 2, 3], e[0, 2, 1, 1] = float("nan"), float("inf"), float("-inf")
+        return e.permute(0, 2, 3, 1).contiguous().half()
+    guide.eps_pred = eps_pred
+    real_randint = torch.randint
+    for tag in ("plain", "local", "stage_late", "stage_early", "nonfinite"):
+        opt.stage_time, opt.iters = bool(g[f"{tag}__stage_time"]), 1000
+        state["poison"] = tag == "nonfinite"
+        seen = {}
+
+        def fake_randint(lo, hi, size, **kw):                            # replay the reference's draw, record the range asked for
+            seen["range"] = (lo, hi)
+            return torch.tensor([int(g[f"{tag}__t_draw"][0])])
+        torch.randint = fake_randint
+        try:
+            lat = torch.from_numpy(g[f"{tag}__latents"]).cuda().requires_grad_(True)
+            loss, _ = guide.train_step(lat, text, system=types.SimpleNamespace(global_step=int(g[f"{tag}__global_step"])), t_ratio=float(g[f"{tag}__t_ratio"]),
+                                       noise=torch.from_numpy(g[f"{tag}__noise"]).cuda())
+        finally:
+            torch.randint = real_randint
+        loss.backward()
+        assert seen["range"] == tuple(int(v) for v in g[f"{tag}__randint_lo_hi"])
+        want, got = g[f"{tag}__grad_latents"], lat.grad.cpu().numpy()
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin])      # the infinities of the reference's quirk, same places
+        scale = np.abs(want[fin]).max()
+        assert np.abs(got[fin] - want[fin]).max() <= 2e-2 * scale, (tag, np.abs(got[fin] - want[fin]).max(), scale)
+        if fin.all():
+            np.testing.assert_allclose(float(loss), float(g[f"{tag}__loss"]), rtol=3e-2)
+    assert lat.grad[0, 0, 0, 0] == 0                                      # NaN -> 0

@@ -186,3 +186,51 @@ def test_update_extra_state_against_reference(golden):
         diff = np.unpackbits(bits ^ g[f"r{rnd}__bitfield"], bitorder="little").astype(bool)
         assert not diff[np.abs(want.reshape(-1) - thr) > 1e-4].any()                 # bits may differ only for cells at the threshold
         assert diff.sum() <= 2
+
+
+SDS_CASES = ["plain", "local", "stage_late", "stage_early", "nonfinite"]
+
+
+def _poisoned_toy_eps(x, t, ctx):
+    from oracle.toy_field import toy_eps
+    e = toy_eps(x, t, ctx).clone()
+    e[1, 0, 0, 0], e[1, 1, 2, 3], e[0, 2, 1, 1] = float("nan"), float("inf"), float("-inf")
+    return e
+
+
+def test_sds_train_step_against_reference(golden):
+    """oracle/sd_oracle.sds_grad against the reference's own StableDiffusion.train_step (nerf/sd.py:115-155, run by make_golden.py with a
+    closed-form epsilon predictor and the published scheduler formula): timestep range and `t * t_ratio` truncation, add_noise, the CFG
+    combination, (1 - abar_t) weighting, lambda_sd, nan_to_num, and the loss whose latent gradient is the SDS gradient."""
+    from oracle import sd_oracle as so
+    from oracle.toy_field import toy_eps
+    g = golden("sds")
+    alphas, text = T(g["alphas_cumprod"]), T(g["text"])
+    for tag in SDS_CASES:
+        lo, hi = [int(v) for v in g[f"{tag}__randint_lo_hi"]]
+        late = bool(g[f"{tag}__stage_time"]) and int(g[f"{tag}__global_step"]) > 1000 / 2
+        assert lo == int(1000 * 0.02) and hi == (int(int(1000 * 0.98) * 0.5) if late else int(1000 * 0.98)) + 1
+        t = int(int(g[f"{tag}__t_draw"][0]) * float(g[f"{tag}__t_ratio"]))               # (t * t_ratio).to(torch.long): truncation
+        lat, noise = T(g[f"{tag}__latents"]), T(g[f"{tag}__noise"])
+        grad = so.sds_grad(None, None, lat, text, t, noise, alphas, 100.0, 0.01, eps_fn=_poisoned_toy_eps if tag == "nonfinite" else toy_eps)
+        assert torch.isfinite(grad).all()                                                  # nan_to_num
+        lat_g = lat.clone().requires_grad_(True)                                           # sd.py:150-152, as oracle.train_step_sd does
+        loss = 0.5 * torch.nn.functional.mse_loss(lat_g, (lat_g - grad).detach(), reduction="sum")
+        loss.backward()
+        want = g[f"{tag}__grad_latents"]
+        np.testing.assert_allclose(lat_g.grad.numpy(), want, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-5)
+        assert float(g[f"{tag}__loss"]) == float(g[f"{tag}__loss_sds"])
+        if tag != "nonfinite":
+            np.testing.assert_allclose(grad.numpy(), want, rtol=1e-5, atol=1e-7)           # d loss / d latents = grad
+    # what the reference does with a non-finite prediction: NaN -> 0; +-inf -> +-FLT_MAX in `grad`, which the mse backward (2 (x - y) first)
+    # turns back into an infinite latent gradient — the loss scaler then skips the step
+    w = g["nonfinite__grad_latents"]
+    assert w[0, 0, 0, 0] == 0.0 and np.isinf(w[0, 1, 2, 3]) and np.isinf(w[0, 2, 1, 1]) and np.isinf(float(g["nonfinite__loss"]))
+
+
+def test_noise_schedule_matches_the_published_one(golden):
+    """customnerf_amd.sd.arch.alphas_cumprod (host logic of the product: the table `train_step` indexes) against the scheduler stand-in the
+    reference's train_step ran with: scaled-linear betas 0.00085 .. 0.012 over 1000 steps, cumulative product of (1 - beta)."""
+    from customnerf_amd.sd import arch
+    np.testing.assert_allclose(arch.alphas_cumprod(1000).numpy(), golden("sds")["alphas_cumprod"], rtol=2e-6)
