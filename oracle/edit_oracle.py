@@ -5,8 +5,11 @@ The composed LGIE editing step of the reference's trainer, restated on the CPU f
 + cached render of the frozen pretrained field (`get_pt`, utils_init_nerf.py:243-265) + the global / local SDS term (`train_step_sd`,
 :282-308, on `sd_oracle.train_step_sd` = sd.py:97-155) + the background-preservation L1 (:388-391) with the `ori_bg` substitution (:378-380).
 
-PARITY: the renderer half is pinned by the reference-produced golden vectors (tests/test_oracle_golden.py); the SDS half is a restatement of
-third-party diffusers code that is absent offline (parity unpinned); the composition itself follows the cited lines.
+PARITY: the renderer half is pinned by the reference-produced golden vectors (tests/test_oracle_golden.py); the composition — which image and
+prompt the SDS term takes, `local_t_ratio`, the `keep_bg` L1 — and the SDS arithmetic are pinned by tests/golden/editing.npz / sds.npz: the
+reference's own train_step_editing / train_step run with a closed-form VAE and epsilon predictor (`encode_fn` / `eps_fn` here).  What stays
+unpinned is the arithmetic INSIDE the UNet / VAE (third-party diffusers code, absent offline: DESIGN.md §2).  The `ori_bg` substitution follows
+the evident intent of :378-380; as written the reference multiplies [B, 3, H, W] by [B, H, W, 1] and raises (recorded in editing.npz).
 Every random draw of the step is an argument, so that the HIP path can be fed the same numbers.
 """
 import torch
@@ -17,7 +20,7 @@ from . import torch_oracle as to
 
 
 def train_step_editing(field, field_pretrained, rays_o, rays_d, rgbs, H, W, aabb, opt, vae_sd, vae_cfg, unet_sd, unet_cfg, text_z, text_z_fg,
-                       alphas, draws, draws_pt, branch, t_draw, sample_noise, noise, size=(512, 512)):
+                       alphas, draws, draws_pt, branch, t_draw, sample_noise, noise, size=(512, 512), encode_fn=None, eps_fn=None):
     """One editing step for one view (B = 1).  rays_o / rays_d [1, N, 3], rgbs [1, N, 3] (ground-truth colours, read by `ori_bg` only).
     draws / draws_pt: the run() draws of the edited / the pretrained render; branch: 'global' | 'local' (the outcome of the
     np.random.random() < global_ratio test of :296, or what g_only / l_only force); t_draw: the torch.randint timestep of sd.py:131 BEFORE
@@ -45,7 +48,7 @@ def train_step_editing(field, field_pretrained, rays_o, rays_d, rgbs, H, W, aabb
             text_emb, img_rgb, t_ratio = text_z_fg, pred_rgb_fg, opt.local_t_ratio
         t = int(t_draw * t_ratio)                                                                                   # sd.py:132
         loss_sd, latents, grad = so.train_step_sd(vae_sd, vae_cfg, unet_sd, unet_cfg, img_rgb, text_emb, t, sample_noise, noise, alphas,
-                                                  float(opt.cfg), float(opt.lambda_sd), size=size)
+                                                  float(opt.cfg), float(opt.lambda_sd), size=size, encode_fn=encode_fn, eps_fn=eps_fn)
         loss = loss_sd
         loss_dict['loss_sds'] = loss_sd.detach()
         loss_dict['t'] = t

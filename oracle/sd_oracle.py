@@ -148,13 +148,15 @@ def sds_grad(unet_sd, unet_cfg, latents, text_embeddings, t, noise, alphas, guid
     return torch.nan_to_num((1 - ab) * (e - noise) * lambda_sd)
 
 
-def train_step_sd(vae_sd, vae_cfg, unet_sd, unet_cfg, img_rgb, text_embeddings, t, sample_noise, noise, alphas, guidance_scale, lambda_sd, size=(512, 512)):
+def train_step_sd(vae_sd, vae_cfg, unet_sd, unet_cfg, img_rgb, text_embeddings, t, sample_noise, noise, alphas, guidance_scale, lambda_sd, size=(512, 512),
+                  encode_fn=None, eps_fn=None):
     """utils_init_nerf.py:303-308 + sd.py:97-155 for one view: img_rgb [1,3,H,W] in [0,1] (requires_grad for the image gradient).
-    Returns (loss, latents, grad): loss = 0.5 * sum (latents - (latents - grad).detach())^2, so d loss / d latents = grad."""
+    Returns (loss, latents, grad): loss = 0.5 * sum (latents - (latents - grad).detach())^2, so d loss / d latents = grad.
+    encode_fn(imgs in [0,1]) / eps_fn replace the VAE / the UNet (tests/golden/editing.npz: the reference's own step was run with closed-form ones)."""
     pred_512 = F.interpolate(img_rgb, size, mode="bilinear", align_corners=False)
-    latents = encode_imgs(vae_sd, vae_cfg, pred_512, sample_noise)
+    latents = encode_fn(pred_512) if encode_fn is not None else encode_imgs(vae_sd, vae_cfg, pred_512, sample_noise)
     with torch.no_grad():
-        grad = sds_grad(unet_sd, unet_cfg, latents.detach(), text_embeddings, t, noise, alphas, guidance_scale, lambda_sd)
+        grad = sds_grad(unet_sd, unet_cfg, latents.detach(), text_embeddings, t, noise, alphas, guidance_scale, lambda_sd, eps_fn=eps_fn)
     target = (latents - grad).detach()
     loss = 0.5 * F.mse_loss(latents, target, reduction="sum")
     return loss, latents, grad

@@ -487,6 +487,114 @@ def main():
         sds_out[f"{tag}__loss_sds"] = np.float64(ld["loss_sds"])
         sds_out[f"{tag}__grad_latents"] = lat.grad.numpy()
     np.savez_compressed(os.path.join(args.out, "sds.npz"), **sds_out)
+
+    # ---- the composed editing step: the reference's own Trainer_Nerf.train_step_editing / train_step_sd / get_pt (nerf/utils_init_nerf.py:243-308,
+    # 353-394), the object built without its __init__; model / pretrained model = the reference renderer with the toy field (six parameters `theta`
+    # for a parameter gradient), guidance = the reference StableDiffusion of the section above + the closed-form toy VAE.
+    for name in ("cv2", "imageio", "tensorboardX", "clip", "torch_ema", "lpips"):
+        _stub(name)
+    _stub("torchvision.transforms")
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from nerf import utils_init_nerf as ref_tr
+    from oracle.toy_field import toy_vae_latents
+
+    class _VAE:
+        def encode(self, x):
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: toy_vae_latents(x)))
+
+    class ToyParamRenderer(ref_renderer.NeRFRenderer):
+        def __init__(self, opt, theta):
+            super().__init__(opt)
+            self.theta = torch.nn.Parameter(theta.clone())
+            self.f = ToyField(self.theta)
+
+        def forward(self, x, d):
+            return self.f(x, d)
+
+        def density(self, x):
+            return self.f.density(x)
+
+    He = We = 16
+    c2w, fx, fy, cx, cy = scene_rays(He, We, view=2, opencv=True)
+    pose = torch.eye(4).unsqueeze(0).clone()
+    pose[0, :3, :4] = torch.from_numpy(c2w)
+    r = ref_pu.get_rays(pose, (fx, fy, cx, cy), He, We, -1)
+    e_o, e_d = r['rays_o'].contiguous(), r['rays_d'].contiguous()
+    g = torch.Generator().manual_seed(91)
+    e_rgbs, e_mask = torch.rand(1, He * We, 3, generator=g), (torch.rand(1, He * We, 1, generator=g) > 0.5).float()
+    theta_edit, theta_pre = torch.tensor([0.10, 0.6, 0.2, -0.3, 0.1, 0.4]), torch.tensor([-0.05, 0.3, -0.1, 0.2, 0.0, -0.2])
+    tz, tz_fg = torch.randn(2, 77, 16, generator=g), torch.randn(2, 77, 16, generator=g)
+    ed_out = {"rays_o": e_o.numpy(), "rays_d": e_d.numpy(), "rgbs": e_rgbs.numpy(), "mask": e_mask.numpy(), "H": np.int64(He), "W": np.int64(We),
+              "theta_edit": theta_edit.numpy(), "theta_pre": theta_pre.numpy(), "text_z": tz.numpy(), "text_z_fg": tz_fg.numpy(),
+              "alphas_cumprod": abar.numpy()}
+    ed_base = dict(bound=2.0, cuda_ray=False, min_near=0.01, density_thresh=10, train_conf=0.01, soft_mask=True, conf_thr=0.5, detach_bg=False,
+                   detach_mask_from_field=False, backbone='grid', num_steps=8, upsample_steps=8, random_bg_c=False, black_bg_c=False, white_bg_c=False,
+                   ori_bg=False, lambda_sd=0.01, keep_bg=1000.0, g_only=False, l_only=False, local_t_ratio=0.4, global_ratio=0.5, clip_view=False,
+                   cfg=100.0, stage_time=False, iters=1000, max_ratio=0.98)
+    ed_out["opt_keys"] = np.array(sorted(ed_base.keys()))
+    for k in ("num_steps", "upsample_steps", "lambda_sd", "keep_bg", "local_t_ratio", "cfg", "train_conf", "conf_thr", "min_near", "bound"):
+        ed_out[f"opt__{k}"] = np.float64(ed_base[k])
+    for tag, kw in (("g_only", dict(g_only=True)), ("l_only", dict(l_only=True)), ("ori_bg", dict(g_only=True, ori_bg=True))):
+        o = argparse.Namespace(**dict(ed_base, **kw))
+        tr = ref_tr.Trainer_Nerf.__new__(ref_tr.Trainer_Nerf)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.model, tr.model_pretrained = ToyParamRenderer(o, theta_edit), ToyParamRenderer(o, theta_pre)
+        tr.model.train(); tr.model_pretrained.train()
+        tr.opt, tr.pt_dict, tr.global_step, tr.log_ptr = o, {}, 0, None
+        guide = ref_sd.StableDiffusion.__new__(ref_sd.StableDiffusion)
+        torch.nn.Module.__init__(guide)
+        guide.device, guide.opt = "cpu", o
+        guide.scheduler, guide.unet, guide.vae = _Sched(), _UNet(), _VAE()
+        guide.num_train_timesteps = 1000
+        guide.min_step, guide.max_step = int(1000 * 0.02), int(1000 * o.max_ratio)
+        guide.alphas = abar
+        poison.clear()
+        tr.guidance = guide
+        tr.text_z, tr.text_z_fg, tr.text_z_norm, tr.text_z_norm_fg = tz, tz_fg, tz, tz_fg
+        torch.manual_seed(123)
+        drawn = []
+        randint, randn_like = torch.randint, torch.randn_like
+
+        def rec_randint(*a, **k):
+            k.pop("device", None)
+            rr = randint(*a, **k)
+            drawn.append(rr.clone())
+            return rr
+
+        def rec_randn_like(t_, *a, **k):
+            rr = randn_like(t_, *a, **k)
+            drawn.append(rr.clone())
+            return rr
+        torch.randint, torch.randn_like = rec_randint, rec_randn_like
+        err = None
+        try:
+            with _Recorder() as rec:
+                try:
+                    pred_rgb, pred_ws, loss, ld = tr.train_step_editing((e_rgbs, e_mask, e_o, e_d, He, We, "view2"))
+                except RuntimeError as ex:
+                    err = str(ex)
+        finally:
+            torch.randint, torch.randn_like = randint, randn_like
+        if tag == "ori_bg":
+            # utils_init_nerf.py:378-380 multiplies rgbs [B, 3, H, W] by non_edit [B, H, W, 1]: not broadcastable for H != 3 — the reference raises
+            ed_out["ori_bg__raises"] = np.int64(err is not None)
+            ed_out["ori_bg__message"] = np.array(err or "")
+            continue
+        assert err is None, err
+        loss.backward()
+        kinds = [k for k, _ in rec.draws]
+        assert kinds == ["randn", "rand", "rand", "randn", "rand", "rand"], kinds               # edited render, then the pretrained render (get_pt)
+        for i, nm in enumerate(("light", "z", "u", "pt_light", "pt_z", "pt_u")):
+            ed_out[f"{tag}__{nm}"] = rec.draws[i][1].numpy()
+        ed_out[f"{tag}__t_draw"] = drawn[0].numpy()
+        ed_out[f"{tag}__noise"] = drawn[1].numpy()
+        ed_out[f"{tag}__pred_rgb"] = pred_rgb.detach().numpy()
+        ed_out[f"{tag}__pred_ws"] = pred_ws.detach().numpy()
+        ed_out[f"{tag}__loss"] = np.float64(loss.item())
+        ed_out[f"{tag}__loss_sds"] = np.float64(ld["loss_sds"])
+        ed_out[f"{tag}__loss_bg"] = np.float64(ld["loss_bg"])
+        ed_out[f"{tag}__grad_theta"] = tr.model.theta.grad.numpy().copy()
+    np.savez_compressed(os.path.join(args.out, "editing.npz"), **ed_out)
     print("golden vectors written to", args.out)
 
 

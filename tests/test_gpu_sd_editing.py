@@ -245,3 +245,63 @@ def test_sds_train_step_matches_reference_golden(golden):
         if fin.all():
             np.testing.assert_allclose(float(loss), float(g[f"{tag}__loss"]), rtol=3e-2)
     assert lat.grad[0, 0, 0, 0] == 0                                      # NaN -> 0
+
+
+@pytest.mark.parametrize("tag", ["g_only", "l_only"])
+def test_editing_step_matches_reference_golden(golden, tag):
+    """EditTrainer.train_step_editing (fused render kernels, get_pt cache, global / local SDS term through cnerf_sd_add_noise / cnerf_sd_sds_grad,
+    keep_bg L1) replaying the reference's own Trainer_Nerf.train_step_editing (nerf/utils_init_nerf.py:243-308, 353-394; tests/golden/editing.npz):
+    toy field with six parameters on both sides, closed-form VAE and epsilon predictor, the reference's RNG draws."""
+    import types
+    import numpy as _np
+    import torch.nn.functional as F
+    from customnerf_amd import scene as sc
+    from customnerf_amd.nerf.renderer import NeRFRenderer
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd.guidance import StableDiffusion
+    from customnerf_amd.sd.editing import EditTrainer
+    from oracle.toy_field import ToyField, toy_eps, toy_encode_imgs
+    g = golden("editing")
+    H, W = int(g["H"]), int(g["W"])
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    opt = sc.make_opt(fp16=False, num_steps=int(g["opt__num_steps"]), upsample_steps=int(g["opt__upsample_steps"]), train_conf=float(g["opt__train_conf"]),
+                      conf_thr=float(g["opt__conf_thr"]), min_near=float(g["opt__min_near"]), lambda_sd=float(g["opt__lambda_sd"]),
+                      keep_bg=float(g["opt__keep_bg"]), local_t_ratio=float(g["opt__local_t_ratio"]), cfg=float(g["opt__cfg"]), log_loss_item=False,
+                      g_only=tag == "g_only", l_only=tag == "l_only")
+
+    class ToyParam(NeRFRenderer):
+        def __init__(self, opt, theta):
+            super().__init__(opt)
+            self.theta = torch.nn.Parameter(theta.clone())
+            self.f = ToyField(self.theta)
+
+        def forward(self, x, d, *a, **k):
+            return self.f(x, d)
+
+        def density(self, x):
+            return self.f.density(x)
+    model, pre = ToyParam(opt, T(g["theta_edit"])).cuda().train(), ToyParam(opt, T(g["theta_pre"])).cuda().train()
+    for m, p in ((model, ""), (pre, "pt_")):                              # replay the reference's draws of the two renders
+        draws = dict(light=T(g[f"{tag}__{p}light"]), z=T(g[f"{tag}__{p}z"]), u=T(g[f"{tag}__{p}u"]))
+        m.render = (lambda mm, dd: (lambda ro, rd, **kw: NeRFRenderer.render(mm, ro, rd, _draws=dd, **kw)))(m, draws)
+    usd = arch.random_state_dict(arch.unet_params(arch.UNET_TINY), 1)
+    vsd = arch.random_state_dict(arch.vae_encoder_params(arch.VAE_TINY), 2)
+    guide = StableDiffusion("cuda", "1.5", opt, unet_state=usd, vae_state=vsd, unet_cfg=arch.UNET_TINY, vae_cfg=arch.VAE_TINY)
+    guide.encode_imgs = lambda imgs, sample_noise=None, resize=None: toy_encode_imgs(F.interpolate(imgs, resize, mode="bilinear", align_corners=False))
+    guide.eps_pred = lambda unet_in, t, ctx: toy_eps(unet_in[..., :4].permute(0, 3, 1, 2).float(), torch.full((2,), float(t)), ctx).permute(0, 2, 3, 1).contiguous().half()
+    tr = EditTrainer.__new__(EditTrainer)
+    tr.model, tr.model_pretrained, tr.guidance, tr.opt = model, pre, guide, opt
+    tr.text_z, tr.text_z_fg, tr.clip_view, tr.fp16, tr.pt_dict = T(g["text_z"]), T(g["text_z_fg"]), False, False, {}
+    tr._rng, tr.sds_resolution, tr.global_step = _np.random.RandomState(0), 512, 0
+    tr._render_kw = {k: v for k, v in vars(opt).items() if k != 'bg_color'}
+    tr.replay = dict(branch="global" if tag == "g_only" else "local", t=int(g[f"{tag}__t_draw"][0]), noise=T(g[f"{tag}__noise"]))
+    pred_rgb, pred_ws, loss, ld = tr.train_step_editing((T(g["rgbs"]), T(g["mask"]), T(g["rays_o"]), T(g["rays_d"]), H, W, "view2"))
+    loss.backward()
+    np.testing.assert_allclose(pred_rgb.detach().cpu().numpy(), g[f"{tag}__pred_rgb"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(pred_ws.detach().cpu().numpy(), g[f"{tag}__pred_ws"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=2e-3)
+    np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=5e-2)         # float16 UNet input / output, cfg = 100
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=5e-3)
+    want = g[f"{tag}__grad_theta"]
+    assert np.abs(model.theta.grad.cpu().numpy() - want).max() <= 3e-2 * np.abs(want).max(), (model.theta.grad.cpu().numpy(), want)
+    assert pre.theta.grad is None                                         # the cached pretrained render carries no graph here

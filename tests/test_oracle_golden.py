@@ -234,3 +234,35 @@ def test_noise_schedule_matches_the_published_one(golden):
     reference's train_step ran with: scaled-linear betas 0.00085 .. 0.012 over 1000 steps, cumulative product of (1 - beta)."""
     from customnerf_amd.sd import arch
     np.testing.assert_allclose(arch.alphas_cumprod(1000).numpy(), golden("sds")["alphas_cumprod"], rtol=2e-6)
+
+
+def test_editing_step_against_reference(golden):
+    """oracle/edit_oracle.train_step_editing against the reference's own Trainer_Nerf.train_step_editing / train_step_sd / get_pt
+    (nerf/utils_init_nerf.py:243-308, 353-394; tests/golden/editing.npz: toy field with six parameters, closed-form VAE and epsilon predictor):
+    rendered image, the SDS and the background term, the total loss and its gradient with respect to the field's parameters, for the global
+    (`g_only`) and the local (`l_only`, `local_t_ratio`) branch.  `ori_bg`: the reference raises on its own broadcast (recorded)."""
+    import argparse
+    from oracle import edit_oracle as eo
+    from oracle.toy_field import toy_eps, toy_encode_imgs
+    g = golden("editing")
+    H, W = int(g["H"]), int(g["W"])
+    assert int(g["ori_bg__raises"]) == 1 and "must match" in str(g["ori_bg__message"])
+    aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2])
+    for tag in ("g_only", "l_only"):
+        opt = argparse.Namespace(num_steps=int(g["opt__num_steps"]), upsample_steps=int(g["opt__upsample_steps"]), train_conf=float(g["opt__train_conf"]),
+                                 soft_mask=True, conf_thr=float(g["opt__conf_thr"]), detach_bg=False, detach_mask_from_field=False,
+                                 min_near=float(g["opt__min_near"]), lambda_sd=float(g["opt__lambda_sd"]), keep_bg=float(g["opt__keep_bg"]),
+                                 local_t_ratio=float(g["opt__local_t_ratio"]), cfg=float(g["opt__cfg"]), ori_bg=False)
+        theta = T(g["theta_edit"]).clone().requires_grad_(True)
+        draws = dict(light=T(g[f"{tag}__light"]), z=T(g[f"{tag}__z"]), u=T(g[f"{tag}__u"]))
+        draws_pt = dict(light=T(g[f"{tag}__pt_light"]), z=T(g[f"{tag}__pt_z"]), u=T(g[f"{tag}__pt_u"]))
+        loss, ld, out = eo.train_step_editing(ToyField(theta), ToyField(T(g["theta_pre"])), T(g["rays_o"]), T(g["rays_d"]), T(g["rgbs"]), H, W, aabb, opt,
+                                              None, None, None, None, T(g["text_z"]), T(g["text_z_fg"]), T(g["alphas_cumprod"]), draws, draws_pt,
+                                              "global" if tag == "g_only" else "local", int(g[f"{tag}__t_draw"][0]), None, T(g[f"{tag}__noise"]),
+                                              encode_fn=toy_encode_imgs, eps_fn=toy_eps)
+        loss.backward()
+        np.testing.assert_allclose(out["image"].detach().numpy().reshape(1, H, W, 3).transpose(0, 3, 1, 2), g[f"{tag}__pred_rgb"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=2e-4)
+        np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=1e-5)
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-5)
+        np.testing.assert_allclose(theta.grad.numpy(), g[f"{tag}__grad_theta"], rtol=2e-4, atol=1e-5)
