@@ -594,6 +594,28 @@ def main():
         ed_out[f"{tag}__loss_sds"] = np.float64(ld["loss_sds"])
         ed_out[f"{tag}__loss_bg"] = np.float64(ld["loss_bg"])
         ed_out[f"{tag}__grad_theta"] = tr.model.theta.grad.numpy().copy()
+    # ---- the reconstruction step: the reference's own Trainer_Nerf.train_step_pretrain (utils_init_nerf.py:194-241), same rays / toy field
+    for tag, kw in (("conf", dict(train_rgb=1.0, train_conf=0.01, batch_rays=0)), ("conf2", dict(train_rgb=2.5, train_conf=0.05, batch_rays=0))):
+        o = argparse.Namespace(**dict(ed_base, **kw))
+        tr = ref_tr.Trainer_Nerf.__new__(ref_tr.Trainer_Nerf)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.model = ToyParamRenderer(o, theta_edit)
+        tr.model.train()
+        tr.opt, tr.device, tr.log_ptr = o, "cpu", None
+        torch.manual_seed(321)
+        with _Recorder() as rec:
+            pred_rgb, mask_volume, loss, ld = tr.train_step_pretrain((e_rgbs, e_mask, e_o, e_d, He, We, "view2"))
+        loss.backward()
+        assert [k for k, _ in rec.draws] == ["randn", "rand", "rand"]
+        for i, nm in enumerate(("light", "z", "u")):
+            ed_out[f"pre_{tag}__{nm}"] = rec.draws[i][1].numpy()
+        ed_out[f"pre_{tag}__train_rgb"], ed_out[f"pre_{tag}__train_conf"] = np.float64(kw["train_rgb"]), np.float64(kw["train_conf"])
+        ed_out[f"pre_{tag}__pred_rgb"] = pred_rgb.detach().numpy()
+        ed_out[f"pre_{tag}__mask_volume"] = mask_volume.detach().numpy()
+        ed_out[f"pre_{tag}__loss"] = np.float64(loss.item())
+        ed_out[f"pre_{tag}__loss_c"] = np.float64(ld["loss_c"])
+        ed_out[f"pre_{tag}__loss_m"] = np.float64(ld.get("loss_m", 0.0))
+        ed_out[f"pre_{tag}__grad_theta"] = tr.model.theta.grad.numpy().copy()
     np.savez_compressed(os.path.join(args.out, "editing.npz"), **ed_out)
     print("golden vectors written to", args.out)
 

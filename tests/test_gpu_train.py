@@ -399,3 +399,42 @@ def test_dp_pack_and_reduce_kernels(n, world):
     check(lib.cnerf_dp_reduce(ptr(recv), world, shard, ptr(out), ptr(state), stream()), "dp_reduce")
     assert float(state[2]) == 1.0 and torch.isinf(out[-1])
     assert lib.cnerf_dp_reduce(ptr(recv), world, shard + 8, ptr(out), None, stream()) < 0      # shard not a multiple of 64: rejected
+
+
+@pytest.mark.parametrize("tag", ["conf", "conf2"])
+def test_recon_step_matches_reference_golden(tag):
+    """ReconTrainer.loss on the fused renderer (cnerf_composite_run + the one-launch loss kernel and its gradient) replaying the reference's own
+    Trainer_Nerf.train_step_pretrain (nerf/utils_init_nerf.py:194-241; tests/golden/editing.npz): image, loss and the gradient of the toy field's
+    six parameters."""
+    import argparse
+    import os
+    from customnerf_amd import scene as sc
+    from customnerf_amd.nerf.renderer import NeRFRenderer
+    from customnerf_amd.trainer import ReconTrainer
+    from oracle.toy_field import ToyField
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "editing.npz"))
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    opt = sc.make_opt(fp16=False, num_steps=int(g["opt__num_steps"]), upsample_steps=int(g["opt__upsample_steps"]), min_near=float(g["opt__min_near"]),
+                      train_conf=float(g[f"pre_{tag}__train_conf"]), train_rgb=float(g[f"pre_{tag}__train_rgb"]))
+
+    class ToyParam(NeRFRenderer):
+        def __init__(self, opt, theta):
+            super().__init__(opt)
+            self.theta = torch.nn.Parameter(theta.clone())
+            self.f = ToyField(self.theta)
+
+        def forward(self, x, d, *a, **k):
+            return self.f(x, d)
+
+        def density(self, x):
+            return self.f.density(x)
+    model = ToyParam(opt, T(g["theta_edit"])).cuda().train()
+    draws = dict(light=T(g[f"pre_{tag}__light"]), z=T(g[f"pre_{tag}__z"]), u=T(g[f"pre_{tag}__u"]))
+    out = model.render(T(g["rays_o"]), T(g["rays_d"]), staged=False, perturb=True, force_all_rays=True, _draws=draws, **{k: v for k, v in vars(opt).items() if k != "bg_color"})
+    assert "_out_ray" in out                                                   # the fused path: the loss below is the one-launch kernel
+    loss = ReconTrainer.loss(argparse.Namespace(opt=opt), out, T(g["rgbs"]), T(g["mask"]))
+    loss.backward()
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), g[f"pre_{tag}__pred_rgb"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"pre_{tag}__loss"]), rtol=2e-4)
+    want = g[f"pre_{tag}__grad_theta"]
+    assert np.abs(model.theta.grad.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max(), (model.theta.grad.cpu().numpy(), want)

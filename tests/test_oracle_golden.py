@@ -266,3 +266,24 @@ def test_editing_step_against_reference(golden):
         np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=1e-5)
         np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-5)
         np.testing.assert_allclose(theta.grad.numpy(), g[f"{tag}__grad_theta"], rtol=2e-4, atol=1e-5)
+
+
+def test_pretrain_step_against_reference(golden):
+    """The reconstruction step — oracle run() + train_rgb * mse(image, rgbs) + train_conf * mse(render_mask, mask) — against the reference's own
+    Trainer_Nerf.train_step_pretrain (nerf/utils_init_nerf.py:194-241; tests/golden/editing.npz, toy field with six parameters)."""
+    import torch.nn.functional as F
+    g = golden("editing")
+    aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2])
+    for tag in ("conf", "conf2"):
+        theta = T(g["theta_edit"]).clone().requires_grad_(True)
+        draws = dict(light=T(g[f"pre_{tag}__light"]), z=T(g[f"pre_{tag}__z"]), u=T(g[f"pre_{tag}__u"]))
+        out = to.run(ToyField(theta), T(g["rays_o"]), T(g["rays_d"]), aabb, float(g["opt__min_near"]), num_steps=int(g["opt__num_steps"]),
+                     upsample_steps=int(g["opt__upsample_steps"]), perturb=True, training=True, train_conf=float(g[f"pre_{tag}__train_conf"]), draws=draws)
+        loss_c = float(g[f"pre_{tag}__train_rgb"]) * F.mse_loss(out["image"].reshape(-1, 3), T(g["rgbs"]).reshape(-1, 3))
+        loss_m = float(g[f"pre_{tag}__train_conf"]) * F.mse_loss(out["render_mask"].reshape(-1), T(g["mask"]).reshape(-1))
+        (loss_c + loss_m).backward()
+        np.testing.assert_allclose(out["image"].detach().numpy(), g[f"pre_{tag}__pred_rgb"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(out["weights_sum"].detach().numpy().reshape(1, -1).clip(1e-5, 1 - 1e-5), g[f"pre_{tag}__mask_volume"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(float(loss_c.detach()), float(g[f"pre_{tag}__loss_c"]), rtol=1e-5)
+        np.testing.assert_allclose(float(loss_m.detach()), float(g[f"pre_{tag}__loss_m"]), rtol=1e-5)
+        np.testing.assert_allclose(theta.grad.numpy(), g[f"pre_{tag}__grad_theta"], rtol=2e-4, atol=1e-7)
