@@ -617,6 +617,71 @@ def main():
         ed_out[f"pre_{tag}__loss_m"] = np.float64(ld.get("loss_m", 0.0))
         ed_out[f"pre_{tag}__grad_theta"] = tr.model.theta.grad.numpy().copy()
     np.savez_compressed(os.path.join(args.out, "editing.npz"), **ed_out)
+
+    # ---- the field's glue: the reference's own NeRFNetwork.forward / density (nerf/network_grid.py:66-193) with its real GridEncoder wrapper
+    # (gridencoder/grid.py), get_encoder (encoding.py), get_embedder (base.py) and trunc_exp — input mapping, [L, B, C] permute, gaussian blob, the
+    # [dir embedding, features] concatenation order, output activations.  The two native pieces underneath are stand-ins BY THIS BUILD (so this
+    # section pins the glue, not them): `_gridencoder.grid_encode_forward / _backward` = the C restatement (oracle/gridencoder_ref.c),
+    # `tinycudann.Network` = oracle.torch_oracle.mlp_forward on one flat parameter vector (the layout assumption of DESIGN.md section 2).
+    from oracle import c_oracle as co_
+    from oracle import torch_oracle as to_
+
+    class _TcnnNetwork(torch.nn.Module):
+        def __init__(self, n_input_dims, n_output_dims, network_config):
+            super().__init__()
+            self.cfg = (n_input_dims, n_output_dims, network_config["n_neurons"], network_config["n_hidden_layers"])
+            self.act = network_config["output_activation"]
+            self.params = torch.nn.Parameter(torch.zeros(to_.mlp_n_params(*self.cfg)))
+
+        def forward(self, x):
+            return to_.mlp_forward(x.float(), self.params, *self.cfg, self.act, False)
+    sys.modules["tinycudann"].Network = _TcnnNetwork
+
+    def _ge_fwd(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, Hb, dy_dx, gridtype, align_corners, interp):
+        out, _ = co_.grid_encode_forward(inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(), float(2.0 ** S), int(Hb), False, int(gridtype),
+                                         bool(align_corners), int(interp), int(max_level))
+        outputs.copy_(torch.from_numpy(out.reshape(B, L, C).transpose(1, 0, 2).copy()))
+
+    def _ge_bwd(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, Hb, dy_dx, grad_inputs, gridtype, align_corners, interp):
+        gflat = grad.detach().numpy().transpose(1, 0, 2).reshape(B, L * C)               # the wrapper hands over [L, B, C]
+        ge, _ = co_.grid_encode_backward(gflat, inputs.detach().numpy(), tuple(embeddings.shape), offsets.numpy(), float(2.0 ** S), int(Hb), None,
+                                         int(gridtype), bool(align_corners), int(interp), int(max_level))
+        grad_embeddings.add_(torch.from_numpy(ge))
+    import gridencoder.grid as _rg
+    _rg._backend.grid_encode_forward, _rg._backend.grid_encode_backward = _ge_fwd, _ge_bwd
+    from nerf import network_grid as ref_ng
+    fo = argparse.Namespace(bound=2.0, cuda_ray=False, min_near=0.01, density_thresh=10, train_conf=0.01, detach_mask_from_field=False, mask_no_dir=False,
+                            keyword2=None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_ng.NeRFNetwork(fo, device=torch.device("cpu"))
+    n_emb = net.pos_en.embeddings.shape[0]
+    with torch.no_grad():                                                               # a closed-form table: the tests rebuild it from the index
+        idx = torch.arange(n_emb, dtype=torch.float64)
+        net.pos_en.embeddings.copy_(torch.stack([torch.sin(idx * 0.37) * 0.5, torch.cos(idx * 0.11 + 1.3) * 0.5], -1).float())
+    g = torch.Generator().manual_seed(77)
+    fld = {"n_embeddings": np.int64(n_emb), "offsets": net.pos_en.offsets.numpy(), "per_level_scale": np.float64(net.pos_en.per_level_scale),
+           "gridtype": np.array(net.pos_en.gridtype), "bound": np.float32(fo.bound)}
+    for nm, mod in (("network", net.network), ("density_network", net.density_network), ("rgb_network", net.rgb_network)):
+        with torch.no_grad():
+            mod.params.copy_(to_.xavier_params(*mod.cfg, generator=g))
+        fld[f"{nm}__params"] = mod.params.detach().numpy().copy()
+        fld[f"{nm}__cfg"] = np.array(mod.cfg, np.int64)
+    P = 192
+    fx_ = (torch.rand(P, 3, generator=g) * 2 - 1) * 1.9
+    fx_[:8] *= 0.05                                                                     # points inside the gaussian blob
+    fd_ = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    w_s, w_r = torch.rand(P, generator=g), torch.rand(P, 4, generator=g)
+    sigma, rad, _ = net(fx_, fd_)
+    dens = net.density(fx_)["sigma"]
+    loss = (sigma * w_s * 0.01).sum() + (rad * w_r).sum()
+    loss.backward()
+    ge = net.pos_en.embeddings.grad
+    nz = torch.nonzero(ge.abs().sum(-1)).reshape(-1)
+    fld.update({"x": fx_.numpy(), "d": fd_.numpy(), "w_sigma": w_s.numpy(), "w_rad": w_r.numpy(), "sigma": sigma.detach().numpy(), "radiances": rad.detach().numpy(),
+                "density_sigma": dens.detach().numpy(), "loss": np.float64(loss.item()), "grad_emb_idx": nz.numpy(), "grad_emb_val": ge[nz].numpy()})
+    for nm, mod in (("network", net.network), ("density_network", net.density_network), ("rgb_network", net.rgb_network)):
+        fld[f"{nm}__grad"] = mod.params.grad.numpy().copy()
+    np.savez_compressed(os.path.join(args.out, "field.npz"), **fld)
     print("golden vectors written to", args.out)
 
 

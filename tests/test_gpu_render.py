@@ -647,3 +647,48 @@ def test_samplers_write_the_grid_coordinates_bit_for_bit():
         zb, xg, srb = render_ops.sample_fine_merge_split(o, d, nears, fars, aabb, z, sig, t, u)
         assert torch.equal(za, zb) and torch.equal(xf, xg) and torch.equal(src, srb)
         assert torch.equal(unit_f, (xf + bound) / (2 * bound))
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_field_matches_reference_glue_golden(golden, half):
+    """The fused field (k_grid_fwd / k_field_fwd / k_field_bwd_* / the binned scatter) at the reference field's own geometry (tiledgrid, T = 2^21,
+    desired 8192: network_grid.py:89-96) against tests/golden/field.npz — the reference's own NeRFNetwork glue over this build's restatements of
+    the kernel and of tinycudann: outputs and every parameter gradient (float32), and within float16 rounding under autocast."""
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.scene import make_opt
+    from customnerf_amd import tcnn
+    g = golden("field")
+    tcnn.set_default_dtype(torch.float16 if half else torch.float32)
+    try:
+        opt = make_opt(fp16=half, grid_type='tiledgrid', log2_hashmap_size=21, desired_resolution=8192)
+        model = NeRFNetwork(opt).cuda()
+        n = int(g["n_embeddings"])
+        assert model.pos_en.embeddings.shape[0] == n
+        idx = torch.arange(n, dtype=torch.float64)
+        with torch.no_grad():
+            model.pos_en.embeddings.copy_(torch.stack([torch.sin(idx * 0.37) * 0.5, torch.cos(idx * 0.11 + 1.3) * 0.5], -1).float().cuda())
+            model.pos_en.invalidate_half_table()
+            model.network.params.copy_(T(g["network__params"]).cuda())
+            model.density_network.params.copy_(T(g["density_network__params"]).cuda())
+            model.rgb_network.params.copy_(T(g["rgb_network__params"]).cuda())
+        x, d = T(g["x"]).cuda(), T(g["d"]).cuda()
+        with torch.autocast('cuda', dtype=torch.float16, enabled=half):
+            sigma, rad, _ = model(x, d)
+            dens = model.density(x)["sigma"]
+            loss = (sigma.float() * T(g["w_sigma"]).cuda() * 0.01).sum() + (rad.float() * T(g["w_rad"]).cuda()).sum()
+        loss.backward()
+        rt, at = (2e-2, 2e-3) if half else (2e-4, 1e-6)
+        np.testing.assert_allclose(sigma.float().detach().cpu().numpy(), g["sigma"], rtol=rt, atol=at)
+        np.testing.assert_allclose(dens.float().detach().cpu().numpy(), g["density_sigma"], rtol=rt, atol=at)
+        np.testing.assert_allclose(rad.float().detach().cpu().numpy(), g["radiances"], rtol=rt, atol=at)
+        for nm in ("network", "density_network", "rgb_network"):
+            got, want = getattr(model, nm).params.grad.float().cpu().numpy(), g[f"{nm}__grad"]
+            assert np.abs(got - want).max() <= (3e-2 if half else 5e-4) * np.abs(want).max(), nm
+        ge = model.pos_en.embeddings.grad.float().cpu()
+        want = torch.zeros_like(ge)
+        want[torch.from_numpy(g["grad_emb_idx"])] = T(g["grad_emb_val"])
+        assert float((ge - want).abs().max()) <= (3e-2 if half else 5e-4) * float(want.abs().max())
+        if not half:
+            assert np.array_equal(torch.nonzero(ge.abs().sum(-1)).reshape(-1).numpy(), g["grad_emb_idx"])
+    finally:
+        tcnn.set_default_dtype(torch.float32)

@@ -287,3 +287,38 @@ def test_pretrain_step_against_reference(golden):
         np.testing.assert_allclose(float(loss_c.detach()), float(g[f"pre_{tag}__loss_c"]), rtol=1e-5)
         np.testing.assert_allclose(float(loss_m.detach()), float(g[f"pre_{tag}__loss_m"]), rtol=1e-5)
         np.testing.assert_allclose(theta.grad.numpy(), g[f"pre_{tag}__grad_theta"], rtol=2e-4, atol=1e-7)
+
+
+def _field_table(n):
+    idx = torch.arange(n, dtype=torch.float64)
+    return torch.stack([torch.sin(idx * 0.37) * 0.5, torch.cos(idx * 0.11 + 1.3) * 0.5], -1).float()
+
+
+def test_field_glue_against_reference(golden):
+    """oracle FieldRef (the field as the oracle states it) against the reference's own NeRFNetwork.forward / density (nerf/network_grid.py:66-193)
+    with its real GridEncoder wrapper, get_encoder, get_embedder and trunc_exp; the native kernel and tinycudann underneath were this build's
+    restatements when tests/golden/field.npz was made, so what is pinned here is the glue: input mapping, [L, B, C] layout, the gaussian blob,
+    the [dir embedding, features] order, activations, and the wrapper's backward."""
+    g = golden("field")
+    ref = to.FieldRef(bound=float(g["bound"]), num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=21, desired_resolution=8192,
+                      gridtype=str(g["gridtype"]), n_hidden_geo=2)
+    assert ref.pos_en.embeddings.shape[0] == int(g["n_embeddings"]) and np.array_equal(np.asarray(ref.pos_en.offsets), g["offsets"])
+    with torch.no_grad():
+        ref.pos_en.embeddings.copy_(_field_table(int(g["n_embeddings"])))
+        for nm in ("network", "density_network", "rgb_network"):
+            getattr(ref, nm).copy_(T(g[f"{nm}__params"]))
+    assert tuple(g["network__cfg"]) == ref.cfg_net and tuple(g["density_network__cfg"]) == ref.cfg_den and tuple(g["rgb_network__cfg"]) == ref.cfg_rgb
+    x, d = T(g["x"]), T(g["d"])
+    sigma, rad, _ = ref(x, d)
+    np.testing.assert_allclose(sigma.detach().numpy(), g["sigma"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rad.detach().numpy(), g["radiances"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ref.density(x)["sigma"].detach().numpy(), g["density_sigma"], rtol=1e-5, atol=1e-7)
+    loss = (sigma * T(g["w_sigma"]) * 0.01).sum() + (rad * T(g["w_rad"])).sum()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    for nm in ("network", "density_network", "rgb_network"):
+        np.testing.assert_allclose(getattr(ref, nm).grad.numpy(), g[f"{nm}__grad"], rtol=2e-4, atol=1e-7, err_msg=nm)
+    ge = ref.pos_en.embeddings.grad
+    nz = torch.nonzero(ge.abs().sum(-1)).reshape(-1).numpy()
+    assert np.array_equal(nz, g["grad_emb_idx"])
+    np.testing.assert_allclose(ge[nz].numpy(), g["grad_emb_val"], rtol=2e-4, atol=1e-8)
