@@ -9,6 +9,9 @@ vocabulary, and the reference's own glue around it:
     encode_imgs   nerf/sd.py:97-105        (2x-1, VAE encode, posterior sample, x0.18215)
     train_step    nerf/sd.py:115-155       (t draw, add_noise, CFG with the reference's `text + g (text - uncond)`, SDS gradient)
     train_step_sd nerf/utils_init_nerf.py:286-309 (bilinear 512 resize in front of encode_imgs)
+That glue IS pinned: tests/golden/sds.npz / editing.npz hold the outputs of the reference's own train_step / train_step_editing run with a
+closed-form epsilon predictor and VAE (tests/golden/make_golden.py), and tests/test_oracle_golden.py replays them through `sds_grad` /
+`train_step_sd` here (their `eps_fn` / `encode_fn` arguments).  Unpinned remains what happens INSIDE the UNet / VAE.
 """
 import math
 

@@ -5,7 +5,10 @@ torch-CPU restatement of the reference's *Python* hot path: the pure-PyTorch ren
 (`nerf/network_grid.py`), the small helpers (`nerf/provider_utils.py`, `nerf/base.py`) and the ray
 generators (`nerf/provider.py`, `nerf/provider_utils.py`).  Every function cites the reference lines it
 follows.  It is pinned against golden vectors produced by importing the reference itself
-(tests/golden/make_golden.py -> tests/golden/*.npz, checked by tests/test_oracle_golden.py).
+(tests/golden/make_golden.py -> tests/golden/*.npz, checked by tests/test_oracle_golden.py): sample_pdf, weights_sum_i, run() in five
+configurations, the ray generators incl. fisheye, trunc_exp, the embedder, the offset tables, update_extra_state (occupancy.npz), and the
+field's glue — NeRFNetwork.forward / density over the real GridEncoder wrapper (field.npz; the kernel and the MLP underneath being the
+restatements of this directory).
 
 The grid encoder / ray-marching arithmetic comes from the C restatement (oracle/c_oracle.py).
 
