@@ -204,6 +204,15 @@ def test_image_front_end_and_sds_tail():
     # non-integer scale (utils_init_nerf.py:303 is called with whatever H, W the view has)
     img2 = torch.rand(2, 3, 24, 40, generator=g)
     close(ops.image_to_vae_input(img2.cuda(), 64, 64)[..., :3].permute(0, 3, 1, 2), 2 * F.interpolate(img2, (64, 64), mode="bilinear", align_corners=False) - 1, 1e-3, 1e-3)
+    # ... and its input gradient (a gather over the bilinear footprint: fixed summation order, so repeatable bit for bit), up- and down-scaling
+    for (Hi, Wi, Ho, Wo) in ((24, 40, 64, 64), (128, 128, 512, 512), (50, 30, 20, 45), (7, 5, 7, 5), (1, 3, 9, 2)):
+        im = torch.rand(2, 3, Hi, Wi, generator=g).requires_grad_(True)
+        rf = 2 * F.interpolate(im, (Ho, Wo), mode="bilinear", align_corners=False) - 1
+        dy = h(torch.randn(2, Ho, Wo, 8, generator=g))
+        rf.backward(dy[..., :3].permute(0, 3, 1, 2))
+        got = ops.image_to_vae_input_backward(dy.half().cuda(), 2, Hi, Wi)
+        close(got, im.grad, 1e-4, 2e-4)
+        assert torch.equal(got, ops.image_to_vae_input_backward(dy.half().cuda(), 2, Hi, Wi))
     # timestep embedding (diffusers get_timestep_embedding, flip_sin_to_cos=True, freq shift 0)
     t = torch.tensor([981.0, 20.0])
     half = 160
