@@ -195,19 +195,20 @@ def run_edit(args, world, rank, dev):
     with torch.no_grad():                                               # both prompts' UNet graphs are captured before the timed region, whichever
         for tz in (trainer.text_z, trainer.text_z_fg):                  # branch (global / local) the warm-up steps happen to draw
             guidance.eps_pred(torch.zeros(2 * nv, 64, 64, 8, device=dev, dtype=torch.float16), 500, tz)   # NHWC CFG pair(s), channels padded to 8 (ops.add_noise)
-    for i in range(max(args.warmup, V // (world * nv) + 1)):            # warm-up also fills the per-view cache of the pretrained render
+    n_warm = max(args.warmup, V // (world * nv) + 1)                    # warm-up also fills the per-view cache of the pretrained render (all V views)
+    for i in range(n_warm):
         step(i)
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
     dt, (loss, ld) = _timed(step, args, world, dist)
     skipped = args.steps - (trainer.scaler.good_steps() - good0) if trainer.scaler is not None else 0
     if rank != 0:
         return None
-    result = {"metric": "SDS edit-steps/s", "value": world * args.steps / dt, "unit": "edit-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    result = {"metric": "SDS edit-steps/s", "value": world * args.steps / dt, "unit": "edit-steps/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
               "config": {"workload": f"cfg3 synthetic: {nv} {H}x{W} view(s)/step/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on "
                                      f"{nv} CFG pair(s) at 64x64 latents + VAE encoder fwd/input-grad at 512x512, lambda_sd=0.01, keep_bg=1000, LGIE global/local alternation, fwd+bwd+Adam",
                          "sds_views_per_step": nv, "views_per_s": world * nv * args.steps / dt,
-                         "parallelism": f"dp{world} (view-parallel SDS, RCCL grad all-reduce)" if world > 1 else "single GPU", "final_loss": float(loss),
+                         "parallelism": f"dp{world} (view-parallel SDS, RCCL {trainer.dp_describe()})" if world > 1 else "single GPU", "final_loss": float(loss),
                          "loss_scale": f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}", "steps_skipped_on_overflow": skipped}}
     if not args.no_roofline:
         prof = []
@@ -293,13 +294,23 @@ def run_recon(args, world, rank, dev):
         v = (i % V) if strong else (i * world + rank) % V      # weak: each rank renders its own view (view-parallel data parallelism)
         return trainer.train_step(rays_o[v], rays_d[v], rgb[v], mask[v], **render_kw)
 
+    if args.prefit > 0:
+        # `trained_field`: the benchmark's random-initialised field spreads its importance samples almost uniformly; a fitted field clusters them
+        # around its surface, which is the state the reference's gather runs in for all but the first few hundred iterations.  Fit the analytic
+        # sphere scene (multi-view consistent targets) for `prefit` untimed steps, then time the SAME step on the SAME targets.
+        rgb, mask = sc.sphere_targets(rays_o.reshape(V, -1, 3), rays_d.reshape(V, -1, 3))          # (this rank's rays: already the chunk under --scaling strong)
+        for i in range(args.prefit):
+            step(i)
     for i in range(args.warmup):
         step(i)
     prof = [] if not args.no_roofline else None
     ge.set_profile(prof)
+    xev = [] if trainer._dp is not None else None
+    trainer._exchange_events = xev
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
     dt, (loss, out) = _timed(step, args, world, dist)
     ge.set_profile(None)
+    trainer._exchange_events = None
 
     result = None
     if rank == 0:
@@ -320,6 +331,12 @@ def run_recon(args, world, rank, dev):
         }
         if args.path == "march":
             result["config"]["samples_per_ray"] = out.get('num_points', 0) / n_rays
+        if args.prefit > 0:
+            result["config"]["prefit_steps"] = args.prefit
+            result["config"]["workload"] += f", field pre-fitted for {args.prefit} steps to the analytic sphere scene (targets of the timed steps too)"
+        if xev:
+            # gradient exchange (pack + all-to-all + fp32 sum + sharded Adam + shadow all-gather + MLP all-reduce), event pairs on the compute stream
+            result["config"]["exchange_ms"] = sum(a.elapsed_time(b) for a, b in xev) / len(xev)
         if prof:
             ms = [e0.elapsed_time(e1) for e0, e1, *_ in prof]
             pts = [p[2] for p in prof]
@@ -333,6 +350,8 @@ def run_recon(args, world, rank, dev):
                                   "traffic": traffic, "traffic_source": (traffic_src + " (committed rocprofv3 --pmc passes of this command; not re-measured in this run)") if traffic_src else None,
                                   "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
                                   "algorithmic_bytes_per_point": bpp}
+            if args.grid == "synthetic" and args.prefit == 0:         # the PMC pass was taken on this table in this (random-initialised) state
+                result["roofline"]["l2_fabric"] = l2_fabric(args.dtype, sum(pts) / len(pts), tot_ms / len(ms))
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(opt)
@@ -341,6 +360,91 @@ def run_recon(args, world, rank, dev):
     del trainer, model
     torch.cuda.empty_cache()
     return result
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_envs(n, port):
+    """the N child environments of the self-launcher: one process per GPU, rendezvous on 127.0.0.1 (the reference never wired its DDP
+    scaffolding — utils_init_nerf.py:76-78 — so there is no launcher to mirror; these are torchrun's variables)"""
+    return [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+             "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")} for r in range(n)]
+
+
+def launch_ranks(args, argv, child_cmd=None, check_devices=True):
+    """`python bench.py --gpus N` without torchrun: spawn N fresh worker processes (one per device) BEFORE this process makes any GPU call —
+    the parent never initialises HIP, the children are new processes (no exec from a process that touched the GPU) — forward rank 0's record,
+    exit non-zero if any child fails or if the record does not show N RCCL ranks.  --dry-launch prints the N child environments instead."""
+    import subprocess
+    n = args.gpus
+    envs = child_envs(n, _free_port())
+    child_argv = (child_cmd if child_cmd is not None else [sys.executable, os.path.abspath(__file__)]) + [a for a in argv if a != "--dry-launch"]
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "n_ranks": n, "argv": child_argv, "env": envs}))
+        return 0
+    have = torch.cuda.device_count() if check_devices else n      # counting devices does not initialise the GPU runtime
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible\n")
+        return 3
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen(child_argv, env={**os.environ, **e},
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)      # a blocking read here would outlive a dead peer
+    reader.start()
+    failed = False
+    deadline = time.time() + 3600
+    pending = list(range(n))
+    while pending and time.time() < deadline:
+        for r in list(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.remove(r)
+                if rc != 0 and not failed:               # one rank down: the others would wait in a collective forever
+                    failed = True
+                    for q in pending:
+                        procs[q].terminate()
+        time.sleep(0.05)
+    for r in pending:
+        procs[r].kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = b"".join(chunks).decode()
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no record\n")
+        return 1
+    rec = json.loads(line[-1])
+    if rec.get("n_gpus") != n or rec.get("rccl_ranks") != n:
+        sys.stderr.write(f"bench.py: asked for {n} ranks, the record shows n_gpus={rec.get('n_gpus')} rccl_ranks={rec.get('rccl_ranks')}\n")
+        return 1
+    print(line[-1])
+    return 0
+
+
+def l2_fabric(dtype, points_per_launch, avg_launch_ms):
+    """L1 -> L2 request traffic of the gather (what actually binds it: VERDICT r3) from the committed PMC pass: TCP_TCC_READ_REQ x 128-byte
+    lines per launch / this run's live launch time, against the guide's L2 ceiling (MI355X_MICROARCH.md §L2: ~34.5 TB/s)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gather_pmc.json")))
+    try:
+        e = json.load(open(files[-1]))[dtype]
+        gb = e["tcp_tcc_read_req"] * 128.0 * points_per_launch / e["points"] / 1e9
+        ach = gb / (avg_launch_ms * 1e-3)
+        return {"achieved": ach, "peak": 34500.0, "unit": "GB/s", "frac": ach / 34500.0, "requests_per_point": e["tcp_tcc_read_req"] / e["points"],
+                "line_bytes": 128, "source": os.path.relpath(files[-1], ROOT) + " (committed --pmc TCP_TCC_READ_REQ_sum pass; launch time live)"}
+    except Exception:
+        return None
 
 
 def main():
@@ -357,14 +461,22 @@ def main():
                     help="synthetic = the benchmark scene of SURVEY.md 8d (hash, T=2^19, desired 2048; the headline number); "
                          "bear = the reference field's own table (tiledgrid, T=2^21, desired 8192; network_grid.py:89-96)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="recon leg at N>1: weak = one 128x128 view per GPU (default), strong = one view's rays split over the GPUs")
+                    help="recon leg at N>1: weak = one 128x128 view per GPU (default; a `strong` sub-record is added), strong = one view's rays split over the GPUs")
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded",
-                    help="N>1 gradient exchange: sharded = fp16 reduce-scatter + sharded Adam + all-gather of the fp16 shadow; allreduce = one fp32 all-reduce")
+                    help="N>1 gradient exchange: sharded = fp16 (fp32 without a loss scaler) all-to-all + sharded Adam + all-gather of the shadow; allreduce = one fp32 all-reduce")
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
+    ap.add_argument("--prefit", type=int, default=0,
+                    help="recon leg: fit the field to the analytic sphere scene for this many untimed steps first, so that the importance samples cluster around a surface")
     ap.add_argument("--dp-selftest", action="store_true", help="one GPU: force the sharded gradient exchange on over a one-rank RCCL group (no link time)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the child environments `--gpus N` would spawn and exit (no GPU needed)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the `variants` sub-records (bear table, march path, trained field; strong scaling at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (no torchrun): this process becomes the launcher — before anything here touches the GPU runtime
+    if args.dry_launch or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON record.  Native libraries write there too (RCCL prints a version banner at communicator creation and
     # flushes it at exit): keep a private duplicate of the real stdout for the record and point fd 1 at stderr for everybody else.
@@ -375,7 +487,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -384,36 +496,75 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
+
+    import copy as _copy
+
+    def variant(fn, **over):
+        """the same leg with some arguments replaced — EVERY rank calls it (the legs issue collectives); at world > 1 an exception propagates:
+        a rank that swallowed one would leave its peers waiting in a collective"""
+        a = _copy.copy(args)
+        a.no_cpu_baseline = True
+        for k, v in over.items():
+            setattr(a, k, v)
+        if world > 1:
+            return fn(a, world, rank, dev)
+        try:
+            return fn(a, world, rank, dev)
+        except Exception as e:
+            return {"error": repr(e)}
+
+    def brief(r):
+        if r is None or "error" in r:
+            return r
+        out = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"]}
+        for k in ("samples_per_ray", "prefit_steps", "exchange_ms"):
+            if k in r["config"]:
+                out[k] = r["config"][k]
+        if "roofline" in r:
+            out["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "points_per_launch") if k in r["roofline"]}
+        return out
 
     result = None
     if args.task in ("both", "recon"):
         result = run_recon(args, world, rank, dev)
+        plain = args.path == "run" and args.grid == "synthetic" and args.prefit == 0 and not args.no_variants       # rank-independent conditions only
+        if plain and world == 1 and not args.dp_selftest:
+            # the claims that used to live in builder-run profiles/, under the driver's clock: the reference field's own table
+            # (network_grid.py:89-96), the occupancy-march path (renderer.py:597-718) and the gather on a FITTED field
+            v = {"bear_table": brief(variant(run_recon, grid="bear")),
+                 "march_path": brief(variant(run_recon, path="march", no_roofline=True)),
+                 "trained_field": brief(variant(run_recon, prefit=300))}
+            if rank == 0:
+                result["variants"] = v
+        if plain and world > 1 and args.scaling == "weak":
+            st = brief(variant(run_recon, scaling="strong", no_roofline=True))
+            if rank == 0:
+                result["strong"] = st
     if args.task in ("both", "edit"):
-        try:
+        if world > 1 or args.task == "edit":
             edit = run_edit(args, world, rank, dev)
-        except Exception as e:                                            # in the combined line a failing edit leg must not take the rays/s half down
-            if args.task == "edit":
-                raise
-            edit = {"metric": "SDS edit-steps/s", "value": None, "unit": "edit-steps/s", "error": repr(e)} if rank == 0 else None
-        if args.task == "both" and args.sds_views == 1 and edit is not None and edit.get("value"):
-            # the same leg with 4 camera views per step through one UNet batch of 8 (north_star: "optionally SDS camera views"), reported beside
-            # the single-view figure: fixed per-launch costs amortise and the GEMMs' M quadruples
+        else:
             try:
-                import copy as _copy
-                a4 = _copy.copy(args)
-                a4.sds_views, a4.no_cpu_baseline = 4, True
-                mv = run_edit(a4, world, rank, dev)
-                if rank == 0 and mv is not None:
-                    edit["multi_view"] = {"sds_views_per_step": 4, "edit_steps_per_s": mv["value"], "views_per_s": mv["config"]["views_per_s"],
-                                          "ms_per_step": mv["ms_per_step"], "roofline": mv.get("roofline")}
-            except Exception as e:
-                if rank == 0:
-                    edit["multi_view"] = {"error": repr(e)}
+                edit = run_edit(args, world, rank, dev)
+            except Exception as e:                                        # one GPU, combined line: a failing edit leg must not take the rays/s half down
+                edit = {"metric": "SDS edit-steps/s", "value": None, "unit": "edit-steps/s", "error": repr(e)}
+        if args.task == "both" and args.sds_views == 1 and not args.no_variants and not (world == 1 and edit.get("error")):
+            # the same leg with 4 camera views per step through one UNet batch of 8 (north_star: "optionally SDS camera views"), reported beside
+            # the single-view figure: fixed per-launch costs amortise and the GEMMs' M quadruples.  The condition is rank-independent.
+            mv = variant(run_edit, sds_views=4)
+            if rank == 0:
+                edit["multi_view"] = mv if (mv is None or "error" in mv) else {
+                    "sds_views_per_step": 4, "edit_steps_per_s": mv["value"], "views_per_s": mv["config"]["views_per_s"],
+                    "ms_per_step": mv["ms_per_step"], "roofline": mv.get("roofline")}
         if args.task == "edit":
             result = edit
         elif rank == 0:
             result["secondary"] = edit
     if rank == 0:
+        result["rccl_ranks"] = rccl_ranks
         os.write(record_fd, (json.dumps(result) + "\n").encode())
     os.close(record_fd)
     if world > 1:

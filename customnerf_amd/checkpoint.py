@@ -13,6 +13,10 @@ import torch
 
 
 def checkpoint_state(model, epoch=0, global_step=0, stats=None, optimizer=None, full=False, scaler=None, lr_scheduler=None, ema=None):
+    stale = [k for k, p in model.named_parameters() if getattr(p, '_cnerf_stale', False)]
+    if stale:
+        raise RuntimeError(f"{stale}: the float32 parameter lags the sharded optimiser's master shards (customnerf_amd.dp, fp16-shadow mode); "
+                           "save through trainer.save_checkpoint() / trainer.state_dict() (collective: every rank calls it), which consolidate first")
     state = {'epoch': int(epoch), 'global_step': int(global_step),
              'stats': stats if stats is not None else {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}}
     if getattr(model, 'cuda_ray', False):

@@ -6,7 +6,10 @@ time — instead of a ring that is bound by one link.
 Per step, for the big parameter (the hash-grid table: 12.2 M floats here, 47.9 M for the reference's bear field):
 
   1. pack      local float32 gradient * (1 / world) -> float16 payload (half the bytes; the same precision the reference's own fp16 training
-               gives the table gradient: `__half2` atomics under the same GradScaler — gridencoder.cu:324-330), the float32 source is zeroed;
+               gives the table gradient: `__half2` atomics under the same GradScaler — gridencoder.cu:324-330), the float32 source is zeroed.
+               The float16 payload exists ONLY under a dynamic loss scaler (scaled gradients, overflow found by the scaler's check of the
+               reduced shard); float32 training and static loss scales send float32 — unscaled table gradients of 1e-7 and below would flush
+               to zero in half precision (ADVICE r3);
   2. exchange  `all_to_all_single`: rank j receives slice j of every rank's payload (world x shard halves);
   3. reduce    the `world` slices are summed in FLOAT32 on arrival (no half-precision accumulation across ranks);
   4. update    Adam on the owned shard only (moments exist for the shard only: 1/world of the optimiser state per GPU), writing the
@@ -60,13 +63,14 @@ class ShardedExchange:
             self.small_seg = flat[lo:hi]
         else:
             self.small_seg = None
+        self.payload_dtype = torch.float16 if scaler is not None else torch.float32
         self.state = []
         for p, o, n in self.big:
             s = ((n + world_size - 1) // world_size + ALIGN - 1) // ALIGN * ALIGN
             dev = p.device
             st = dict(p=p, off=o, n=n, shard=s,
-                      send=torch.zeros(world_size * s, dtype=torch.float16, device=dev),      # pad stays zero
-                      recv=torch.empty(world_size, s, dtype=torch.float16, device=dev),
+                      send=torch.zeros(world_size * s, dtype=self.payload_dtype, device=dev),      # pad stays zero
+                      recv=torch.empty(world_size, s, dtype=self.payload_dtype, device=dev),
                       g32=torch.empty(s, dtype=torch.float32, device=dev),
                       m=torch.zeros(s, dtype=torch.float32, device=dev), v=torch.zeros(s, dtype=torch.float32, device=dev),
                       # the float32 master of the OWNED shard (a padded private copy: the parameter's own storage stays the full table so that
@@ -89,7 +93,7 @@ class ShardedExchange:
         self.async_ops = False
 
     def describe(self):
-        return (f"fp16 all-to-all of the table gradient (1/{self.world} pre-scaled, fp32 sum on arrival) + sharded Adam + all-gather of the "
+        return (f"{'fp16' if self.payload_dtype == torch.float16 else 'fp32'} all-to-all of the table gradient (1/{self.world} pre-scaled, fp32 sum on arrival) + sharded Adam + all-gather of the "
                 f"{'fp16 shadow' if 'shadow' in self.state[0] else 'fp32 master'} shards; MLP gradients fp32 all-reduce{' under the grid scatter' if self.async_ops else ''}")
 
     def shadow_table(self, p):
@@ -113,7 +117,7 @@ class ShardedExchange:
         works = []
         for st in self.state:
             src = self.flat[st['off']:st['off'] + st['n']]
-            if src.is_cuda:                                              # one pass: float32 -> pre-scaled float16 payload, source zeroed
+            if src.is_cuda and self.payload_dtype == torch.float16:      # one pass: float32 -> pre-scaled float16 payload, source zeroed
                 from ._lib import lib, check, ptr, stream
                 check(lib.cnerf_dp_pack(ptr(src), ptr(st['send']), st['n'], inv_world, stream()), "dp_pack")
             else:
@@ -124,7 +128,7 @@ class ShardedExchange:
         for st, w in zip(self.state, works):
             if w is not None:
                 w.wait()
-            if st['recv'].is_cuda:                                       # float32 accumulation on arrival (+ the scaler's found-inf test of the shard)
+            if st['recv'].is_cuda and self.payload_dtype == torch.float16:   # float32 accumulation on arrival (+ the scaler's found-inf test of the shard)
                 from ._lib import lib, check, ptr, stream
                 check(lib.cnerf_dp_reduce(ptr(st['recv']), self.world, st['shard'], ptr(st['g32']),
                                           ptr(self.scaler.state) if self.scaler is not None else None, stream()), "dp_reduce")
@@ -139,7 +143,7 @@ class ShardedExchange:
         if self.scaler is None:
             return
         for st in self.state:
-            if not st['g32'].is_cuda:                                    # on the device cnerf_dp_reduce already tested the shard
+            if not (st['g32'].is_cuda and self.payload_dtype == torch.float16):      # on the device cnerf_dp_reduce already tested the shard
                 self.scaler.check(st['g32'])
         if self.small_seg is not None:
             self.scaler.check(self.small_seg)
@@ -167,6 +171,7 @@ class ShardedExchange:
                 _adam_host(st['master'], st['g32'], st['m'], st['v'], half_out, lr, self.betas, self.eps, st['step'], 1.0 / loss_scale)
             if 'shadow' in st:
                 dist.all_gather_into_tensor(st['shadow'], st['shadow'][lo:lo + s], group=self.group)          # in place: 2 bytes per parameter
+                p._cnerf_stale = True            # the float32 nn.Parameter now lags the owners' master shards until consolidate() (checkpoint.py refuses it)
             else:
                 dist.all_gather_into_tensor(st['gather32'], st['master'], group=self.group)
                 p.data.reshape(-1).copy_(st['gather32'][:n])
@@ -219,3 +224,4 @@ class ShardedExchange:
             full = torch.empty(self.world * st['shard'], dtype=torch.float32, device=st['p'].device)
             dist.all_gather_into_tensor(full, st['master'], group=self.group)
             st['p'].data.reshape(-1).copy_(full[:st['n']])
+            st['p']._cnerf_stale = False

@@ -255,11 +255,15 @@ class NeRFRenderer(nn.Module):
         """One alpha composite with the reference's signature (renderer.py:407-474) on the compositing kernel of run() (its "all" variant
         takes sigma as given): sigmas [N,S(,1)], rgbs [N,S,3], masks [N,S,1] | None, z_vals [N,S], nears / fars / sample_dist [N,1].
         Differentiable in sigmas / rgbs / masks.  `num_steps` = (far - near) / sample_dist, the kernel's form of the last interval; when it is
-        not passed it is recovered from the first ray (one host read)."""
+        not passed it is recovered from the first ray that hits the box (one host read; rays with near >= far carry no interval)."""
         N, S = z_vals.shape
         nears, fars = nears.reshape(N).contiguous().float(), fars.reshape(N).contiguous().float()
         if num_steps is None:
-            num_steps = int(torch.round((fars[0] - nears[0]) / sample_dist.reshape(-1)[0]).item())
+            sd_ = sample_dist.reshape(-1).float().expand(N) if sample_dist.numel() in (1, N) else sample_dist.reshape(-1).float()[:N]
+            ratio = torch.where((fars > nears) & (sd_ > 0), (fars - nears) / sd_.clamp_min(1e-30), torch.full_like(nears, -1.0))
+            num_steps = int(torch.round(ratio.max()).item())         # every valid ray has the same (far - near) / sample_dist = the sample count
+            if num_steps <= 0:
+                raise ValueError("weights_sum_i: no ray intersects the box (near >= far everywhere); pass num_steps")
         conf = masks.reshape(N, S, 1).float() if masks is not None else torch.zeros(N, S, 1, device=z_vals.device)
         rgbc = torch.cat([rgbs.reshape(N, S, 3).float(), conf], dim=-1)
         detach_bg = bool(is_all and getattr(self.opt, 'detach_bg', False))                           # :409-418
@@ -386,10 +390,11 @@ class NeRFRenderer(nn.Module):
 
     def _mean_sample_count(self, total_step):
         """average samples per march_rays_train call over the last `total_step` calls (:1714-1716); data-parallel ranks average it too, so
-        that every rank sizes its sample budget alike"""
+        that every rank sizes its sample budget alike.  That makes update_extra_state a COLLECTIVE under torch.distributed (every rank must
+        call it); `opt.sync_mean_count = False` keeps it rank-local (e.g. a rank-0-only evaluation that refreshes the occupancy grid)."""
         tot = self.step_counter[:total_step, 0].sum().float()
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if getattr(self.opt, 'sync_mean_count', True) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(tot)
             tot = tot / dist.get_world_size()
         return int(tot.item() / total_step)

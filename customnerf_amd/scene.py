@@ -41,6 +41,20 @@ def targets(n_views, H, W, seed=0):
     return rgb, m
 
 
+def sphere_targets(rays_o, rays_d, radius=1.0):
+    """Multi-view CONSISTENT targets (bench.py --prefit: a field fitted to them has a surface for the importance samples to cluster around):
+    the analytic unit sphere at the origin, colour = 0.5 + 0.5 * surface normal where the ray hits it, black elsewhere; mask = hit.
+    rays_o, rays_d [V, N, 3] (unit directions) -> rgb [V, N, 3], mask [V, N, 1] on the rays' device."""
+    b = (rays_o * rays_d).sum(-1)
+    c = (rays_o * rays_o).sum(-1) - radius * radius
+    disc = b * b - c
+    hit = (disc > 0) & (-b - disc.clamp_min(0).sqrt() > 0)
+    t = -b - disc.clamp_min(0).sqrt()
+    n = (rays_o + t.unsqueeze(-1) * rays_d) / radius
+    rgb = torch.where(hit.unsqueeze(-1), 0.5 + 0.5 * n, torch.zeros_like(n))
+    return rgb.contiguous(), hit.unsqueeze(-1).to(rgb.dtype).contiguous()
+
+
 def sphere_density_grid(cascade=2, grid_size=128, bound=2.0, radius=1.0, value=100.0):
     """density_grid [cascade, H^3] in MORTON order: `value` where the cell centre is inside the sphere, else 0."""
     H = grid_size

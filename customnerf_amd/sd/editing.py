@@ -10,11 +10,11 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
-from ..trainer import (allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
+from ..trainer import (CheckpointMixin, allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
                        setup_sharded_dp)
 
 
-class EditTrainer:
+class EditTrainer(CheckpointMixin):
     def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale='dynamic', seed=0,
                  clip_guidance=None, clip_match_text=None, dp_mode='allreduce'):
         """text_z / text_z_fg: the [2, 77, 768] (uncond, cond) embeddings of the global / local prompt; with `opt.clip_view` they are
@@ -52,6 +52,12 @@ class EditTrainer:
 
     def lr_factor(self):
         return 0.1 ** min(self.global_step / self.opt.iters, 1)
+
+    def dp_describe(self):
+        """one-line description of the gradient exchange (bench.py's config.parallelism)"""
+        if self._dp is not None:
+            return self._dp.describe()
+        return "fp32 grad all-reduce, in place on the flat buffer"
 
     def _bg_color(self, rays_o, B, N):
         if getattr(self.opt, 'random_bg_c', False):

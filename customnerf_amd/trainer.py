@@ -122,9 +122,16 @@ def apply_optimizer_step(trainer):
     dp = getattr(trainer, '_dp', None)
     trainer.optimizer.grad_scale_inv = 1.0 / (trainer.loss_scale * trainer.world_size)
     if dp is not None:
+        ev = getattr(trainer, '_exchange_events', None)              # bench.py: event pairs around the exchange (None = off)
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dp.exchange()
         dp.check()
         dp.step(f, trainer.loss_scale)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         trainer.optimizer.step()                                     # the small (replicated) parameters; the big ones are in skip_params
         if trainer.scaler is not None:
             trainer.scaler.update()
@@ -139,7 +146,33 @@ def apply_optimizer_step(trainer):
     refresh_half_shadow(trainer.optimizer, trainer.model)
 
 
-class ReconTrainer:
+class CheckpointMixin:
+    """Checkpoints of a (possibly sharded data-parallel) trainer.  In dp_mode 'sharded' with the fp16 shadow the optimiser updates the owners'
+    float32 master SHARDS and the shadow table only; the float32 nn.Parameter is refreshed here (ShardedExchange.consolidate — a collective, so
+    EVERY rank calls these methods; rank 0 writes the file).  checkpoint.checkpoint_state refuses a model whose parameters are marked stale."""
+
+    def state_dict(self):
+        if getattr(self, '_dp', None) is not None:
+            self._dp.consolidate()
+        return self.model.state_dict()
+
+    def save_checkpoint(self, path, epoch=0, stats=None, full=False, rank=None):
+        from . import checkpoint
+        dp = getattr(self, '_dp', None)
+        if dp is not None:
+            if full:
+                dp.export_optimizer_state(self.optimizer)         # consolidates + gathers the sharded Adam moments into the unsharded layout
+            else:
+                dp.consolidate()
+        if rank is None:
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        if rank != 0:
+            return None
+        return checkpoint.save_checkpoint(path, self.model, epoch=epoch, global_step=self.global_step, stats=stats, optimizer=self.optimizer, full=full,
+                                          scaler=self.scaler)
+
+
+class ReconTrainer(CheckpointMixin):
     def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic', dp_mode='allreduce'):
         """dp_mode (world_size > 1): 'allreduce' = one in-place fp32 all-reduce of the flat gradient buffer; 'sharded' = customnerf_amd.dp.ShardedExchange
         (fp16 all-to-all payload summed in fp32 on arrival, sharded Adam, all-gather of the fp16 shadow; MLP groups all-reduced in fp32).
@@ -196,8 +229,23 @@ class ReconTrainer:
         """One flattened RCCL all-reduce (sum) per step; the 1/world factor is folded into the Adam un-scale."""
         self._flat = allreduce_grads_flat(list(self.model.parameters()), self._flat, self.world_size)
 
-    def train_step(self, rays_o, rays_d, rgbs, mask, **render_kw):
+    def select_rays(self, rays_o, rays_d, rgbs, mask, select_inds=None):
+        """`--batch_rays` (utils_init_nerf.py:210-215): a random subset of `opt.batch_rays` rays of the view, drawn without replacement by
+        numpy on the host as the reference does (`np.random.choice`; `select_inds` replays a recorded draw), gathered on the device."""
+        n = int(getattr(self.opt, 'batch_rays', 0) or 0)
+        if not n and select_inds is None:
+            return rays_o, rays_d, rgbs, mask
+        N = rays_o.reshape(-1, 3).shape[0]
+        if select_inds is None:
+            import numpy as np
+            select_inds = np.random.choice(N, size=[n], replace=False)
+        idx = torch.as_tensor(select_inds, dtype=torch.long).to(rays_o.device)
+        pick = lambda t, c: t.reshape(1, N, c).index_select(1, idx) if t is not None else None
+        return pick(rays_o, 3), pick(rays_d, 3), pick(rgbs, 3), pick(mask, 1)
+
+    def train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
         self.model.train()
+        rays_o, rays_d, rgbs, mask = self.select_rays(rays_o, rays_d, rgbs, mask, select_inds)
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
             loss = self.loss(outputs, rgbs, mask)

@@ -436,18 +436,26 @@ def main():
                 e[1, 0, 0, 0], e[1, 1, 2, 3], e[0, 2, 1, 1] = float("nan"), float("inf"), float("-inf")
             return types.SimpleNamespace(sample=e)
 
+    class _UNetHalfIO(_UNet):
+        """the same closed form with HALF-PRECISION input and output — what the real UNet has under the reference's fp16 autocast (main.py:152-153:
+        its first convolution casts the input to half, its last one emits half).  The product carries exactly these two roundings, so against these
+        cases (tags ending in `_h`) it can be held to 1e-3 where the float32-epsilon cases need cfg x half-epsilon = a few per cent."""
+        def __call__(self, x, t, encoder_hidden_states=None, class_labels=None):
+            return types.SimpleNamespace(sample=super().__call__(x.half().float(), t, encoder_hidden_states).sample.half().float())
+
     sds_out = {"alphas_cumprod": abar.numpy()}
     g = torch.Generator().manual_seed(44)
     text = torch.randn(2, 77, 16, generator=g)
     sds_out["text"] = text.numpy()
     cases = {"plain": dict(t_ratio=1), "local": dict(t_ratio=0.4), "stage_late": dict(t_ratio=1, stage_time=True, step=900),
-             "stage_early": dict(t_ratio=1, stage_time=True, step=100), "nonfinite": dict(t_ratio=1, poison=True)}
+             "stage_early": dict(t_ratio=1, stage_time=True, step=100), "nonfinite": dict(t_ratio=1, poison=True),
+             "plain_h": dict(t_ratio=1, half_io=True), "local_h": dict(t_ratio=0.4, half_io=True)}
     for tag, c in cases.items():
         guide = ref_sd.StableDiffusion.__new__(ref_sd.StableDiffusion)
         torch.nn.Module.__init__(guide)
         guide.device = "cpu"
         guide.opt = argparse.Namespace(cfg=100.0, stage_time=bool(c.get("stage_time")), iters=1000, lambda_sd=0.01, max_ratio=0.98)
-        guide.scheduler, guide.unet = _Sched(), _UNet()
+        guide.scheduler, guide.unet = _Sched(), (_UNetHalfIO() if c.get("half_io") else _UNet())
         guide.num_train_timesteps = 1000
         guide.min_step, guide.max_step = int(1000 * 0.02), int(1000 * 0.98)                 # sd.py:69-70
         guide.alphas = abar
@@ -534,7 +542,8 @@ def main():
     ed_out["opt_keys"] = np.array(sorted(ed_base.keys()))
     for k in ("num_steps", "upsample_steps", "lambda_sd", "keep_bg", "local_t_ratio", "cfg", "train_conf", "conf_thr", "min_near", "bound"):
         ed_out[f"opt__{k}"] = np.float64(ed_base[k])
-    for tag, kw in (("g_only", dict(g_only=True)), ("l_only", dict(l_only=True)), ("ori_bg", dict(g_only=True, ori_bg=True))):
+    for tag, kw in (("g_only", dict(g_only=True)), ("l_only", dict(l_only=True)), ("ori_bg", dict(g_only=True, ori_bg=True)),
+                    ("g_only_h", dict(g_only=True)), ("l_only_h", dict(l_only=True))):                  # `_h`: epsilon predictor with half-precision I/O
         o = argparse.Namespace(**dict(ed_base, **kw))
         tr = ref_tr.Trainer_Nerf.__new__(ref_tr.Trainer_Nerf)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -544,7 +553,7 @@ def main():
         guide = ref_sd.StableDiffusion.__new__(ref_sd.StableDiffusion)
         torch.nn.Module.__init__(guide)
         guide.device, guide.opt = "cpu", o
-        guide.scheduler, guide.unet, guide.vae = _Sched(), _UNet(), _VAE()
+        guide.scheduler, guide.unet, guide.vae = _Sched(), (_UNetHalfIO() if tag.endswith("_h") else _UNet()), _VAE()
         guide.num_train_timesteps = 1000
         guide.min_step, guide.max_step = int(1000 * 0.02), int(1000 * o.max_ratio)
         guide.alphas = abar
@@ -595,7 +604,9 @@ def main():
         ed_out[f"{tag}__loss_bg"] = np.float64(ld["loss_bg"])
         ed_out[f"{tag}__grad_theta"] = tr.model.theta.grad.numpy().copy()
     # ---- the reconstruction step: the reference's own Trainer_Nerf.train_step_pretrain (utils_init_nerf.py:194-241), same rays / toy field
-    for tag, kw in (("conf", dict(train_rgb=1.0, train_conf=0.01, batch_rays=0)), ("conf2", dict(train_rgb=2.5, train_conf=0.05, batch_rays=0))):
+    # ("batch": --batch_rays subsampling, :210-215 — the index draw of np.random.choice is recorded)
+    for tag, kw in (("conf", dict(train_rgb=1.0, train_conf=0.01, batch_rays=0)), ("conf2", dict(train_rgb=2.5, train_conf=0.05, batch_rays=0)),
+                    ("batch", dict(train_rgb=1.0, train_conf=0.01, batch_rays=100))):
         o = argparse.Namespace(**dict(ed_base, **kw))
         tr = ref_tr.Trainer_Nerf.__new__(ref_tr.Trainer_Nerf)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -603,10 +614,25 @@ def main():
         tr.model.train()
         tr.opt, tr.device, tr.log_ptr = o, "cpu", None
         torch.manual_seed(321)
-        with _Recorder() as rec:
-            pred_rgb, mask_volume, loss, ld = tr.train_step_pretrain((e_rgbs, e_mask, e_o, e_d, He, We, "view2"))
+        np.random.seed(4242)
+        picked = []
+        np_choice = np.random.choice
+
+        def rec_choice(*a, **k):
+            sel = np_choice(*a, **k)
+            picked.append(np.asarray(sel).copy())
+            return sel
+        np.random.choice = rec_choice
+        try:
+            with _Recorder() as rec:
+                pred_rgb, mask_volume, loss, ld = tr.train_step_pretrain((e_rgbs, e_mask, e_o, e_d, He, We, "view2"))
+        finally:
+            np.random.choice = np_choice
         loss.backward()
         assert [k for k, _ in rec.draws] == ["randn", "rand", "rand"]
+        assert len(picked) == (1 if kw["batch_rays"] else 0)
+        ed_out[f"pre_{tag}__batch_rays"] = np.int64(kw["batch_rays"])
+        ed_out[f"pre_{tag}__select_inds"] = picked[0].astype(np.int64) if picked else np.zeros(0, np.int64)
         for i, nm in enumerate(("light", "z", "u")):
             ed_out[f"pre_{tag}__{nm}"] = rec.draws[i][1].numpy()
         ed_out[f"pre_{tag}__train_rgb"], ed_out[f"pre_{tag}__train_conf"] = np.float64(kw["train_rgb"]), np.float64(kw["train_conf"])

@@ -1,0 +1,57 @@
+"""bench.py's self-launcher (`python bench.py --gpus N` without torchrun): child environments, record forwarding,
+failure handling.  No GPU: the children here are tiny stand-in scripts."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_dry_launch_prints_n_child_envs():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--dry-launch"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_ranks"] == 8 and len(rec["env"]) == 8
+    assert [e["RANK"] for e in rec["env"]] == [str(r) for r in range(8)] and [e["LOCAL_RANK"] for e in rec["env"]] == [str(r) for r in range(8)]
+    assert all(e["WORLD_SIZE"] == "8" and e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in rec["env"])
+    assert len({e["MASTER_PORT"] for e in rec["env"]}) == 1
+    assert "--dry-launch" not in rec["argv"] and rec["argv"][-4:] == ["--gpus", "8", "--steps", "3"]
+
+
+def test_gpus_gt_1_without_devices_fails_loudly():
+    """no GPU in the build container: asking for 2 ranks must exit non-zero, not fall back to one GPU and report n_gpus 1"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode != 0 and "device" in out.stderr
+
+
+def _launch(tmp_path, body, n=2):
+    import bench
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, json, time\nrank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n" + body)
+    args = argparse.Namespace(gpus=n, dry_launch=False)
+    return bench.launch_ranks(args, [], child_cmd=[sys.executable, str(script)], check_devices=False)
+
+
+def test_launcher_forwards_rank0_record(tmp_path, capfd):
+    rc = _launch(tmp_path, "if rank == 0:\n    print('banner noise'); print(json.dumps({'n_gpus': world, 'rccl_ranks': world, 'value': 1.0}))\n", n=3)
+    assert rc == 0
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 3, "rccl_ranks": 3, "value": 1.0}
+
+
+def test_launcher_rejects_wrong_rank_count(tmp_path):
+    assert _launch(tmp_path, "if rank == 0:\n    print(json.dumps({'n_gpus': 1, 'rccl_ranks': 1, 'value': 1.0}))\n") == 1
+
+
+def test_launcher_fails_fast_when_a_rank_dies(tmp_path):
+    """rank 1 dies; rank 0 would sit in a collective forever: the launcher terminates it and returns non-zero"""
+    t0 = time.time()
+    rc = _launch(tmp_path, "if rank == 1:\n    sys.exit(7)\ntime.sleep(600)\n")
+    assert rc == 1 and time.time() - t0 < 60

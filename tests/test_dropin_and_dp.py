@@ -98,7 +98,11 @@ from customnerf_amd.dp import ShardedExchange, BIG_PARAM_MIN
 from customnerf_amd.trainer import flat_grad_buffer
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-for half_shadow in (True, False):
+class HostScaler:                                                    # duck-typed stand-in for optim.DynamicLossScaler (whose check is a HIP kernel)
+    def __init__(self): self.state = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    def check(self, g):
+        if not bool(torch.isfinite(g).all()): self.state[2] = 1.0
+for half_shadow, scaled in ((True, True), (True, False), (False, False)):
     g0 = torch.Generator().manual_seed(0)
     n_big = BIG_PARAM_MIN + 1234                                   # not a multiple of world * 64: the last shard is padded
     big = torch.nn.Parameter(torch.randn(n_big // 2, 2, generator=g0) * 0.1)
@@ -109,7 +113,9 @@ for half_shadow in (True, False):
     ref_opt = torch.optim.Adam([{'params': [torch.nn.Parameter(r) for r in ref]}], lr=1.0, betas=(0.9, 0.99), eps=1e-15)
     rp = ref_opt.param_groups[0]['params']
     lrs = {id(big): 5e-3, id(s1): 5e-4, id(s2): 5e-4}
-    dp = ShardedExchange(params, flat, lambda p: lrs[id(p)], world, rank, half_shadow=half_shadow)
+    dp = ShardedExchange(params, flat, lambda p: lrs[id(p)], world, rank, half_shadow=half_shadow, scaler=HostScaler() if scaled else None)
+    # the float16 payload exists only under a loss scaler; unscaled (float32 / static-scale) training sends float32 (ADVICE r3)
+    assert dp.payload_dtype == (torch.float16 if scaled else torch.float32) and dp.state[0]['send'].dtype == dp.payload_dtype
     dp.async_ops = not half_shadow                                  # both forms of the collectives (blocking is the default)
     small_opt = torch.optim.Adam([s1, s2], lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
     assert len(dp.state) == 1 and dp.small_seg.numel() >= 100 + 21
@@ -124,11 +130,18 @@ for half_shadow in (True, False):
         assert float(flat[:n_big].abs().max()) == 0.0              # the big gradient slot was packed and zeroed
         dp.check()
         dp.step(1.0)
+        if half_shadow:                                            # the float32 parameter now lags the master shards: a direct checkpoint must refuse
+            from customnerf_amd import checkpoint
+            holder_m = torch.nn.Module(); holder_m.big = big
+            try:
+                checkpoint.checkpoint_state(holder_m); raise AssertionError("stale parameter went into a checkpoint")
+            except RuntimeError as e:
+                assert "consolidate" in str(e)
         for p in (s1, s2):
             p.grad.mul_(1.0 / world)                               # the small gradients arrive as SUMS
         small_opt.step(); small_opt.zero_grad(set_to_none=False)
         # ---- reference
-        mean16 = sum((gl[0] * (1.0 / world)).half().float() for gl in grads)          # float16 payload, float32 sum on arrival
+        mean16 = sum(((gl[0] * (1.0 / world)).half().float() if scaled else gl[0] * (1.0 / world)) for gl in grads)   # payload precision, float32 sum on arrival
         rp[0].grad = mean16.clone(); rp[1].grad = sum(gl[1] for gl in grads) / world; rp[2].grad = sum(gl[2] for gl in grads) / world
         # per-parameter lr: three single-parameter Adams share the state layout of one; emulate with explicit lr scaling
         for q, lr in zip(rp, (5e-3, 5e-4, 5e-4)):
@@ -139,6 +152,7 @@ for half_shadow in (True, False):
             st['m'].mul_(0.9).add_(q.grad, alpha=0.1); st['v'].mul_(0.99).addcmul_(q.grad, q.grad, value=0.01)
             q.data.addcdiv_(st['m'], (st['v'].sqrt() / (1 - 0.99 ** st['t']) ** 0.5).add_(1e-15), value=-lr / (1 - 0.9 ** st['t']))
         dp.consolidate()
+        assert not getattr(big, '_cnerf_stale', False)
         assert torch.allclose(big.detach(), rp[0].detach(), rtol=1e-5, atol=1e-6), (step, (big.detach() - rp[0]).abs().max())
         assert torch.allclose(s1.detach(), rp[1].detach(), rtol=1e-5, atol=1e-6) and torch.allclose(s2.detach(), rp[2].detach(), rtol=1e-5, atol=1e-6)
         if half_shadow:
@@ -159,7 +173,7 @@ for half_shadow in (True, False):
     big2 = torch.nn.Parameter(big.detach().clone())
     params2 = [big2, torch.nn.Parameter(s1.detach().clone()), torch.nn.Parameter(s2.detach().clone())]
     flat2 = flat_grad_buffer(params2)
-    dp2 = ShardedExchange(params2, flat2, lambda p: 5e-3 if p is big2 else 5e-4, world, rank, half_shadow=half_shadow)
+    dp2 = ShardedExchange(params2, flat2, lambda p: 5e-3 if p is big2 else 5e-4, world, rank, half_shadow=half_shadow, scaler=HostScaler() if scaled else None)
     holder2 = torch.optim.Adam([big2], lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
     holder2.state[big2] = saved
     dp2.import_optimizer_state(holder2)

@@ -220,7 +220,9 @@ def test_sds_train_step_matches_reference_golden(golden):
         return e.permute(0, 2, 3, 1).contiguous().half()
     guide.eps_pred = eps_pred
     real_randint = torch.randint
-    for tag in ("plain", "local", "stage_late", "stage_early", "nonfinite"):
+    # `_h` cases: the reference ran with a half-precision-I/O epsilon predictor (what its real UNet has under fp16 autocast) — the two roundings the
+    # product pipeline carries — and are held to 1e-3; the float32-epsilon cases differ from the product by cfg x half-epsilon
+    for tag in ("plain", "local", "stage_late", "stage_early", "nonfinite", "plain_h", "local_h"):
         opt.stage_time, opt.iters = bool(g[f"{tag}__stage_time"]), 1000
         state["poison"] = tag == "nonfinite"
         seen = {}
@@ -241,13 +243,15 @@ def test_sds_train_step_matches_reference_golden(golden):
         fin = np.isfinite(want)
         assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin])      # the infinities of the reference's quirk, same places
         scale = np.abs(want[fin]).max()
-        assert np.abs(got[fin] - want[fin]).max() <= 2e-2 * scale, (tag, np.abs(got[fin] - want[fin]).max(), scale)
+        tol_g, tol_l = (1e-3, 1e-3) if tag.endswith("_h") else (2e-2, 3e-2)
+        print(f"[sds golden {tag}] grad max|diff| / max = {np.abs(got[fin] - want[fin]).max() / scale:.3e}, loss rel = {abs(float(loss) / float(g[f'{tag}__loss']) - 1):.3e}")
+        assert np.abs(got[fin] - want[fin]).max() <= tol_g * scale, (tag, np.abs(got[fin] - want[fin]).max(), scale)
         if fin.all():
-            np.testing.assert_allclose(float(loss), float(g[f"{tag}__loss"]), rtol=3e-2)
+            np.testing.assert_allclose(float(loss), float(g[f"{tag}__loss"]), rtol=tol_l)
     assert lat.grad[0, 0, 0, 0] == 0                                      # NaN -> 0
 
 
-@pytest.mark.parametrize("tag", ["g_only", "l_only"])
+@pytest.mark.parametrize("tag", ["g_only", "l_only", "g_only_h", "l_only_h"])
 def test_editing_step_matches_reference_golden(golden, tag):
     """EditTrainer.train_step_editing (fused render kernels, get_pt cache, global / local SDS term through cnerf_sd_add_noise / cnerf_sd_sds_grad,
     keep_bg L1) replaying the reference's own Trainer_Nerf.train_step_editing (nerf/utils_init_nerf.py:243-308, 353-394; tests/golden/editing.npz):
@@ -267,7 +271,7 @@ def test_editing_step_matches_reference_golden(golden, tag):
     opt = sc.make_opt(fp16=False, num_steps=int(g["opt__num_steps"]), upsample_steps=int(g["opt__upsample_steps"]), train_conf=float(g["opt__train_conf"]),
                       conf_thr=float(g["opt__conf_thr"]), min_near=float(g["opt__min_near"]), lambda_sd=float(g["opt__lambda_sd"]),
                       keep_bg=float(g["opt__keep_bg"]), local_t_ratio=float(g["opt__local_t_ratio"]), cfg=float(g["opt__cfg"]), log_loss_item=False,
-                      g_only=tag == "g_only", l_only=tag == "l_only")
+                      g_only=tag.startswith("g_only"), l_only=tag.startswith("l_only"))
 
     class ToyParam(NeRFRenderer):
         def __init__(self, opt, theta):
@@ -294,14 +298,19 @@ def test_editing_step_matches_reference_golden(golden, tag):
     tr.text_z, tr.text_z_fg, tr.clip_view, tr.fp16, tr.pt_dict = T(g["text_z"]), T(g["text_z_fg"]), False, False, {}
     tr._rng, tr.sds_resolution, tr.global_step = _np.random.RandomState(0), 512, 0
     tr._render_kw = {k: v for k, v in vars(opt).items() if k != 'bg_color'}
-    tr.replay = dict(branch="global" if tag == "g_only" else "local", t=int(g[f"{tag}__t_draw"][0]), noise=T(g[f"{tag}__noise"]))
+    tr.replay = dict(branch="global" if tag.startswith("g_only") else "local", t=int(g[f"{tag}__t_draw"][0]), noise=T(g[f"{tag}__noise"]))
     pred_rgb, pred_ws, loss, ld = tr.train_step_editing((T(g["rgbs"]), T(g["mask"]), T(g["rays_o"]), T(g["rays_d"]), H, W, "view2"))
     loss.backward()
-    np.testing.assert_allclose(pred_rgb.detach().cpu().numpy(), g[f"{tag}__pred_rgb"], rtol=0, atol=2e-4)
-    np.testing.assert_allclose(pred_ws.detach().cpu().numpy(), g[f"{tag}__pred_ws"], rtol=0, atol=2e-4)
-    np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=2e-3)
-    np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=5e-2)         # float16 UNet input / output, cfg = 100
-    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=5e-3)
     want = g[f"{tag}__grad_theta"]
-    assert np.abs(model.theta.grad.cpu().numpy() - want).max() <= 3e-2 * np.abs(want).max(), (model.theta.grad.cpu().numpy(), want)
+    gerr = np.abs(model.theta.grad.cpu().numpy() - want).max() / np.abs(want).max()
+    print(f"[editing golden {tag}] pred_rgb max|diff| {np.abs(pred_rgb.detach().cpu().numpy() - g[f'{tag}__pred_rgb']).max():.3e}, "
+          f"pred_ws {np.abs(pred_ws.detach().cpu().numpy() - g[f'{tag}__pred_ws']).max():.3e}, loss_bg rel {abs(float(ld['loss_bg']) / float(g[f'{tag}__loss_bg']) - 1):.3e}, "
+          f"loss_sds rel {abs(float(ld['loss_sds']) / float(g[f'{tag}__loss_sds']) - 1):.3e}, grad_theta {gerr:.3e}")
+    half_io = tag.endswith("_h")      # the reference ran with a half-precision-I/O epsilon predictor (its real UNet's I/O under fp16 autocast): the product's own roundings
+    np.testing.assert_allclose(pred_rgb.detach().cpu().numpy(), g[f"{tag}__pred_rgb"], rtol=0, atol=1e-4)       # north_star: 1e-4 fp32
+    np.testing.assert_allclose(pred_ws.detach().cpu().numpy(), g[f"{tag}__pred_ws"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=2e-3)
+    np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=1e-3 if half_io else 5e-2)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-3 if half_io else 5e-3)
+    assert gerr <= (1e-3 if half_io else 3e-2), (model.theta.grad.cpu().numpy(), want)
     assert pre.theta.grad is None                                         # the cached pretrained render carries no graph here

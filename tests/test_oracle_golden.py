@@ -274,13 +274,15 @@ def test_pretrain_step_against_reference(golden):
     import torch.nn.functional as F
     g = golden("editing")
     aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2])
-    for tag in ("conf", "conf2"):
+    for tag in ("conf", "conf2", "batch"):                       # "batch": --batch_rays subsampling (:210-215) with the recorded index draw
         theta = T(g["theta_edit"]).clone().requires_grad_(True)
         draws = dict(light=T(g[f"pre_{tag}__light"]), z=T(g[f"pre_{tag}__z"]), u=T(g[f"pre_{tag}__u"]))
-        out = to.run(ToyField(theta), T(g["rays_o"]), T(g["rays_d"]), aabb, float(g["opt__min_near"]), num_steps=int(g["opt__num_steps"]),
+        sel = torch.from_numpy(g[f"pre_{tag}__select_inds"]) if int(g[f"pre_{tag}__batch_rays"]) else torch.arange(T(g["rays_o"]).reshape(-1, 3).shape[0])
+        pick = lambda a, c: T(a).reshape(1, -1, c)[:, sel]
+        out = to.run(ToyField(theta), pick(g["rays_o"], 3), pick(g["rays_d"], 3), aabb, float(g["opt__min_near"]), num_steps=int(g["opt__num_steps"]),
                      upsample_steps=int(g["opt__upsample_steps"]), perturb=True, training=True, train_conf=float(g[f"pre_{tag}__train_conf"]), draws=draws)
-        loss_c = float(g[f"pre_{tag}__train_rgb"]) * F.mse_loss(out["image"].reshape(-1, 3), T(g["rgbs"]).reshape(-1, 3))
-        loss_m = float(g[f"pre_{tag}__train_conf"]) * F.mse_loss(out["render_mask"].reshape(-1), T(g["mask"]).reshape(-1))
+        loss_c = float(g[f"pre_{tag}__train_rgb"]) * F.mse_loss(out["image"].reshape(-1, 3), pick(g["rgbs"], 3).reshape(-1, 3))
+        loss_m = float(g[f"pre_{tag}__train_conf"]) * F.mse_loss(out["render_mask"].reshape(-1), pick(g["mask"], 1).reshape(-1))
         (loss_c + loss_m).backward()
         np.testing.assert_allclose(out["image"].detach().numpy(), g[f"pre_{tag}__pred_rgb"], rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(out["weights_sum"].detach().numpy().reshape(1, -1).clip(1e-5, 1 - 1e-5), g[f"pre_{tag}__mask_volume"], rtol=1e-4, atol=2e-6)
