@@ -350,6 +350,10 @@ def run_recon(args, world, rank, dev):
                                   "traffic": traffic, "traffic_source": (traffic_src + " (committed rocprofv3 --pmc passes of this command; not re-measured in this run)") if traffic_src else None,
                                   "launches": len(ms), "avg_launch_ms": tot_ms / len(ms), "points_per_launch": sum(pts) / len(pts),
                                   "algorithmic_bytes_per_point": bpp}
+            if args.path == "run" and len(ms) == 2 * args.steps:       # run(): launch 2k = the stratified coarse samples, 2k + 1 = the importance samples
+                for nm, sel in (("coarse", ms[0::2]), ("fine", ms[1::2])):
+                    a_ = sum(pts[0::2]) * bpp / (sum(sel) * 1e-3) / 1e9
+                    result["roofline"][nm] = {"avg_launch_ms": sum(sel) / len(sel), "achieved": a_, "frac": a_ / HBM_PEAK_GBS}
             if args.grid == "synthetic" and args.prefit == 0:         # the PMC pass was taken on this table in this (random-initialised) state
                 result["roofline"]["l2_fabric"] = l2_fabric(args.dtype, sum(pts) / len(pts), tot_ms / len(ms))
         if not args.no_cpu_baseline and world == 1:
@@ -524,7 +528,7 @@ def main():
             if k in r["config"]:
                 out[k] = r["config"][k]
         if "roofline" in r:
-            out["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "points_per_launch") if k in r["roofline"]}
+            out["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "points_per_launch", "coarse", "fine") if k in r["roofline"]}
         return out
 
     result = None

@@ -243,12 +243,13 @@ def test_sds_train_step_matches_reference_golden(golden):
         fin = np.isfinite(want)
         assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin])      # the infinities of the reference's quirk, same places
         scale = np.abs(want[fin]).max()
-        tol_g, tol_l = (1e-3, 1e-3) if tag.endswith("_h") else (2e-2, 3e-2)
+        tol_g, tol_l = (1e-5, 1e-5) if tag.endswith("_h") else (2e-2, 3e-3)       # measured: 7.8e-7 / 6.8e-8 (half-I/O epsilon), 7.7e-3 / 7.5e-4 (float32 epsilon)
         print(f"[sds golden {tag}] grad max|diff| / max = {np.abs(got[fin] - want[fin]).max() / scale:.3e}, loss rel = {abs(float(loss) / float(g[f'{tag}__loss']) - 1):.3e}")
         assert np.abs(got[fin] - want[fin]).max() <= tol_g * scale, (tag, np.abs(got[fin] - want[fin]).max(), scale)
         if fin.all():
             np.testing.assert_allclose(float(loss), float(g[f"{tag}__loss"]), rtol=tol_l)
-    assert lat.grad[0, 0, 0, 0] == 0                                      # NaN -> 0
+        if tag == "nonfinite":
+            assert lat.grad[0, 0, 0, 0] == 0                              # NaN -> 0
 
 
 @pytest.mark.parametrize("tag", ["g_only", "l_only", "g_only_h", "l_only_h"])
@@ -307,10 +308,11 @@ def test_editing_step_matches_reference_golden(golden, tag):
           f"pred_ws {np.abs(pred_ws.detach().cpu().numpy() - g[f'{tag}__pred_ws']).max():.3e}, loss_bg rel {abs(float(ld['loss_bg']) / float(g[f'{tag}__loss_bg']) - 1):.3e}, "
           f"loss_sds rel {abs(float(ld['loss_sds']) / float(g[f'{tag}__loss_sds']) - 1):.3e}, grad_theta {gerr:.3e}")
     half_io = tag.endswith("_h")      # the reference ran with a half-precision-I/O epsilon predictor (its real UNet's I/O under fp16 autocast): the product's own roundings
-    np.testing.assert_allclose(pred_rgb.detach().cpu().numpy(), g[f"{tag}__pred_rgb"], rtol=0, atol=1e-4)       # north_star: 1e-4 fp32
-    np.testing.assert_allclose(pred_ws.detach().cpu().numpy(), g[f"{tag}__pred_ws"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pred_rgb.detach().cpu().numpy(), g[f"{tag}__pred_rgb"], rtol=0, atol=1e-5)       # north_star asks 1e-4 fp32; measured 1.2e-7
+    np.testing.assert_allclose(pred_ws.detach().cpu().numpy(), g[f"{tag}__pred_ws"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(float(ld["loss_bg"]), float(g[f"{tag}__loss_bg"]), rtol=2e-3)
-    np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=1e-3 if half_io else 5e-2)
-    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-3 if half_io else 5e-3)
-    assert gerr <= (1e-3 if half_io else 3e-2), (model.theta.grad.cpu().numpy(), want)
+    # measured on MI355X (round 4): pred_rgb 1.2e-7, loss_sds 2e-4 / 8e-8 (float32 / half-I/O epsilon), grad_theta 4.6e-5 / 1.3e-6
+    np.testing.assert_allclose(float(ld["loss_sds"]), float(g[f"{tag}__loss_sds"]), rtol=1e-5 if half_io else 1e-3)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-5 if half_io else 1e-3)
+    assert gerr <= (1e-4 if half_io else 1e-3), (model.theta.grad.cpu().numpy(), want)
     assert pre.theta.grad is None                                         # the cached pretrained render carries no graph here

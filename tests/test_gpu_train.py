@@ -441,7 +441,7 @@ def test_recon_step_matches_reference_golden(tag):
     loss = ReconTrainer.loss(shim, out, rgbs, mask)
     loss.backward()
     print(f"[pretrain golden {tag}] image max|diff| {np.abs(out['image'].detach().cpu().numpy() - g[f'pre_{tag}__pred_rgb']).max():.3e}")
-    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), g[f"pre_{tag}__pred_rgb"], rtol=0, atol=1e-4)      # north_star: 1e-4 fp32
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), g[f"pre_{tag}__pred_rgb"], rtol=0, atol=1e-5)      # north_star asks 1e-4 fp32; measured 1.5e-7
     np.testing.assert_allclose(float(loss.detach()), float(g[f"pre_{tag}__loss"]), rtol=2e-4)
     want = g[f"pre_{tag}__grad_theta"]
     assert np.abs(model.theta.grad.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max(), (model.theta.grad.cpu().numpy(), want)
