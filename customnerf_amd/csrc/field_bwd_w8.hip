@@ -1,19 +1,21 @@
-// Fused field backward for gfx950 (fp16, enc_pad == 32), round 4: k_field_bwd_w8 — TWO waves per SIMD.
+// Fused field backward for gfx950 (fp16, enc_pad == 32), round 4: k_field_bwd_w8 — TWO busy waves per SIMD.
 //
 // Why a new kernel: k_field_bwd_x2 (field_bwd_x2.hip) keeps the 24 persistent 32x32 weight-gradient tiles of a wave pair in the registers of
 // the two waves that also run the MLP chains — 246 VGPRs + 256 AGPRs per lane, ONE wave per SIMD, and a lone wave issues 43 % of the time
-// (profiles/r03_field_bwd_pmc.txt: vector ALU 31 %, matrix pipe 29 %, LDS 13 %, nothing overlapping).  Here the work of a tile pipeline is
-// split over FOUR waves so that every wave stays below 256 registers and two of them share each SIMD:
+// (profiles/r03_field_bwd_pmc.txt: vector ALU 31 %, matrix pipe 29 %, LDS 13 %, nothing overlapping).  Here a tile stream is a four-stage
+// pipeline over FOUR waves, every one below 256 registers, two per SIMD, each carrying a comparable share of chain AND weight-gradient work:
 //
-//   A   geometry chain   forward of tile i in phase i, backward (dz_3 -> dz_1, d/d(grid features)) of tile i in phase i + 2      40 MFMA 16x16x32
-//   B   both heads       forward + backward of tile i in phase i + 1                                                             48 MFMA 16x16x32
-//   A'  weight gradients of the geometry layers (tile i in phase i + 3) and of the density output layer (tile i in phase i + 2)  12 MFMA 32x32x16
-//   B'  weight gradients of the colour head and of the density hidden layer (tile i in phase i + 2)                              12 MFMA 32x32x16
+//   Af  geometry forward   tile i in phase i       n0, n1, n2                                   20 MFMA 16x16x32
+//   Bf  heads forward      tile i in phase i + 1   d0 | r0, dO | rO, output-layer gradients      24 MFMA 16x16x32 + dW_rO, dW_dO      (4 MFMA 32x32x16)
+//   Bb  heads backward     tile i in phase i + 2   dO^T | rO^T, d0^T + r0^T -> dz_3              24 MFMA 16x16x32 + dW_r0, dW_d0     (10 MFMA 32x32x16)
+//   Ab  geometry backward  tile i in phase i + 3   n2^T, n1^T, n0^T -> d/d(grid features)        20 MFMA 16x16x32 + dW_n2, dW_n1, dW_n0 (10)
 //
-// The chain waves carry no accumulators (MFMA results land in VGPRs: no v_accvgpr_read), the shadow waves carry twelve 32x32 tiles each
-// (192 registers) and nothing else but operand fragments.  Shadows lag their chain by one phase, so everything they read is double
-// buffered in LDS — which is what fixes the tile at SIXTEEN samples: the images of a 32-sample tile, double buffered for two pipelines,
-// do not fit beside the weights (184 KiB); at 16 samples they take 104 KiB + 44 KiB of weight fragments.  Chains therefore run on
+// (The first version of this file had two chain waves and two "shadow" waves that only accumulated weight gradients: correct, but the
+// shadows issued 50 instructions per phase against 340 of a chain wave — still one busy wave per SIMD, 470 us against the 450 us of
+// k_field_bwd_x2.)  Every wave's weight-gradient operands are images it published itself in the same phase (DS operations of one wave
+// execute in order: no barrier, single buffer) or images an earlier stage published in an earlier phase (ring buffers below, one
+// workgroup barrier per phase).  The tile is SIXTEEN samples: the images of a 32-sample tile with these lifetimes, for two streams, do
+// not fit beside the weights; at 16 samples they take 104 KiB + 44 KiB of weight fragments.  Chains therefore run on
 // v_mfma_f32_16x16x32_f16 (16 outputs x 16 samples x 32 inputs), the weight gradients on v_mfma_f32_32x32x16_f16 with the 16 samples of a
 // tile on the contraction index: one MFMA per 32x32 tile of dW per sample tile.
 //
@@ -26,9 +28,18 @@
 //   W^T          (backward chain) fragments are transposing reads (ds_read_b64_tr_b16) of the forward fragment store: four consecutive
 //                output rows sit 16 bytes apart in one (m, s) block, the sixteen input features of a 16-lane group in four 8-byte chunks.
 //   images       [K-step][g][n] 16-byte slots = the B fragments as the chain holds them, the slot's bits 6..7 XORed with g (conflict-free
-//                transposing reads); a shadow wave reads "feature slot f = 8 g + j" of 8 consecutive samples with two transposing reads.
+//                transposing reads); a weight-gradient operand = "feature slot f = 8 g + j" of 8 consecutive samples, two transposing reads.
+//
+// OUTCOME (round 4, profiles/r04_field_bwd_w8.txt): bit-for-bit deterministic, parity green (tests/test_gpu_field.py with the kernel switched on),
+// 1.78-1.91 waves per SIMD by SQ_WAVE_CYCLES, no scratch, 256 VGPRs / 0 AGPRs — and 430 us per 2.1 M samples standalone against 450 us of
+// k_field_bwd_x2, 2.17 against 2.15 ms per training step in place: NOT faster.  The 16-sample tile doubles the LDS instruction count per
+// sample (one weight fragment per MFMA, two 8-byte transposing reads per W^T fragment — 8-byte reads from one or two waves per SIMD reach a
+// fraction of the LDS rate), the LDS is busy 45 % of the time with 24 % of that in bank conflicts, and every stage is still a chain of
+// dependent LDS round trips: three of the four waves take ~3 k cycles per 16-sample phase for ~220 instructions each.  The release library
+// therefore keeps k_field_bwd_x2; this kernel is compiled into tuning builds only (make TUNING=1, CNERF_FIELD_W8_BWD=1).
 #include "field_bwd_common.h"
 
+#ifdef CNERF_TUNING
 typedef float w8_f4 __attribute__((ext_vector_type(4)));
 typedef short w8_s4 __attribute__((__vector_size__(4 * sizeof(short))));
 
@@ -46,27 +57,29 @@ typedef short w8_s4 __attribute__((__vector_size__(4 * sizeof(short))));
 #define W8_W_RO (W8_W_R0 + 12 * 512)
 #define W8_W_END (W8_W_RO + 2 * 512)               // 22528 halves = 44 KiB
 
-// per-pipeline LDS (bytes, dynamic)
-#define W8_FEA 0                                   // 3 x 2 KiB  A -> B (phase +1), B' (phase +2)
-#define W8_Z3 (W8_FEA + 3 * 2 * W8_K)              // 3 x 2 KiB  B -> A (phase +1), A' (phase +2)
-#define W8_AIMG (W8_Z3 + 3 * 2 * W8_K)             // 2 x 9 KiB  x0 1, h1 2, h2 2, z2 2, z1 2
-#define W8_A_X0 0
-#define W8_A_H1 (1 * W8_K)
-#define W8_A_H2 (3 * W8_K)
-#define W8_A_Z2 (5 * W8_K)
-#define W8_A_Z1 (7 * W8_K)
-#define W8_A_BYTES (9 * W8_K)
-#define W8_BIMG (W8_AIMG + 2 * W8_A_BYTES)         // 2 x 11 KiB  dir 1, hd 2, hr 2, zr 2, zd 2, bro 1, bdo 1
-#define W8_B_DIR 0
-#define W8_B_HD (1 * W8_K)
-#define W8_B_HR (3 * W8_K)
-#define W8_B_ZR (5 * W8_K)
-#define W8_B_ZD (7 * W8_K)
-#define W8_B_BRO (9 * W8_K)
-#define W8_B_BDO (10 * W8_K)
-#define W8_B_BYTES (11 * W8_K)
-#define W8_SCR (W8_BIMG + 2 * W8_B_BYTES)          // 256 B: direction-feature scratch of wave B
-#define W8_PIPE_BYTES (W8_SCR + 256)               // 53 504 B per pipeline
+// per-stream LDS (bytes, dynamic).  Ring depths follow the lifetimes: written in phase w, last read in phase r -> r - w + 1 buffers.
+#define W8_AF 0                                    // 4 x 5 KiB  x0 1, h1 2, h2 2: Af (phase i) -> Ab (phase i + 3)
+#define W8_AF_X0 0
+#define W8_AF_H1 (1 * W8_K)
+#define W8_AF_H2 (3 * W8_K)
+#define W8_AF_BYTES (5 * W8_K)
+#define W8_FEA (W8_AF + 4 * W8_AF_BYTES)           // 3 x 2 KiB  Af (i) -> Bf (i + 1), Bb's dW (i + 2)
+#define W8_BF (W8_FEA + 3 * 2 * W8_K)              // 2 x 7 KiB  dir 1, hd 2, hr 2, bro 1, bdo 1: Bf (i + 1) -> Bb (i + 2)
+#define W8_BF_DIR 0
+#define W8_BF_HD (1 * W8_K)
+#define W8_BF_HR (3 * W8_K)
+#define W8_BF_BRO (5 * W8_K)
+#define W8_BF_BDO (6 * W8_K)
+#define W8_BF_BYTES (7 * W8_K)
+#define W8_Z3 (W8_BF + 2 * W8_BF_BYTES)            // 2 x 2 KiB  Bb (i + 2) -> Ab (i + 3)
+#define W8_BB (W8_Z3 + 2 * 2 * W8_K)               // 4 KiB      zr 2, zd 2: private to Bb
+#define W8_BB_ZR 0
+#define W8_BB_ZD (2 * W8_K)
+#define W8_AB (W8_BB + 4 * W8_K)                   // 4 KiB      z2 2, z1 2: private to Ab
+#define W8_AB_Z2 0
+#define W8_AB_Z1 (2 * W8_K)
+#define W8_SCR (W8_AB + 4 * W8_K)                  // 256 B: direction-feature scratch of Bf
+#define W8_PIPE_BYTES (W8_SCR + 256)               // 53 504 B per stream
 
 struct W8Off {
     uint32_t n0, n1, n2, d0, dO, r0, rO, total;
@@ -244,6 +257,15 @@ __device__ __forceinline__ W8Op w8_lane_off_op(uint32_t l) {
     return o;
 }
 __device__ __forceinline__ cn_h8 w8_op(const unsigned char *img, W8Op lo, int u) { return w8_pack(w8_tr(img + u * W8_K + lo.c0), w8_tr(img + u * W8_K + lo.c1)); }
+// the gradient-side operand of a tile outside the stream's range is forced to zero with a wave-uniform select: control flow around the
+// accumulating MFMAs makes the compiler copy the accumulator tiles (160 v_mov per phase)
+__device__ __forceinline__ cn_h8 w8_op_if(bool on, const unsigned char *img, W8Op lo, int u) {
+    union { cn_h8 h; uint32_t w[4]; } f;
+    f.h = w8_op(img, lo, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) f.w[k] = on ? f.w[k] : 0u;
+    return f.h;
+}
 
 __device__ __forceinline__ void w8_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // measurement aid (CNERF_W8_ABLATE bit 5, tuning builds): per wave, cycles spent working / waiting at the phase barrier
@@ -299,18 +321,22 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
     w8_stage_layer<1>(w8_w + W8_W_DO, dO, 16, FLD_HID, 1, 2, FLD_HID);
     w8_stage_layer<2>(w8_w + W8_W_R0, r0, FLD_HID, in_r0, 4, 3, in_r0);
     w8_stage_layer<1>(w8_w + W8_W_RO, rO, 16, FLD_HID, 1, 2, FLD_HID);
+    // the image rings start out as zeros: stages that run ahead of / behind the stream's range read rings nobody has written yet, and although
+    // their gradient-side operands are forced to zero, 0 x (uninitialised NaN pattern) would still poison an accumulator
+    for (uint32_t i = threadIdx.x; i < 2 * W8_PIPE_BYTES / 16; i += W8_THREADS) reinterpret_cast<uint4 *>(w8_lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // waves w and w + 4 share a SIMD (dispatch order 0 -> 2 -> 1 -> 3): a chain and its shadow sit side by side
-    const uint32_t pipe = (wave >> 1) & 1, shadow = wave >> 2, isB = wave & 1;
+    // waves w and w + 4 share a SIMD (dispatch order 0 -> 2 -> 1 -> 3): the short forward stages sit beside the long backward ones
+    const uint32_t pipe = (wave >> 1) & 1;
+    const uint32_t role = wave < 4 ? (wave & 1) : 3 - (wave & 1);                  // 0 Af, 1 Bf, 2 Bb, 3 Ab: (Af, Ab) and (Bf, Bb) share a SIMD
     unsigned char *px = w8_lds + pipe * W8_PIPE_BYTES;
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(w8_w);
     const uint32_t n_tiles = (P_ + W8_TILE - 1) / W8_TILE;
     const uint32_t G = gridDim.x * 2, gp = blockIdx.x * 2 + pipe;
     const uint32_t n_iter = (n_tiles + G - 1) / G;                                 // workgroup-uniform
-    const uint32_t n_phase = (n_iter + 3 + 1) & ~1u;                               // n_iter + 3 phases drain the pipeline; even: unrolled by two
+    const uint32_t n_phase = n_iter + 3;                                           // tile i leaves the pipeline in phase i + 3
     float *part = partials + (size_t)gp * po.total;
     const uint32_t lane16 = (lane * 16) ^ ((g >> 1) << 7), slot = w8_slot(lane);       // forward fragment slot of this lane (swizzled: w8_stage_layer)
     const uint32_t i16 = lane & 15, tq = i16 & 3, trow = (4 * g + (i16 >> 2)) * 16;
@@ -319,19 +345,11 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
     const uint32_t lane_off_Tn1 = (tq >> 1) * 256 + (trow ^ 128u) + 8 * (tq & 1);                              // mp = 1: g_f = 2 + (q >> 1)
     const W8Op lop = w8_lane_off_op(lane);
     [[maybe_unused]] unsigned long long tw_ = 0, tb_ = 0;
+    // Tiles outside [0, n_iter) are computed on clamped inputs and ignored by every consumer: the chains are straight-line code, only the
+    // accumulations and the global stores test the tile index.
 
-    if (!shadow && !isB) {
-        // ======================================================================== wave A: geometry chain
-        // One straight-line block per phase: the backward of tile p - 2 and the forward of tile p are independent chains and run side by side,
-        // stage by stage (n2^T | n0, n1^T | n1, n0^T | n2); the weight fragments of stage k + 1 are requested before the MFMAs of stage k
-        // issue.  Tiles outside the pipeline's range are computed on clamped inputs and ignored by every consumer (stores and shadows test the
-        // tile index), so there are no branches around the chains.
-        struct ASet { cn_h8 x0[1], h1[2], h2[2]; uint32_t p; bool v; };
-        ASet S0, S1;
-        S0.x0[0] = S1.x0[0] = Prec<true>::zero();
-#pragma unroll
-        for (int s = 0; s < 2; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = Prec<true>::zero();
-        S0.p = S1.p = 0; S0.v = S1.v = false;
+    if (role == 0) {
+        // ======================================================================== Af: geometry forward of tile p
         auto enc_request = [&](uint32_t tile, uint32_t (&raw)[4]) __attribute__((always_inline)) {
             const uint32_t *e = reinterpret_cast<const uint32_t *>(enc) + min(tile * W8_TILE + n, P_ - 1);
 #pragma unroll
@@ -342,106 +360,59 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) N1[jj] = 0;
         const unsigned char *w_n0 = wb + 2 * W8_W_N0, *w_n1 = wb + 2 * W8_W_N1, *w_n2 = wb + 2 * W8_W_N2;
-        auto phase = [&](uint32_t p, ASet &S, uint32_t (&xcur)[4], uint32_t (&xnext)[4]) __attribute__((always_inline)) {
+        auto phase = [&](uint32_t p, uint32_t (&xcur)[4], uint32_t (&xnext)[4]) __attribute__((always_inline)) {
             W8_T0();
             asm volatile("" ::: "memory");
             enc_request(gp + (p + 1) * G, xnext);
-            const uint32_t ib = p + 1;                                              // == p - 2 (mod 3) and (mod 2 it is p & 1): buffer indices of the backward tile
-            unsigned char *my = px + W8_AIMG + (p & 1) * W8_A_BYTES;
-            const bool bwd_on = p >= 2 && p - 2 < n_iter;
-            // ---- stage 0: operands of both chains, weight fragments of stage 1
-            cn_h8 z3[2];
-            w8_fetch<2>(px + W8_Z3 + (ib % 3) * 2 * W8_K, slot, z3);
-            cn_h8 wT[16], wF[8];
-            w8_load_T<4, 2, 2>(w_n2, lane_off_T, wT);
-            w8_load_F<4, 1, 1>(w_n0, lane16, wF);
-            w8_publish<1>(my + W8_A_X0, slot, S.x0);
-            w8_publish<2>(my + W8_A_H1, slot, S.h1);
-            if (NGEO == 2) w8_publish<2>(my + W8_A_H2, slot, S.h2);
-            const uint32_t tile = gp + p * G;
-            const uint32_t np = tile * W8_TILE + n;
-            const bool nv = p < n_iter && np < P_;
-            cn_h8 x0n[1], h1n[2], h2n[2] = {Prec<true>::zero(), Prec<true>::zero()};
+            unsigned char *my = px + W8_AF + (p & 3) * W8_AF_BYTES;
+            const bool nv = p < n_iter && (gp + p * G) * W8_TILE + n < P_;
+            cn_h8 wa[4], wb1[8], wb2[8];
+            w8_load_F<4, 1, 1>(w_n0, lane16, wa);
+            if (NGEO == 2) w8_load_F<4, 2, 2>(w_n1, lane16, wb1);
+            cn_h8 x0[1], h1[2], h2[2];
             {
                 union { cn_h8 h; uint32_t u[4]; } f;
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) f.u[jj] = (nv && (4 * g + jj) < dm.L) ? xcur[jj] : 0u;
-                x0n[0] = f.h;
+                x0[0] = f.h;
             }
+            w8_publish<1>(my + W8_AF_X0, slot, x0);
+            w8_f4 acc[4];
+            w8_zero(acc);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 1: n2^T dz3 | n0 x0
-            w8_f4 accb[4], accf[4];
-            w8_zero(accb); w8_zero(accf);
-            cn_h8 wT2[16], wF2[8];
+            w8_mm<4, 1>(wa, x0, acc);
+            w8_load_F<4, 2, 2>(w_n2, lane16, wb2);
+            __builtin_amdgcn_sched_barrier(0);
+            w8_c_to_b<1>(acc, nullptr, h1);
+            w8_publish<2>(my + W8_AF_H1, slot, h1);
             if (NGEO == 2) {
-                w8_load_T<4, 2, 2>(w_n1, lane_off_T, wT2);
-                w8_load_F<4, 2, 2>(w_n1, lane16, wF2);
-            } else {
-                w8_load_F<4, 2, 2>(w_n2, lane16, wF2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            w8_mm<4, 2>(wT, z3, accb);
-            w8_mm<4, 1>(wF, x0n, accf);
-            __builtin_amdgcn_sched_barrier(0);
-            cn_h8 z1[2];
-            cn_h8 wT3[8], wF3[8];
-            if (NGEO == 2) {
-                // ---- stage 2: n1^T dz2 | n1 h1
-                cn_h8 z2[2];
-                w8_c_to_b<2>(accb, S.h2, z2);
-                w8_c_to_b<1>(accf, nullptr, h1n);
-                w8_publish<2>(my + W8_A_Z2, slot, z2);
-                w8_load_Tn<2, 2>(w_n0, lane_off_Tn0, lane_off_Tn1, wT3);
-                w8_load_F<4, 2, 2>(w_n2, lane16, wF3);
-                w8_zero(accb); w8_zero(accf);
+                w8_zero(acc);
                 __builtin_amdgcn_sched_barrier(0);
-                w8_mm<4, 2>(wT2, z2, accb);
-                w8_mm<4, 2>(wF2, h1n, accf);
+                w8_mm<4, 2>(wb1, h1, acc);
                 __builtin_amdgcn_sched_barrier(0);
-                w8_c_to_b<2>(accb, S.h1, z1);
-                w8_c_to_b<1>(accf, nullptr, h2n);
-            } else {
-                w8_c_to_b<2>(accb, S.h1, z1);
-                w8_c_to_b<1>(accf, nullptr, h1n);
-                w8_load_Tn<2, 2>(w_n0, lane_off_Tn0, lane_off_Tn1, wT3);
-#pragma unroll
-                for (int k = 0; k < 8; k++) wF3[k] = wF2[k];
+                w8_c_to_b<1>(acc, nullptr, h2);
+                w8_publish<2>(my + W8_AF_H2, slot, h2);
             }
-            // ---- stage 3: n0^T dz1 | n2 h_last
-            w8_publish<2>(my + W8_A_Z1, slot, z1);
-            w8_f4 denc[2];
-            w8_zero(denc); w8_zero(accf);
+            w8_zero(acc);
             __builtin_amdgcn_sched_barrier(0);
-            w8_mm<2, 2>(wT3, z1, denc);
-            w8_mm<4, 2>(wF3, (NGEO == 2) ? h2n : h1n, accf);
+            w8_mm<4, 2>(wb2, (NGEO == 2) ? h2 : h1, acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (bwd_on && S.v) {
-#pragma unroll
-                for (int mp = 0; mp < 2; mp++) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const uint32_t level = 8 * mp + 2 * g + h;
-                        if (level < dm.L) reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + S.p] = w8_cvt_pk(denc[mp][2 * h], denc[mp][2 * h + 1]);
-                    }
-                }
-            }
             cn_h8 fea[2];
-            w8_c_to_b<0>(accf, nullptr, fea);
+            w8_c_to_b<0>(acc, nullptr, fea);
             w8_publish<2>(px + W8_FEA + (p % 3) * 2 * W8_K, slot, fea);
-            S.x0[0] = x0n[0];
-#pragma unroll
-            for (int s = 0; s < 2; s++) { S.h1[s] = h1n[s]; S.h2[s] = h2n[s]; }
-            S.p = np; S.v = nv;
             W8_T1();
         };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, S0, N0, N1);
-            phase(p + 1, S1, N1, N0);
+        uint32_t p = 0;
+        for (; p + 1 < n_phase; p += 2) {
+            phase(p, N0, N1);
+            phase(p + 1, N1, N0);
         }
-    } else if (!shadow && isB) {
-        // ======================================================================== wave B: density and colour heads (tile p - 1 in phase p)
-        // The two heads are independent between fea and dfea: their layers run side by side (d0 | r0, dO | rO, dO^T | rO^T, d0^T | r0^T), the
-        // weight fragments of the next stage in flight under the MFMAs of the current one.
+        if (p < n_phase) phase(p, N0, N1);
+    } else if (role == 1) {
+        // ======================================================================== Bf: heads forward of tile p - 1, output-layer gradients, dW_rO, dW_dO
+        cn_f16v wro[2], wdo[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) { w8_zero16(wro[a]); w8_zero16(wdo[a]); }
         struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; };
         auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
             BIn r;
@@ -461,13 +432,13 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             W8_T0();
             asm volatile("" ::: "memory");
             if (p >= 1) nxt = load_in(gp + p * G);
-            const uint32_t ib = p + 2;                                              // == p - 1 (mod 3); (p + 1) & 1 == (p - 1) & 1
-            const uint32_t tile = gp + (p - 1) * G;                                 // (wraps at p == 0: such a tile is outside the range and ignored)
-            const bool valid = p >= 1 && p - 1 < n_iter && tile * W8_TILE + n < P_;
-            unsigned char *my = px + W8_BIMG + ((p + 1) & 1) * W8_B_BYTES;
+            const uint32_t tile = gp + (p - 1) * G;                                 // (wraps at p == 0: outside the range, ignored)
+            const bool on_tile = p >= 1 && p - 1 < n_iter;
+            const bool valid = on_tile && tile * W8_TILE + n < P_;
+            unsigned char *my = px + W8_BF + ((p + 1) & 1) * W8_BF_BYTES;
             // ---- stage 0: fea, direction features, fragments of d0 / r0
             cn_h8 x3[3];                                                            // [fea K-step 0, fea K-step 1, direction features]
-            w8_fetch<2>(px + W8_FEA + (ib % 3) * 2 * W8_K, slot, x3);
+            w8_fetch<2>(px + W8_FEA + ((p + 2) % 3) * 2 * W8_K, slot, x3);
             cn_h8 wd[8], wr[12];
             w8_load_F<4, 2, 2>(w_d0, lane16, wd);
             w8_load_F<4, 3, 3>(w_r0, lane16, wr);
@@ -496,10 +467,10 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
                     x3[2] = f;
                 }
             }
-            w8_publish<1>(my + W8_B_DIR, slot, x3 + 2);
-            cn_h8 wdo[2], wro[2];
-            w8_load_F<1, 2, 2>(w_dO, lane16, wdo);
-            w8_load_F<1, 2, 2>(w_rO, lane16, wro);
+            w8_publish<1>(my + W8_BF_DIR, slot, x3 + 2);
+            cn_h8 wdo_f[2], wro_f[2];
+            w8_load_F<1, 2, 2>(w_dO, lane16, wdo_f);
+            w8_load_F<1, 2, 2>(w_rO, lane16, wro_f);
             __builtin_amdgcn_sched_barrier(0);
             // ---- stage 1: d0 fea | r0 [fea, dir]
             w8_f4 accd[4], accr[4];
@@ -507,26 +478,22 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             w8_mm<4, 2>(wd, x3, accd);
             w8_mm<4, 3>(wr, x3, accr);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 2: output layers; fragments of dO^T / rO^T
+            // ---- stage 2: output layers
             cn_h8 hd[2], hr[2];
             w8_c_to_b<1>(accd, nullptr, hd);
             w8_c_to_b<1>(accr, nullptr, hr);
-            w8_publish<2>(my + W8_B_HD, slot, hd);
-            w8_publish<2>(my + W8_B_HR, slot, hr);
-            cn_h8 wdoT[4], wroT[4];
-            w8_load_T16<4, 2>(w_dO, lane_off_T, wdoT);
-            w8_load_T16<4, 2>(w_rO, lane_off_T, wroT);
+            w8_publish<2>(my + W8_BF_HD, slot, hd);
+            w8_publish<2>(my + W8_BF_HR, slot, hr);
             w8_f4 outd[1], outr[1];
             w8_zero(outd); w8_zero(outr);
             __builtin_amdgcn_sched_barrier(0);
-            w8_mm<1, 2>(wdo, hd, outd);
-            w8_mm<1, 2>(wro, hr, outr);
+            w8_mm<1, 2>(wdo_f, hd, outd);
+            w8_mm<1, 2>(wro_f, hr, outr);
+            // the activation operands of this wave's weight gradients: its own images, read back transposed (in-order DS: no barrier)
+            const cn_h8 ahd0 = w8_op(my + W8_BF_HD, lop, 0), ahd1 = w8_op(my + W8_BF_HD, lop, 1);
+            const cn_h8 ahr0 = w8_op(my + W8_BF_HR, lop, 0), ahr1 = w8_op(my + W8_BF_HR, lop, 1);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 3: output-layer gradients (sigmoid', clamped exp': provider_utils.py:26-29): rows 0..3 live in the g == 0 lanes;
-            // fragments of d0^T / r0^T (fea columns)
-            cn_h8 wdT[16], wrT[16];
-            w8_load_T<4, 2, 2>(w_d0, lane_off_T, wdT);
-            w8_load_T<4, 2, 3>(w_r0, lane_off_T, wrT);
+            // ---- stage 3: output-layer gradients (sigmoid', clamped exp': provider_utils.py:26-29): rows 0..3 live in the g == 0 lanes
             cn_h8 bro = Prec<true>::zero(), bdo = Prec<true>::zero();
             {
                 const float raw = (float)(_Float16)outd[0][0];
@@ -541,122 +508,104 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
                     bro[k] = (_Float16)((on && k < (int)dm.n_rgb_out) ? gcv[k] * sg * (1.0f - sg) : 0.0f);
                 }
             }
-            w8_publish<1>(my + W8_B_BRO, slot, &bro);
-            w8_publish<1>(my + W8_B_BDO, slot, &bdo);
-            w8_zero(accd); w8_zero(accr);
-            __builtin_amdgcn_sched_barrier(0);
-            w8_mm<4, 1>(wdoT, &bdo, accd);
-            w8_mm<4, 1>(wroT, &bro, accr);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 4: d(fea) = d0^T dz_d + r0^T dz_r
-            cn_h8 zd[2], zr[2];
-            w8_c_to_b<2>(accd, hd, zd);
-            w8_c_to_b<2>(accr, hr, zr);
-            w8_publish<2>(my + W8_B_ZD, slot, zd);
-            w8_publish<2>(my + W8_B_ZR, slot, zr);
-            w8_f4 dfea[4];
-            w8_zero(dfea);
-            __builtin_amdgcn_sched_barrier(0);
-            w8_mm<4, 2>(wdT, zd, dfea);
-            w8_mm<4, 2>(wrT, zr, dfea);
-            __builtin_amdgcn_sched_barrier(0);
-            cn_h8 z3[2];
-            w8_c_to_b<0>(dfea, nullptr, z3);
-            w8_publish<2>(px + W8_Z3 + (ib % 3) * 2 * W8_K, slot, z3);
+            w8_publish<1>(my + W8_BF_BRO, slot, &bro);
+            w8_publish<1>(my + W8_BF_BDO, slot, &bdo);
+            {
+                const cn_h8 zro = w8_op_if(on_tile, my + W8_BF_BRO, lop, 0), zdo = w8_op_if(on_tile, my + W8_BF_BDO, lop, 0);
+                wro[0] = w8_mfma32(zro, ahr0, wro[0]); wro[1] = w8_mfma32(zro, ahr1, wro[1]);
+                wdo[0] = w8_mfma32(zdo, ahd0, wdo[0]); wdo[1] = w8_mfma32(zdo, ahd1, wdo[1]);
+            }
             W8_T1();
         };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
+        uint32_t p = 0;
+        for (; p + 1 < n_phase; p += 2) {
             phase(p, I1, I0);
             phase(p + 1, I0, I1);
         }
-    } else if (shadow && !isB) {
-        // ======================================================================== wave A': dW of the geometry layers (tile p - 3) and of the density output layer (tile p - 2)
-        cn_f16v wn2[2][2], wn1[2][2], wn0[2], wdo[2];
+        if (p < n_phase) phase(p, I1, I0);
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-            w8_zero16(wn0[a]); w8_zero16(wdo[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) { w8_zero16(wn2[a][b]); w8_zero16(wn1[a][b]); }
+        for (int b = 0; b < 2; b++) {
+            w8_store<false, true>(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, lane, wro[b]);
+            w8_store<false, true>(part, po.dO, 64, 0, 1, 64, 0, b, lane, wdo[b]);
         }
-        for (uint32_t p = 0; p < n_phase; p++) {
-            W8_T0();
-            if (p >= 3 && p - 3 < n_iter && !(ablate & 8)) {
-                const uint32_t i = p - 3;
-                const unsigned char *im = px + W8_AIMG + (i & 1) * W8_A_BYTES;
-                const unsigned char *z3i = px + W8_Z3 + (i % 3) * 2 * W8_K;
-                const unsigned char *hl = im + ((NGEO == 2) ? W8_A_H2 : W8_A_H1);
-                {
-                    const cn_h8 z0 = w8_op(z3i, lop, 0), z1 = w8_op(z3i, lop, 1), a0 = w8_op(hl, lop, 0), a1 = w8_op(hl, lop, 1);
-                    wn2[0][0] = w8_mfma32(z0, a0, wn2[0][0]); wn2[0][1] = w8_mfma32(z0, a1, wn2[0][1]);
-                    wn2[1][0] = w8_mfma32(z1, a0, wn2[1][0]); wn2[1][1] = w8_mfma32(z1, a1, wn2[1][1]);
-                }
-                if (NGEO == 2) {
-                    const cn_h8 z0 = w8_op(im + W8_A_Z2, lop, 0), z1 = w8_op(im + W8_A_Z2, lop, 1), a0 = w8_op(im + W8_A_H1, lop, 0), a1 = w8_op(im + W8_A_H1, lop, 1);
-                    wn1[0][0] = w8_mfma32(z0, a0, wn1[0][0]); wn1[0][1] = w8_mfma32(z0, a1, wn1[0][1]);
-                    wn1[1][0] = w8_mfma32(z1, a0, wn1[1][0]); wn1[1][1] = w8_mfma32(z1, a1, wn1[1][1]);
-                }
-                {
-                    const cn_h8 z0 = w8_op(im + W8_A_Z1, lop, 0), z1 = w8_op(im + W8_A_Z1, lop, 1), a0 = w8_op(im + W8_A_X0, lop, 0);
-                    wn0[0] = w8_mfma32(z0, a0, wn0[0]); wn0[1] = w8_mfma32(z1, a0, wn0[1]);
-                }
-            }
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 8)) {
-                const uint32_t i = p - 2;
-                const unsigned char *im = px + W8_BIMG + (i & 1) * W8_B_BYTES;
-                const cn_h8 zo = w8_op(im + W8_B_BDO, lop, 0), a0 = w8_op(im + W8_B_HD, lop, 0), a1 = w8_op(im + W8_B_HD, lop, 1);
-                wdo[0] = w8_mfma32(zo, a0, wdo[0]); wdo[1] = w8_mfma32(zo, a1, wdo[1]);
-            }
-            W8_T1();
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            w8_store<true, false>(part, po.n0, dm.enc_pad, 0, 64, dm.enc_pad, a, 0, lane, wn0[a]);
-            w8_store<false, true>(part, po.dO, 64, 0, 1, 64, 0, a, lane, wdo[a]);
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                w8_store<true, true>(part, po.n2, 64, 0, 64, 64, a, b, lane, wn2[a][b]);
-                if (NGEO == 2) w8_store<true, true>(part, po.n1, 64, 0, 64, 64, a, b, lane, wn1[a][b]);
-            }
-        }
-        // the padding rows of the density output layer (the partial row is summed entry by entry: it is written in full, never zero-filled)
+        // the padding rows of the two output layers (the partial row is summed entry by entry: it is written in full, never zero-filled)
+        for (uint32_t i = dm.n_rgb_out * 64 + lane; i < 16 * 64; i += 64) part[po.rO + i] = 0.0f;
         for (uint32_t i = 64 + lane; i < 16 * 64; i += 64) part[po.dO + i] = 0.0f;
-    } else {
-        // ======================================================================== wave B': dW of the colour head and of the density hidden layer (tile p - 2)
-        cn_f16v wro[2], wrd[2], wrf[2][2], wd0[2][2];
+    } else if (role == 2) {
+        // ======================================================================== Bb: heads backward of tile p - 2, dW_r0, dW_d0
+        cn_f16v wrd[2], wrf[2][2], wd0[2][2];
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            w8_zero16(wro[a]); w8_zero16(wrd[a]);
+            w8_zero16(wrd[a]);
 #pragma unroll
             for (int b = 0; b < 2; b++) { w8_zero16(wrf[a][b]); w8_zero16(wd0[a][b]); }
         }
+        const unsigned char *w_d0 = wb + 2 * W8_W_D0, *w_dO = wb + 2 * W8_W_DO, *w_r0 = wb + 2 * W8_W_R0, *w_rO = wb + 2 * W8_W_RO;
+        unsigned char *mine = px + W8_BB;
         for (uint32_t p = 0; p < n_phase; p++) {
             W8_T0();
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 16)) {
-                const uint32_t i = p - 2;
-                const unsigned char *im = px + W8_BIMG + (i & 1) * W8_B_BYTES;
-                const unsigned char *fe = px + W8_FEA + (i % 3) * 2 * W8_K;
-                const cn_h8 f0 = w8_op(fe, lop, 0), f1 = w8_op(fe, lop, 1);
+            asm volatile("" ::: "memory");
+            const bool on_tile = p >= 2 && p - 2 < n_iter;
+            const unsigned char *bf = px + W8_BF + (p & 1) * W8_BF_BYTES;          // (p - 2) & 1
+            const unsigned char *fe = px + W8_FEA + ((p + 1) % 3) * 2 * W8_K;      // (p - 2) mod 3
+            // ---- stage 0 / 1: dO^T dz_dO, rO^T dz_rO, masked with the forward's activations (the register budget of this wave — ten 32x32
+            // weight-gradient tiles — leaves room for one head at a time)
+            cn_h8 zd[2], zr[2];
+            {
+                cn_h8 hd[2], bdo[1], wdoT[4];
+                w8_fetch<1>(bf + W8_BF_BDO, slot, bdo);
+                w8_load_T16<4, 2>(w_dO, lane_off_T, wdoT);
+                w8_fetch<2>(bf + W8_BF_HD, slot, hd);
+                w8_f4 accd[4];
+                w8_zero(accd);
+                w8_mm<4, 1>(wdoT, bdo, accd);
+                cn_h8 hr[2], bro[1], wroT[4];
+                w8_fetch<1>(bf + W8_BF_BRO, slot, bro);
+                w8_load_T16<4, 2>(w_rO, lane_off_T, wroT);
+                w8_fetch<2>(bf + W8_BF_HR, slot, hr);
+                w8_f4 accr[4];
+                w8_zero(accr);
+                w8_mm<4, 1>(wroT, bro, accr);
+                __builtin_amdgcn_sched_barrier(0);
+                w8_c_to_b<2>(accd, hd, zd);
+                w8_publish<2>(mine + W8_BB_ZD, slot, zd);
+                w8_c_to_b<2>(accr, hr, zr);
+                w8_publish<2>(mine + W8_BB_ZR, slot, zr);
+            }
+            // ---- stage 2: d(fea) = d0^T dz_d + r0^T dz_r
+            w8_f4 dfea[4];
+            w8_zero(dfea);
+            {
+                cn_h8 wdT[8];
+                w8_load_T<4, 2, 2>(w_d0, lane_off_T, wdT);
+                __builtin_amdgcn_sched_barrier(0);
+                w8_mm<4, 2>(wdT, zd, dfea);
+            }
+            {
+                cn_h8 wrT[8];
+                w8_load_T<4, 2, 3>(w_r0, lane_off_T, wrT);
+                w8_mm<4, 2>(wrT, zr, dfea);
+            }
+            // ---- weight gradients while the chain's tail drains: dz_r x [dir | fea], dz_d x fea
+            {
+                const cn_h8 f0 = w8_op(fe, lop, 0), f1 = w8_op(fe, lop, 1), dd = w8_op(bf + W8_BF_DIR, lop, 0);
                 {
-                    const cn_h8 zo = w8_op(im + W8_B_BRO, lop, 0), a0 = w8_op(im + W8_B_HR, lop, 0), a1 = w8_op(im + W8_B_HR, lop, 1);
-                    wro[0] = w8_mfma32(zo, a0, wro[0]); wro[1] = w8_mfma32(zo, a1, wro[1]);
-                }
-                {
-                    const cn_h8 z0 = w8_op(im + W8_B_ZR, lop, 0), z1 = w8_op(im + W8_B_ZR, lop, 1), d = w8_op(im + W8_B_DIR, lop, 0);
-                    wrd[0] = w8_mfma32(z0, d, wrd[0]); wrd[1] = w8_mfma32(z1, d, wrd[1]);
+                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 0), z1 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 1);
+                    wrd[0] = w8_mfma32(z0, dd, wrd[0]); wrd[1] = w8_mfma32(z1, dd, wrd[1]);
                     wrf[0][0] = w8_mfma32(z0, f0, wrf[0][0]); wrf[0][1] = w8_mfma32(z0, f1, wrf[0][1]);
                     wrf[1][0] = w8_mfma32(z1, f0, wrf[1][0]); wrf[1][1] = w8_mfma32(z1, f1, wrf[1][1]);
                 }
                 {
-                    const cn_h8 z0 = w8_op(im + W8_B_ZD, lop, 0), z1 = w8_op(im + W8_B_ZD, lop, 1);
+                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_BB_ZD, lop, 0), z1 = w8_op_if(on_tile, mine + W8_BB_ZD, lop, 1);
                     wd0[0][0] = w8_mfma32(z0, f0, wd0[0][0]); wd0[0][1] = w8_mfma32(z0, f1, wd0[0][1]);
                     wd0[1][0] = w8_mfma32(z1, f0, wd0[1][0]); wd0[1][1] = w8_mfma32(z1, f1, wd0[1][1]);
                 }
             }
+            cn_h8 z3[2];
+            w8_c_to_b<0>(dfea, nullptr, z3);
+            w8_publish<2>(px + W8_Z3 + (p & 1) * 2 * W8_K, slot, z3);               // (p - 2) & 1
             W8_T1();
         }
-#pragma unroll
-        for (int b = 0; b < 2; b++) w8_store<false, true>(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, lane, wro[b]);
-        for (uint32_t i = dm.n_rgb_out * 64 + lane; i < 16 * 64; i += 64) part[po.rO + i] = 0.0f;
         for (uint32_t i = lane; i < 64 * (96 - FLD_NDIR - 64); i += 64) {
             const uint32_t row = i / (96 - FLD_NDIR - 64), col = FLD_NDIR + 64 + i % (96 - FLD_NDIR - 64);
             part[po.r0 + row * 96 + col] = 0.0f;
@@ -668,6 +617,99 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             for (int b = 0; b < 2; b++) {
                 w8_store<true, true>(part, po.r0, 96, FLD_NDIR, 64, 64, a, b, lane, wrf[a][b]);
                 w8_store<true, true>(part, po.d0, 64, 0, 64, 64, a, b, lane, wd0[a][b]);
+            }
+        }
+    } else {
+        // ======================================================================== Ab: geometry backward of tile p - 3, dW_n2, dW_n1, dW_n0
+        cn_f16v wn2[2][2], wn1[2][2], wn0[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            w8_zero16(wn0[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) { w8_zero16(wn2[a][b]); w8_zero16(wn1[a][b]); }
+        }
+        const unsigned char *w_n0 = wb + 2 * W8_W_N0, *w_n1 = wb + 2 * W8_W_N1, *w_n2 = wb + 2 * W8_W_N2;
+        unsigned char *mine = px + W8_AB;
+        for (uint32_t p = 0; p < n_phase; p++) {
+            W8_T0();
+            asm volatile("" ::: "memory");
+            const bool on_tile = p >= 3 && p - 3 < n_iter;
+            const uint32_t np = (gp + (p - 3) * G) * W8_TILE + n;
+            const bool valid = on_tile && np < P_;
+            const unsigned char *af = px + W8_AF + ((p + 1) & 3) * W8_AF_BYTES;    // (p - 3) & 3
+            const unsigned char *z3i = px + W8_Z3 + ((p + 1) & 1) * 2 * W8_K;      // (p - 3) & 1
+            const unsigned char *hl = af + ((NGEO == 2) ? W8_AF_H2 : W8_AF_H1);
+            // ---- stage 0
+            cn_h8 z3[2];
+            w8_fetch<2>(z3i, slot, z3);
+            cn_h8 wT[8];
+            w8_load_T<4, 2, 2>(w_n2, lane_off_T, wT);
+            w8_f4 acc[4];
+            w8_zero(acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stage 1: n2^T dz3 (+ dW_n2 = dz3 x h_last: both operands are other stages' images)
+            w8_mm<4, 2>(wT, z3, acc);
+            {
+                const cn_h8 z0 = w8_op_if(on_tile, z3i, lop, 0), z1 = w8_op_if(on_tile, z3i, lop, 1), a0 = w8_op(hl, lop, 0), a1 = w8_op(hl, lop, 1);
+                wn2[0][0] = w8_mfma32(z0, a0, wn2[0][0]); wn2[0][1] = w8_mfma32(z0, a1, wn2[0][1]);
+                wn2[1][0] = w8_mfma32(z1, a0, wn2[1][0]); wn2[1][1] = w8_mfma32(z1, a1, wn2[1][1]);
+            }
+            cn_h8 z1f[2];
+            if (NGEO == 2) {
+                w8_load_T<4, 2, 2>(w_n1, lane_off_T, wT);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- stage 2: n1^T dz2 (+ dW_n1 = dz2 x h1)
+                cn_h8 z2[2], h2[2];
+                w8_fetch<2>(af + W8_AF_H2, slot, h2);
+                w8_c_to_b<2>(acc, h2, z2);
+                w8_publish<2>(mine + W8_AB_Z2, slot, z2);
+                w8_zero(acc);
+                __builtin_amdgcn_sched_barrier(0);
+                w8_mm<4, 2>(wT, z2, acc);
+                {
+                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 0), z1 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 1);
+                    const cn_h8 a0 = w8_op(af + W8_AF_H1, lop, 0), a1 = w8_op(af + W8_AF_H1, lop, 1);
+                    wn1[0][0] = w8_mfma32(z0, a0, wn1[0][0]); wn1[0][1] = w8_mfma32(z0, a1, wn1[0][1]);
+                    wn1[1][0] = w8_mfma32(z1, a0, wn1[1][0]); wn1[1][1] = w8_mfma32(z1, a1, wn1[1][1]);
+                }
+            }
+            cn_h8 wTn[4];
+            w8_load_Tn<2, 2>(w_n0, lane_off_Tn0, lane_off_Tn1, wTn);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stage 3: n0^T dz1 -> d(loss)/d(grid features) (+ dW_n0 = dz1 x x0)
+            {
+                cn_h8 h1[2];
+                w8_fetch<2>(af + W8_AF_H1, slot, h1);
+                w8_c_to_b<2>(acc, h1, z1f);
+            }
+            w8_publish<2>(mine + W8_AB_Z1, slot, z1f);
+            w8_f4 denc[2];
+            w8_zero(denc);
+            __builtin_amdgcn_sched_barrier(0);
+            w8_mm<2, 2>(wTn, z1f, denc);
+            {
+                const cn_h8 z0 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 0), z1 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 1), a0 = w8_op(af + W8_AF_X0, lop, 0);
+                wn0[0] = w8_mfma32(z0, a0, wn0[0]); wn0[1] = w8_mfma32(z1, a0, wn0[1]);
+            }
+            if (valid) {
+#pragma unroll
+                for (int mp = 0; mp < 2; mp++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t level = 8 * mp + 2 * g + h;
+                        if (level < dm.L) reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + np] = w8_cvt_pk(denc[mp][2 * h], denc[mp][2 * h + 1]);
+                    }
+                }
+            }
+            W8_T1();
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            w8_store<true, false>(part, po.n0, dm.enc_pad, 0, 64, dm.enc_pad, a, 0, lane, wn0[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                w8_store<true, true>(part, po.n2, 64, 0, 64, 64, a, b, lane, wn2[a][b]);
+                if (NGEO == 2) w8_store<true, true>(part, po.n1, 64, 0, 64, 64, a, b, lane, wn1[a][b]);
             }
         }
     }
@@ -684,7 +726,7 @@ void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t tot
                         hipStream_t st);
 
 bool w8_eligible(const FieldDims &dm) {
-    static const int on = cn_tune_env("CNERF_FIELD_W8_BWD", 1);   // 0 (tuning builds): k_field_bwd_x2
+    static const int on = cn_tune_env("CNERF_FIELD_W8_BWD", 0);   // tuning builds only: 1 selects this kernel instead of k_field_bwd_x2
     return on && dm.enc_pad == 32 && (dm.n_hidden_geo == 1 || dm.n_hidden_geo == 2);
 }
 
@@ -713,3 +755,8 @@ int w8_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     ff_reduce_partials(partials, blocks * 2, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
     return cn_launch_status();
 }
+#else   // release build: the kernel is not compiled in
+bool w8_eligible(const FieldDims &) { return false; }
+int w8_launch(const void *, const float *, const float *, uint32_t, uint32_t, const FieldDims &, const float *, const float *, const float *, const float *,
+              const float *, void *, float *, float *, float *, void *, uint32_t, hipStream_t) { return CNERF_EINVAL; }
+#endif

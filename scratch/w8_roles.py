@@ -23,6 +23,6 @@ torch.cuda.synchronize()
 ws = fmod._WS[next(iter(fmod._WS))]
 total = 64 * 32 + 4096 * 3 + 1024 + 64 * 96 + 1024
 tt = ws[510 * total * 4: 510 * total * 4 + 255 * 8 * 2 * 8].view(torch.int64).view(255, 8, 2).cpu().numpy()
-n_phase = ((P // 16 + 509) // 510 + 4) & ~1
-for r, name in enumerate(["A0", "B0", "A1", "B1", "A'0", "B'0", "A'1", "B'1"]):
+n_phase = (P // 16 + 509) // 510 + 3
+for r, name in enumerate(["Af0", "Bf0", "Af1", "Bf1", "Ab0", "Bb0", "Ab1", "Bb1"]):
     print(name, "work cycles/phase %.0f  barrier wait/phase %.0f" % (tt[:, r, 0].mean() / n_phase, tt[:, r, 1].mean() / n_phase))
