@@ -17,6 +17,7 @@
 // workspace and a separate epilogue pass, so the launch still covers the 256 CUs.
 #include "common.h"
 #include "../../include/customnerf_sd.h"
+#include "sd_gn_fix.h"
 
 typedef _Float16 sd_h8 __attribute__((ext_vector_type(8)));
 typedef float sd_f16v __attribute__((ext_vector_type(16)));
@@ -370,11 +371,11 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     // the (<= 2) groups' sums live in registers; flushed per image into a small LDS table, then one global atomic per (image, group) and tile.
     const bool do_gn = !SPLIT && g.gn_sums != nullptr;
     constexpr int GI = 4;                                // images a tile can touch (gn_rows >= 64)
-    __shared__ float gn_lds[GI][36][2];
+    __shared__ long long gn_lds[GI][36][2];           // 64-bit fixed point (sd_gn_fix.h): exact, order-independent sums
     const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u;
     const uint32_t gn_g0 = n0 / gn_cg, gn_i0 = do_gn ? m0 / g.gn_rows : 0u;
     if (do_gn) {
-        for (uint32_t i = tid; i < GI * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0.0f;
+        for (uint32_t i = tid; i < GI * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0;
         __syncthreads();
     }
     float gs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
@@ -462,10 +463,10 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
             if (img != gn_img) {
                 if (gn_img != 0xFFFFFFFFu) {
                     const uint32_t gl = n / gn_cg - gn_g0;
-                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
-                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
-                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
-                    unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
                     gs[0][0] = gs[0][1] = gs[1][0] = gs[1][1] = 0.0f;
                 }
                 gn_img = img;
@@ -506,19 +507,20 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
     if (do_gn) {
         if (gn_img != 0xFFFFFFFFu) {
             const uint32_t gl = (n0 + (tid % CPR) * 8) / gn_cg - gn_g0;
-            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
-            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
-            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
-            unsafeAtomicAdd(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
         }
         __syncthreads();
         const uint32_t n_img = g.M / g.gn_rows;
         for (uint32_t i = tid; i < GI * 36; i += SG_THREADS) {
             const uint32_t im = i / 36, gl = i % 36, img = gn_i0 + im, grp = gn_g0 + gl;
-            const float a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
-            if (img < n_img && grp < g.gn_groups && (a != 0.0f || b2 != 0.0f)) {
-                unsafeAtomicAdd(&g.gn_sums[((size_t)img * g.gn_groups + grp) * 2], a);
-                unsafeAtomicAdd(&g.gn_sums[((size_t)img * g.gn_groups + grp) * 2 + 1], b2);
+            const long long a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
+            if (img < n_img && grp < g.gn_groups) {
+                long long *dst = reinterpret_cast<long long *>(g.gn_sums) + ((size_t)img * g.gn_groups + grp) * 2;
+                gn_add_fixed(dst, a);
+                gn_add_fixed(dst + 1, b2);
             }
         }
     }

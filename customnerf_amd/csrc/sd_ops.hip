@@ -17,9 +17,14 @@ __device__ __forceinline__ float so_wave_max(float v) {
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // Thread t of a block owns one 16-byte channel chunk (8 channels, <= 2 groups when C/G >= 4) and walks down the rows of the
-// block's slab, so its partial sums live in registers; one LDS + one global float atomic per (thread, group) at the end.
+// block's slab, so its partial sums live in registers; one LDS + one global atomic per (thread, group) at the end.
+// The statistics are kept as 64-BIT FIXED POINT (2^-20 units, include/customnerf_sd.h CNERF_SD_GN_FRAC_BITS): a thread's float32 partial
+// sum is a deterministic function of its slab, it is rounded to the fixed-point grid once, and everything after that is integer
+// addition — exact and order-independent, so the atomics no longer make the result depend on arrival order (round 4: the edit step is
+// bit-reproducible; float atomics left it deterministic to ~1e-3 only).  Range +-8.8e12, resolution 1e-6 per partial.
 #define GN_THREADS 256
 #define GN_MAX_G 64
+#include "sd_gn_fix.h"
 
 struct GnGeom {
     uint32_t nchunks, cols_per_pass, rows_per_pass, cg;
@@ -40,12 +45,12 @@ __device__ __forceinline__ GnGeom gn_geom(uint32_t C, uint32_t G) {
 // MODE 0: forward statistics (sum x, sum x^2).  MODE 1: backward statistics (sum g, sum g xhat), g = dy * act'(z) * gamma.
 template <int MODE>
 __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,
-                                                         const float *__restrict__ beta, const float *__restrict__ fsums, uint32_t HW, uint32_t C,
-                                                         uint32_t G, float eps, int silu, uint32_t rows_per_block, float *__restrict__ out) {
-    __shared__ float acc[GN_MAX_G][2];
+                                                         const float *__restrict__ beta, const long long *__restrict__ fsums, uint32_t HW, uint32_t C,
+                                                         uint32_t G, float eps, int silu, uint32_t rows_per_block, long long *__restrict__ out) {
+    __shared__ long long acc[GN_MAX_G][2];
     const GnGeom q = gn_geom(C, G);
     const uint32_t b = blockIdx.y, r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
-    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) acc[i >> 1][i & 1] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) acc[i >> 1][i & 1] = 0;
     __syncthreads();
     const uint32_t tcol = threadIdx.x % q.cols_per_pass, trow = threadIdx.x / q.cols_per_pass;
     const float inv_n = 1.0f / ((float)HW * (float)q.cg);
@@ -59,8 +64,8 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restr
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t g = k ? g_hi : g_lo;
-                    const float m = fsums[((size_t)b * G + g) * 2] * inv_n;
-                    const float v = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - m * m;
+                    const float m = gn_unfix(fsums[((size_t)b * G + g) * 2]) * inv_n;
+                    const float v = gn_unfix(fsums[((size_t)b * G + g) * 2 + 1]) * inv_n - m * m;
                     mean[k] = m;
                     rstd[k] = rsqrtf(fmaxf(v, 0.0f) + eps);
                 }
@@ -93,16 +98,16 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restr
                     }
                 }
             }
-            atomicAdd(&acc[g_lo][0], s[0][0]);
-            atomicAdd(&acc[g_lo][1], s[0][1]);
+            gn_add(&acc[g_lo][0], s[0][0]);
+            gn_add(&acc[g_lo][1], s[0][1]);
             if (g_hi != g_lo) {
-                atomicAdd(&acc[g_hi][0], s[1][0]);
-                atomicAdd(&acc[g_hi][1], s[1][1]);
+                gn_add(&acc[g_hi][0], s[1][0]);
+                gn_add(&acc[g_hi][1], s[1][1]);
             }
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) unsafeAtomicAdd(&out[(size_t)b * G * 2 + i], acc[i >> 1][i & 1]);
+    for (uint32_t i = threadIdx.x; i < G * 2; i += GN_THREADS) gn_add_fixed(&out[(size_t)b * G * 2 + i], acc[i >> 1][i & 1]);
 }
 
 // MODE 0: y = act(xhat gamma + beta).  MODE 1: dx = rstd (g - S1/n - xhat S2/n).
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restr
 // divisions and parameter reloads: 1.4 TB/s on the VAE's 67 MB tensors).
 template <int MODE>
 __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,
-                                                         const float *__restrict__ beta, const float *__restrict__ fsums, const float *__restrict__ bsums,
+                                                         const float *__restrict__ beta, const long long *__restrict__ fsums, const long long *__restrict__ bsums,
                                                          uint32_t HW, uint32_t C, uint32_t G, float eps, int silu, uint32_t rows_per_block,
                                                          _Float16 *__restrict__ out) {
     const GnGeom q = gn_geom(C, G);
@@ -125,16 +130,16 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restr
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const uint32_t g = ((uint32_t)e < split) ? g_lo : g_hi;
-            const float m = fsums[((size_t)b * G + g) * 2] * inv_n;
-            const float v = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - m * m;
+            const float m = gn_unfix(fsums[((size_t)b * G + g) * 2]) * inv_n;
+            const float v = gn_unfix(fsums[((size_t)b * G + g) * 2 + 1]) * inv_n - m * m;
             mean[e] = m;
             rstd[e] = rsqrtf(fmaxf(v, 0.0f) + eps);
             ga[e] = gamma[c0 + e];
             be[e] = beta[c0 + e];
             s1[e] = s2[e] = 0.0f;
             if (MODE == 1) {
-                s1[e] = bsums[((size_t)b * G + g) * 2] * inv_n;
-                s2[e] = bsums[((size_t)b * G + g) * 2 + 1] * inv_n;
+                s1[e] = gn_unfix(bsums[((size_t)b * G + g) * 2]) * inv_n;
+                s2[e] = gn_unfix(bsums[((size_t)b * G + g) * 2 + 1]) * inv_n;
             }
         }
 #pragma unroll 4
@@ -580,35 +585,35 @@ static int so_softmax(const void *P, void *S, uint64_t rows, uint32_t cols, uint
 extern "C" {
 
 int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, float eps,
-                               int silu, float *sums, int zero_sums, void *y, void *stream) {
+                               int silu, int64_t *sums, int zero_sums, void *y, void *stream) {
     int rc = gn_check(B, HW, C, G);
     if (rc) return rc;
     if (!x || !gamma || !beta || !sums || !y) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    if (zero_sums == 1) so_zero(sums, (size_t)B * G * 2, st);
+    if (zero_sums == 1) so_zero(reinterpret_cast<float *>(sums), (size_t)B * G * 4, st);
     const uint32_t rpb = gn_rows_per_block(B, HW, C);
     if (zero_sums != 2)
         hipLaunchKernelGGL((k_gn_stats<0>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
-                           (const float *)nullptr, HW, C, G, eps, silu, rpb, sums);
+                           (const long long *)nullptr, HW, C, G, eps, silu, rpb, reinterpret_cast<long long *>(sums));
     const uint32_t rpa = gn_apply_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_apply<0>), dim3(cn_div_up(HW, rpa), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)nullptr, gamma, beta,
-                       (const float *)sums, (const float *)nullptr, HW, C, G, eps, silu, rpa, (_Float16 *)y);
+                       (const long long *)sums, (const long long *)nullptr, HW, C, G, eps, silu, rpa, (_Float16 *)y);
     return cn_launch_status();
 }
 
 int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
-                                float eps, int silu, const float *sums, float *scratch, void *dx, void *stream) {
+                                float eps, int silu, const int64_t *sums, int64_t *scratch, void *dx, void *stream) {
     int rc = gn_check(B, HW, C, G);
     if (rc) return rc;
     if (!x || !dy || !gamma || !beta || !sums || !scratch || !dx) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    so_zero(scratch, (size_t)B * G * 2, st);
+    so_zero(reinterpret_cast<float *>(scratch), (size_t)B * G * 4, st);
     const uint32_t rpb = gn_rows_per_block(B, HW, C);
-    hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums, HW,
-                       C, G, eps, silu, rpb, scratch);
+    hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta,
+                       (const long long *)sums, HW, C, G, eps, silu, rpb, reinterpret_cast<long long *>(scratch));
     const uint32_t rpa = gn_apply_rows_per_block(B, HW, C);
-    hipLaunchKernelGGL((k_gn_apply<1>), dim3(cn_div_up(HW, rpa), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta, sums,
-                       (const float *)scratch, HW, C, G, eps, silu, rpa, (_Float16 *)dx);
+    hipLaunchKernelGGL((k_gn_apply<1>), dim3(cn_div_up(HW, rpa), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta,
+                       (const long long *)sums, (const long long *)scratch, HW, C, G, eps, silu, rpa, (_Float16 *)dx);
     return cn_launch_status();
 }
 

@@ -52,7 +52,7 @@ def _launch(d, device):
 
 
 def _attach_gn(d, gn, M, N):
-    """gn = (sums [B, G, 2] float32 pre-zeroed, groups, rows_per_image) or None -> whether the request is admissible"""
+    """gn = (sums [B, G, 2] int64 pre-zeroed, groups, rows_per_image) or None -> whether the request is admissible"""
     if gn is None:
         return False
     sums, groups, rows = gn
@@ -120,12 +120,20 @@ def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bi
     return (y, want and not split) if gn is not None else y
 
 
+GN_FRAC_BITS = 20        # include/customnerf_sd.h CNERF_SD_GN_FRAC_BITS: GroupNorm statistics are int64 fixed point (exact, order-independent sums)
+
+
+def gn_sums_to_float(sums):
+    """the fixed-point statistics [B, G, 2] as float64 (sum, sum of squares)"""
+    return sums.double() * (1.0 / (1 << GN_FRAC_BITS))
+
+
 class SumsPool:
-    """One pre-zeroed float32 buffer for the GroupNorm statistics of a whole network pass: a single fill launch instead of one
+    """One pre-zeroed int64 buffer for the GroupNorm statistics of a whole network pass: a single fill launch instead of one
     zero-fill per norm.  take() hands out consecutive [B, G, 2] slices."""
 
     def __init__(self, n_norms, B, groups, device):
-        self.buf = torch.zeros(n_norms, B, groups, 2, dtype=torch.float32, device=device)
+        self.buf = torch.zeros(n_norms, B, groups, 2, dtype=torch.int64, device=device)
         self.i = 0
 
     def take(self):
@@ -135,7 +143,7 @@ class SumsPool:
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu, pool=None, sums=None, sums_ready=True):
-    """x [B, ..., C] half -> (y, sums [B, G, 2] float32: sum and sum of squares per group).
+    """x [B, ..., C] half -> (y, sums [B, G, 2] int64 fixed point: sum and sum of squares per group, gn_sums_to_float()).
     sums given and sums_ready: the statistics were already accumulated by the GEMM that produced x (its gn= request) — only the apply
     pass runs; sums given, not ready: a pre-zeroed buffer to fill (the producer ran split-K and left it untouched)."""
     require_cuda(x, gamma)
@@ -145,7 +153,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu, pool=None, sums=None, sums_read
     y = torch.empty_like(x)
     mode = (2 if sums_ready else 0) if sums is not None else (0 if pool is not None else 1)
     if sums is None:
-        sums = pool.take() if pool is not None else torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        sums = pool.take() if pool is not None else torch.empty(B, groups, 2, dtype=torch.int64, device=x.device)
     check(lib.cnerf_sd_groupnorm_forward(ptr(x), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), mode, ptr(y), stream()),
           "sd_groupnorm_forward")
     return y, sums
@@ -156,7 +164,7 @@ def groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums):
     HW = x.numel() // (B * C)
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    scratch = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(B, groups, 2, dtype=torch.int64, device=x.device)
     check(lib.cnerf_sd_groupnorm_backward(ptr(x), ptr(dy), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(scratch), ptr(dx), stream()),
           "sd_groupnorm_backward")
     return dx

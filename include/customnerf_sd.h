@@ -58,10 +58,11 @@ typedef struct CnerfSdGemm {
     uint64_t sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;    /* residual uses the C strides */
     int32_t mode;             /* 0 dense, 1 implicit conv */
     uint32_t Cin, H_in, W_in, H_out, W_out, KH, KW, stride, pad_t, pad_l, ups, tstride;
-    /* optional GroupNorm statistics of the OUTPUT (the norm that consumes C next): gn_sums [M / gn_rows][gn_groups][2] float, pre-zeroed,
-     * receives sum and sum of squares of the half-rounded outputs per (image, channel group); N % gn_groups == 0, gn_rows >= 64.
+    /* optional GroupNorm statistics of the OUTPUT (the norm that consumes C next): gn_sums [M / gn_rows][gn_groups][2] int64 fixed point
+     * (CNERF_SD_GN_FRAC_BITS fractional bits), pre-zeroed, receives sum and sum of squares of the half-rounded outputs per (image,
+     * channel group); N % gn_groups == 0, gn_rows >= 64.
      * Ignored (left untouched) when the library runs this problem split-K: cnerf_sd_gemm_workspace_bytes() != 0 tells. */
-    float *gn_sums;
+    int64_t *gn_sums;
     uint32_t gn_groups, gn_rows;
 } CnerfSdGemm;
 
@@ -71,16 +72,20 @@ int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *desc, uint64_t *bytes);
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC half activations x [B, HW, C] (torch.nn.GroupNorm(G, C, eps) semantics, biased variance, statistics in
  * float32), optionally followed by SiLU (the `norm -> nonlinearity` pair of every diffusers ResnetBlock2D).
- *   stats:   sums [B][G][2] float (sum, sum of squares) — filled by the call; zero_sums != 0: the call zeroes them first,
+ *   stats:   sums [B][G][2] int64 (sum, sum of squares) in FIXED POINT with CNERF_SD_GN_FRAC_BITS fractional bits: every partial sum is
+ *            rounded to that grid once and added with integer atomics, so the statistics — and everything computed from them — do
+ *            not depend on the order in which workgroups arrive (bit-reproducible).  Filled by the call; zero_sums != 0: the call
+ *            zeroes them first,
  *            zero_sums == 0: the caller passes zeros (one fill for all the norms of a network instead of one launch each);
  *            zero_sums == 2: `sums` already hold the statistics (filled by the producing cnerf_sd_gemm's gn_sums): no statistics pass
  *   forward: y = act((x - mean) * rstd * gamma[c] + beta[c])
- *   backward (frozen gamma/beta): dx from dy, recomputing the forward; `sums` are the forward's; scratch [B][G][2] float.
+ *   backward (frozen gamma/beta): dx from dy, recomputing the forward; `sums` are the forward's; scratch [B][G][2] int64 (same format).
  * ---------------------------------------------------------------------------------------------- */
+#define CNERF_SD_GN_FRAC_BITS 20
 int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C,
-                               uint32_t G, float eps, int silu, float *sums, int zero_sums, void *y, void *stream);
+                               uint32_t G, float eps, int silu, int64_t *sums, int zero_sums, void *y, void *stream);
 int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW,
-                                uint32_t C, uint32_t G, float eps, int silu, const float *sums, float *scratch, void *dx,
+                                uint32_t C, uint32_t G, float eps, int silu, const int64_t *sums, int64_t *scratch, void *dx,
                                 void *stream);
 
 /* LayerNorm over the last dimension of x [rows, C] (half), float32 statistics, eps inside the sqrt. */

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(**optkw):
+def _setup(res=32, **optkw):
     from customnerf_amd import scene as sc, tcnn
     from customnerf_amd.nerf.network_grid import NeRFNetwork
     from customnerf_amd.nerf.provider_utils import generate_rays
@@ -27,7 +27,7 @@ def _setup(**optkw):
     usd = arch.random_state_dict(arch.unet_params(arch.UNET_TINY), 1)
     vsd = arch.random_state_dict(arch.vae_encoder_params(arch.VAE_TINY), 2)
     guide = StableDiffusion("cuda", "1.5", opt, unet_state=usd, vae_state=vsd, unet_cfg=arch.UNET_TINY, vae_cfg=arch.VAE_TINY)
-    H = W = 32
+    H = W = res
     c2w = torch.from_numpy(sc.poses(4)).cuda()
     o, d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
     o, d = o.view(4, 1, H * W, 3), d.view(4, 1, H * W, 3)
@@ -152,6 +152,27 @@ def test_editing_step_matches_composed_oracle(variant):
     assert float(ref.pos_en.embeddings.grad.abs().max()) > 0
     # the SDS gradient passes a float16 UNet and the float16 VAE backward before it reaches the (float32) renderer
     assert all(e < 6e-2 for e in errs.values()), errs
+
+
+def test_edit_training_is_bit_reproducible():
+    """Two identical editing runs (same seeds) end in bit-identical parameters and losses: the GroupNorm statistics of the UNet / VAE — the
+    one place of the SDS half that summed with float atomics — are 64-bit fixed point since round 4 (exact integer sums, any arrival order),
+    the grid scatter sums in fixed point, every other reduction has a fixed order."""
+    def run():
+        # 64 x 64 rays x 32 samples x 8 levels = 2^20 (sample, level) pairs: the grid backward takes the binned fixed-point scatter (below that
+        # the library uses the plain float-atomic kernel, which is not order-independent)
+        tr, model, pre, data = _setup(res=64, keep_bg=1000.0, lambda_sd=0.01)
+        torch.manual_seed(123)
+        losses = []
+        for i in range(4):
+            loss, ld = tr.train_step(data(i % 2))
+            losses.append(torch.stack([loss.detach().float().reshape(()), ld["loss_sds"].detach().float().reshape(()), ld["loss_bg"].detach().float().reshape(())]))
+        return [p.detach().clone() for p in model.parameters()], torch.stack(losses)
+    pa, la = run()
+    pb, lb = run()
+    assert torch.equal(la, lb), (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
 
 
 def test_multi_view_step_is_the_mean_of_single_view_steps():

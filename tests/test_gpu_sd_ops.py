@@ -125,8 +125,18 @@ def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
     close(y.permute(0, 2, 1), ref, 2e-3, 3e-3)
     dy = h(torch.randn_like(ref))
     ref.backward(dy)
-    dx = ops.groupnorm_backward(xg, dy.permute(0, 2, 1).contiguous().half().cuda(), gamma.cuda(), beta.cuda(), G, eps, silu, sums)
+    dyg = dy.permute(0, 2, 1).contiguous().half().cuda()
+    dx = ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums)
     close(dx.permute(0, 2, 1), x.grad, 5e-3, 4e-3)
+    # statistics are exact integer (fixed-point) sums: the same bits on every run, whatever order the workgroups' atomics arrive in
+    assert sums.dtype == torch.int64
+    for _ in range(3):
+        y2, sums2 = ops.groupnorm(xg, gamma.cuda(), beta.cuda(), G, eps, silu)
+        assert torch.equal(sums2, sums) and torch.equal(y2, y)
+        assert torch.equal(ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums), dx)
+    n = HW * (C // G)
+    mean_ref = x.detach().half().float().view(B, G, -1).mean(-1)
+    assert float((ops.gn_sums_to_float(sums)[..., 0].cpu() / n - mean_ref.double()).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("rows,C", [(100, 320), (77, 640), (513, 1280), (3, 768)])
@@ -243,7 +253,7 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     w = pack.pack_conv(torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C)).cuda()
     b = torch.randn(Co, generator=g).cuda()
     gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
-    sums = torch.zeros(B, 32, 2, device="cuda")
+    sums = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")        # 64-bit fixed-point statistics (order-independent sums)
     y, ok = ops.conv2d(x, w, b, 3, gn=(sums, 32, H * H))
     y_ref = ops.conv2d(x, w, b, 3)
     assert torch.equal(y, y_ref)
@@ -251,9 +261,14 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     if not ok:                                           # split-K schedule: the library leaves the statistics to the norm
         assert torch.all(sums == 0)
         return
-    close(sums, s_ref, 2e-4, 1e-2)
+    close(ops.gn_sums_to_float(sums).float(), ops.gn_sums_to_float(s_ref).float(), 2e-4, 1e-2)
     n_fused, _ = ops.groupnorm(y, gamma, beta, 32, 1e-5, True, sums=sums)
     close(n_fused, n_ref, 2e-3, 2e-3)
+    # exact integer sums: a second run of either producer gives the same bits whatever the arrival order of its workgroups
+    sums2 = torch.zeros_like(sums)
+    ops.conv2d(x, w, b, 3, gn=(sums2, 32, H * H))
+    _, s_ref2 = ops.groupnorm(y_ref, gamma, beta, 32, 1e-5, True)
+    assert torch.equal(sums, sums2) and torch.equal(s_ref, s_ref2)
 
 
 @pytest.mark.parametrize("M,C", [(8192, 320), (128, 1280), (77, 64)])
