@@ -5,17 +5,19 @@
 // (profiles/r03_field_bwd_pmc.txt: vector ALU 31 %, matrix pipe 29 %, LDS 13 %, nothing overlapping).  Here a tile stream is a four-stage
 // pipeline over FOUR waves, every one below 256 registers, two per SIMD, each carrying a comparable share of chain AND weight-gradient work:
 //
-//   Af  geometry forward   tile i in phase i       n0, n1, n2                                   20 MFMA 16x16x32
-//   Bf  heads forward      tile i in phase i + 1   d0 | r0, dO | rO, output-layer gradients      24 MFMA 16x16x32 + dW_rO, dW_dO      (4 MFMA 32x32x16)
-//   Bb  heads backward     tile i in phase i + 2   dO^T | rO^T, d0^T + r0^T -> dz_3              24 MFMA 16x16x32 + dW_r0, dW_d0     (10 MFMA 32x32x16)
-//   Ab  geometry backward  tile i in phase i + 3   n2^T, n1^T, n0^T -> d/d(grid features)        20 MFMA 16x16x32 + dW_n2, dW_n1, dW_n0 (10)
+//   Af  geometry forward   tile i in phase i       n0, n1, n2                                   20 MFMA 16x16x32 + dW_n2 (tile i - 3), dW_rO, dW_dO (tile i - 2)  (8 MFMA 32x32x16)
+//   Bf  heads forward      tile i in phase i + 1   d0 | r0, dO | rO, output-layer gradients      24 MFMA 16x16x32 + dW_d0 (tile i - 2)                              (4)
+//   Bb  heads backward     tile i in phase i + 2   dO^T | rO^T, d0^T + r0^T -> dz_3              24 MFMA 16x16x32 + dW_r0 (same tile)                               (6)
+//   Ab  geometry backward  tile i in phase i + 3   n2^T, n1^T, n0^T -> d/d(grid features)        20 MFMA 16x16x32 + dW_n1, dW_n0 (same tile)                        (6)
+// The forward stages are the short ones, so they take the weight-gradient products whose operands are rings written in EARLIER phases:
+// those MFMAs do not depend on the wave's own chain and fill the matrix pipe while its first fetches are in flight.
 //
 // (The first version of this file had two chain waves and two "shadow" waves that only accumulated weight gradients: correct, but the
 // shadows issued 50 instructions per phase against 340 of a chain wave — still one busy wave per SIMD, 470 us against the 450 us of
 // k_field_bwd_x2.)  Every wave's weight-gradient operands are images it published itself in the same phase (DS operations of one wave
 // execute in order: no barrier, single buffer) or images an earlier stage published in an earlier phase (ring buffers below, one
 // workgroup barrier per phase).  The tile is SIXTEEN samples: the images of a 32-sample tile with these lifetimes, for two streams, do
-// not fit beside the weights; at 16 samples they take 104 KiB + 44 KiB of weight fragments.  Chains therefore run on
+// not fit beside the weights; at 16 samples they take 112 KiB + 44 KiB of weight fragments.  Chains therefore run on
 // v_mfma_f32_16x16x32_f16 (16 outputs x 16 samples x 32 inputs), the weight gradients on v_mfma_f32_32x32x16_f16 with the 16 samples of a
 // tile on the contraction index: one MFMA per 32x32 tile of dW per sample tile.
 //
@@ -63,23 +65,23 @@ typedef short w8_s4 __attribute__((__vector_size__(4 * sizeof(short))));
 #define W8_AF_H1 (1 * W8_K)
 #define W8_AF_H2 (3 * W8_K)
 #define W8_AF_BYTES (5 * W8_K)
-#define W8_FEA (W8_AF + 4 * W8_AF_BYTES)           // 3 x 2 KiB  Af (i) -> Bf (i + 1), Bb's dW (i + 2)
-#define W8_BF (W8_FEA + 3 * 2 * W8_K)              // 2 x 7 KiB  dir 1, hd 2, hr 2, bro 1, bdo 1: Bf (i + 1) -> Bb (i + 2)
+#define W8_FEA (W8_AF + 4 * W8_AF_BYTES)           // 4 x 2 KiB  Af (i) -> Bf (i + 1), Bb's dW (i + 2), Bf's dW_d0 (i + 3)
+#define W8_BF (W8_FEA + 4 * 2 * W8_K)              // 2 x 7 KiB  dir 1, hd 2, hr 2, bro 1, bdo 1: Bf (i + 1) -> Bb, Af's dW (i + 2)
 #define W8_BF_DIR 0
 #define W8_BF_HD (1 * W8_K)
 #define W8_BF_HR (3 * W8_K)
 #define W8_BF_BRO (5 * W8_K)
 #define W8_BF_BDO (6 * W8_K)
 #define W8_BF_BYTES (7 * W8_K)
-#define W8_Z3 (W8_BF + 2 * W8_BF_BYTES)            // 2 x 2 KiB  Bb (i + 2) -> Ab (i + 3)
-#define W8_BB (W8_Z3 + 2 * 2 * W8_K)               // 4 KiB      zr 2, zd 2: private to Bb
+#define W8_Z3 (W8_BF + 2 * W8_BF_BYTES)            // 2 x 2 KiB  Bb (i + 2) -> Ab, Af's dW_n2 (i + 3)
+#define W8_ZD (W8_Z3 + 2 * 2 * W8_K)               // 2 x 2 KiB  Bb (i + 2) -> Bf's dW_d0 (i + 3)
+#define W8_BB (W8_ZD + 2 * 2 * W8_K)               // 2 KiB      zr: private to Bb
 #define W8_BB_ZR 0
-#define W8_BB_ZD (2 * W8_K)
-#define W8_AB (W8_BB + 4 * W8_K)                   // 4 KiB      z2 2, z1 2: private to Ab
+#define W8_AB (W8_BB + 2 * W8_K)                   // 4 KiB      z2 2, z1 2: private to Ab
 #define W8_AB_Z2 0
 #define W8_AB_Z1 (2 * W8_K)
 #define W8_SCR (W8_AB + 4 * W8_K)                  // 256 B: direction-feature scratch of Bf
-#define W8_PIPE_BYTES (W8_SCR + 256)               // 53 504 B per stream
+#define W8_PIPE_BYTES (W8_SCR + 256)               // 57 600 B per stream
 
 struct W8Off {
     uint32_t n0, n1, n2, d0, dO, r0, rO, total;
@@ -355,6 +357,13 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) raw[jj] = e[(size_t)min(4 * g + jj, dm.L - 1) * P_];
         };
+        cn_f16v wn2[2][2], wro[2], wdo[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            w8_zero16(wro[a]); w8_zero16(wdo[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) w8_zero16(wn2[a][b]);
+        }
         uint32_t N0[4], N1[4];
         enc_request(gp, N0);
 #pragma unroll
@@ -369,6 +378,20 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             cn_h8 wa[4], wb1[8], wb2[8];
             w8_load_F<4, 1, 1>(w_n0, lane16, wa);
             if (NGEO == 2) w8_load_F<4, 2, 2>(w_n1, lane16, wb1);
+            {   // weight gradients out of earlier phases' rings (independent of this phase's chain): dW_n2 of tile p - 3, dW_rO / dW_dO of tile p - 2
+                const bool on3 = p >= 3 && p - 3 < n_iter, on2 = p >= 2 && p - 2 < n_iter;
+                const unsigned char *z3i = px + W8_Z3 + ((p + 1) & 1) * 2 * W8_K;                       // (p - 3) & 1
+                const unsigned char *hl = px + W8_AF + ((p + 1) & 3) * W8_AF_BYTES + ((NGEO == 2) ? W8_AF_H2 : W8_AF_H1);
+                const unsigned char *bf = px + W8_BF + (p & 1) * W8_BF_BYTES;                          // (p - 2) & 1
+                const cn_h8 z0 = w8_op_if(on3, z3i, lop, 0), z1 = w8_op_if(on3, z3i, lop, 1), a0 = w8_op(hl, lop, 0), a1 = w8_op(hl, lop, 1);
+                const cn_h8 zro = w8_op_if(on2, bf + W8_BF_BRO, lop, 0), zdo = w8_op_if(on2, bf + W8_BF_BDO, lop, 0);
+                const cn_h8 ahr0 = w8_op(bf + W8_BF_HR, lop, 0), ahr1 = w8_op(bf + W8_BF_HR, lop, 1);
+                const cn_h8 ahd0 = w8_op(bf + W8_BF_HD, lop, 0), ahd1 = w8_op(bf + W8_BF_HD, lop, 1);
+                wn2[0][0] = w8_mfma32(z0, a0, wn2[0][0]); wn2[0][1] = w8_mfma32(z0, a1, wn2[0][1]);
+                wn2[1][0] = w8_mfma32(z1, a0, wn2[1][0]); wn2[1][1] = w8_mfma32(z1, a1, wn2[1][1]);
+                wro[0] = w8_mfma32(zro, ahr0, wro[0]); wro[1] = w8_mfma32(zro, ahr1, wro[1]);
+                wdo[0] = w8_mfma32(zdo, ahd0, wdo[0]); wdo[1] = w8_mfma32(zdo, ahd1, wdo[1]);
+            }
             cn_h8 x0[1], h1[2], h2[2];
             {
                 union { cn_h8 h; uint32_t u[4]; } f;
@@ -399,7 +422,7 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             __builtin_amdgcn_sched_barrier(0);
             cn_h8 fea[2];
             w8_c_to_b<0>(acc, nullptr, fea);
-            w8_publish<2>(px + W8_FEA + (p % 3) * 2 * W8_K, slot, fea);
+            w8_publish<2>(px + W8_FEA + (p & 3) * 2 * W8_K, slot, fea);
             W8_T1();
         };
         uint32_t p = 0;
@@ -408,11 +431,23 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             phase(p + 1, N1, N0);
         }
         if (p < n_phase) phase(p, N0, N1);
-    } else if (role == 1) {
-        // ======================================================================== Bf: heads forward of tile p - 1, output-layer gradients, dW_rO, dW_dO
-        cn_f16v wro[2], wdo[2];
 #pragma unroll
-        for (int a = 0; a < 2; a++) { w8_zero16(wro[a]); w8_zero16(wdo[a]); }
+        for (int a = 0; a < 2; a++) {
+            w8_store<false, true>(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, a, lane, wro[a]);
+            w8_store<false, true>(part, po.dO, 64, 0, 1, 64, 0, a, lane, wdo[a]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) w8_store<true, true>(part, po.n2, 64, 0, 64, 64, a, b, lane, wn2[a][b]);
+        }
+        // the padding rows of the two output layers (the partial row is summed entry by entry: it is written in full, never zero-filled)
+        for (uint32_t i = dm.n_rgb_out * 64 + lane; i < 16 * 64; i += 64) part[po.rO + i] = 0.0f;
+        for (uint32_t i = 64 + lane; i < 16 * 64; i += 64) part[po.dO + i] = 0.0f;
+    } else if (role == 1) {
+        // ======================================================================== Bf: heads forward of tile p - 1, output-layer gradients; dW_d0 of tile p - 3
+        cn_f16v wd0[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) w8_zero16(wd0[a][b]);
         struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; };
         auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
             BIn r;
@@ -433,15 +468,21 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             asm volatile("" ::: "memory");
             if (p >= 1) nxt = load_in(gp + p * G);
             const uint32_t tile = gp + (p - 1) * G;                                 // (wraps at p == 0: outside the range, ignored)
-            const bool on_tile = p >= 1 && p - 1 < n_iter;
-            const bool valid = on_tile && tile * W8_TILE + n < P_;
+            const bool valid = p >= 1 && p - 1 < n_iter && tile * W8_TILE + n < P_;
             unsigned char *my = px + W8_BF + ((p + 1) & 1) * W8_BF_BYTES;
             // ---- stage 0: fea, direction features, fragments of d0 / r0
             cn_h8 x3[3];                                                            // [fea K-step 0, fea K-step 1, direction features]
-            w8_fetch<2>(px + W8_FEA + ((p + 2) % 3) * 2 * W8_K, slot, x3);
+            w8_fetch<2>(px + W8_FEA + ((p + 3) & 3) * 2 * W8_K, slot, x3);          // (p - 1) & 3
             cn_h8 wd[8], wr[12];
             w8_load_F<4, 2, 2>(w_d0, lane16, wd);
             w8_load_F<4, 3, 3>(w_r0, lane16, wr);
+            {   // dW_d0 = dz_d x fea of tile p - 3, both out of rings written in earlier phases
+                const bool on3 = p >= 3 && p - 3 < n_iter;
+                const unsigned char *zdi = px + W8_ZD + ((p + 1) & 1) * 2 * W8_K, *fe3 = px + W8_FEA + ((p + 1) & 3) * 2 * W8_K;
+                const cn_h8 z0 = w8_op_if(on3, zdi, lop, 0), z1 = w8_op_if(on3, zdi, lop, 1), f0 = w8_op(fe3, lop, 0), f1 = w8_op(fe3, lop, 1);
+                wd0[0][0] = w8_mfma32(z0, f0, wd0[0][0]); wd0[0][1] = w8_mfma32(z0, f1, wd0[0][1]);
+                wd0[1][0] = w8_mfma32(z1, f0, wd0[1][0]); wd0[1][1] = w8_mfma32(z1, f1, wd0[1][1]);
+            }
             {
                 // direction features (frequency encoding, nerf/base.py:42-60) in natural order.  One direction per tile (run() path): lanes
                 // q < 27 evaluate feature q and the 32 halves go through a 64-byte scratch of this wave; otherwise every lane evaluates the
@@ -489,9 +530,6 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             __builtin_amdgcn_sched_barrier(0);
             w8_mm<1, 2>(wdo_f, hd, outd);
             w8_mm<1, 2>(wro_f, hr, outr);
-            // the activation operands of this wave's weight gradients: its own images, read back transposed (in-order DS: no barrier)
-            const cn_h8 ahd0 = w8_op(my + W8_BF_HD, lop, 0), ahd1 = w8_op(my + W8_BF_HD, lop, 1);
-            const cn_h8 ahr0 = w8_op(my + W8_BF_HR, lop, 0), ahr1 = w8_op(my + W8_BF_HR, lop, 1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- stage 3: output-layer gradients (sigmoid', clamped exp': provider_utils.py:26-29): rows 0..3 live in the g == 0 lanes
             cn_h8 bro = Prec<true>::zero(), bdo = Prec<true>::zero();
@@ -510,11 +548,6 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             }
             w8_publish<1>(my + W8_BF_BRO, slot, &bro);
             w8_publish<1>(my + W8_BF_BDO, slot, &bdo);
-            {
-                const cn_h8 zro = w8_op_if(on_tile, my + W8_BF_BRO, lop, 0), zdo = w8_op_if(on_tile, my + W8_BF_BDO, lop, 0);
-                wro[0] = w8_mfma32(zro, ahr0, wro[0]); wro[1] = w8_mfma32(zro, ahr1, wro[1]);
-                wdo[0] = w8_mfma32(zdo, ahd0, wdo[0]); wdo[1] = w8_mfma32(zdo, ahd1, wdo[1]);
-            }
             W8_T1();
         };
         uint32_t p = 0;
@@ -524,21 +557,17 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
         }
         if (p < n_phase) phase(p, I1, I0);
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            w8_store<false, true>(part, po.rO, 64, 0, dm.n_rgb_out, 64, 0, b, lane, wro[b]);
-            w8_store<false, true>(part, po.dO, 64, 0, 1, 64, 0, b, lane, wdo[b]);
-        }
-        // the padding rows of the two output layers (the partial row is summed entry by entry: it is written in full, never zero-filled)
-        for (uint32_t i = dm.n_rgb_out * 64 + lane; i < 16 * 64; i += 64) part[po.rO + i] = 0.0f;
-        for (uint32_t i = 64 + lane; i < 16 * 64; i += 64) part[po.dO + i] = 0.0f;
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) w8_store<true, true>(part, po.d0, 64, 0, 64, 64, a, b, lane, wd0[a][b]);
     } else if (role == 2) {
-        // ======================================================================== Bb: heads backward of tile p - 2, dW_r0, dW_d0
-        cn_f16v wrd[2], wrf[2][2], wd0[2][2];
+        // ======================================================================== Bb: heads backward of tile p - 2, dW_r0 (same tile)
+        cn_f16v wrd[2], wrf[2][2];
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             w8_zero16(wrd[a]);
 #pragma unroll
-            for (int b = 0; b < 2; b++) { w8_zero16(wrf[a][b]); w8_zero16(wd0[a][b]); }
+            for (int b = 0; b < 2; b++) w8_zero16(wrf[a][b]);
         }
         const unsigned char *w_d0 = wb + 2 * W8_W_D0, *w_dO = wb + 2 * W8_W_DO, *w_r0 = wb + 2 * W8_W_R0, *w_rO = wb + 2 * W8_W_RO;
         unsigned char *mine = px + W8_BB;
@@ -547,60 +576,46 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             asm volatile("" ::: "memory");
             const bool on_tile = p >= 2 && p - 2 < n_iter;
             const unsigned char *bf = px + W8_BF + (p & 1) * W8_BF_BYTES;          // (p - 2) & 1
-            const unsigned char *fe = px + W8_FEA + ((p + 1) % 3) * 2 * W8_K;      // (p - 2) mod 3
-            // ---- stage 0 / 1: dO^T dz_dO, rO^T dz_rO, masked with the forward's activations (the register budget of this wave — ten 32x32
-            // weight-gradient tiles — leaves room for one head at a time)
-            cn_h8 zd[2], zr[2];
-            {
-                cn_h8 hd[2], bdo[1], wdoT[4];
-                w8_fetch<1>(bf + W8_BF_BDO, slot, bdo);
-                w8_load_T16<4, 2>(w_dO, lane_off_T, wdoT);
-                w8_fetch<2>(bf + W8_BF_HD, slot, hd);
-                w8_f4 accd[4];
-                w8_zero(accd);
-                w8_mm<4, 1>(wdoT, bdo, accd);
-                cn_h8 hr[2], bro[1], wroT[4];
-                w8_fetch<1>(bf + W8_BF_BRO, slot, bro);
-                w8_load_T16<4, 2>(w_rO, lane_off_T, wroT);
-                w8_fetch<2>(bf + W8_BF_HR, slot, hr);
-                w8_f4 accr[4];
-                w8_zero(accr);
-                w8_mm<4, 1>(wroT, bro, accr);
-                __builtin_amdgcn_sched_barrier(0);
-                w8_c_to_b<2>(accd, hd, zd);
-                w8_publish<2>(mine + W8_BB_ZD, slot, zd);
-                w8_c_to_b<2>(accr, hr, zr);
-                w8_publish<2>(mine + W8_BB_ZR, slot, zr);
-            }
+            const unsigned char *fe = px + W8_FEA + ((p + 2) & 3) * 2 * W8_K;      // (p - 2) & 3
+            unsigned char *zdo_ = px + W8_ZD + (p & 1) * 2 * W8_K;                 // (p - 2) & 1
+            // ---- stage 0: output-layer gradients, the forward's activations (masks), every transposed fragment of the phase
+            cn_h8 hd[2], hr[2], bro[1], bdo[1];
+            w8_fetch<1>(bf + W8_BF_BDO, slot, bdo);
+            w8_fetch<1>(bf + W8_BF_BRO, slot, bro);
+            cn_h8 wdoT[4], wroT[4];
+            w8_load_T16<4, 2>(w_dO, lane_off_T, wdoT);
+            w8_load_T16<4, 2>(w_rO, lane_off_T, wroT);
+            w8_fetch<2>(bf + W8_BF_HD, slot, hd);
+            w8_fetch<2>(bf + W8_BF_HR, slot, hr);
+            cn_h8 wdT[8], wrT[8];
+            w8_load_T<4, 2, 2>(w_d0, lane_off_T, wdT);
+            w8_load_T<4, 2, 3>(w_r0, lane_off_T, wrT);
+            // the activation operands of dW_r0 = dz_r x [dir | fea]: rings of earlier phases
+            const cn_h8 f0 = w8_op(fe, lop, 0), f1 = w8_op(fe, lop, 1), dd = w8_op(bf + W8_BF_DIR, lop, 0);
+            w8_f4 accd[4], accr[4];
+            w8_zero(accd); w8_zero(accr);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stage 1: dO^T | rO^T
+            w8_mm<4, 1>(wdoT, bdo, accd);
+            w8_mm<4, 1>(wroT, bro, accr);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- stage 2: d(fea) = d0^T dz_d + r0^T dz_r
+            cn_h8 zd[2], zr[2];
+            w8_c_to_b<2>(accr, hr, zr);
+            w8_publish<2>(mine + W8_BB_ZR, slot, zr);
+            w8_c_to_b<2>(accd, hd, zd);
+            w8_publish<2>(zdo_, slot, zd);
             w8_f4 dfea[4];
             w8_zero(dfea);
-            {
-                cn_h8 wdT[8];
-                w8_load_T<4, 2, 2>(w_d0, lane_off_T, wdT);
-                __builtin_amdgcn_sched_barrier(0);
-                w8_mm<4, 2>(wdT, zd, dfea);
-            }
-            {
-                cn_h8 wrT[8];
-                w8_load_T<4, 2, 3>(w_r0, lane_off_T, wrT);
-                w8_mm<4, 2>(wrT, zr, dfea);
-            }
-            // ---- weight gradients while the chain's tail drains: dz_r x [dir | fea], dz_d x fea
-            {
-                const cn_h8 f0 = w8_op(fe, lop, 0), f1 = w8_op(fe, lop, 1), dd = w8_op(bf + W8_BF_DIR, lop, 0);
-                {
-                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 0), z1 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 1);
-                    wrd[0] = w8_mfma32(z0, dd, wrd[0]); wrd[1] = w8_mfma32(z1, dd, wrd[1]);
-                    wrf[0][0] = w8_mfma32(z0, f0, wrf[0][0]); wrf[0][1] = w8_mfma32(z0, f1, wrf[0][1]);
-                    wrf[1][0] = w8_mfma32(z1, f0, wrf[1][0]); wrf[1][1] = w8_mfma32(z1, f1, wrf[1][1]);
-                }
-                {
-                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_BB_ZD, lop, 0), z1 = w8_op_if(on_tile, mine + W8_BB_ZD, lop, 1);
-                    wd0[0][0] = w8_mfma32(z0, f0, wd0[0][0]); wd0[0][1] = w8_mfma32(z0, f1, wd0[0][1]);
-                    wd0[1][0] = w8_mfma32(z1, f0, wd0[1][0]); wd0[1][1] = w8_mfma32(z1, f1, wd0[1][1]);
-                }
-            }
+            // dz_r read back transposed for the weight gradients (in-order DS: after this wave's own publish)
+            const cn_h8 z0 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 0), z1 = w8_op_if(on_tile, mine + W8_BB_ZR, lop, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            w8_mm<4, 2>(wrT, zr, dfea);
+            w8_mm<4, 2>(wdT, zd, dfea);
+            wrd[0] = w8_mfma32(z0, dd, wrd[0]); wrd[1] = w8_mfma32(z1, dd, wrd[1]);
+            wrf[0][0] = w8_mfma32(z0, f0, wrf[0][0]); wrf[0][1] = w8_mfma32(z0, f1, wrf[0][1]);
+            wrf[1][0] = w8_mfma32(z1, f0, wrf[1][0]); wrf[1][1] = w8_mfma32(z1, f1, wrf[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
             cn_h8 z3[2];
             w8_c_to_b<0>(dfea, nullptr, z3);
             w8_publish<2>(px + W8_Z3 + (p & 1) * 2 * W8_K, slot, z3);               // (p - 2) & 1
@@ -614,19 +629,16 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
         for (int a = 0; a < 2; a++) {
             w8_store<true, false>(part, po.r0, 96, 0, 64, FLD_NDIR, a, 0, lane, wrd[a]);
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                w8_store<true, true>(part, po.r0, 96, FLD_NDIR, 64, 64, a, b, lane, wrf[a][b]);
-                w8_store<true, true>(part, po.d0, 64, 0, 64, 64, a, b, lane, wd0[a][b]);
-            }
+            for (int b = 0; b < 2; b++) w8_store<true, true>(part, po.r0, 96, FLD_NDIR, 64, 64, a, b, lane, wrf[a][b]);
         }
     } else {
-        // ======================================================================== Ab: geometry backward of tile p - 3, dW_n2, dW_n1, dW_n0
-        cn_f16v wn2[2][2], wn1[2][2], wn0[2];
+        // ======================================================================== Ab: geometry backward of tile p - 3, dW_n1, dW_n0 (same tile)
+        cn_f16v wn1[2][2], wn0[2];
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             w8_zero16(wn0[a]);
 #pragma unroll
-            for (int b = 0; b < 2; b++) { w8_zero16(wn2[a][b]); w8_zero16(wn1[a][b]); }
+            for (int b = 0; b < 2; b++) w8_zero16(wn1[a][b]);
         }
         const unsigned char *w_n0 = wb + 2 * W8_W_N0, *w_n1 = wb + 2 * W8_W_N1, *w_n2 = wb + 2 * W8_W_N2;
         unsigned char *mine = px + W8_AB;
@@ -638,59 +650,48 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
             const bool valid = on_tile && np < P_;
             const unsigned char *af = px + W8_AF + ((p + 1) & 3) * W8_AF_BYTES;    // (p - 3) & 3
             const unsigned char *z3i = px + W8_Z3 + ((p + 1) & 1) * 2 * W8_K;      // (p - 3) & 1
-            const unsigned char *hl = af + ((NGEO == 2) ? W8_AF_H2 : W8_AF_H1);
-            // ---- stage 0
-            cn_h8 z3[2];
+            // ---- stage 0: dz_3, the forward's activations (masks + weight-gradient operands), every transposed fragment of the phase
+            cn_h8 z3[2], h1[2], h2[2];
             w8_fetch<2>(z3i, slot, z3);
-            cn_h8 wT[8];
-            w8_load_T<4, 2, 2>(w_n2, lane_off_T, wT);
+            cn_h8 wT2[8], wT1[8], wTn[4];
+            w8_load_T<4, 2, 2>(w_n2, lane_off_T, wT2);
+            if (NGEO == 2) {
+                w8_fetch<2>(af + W8_AF_H2, slot, h2);
+                w8_load_T<4, 2, 2>(w_n1, lane_off_T, wT1);
+            }
+            w8_fetch<2>(af + W8_AF_H1, slot, h1);
+            w8_load_Tn<2, 2>(w_n0, lane_off_Tn0, lane_off_Tn1, wTn);
+            const cn_h8 a10 = w8_op(af + W8_AF_H1, lop, 0), a11 = w8_op(af + W8_AF_H1, lop, 1), ax0 = w8_op(af + W8_AF_X0, lop, 0);
             w8_f4 acc[4];
             w8_zero(acc);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 1: n2^T dz3 (+ dW_n2 = dz3 x h_last: both operands are other stages' images)
-            w8_mm<4, 2>(wT, z3, acc);
-            {
-                const cn_h8 z0 = w8_op_if(on_tile, z3i, lop, 0), z1 = w8_op_if(on_tile, z3i, lop, 1), a0 = w8_op(hl, lop, 0), a1 = w8_op(hl, lop, 1);
-                wn2[0][0] = w8_mfma32(z0, a0, wn2[0][0]); wn2[0][1] = w8_mfma32(z0, a1, wn2[0][1]);
-                wn2[1][0] = w8_mfma32(z1, a0, wn2[1][0]); wn2[1][1] = w8_mfma32(z1, a1, wn2[1][1]);
-            }
+            // ---- stage 1: n2^T dz3
+            w8_mm<4, 2>(wT2, z3, acc);
+            __builtin_amdgcn_sched_barrier(0);
             cn_h8 z1f[2];
             if (NGEO == 2) {
-                w8_load_T<4, 2, 2>(w_n1, lane_off_T, wT);
-                __builtin_amdgcn_sched_barrier(0);
                 // ---- stage 2: n1^T dz2 (+ dW_n1 = dz2 x h1)
-                cn_h8 z2[2], h2[2];
-                w8_fetch<2>(af + W8_AF_H2, slot, h2);
+                cn_h8 z2[2];
                 w8_c_to_b<2>(acc, h2, z2);
                 w8_publish<2>(mine + W8_AB_Z2, slot, z2);
                 w8_zero(acc);
+                const cn_h8 z0 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 0), z1 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                w8_mm<4, 2>(wT, z2, acc);
-                {
-                    const cn_h8 z0 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 0), z1 = w8_op_if(on_tile, mine + W8_AB_Z2, lop, 1);
-                    const cn_h8 a0 = w8_op(af + W8_AF_H1, lop, 0), a1 = w8_op(af + W8_AF_H1, lop, 1);
-                    wn1[0][0] = w8_mfma32(z0, a0, wn1[0][0]); wn1[0][1] = w8_mfma32(z0, a1, wn1[0][1]);
-                    wn1[1][0] = w8_mfma32(z1, a0, wn1[1][0]); wn1[1][1] = w8_mfma32(z1, a1, wn1[1][1]);
-                }
+                w8_mm<4, 2>(wT1, z2, acc);
+                wn1[0][0] = w8_mfma32(z0, a10, wn1[0][0]); wn1[0][1] = w8_mfma32(z0, a11, wn1[0][1]);
+                wn1[1][0] = w8_mfma32(z1, a10, wn1[1][0]); wn1[1][1] = w8_mfma32(z1, a11, wn1[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            cn_h8 wTn[4];
-            w8_load_Tn<2, 2>(w_n0, lane_off_Tn0, lane_off_Tn1, wTn);
-            __builtin_amdgcn_sched_barrier(0);
             // ---- stage 3: n0^T dz1 -> d(loss)/d(grid features) (+ dW_n0 = dz1 x x0)
-            {
-                cn_h8 h1[2];
-                w8_fetch<2>(af + W8_AF_H1, slot, h1);
-                w8_c_to_b<2>(acc, h1, z1f);
-            }
+            w8_c_to_b<2>(acc, h1, z1f);
             w8_publish<2>(mine + W8_AB_Z1, slot, z1f);
             w8_f4 denc[2];
             w8_zero(denc);
+            const cn_h8 y0 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 0), y1 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 1);
             __builtin_amdgcn_sched_barrier(0);
             w8_mm<2, 2>(wTn, z1f, denc);
-            {
-                const cn_h8 z0 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 0), z1 = w8_op_if(on_tile, mine + W8_AB_Z1, lop, 1), a0 = w8_op(af + W8_AF_X0, lop, 0);
-                wn0[0] = w8_mfma32(z0, a0, wn0[0]); wn0[1] = w8_mfma32(z1, a0, wn0[1]);
-            }
+            wn0[0] = w8_mfma32(y0, ax0, wn0[0]); wn0[1] = w8_mfma32(y1, ax0, wn0[1]);
+            __builtin_amdgcn_sched_barrier(0);
             if (valid) {
 #pragma unroll
                 for (int mp = 0; mp < 2; mp++) {
@@ -706,10 +707,9 @@ __global__ void __launch_bounds__(W8_THREADS) k_field_bwd_w8(const void *__restr
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             w8_store<true, false>(part, po.n0, dm.enc_pad, 0, 64, dm.enc_pad, a, 0, lane, wn0[a]);
+            if (NGEO == 2) {
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                w8_store<true, true>(part, po.n2, 64, 0, 64, 64, a, b, lane, wn2[a][b]);
-                if (NGEO == 2) w8_store<true, true>(part, po.n1, 64, 0, 64, 64, a, b, lane, wn1[a][b]);
+                for (int b = 0; b < 2; b++) w8_store<true, true>(part, po.n1, 64, 0, 64, 64, a, b, lane, wn1[a][b]);
             }
         }
     }
