@@ -65,6 +65,8 @@ SIGNATURES = {
     "cnerf_composite_run": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp],
     "cnerf_composite_run_backward": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp],
     "cnerf_recon_loss": [vp, vp, vp, u32, f32, f32, vp, vp, vp],
+    "cnerf_recon_loss_scaled": [vp, vp, vp, u32, f32, f32, vp, vp, vp, vp],
+    "cnerf_sample_coarse_unit_aabb": [vp, vp, vp, f32, vp, u32, u32, vp, vp, vp, vp, vp, f32, vp],
     "cnerf_composite_run_indexed": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp, vp, vp, vp],
     "cnerf_composite_run_backward_indexed": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
@@ -73,6 +75,7 @@ SIGNATURES = {
     "cnerf_dp_pack": [vp, vp, u64, f32, vp],
     "cnerf_dp_reduce": [vp, u32, u64, vp, vp, vp],
     "cnerf_scaler_update": [vp, f32, f32, u32, vp],
+    "cnerf_adam_step_scaled_multi": [vp, f32, f32, f32, vp, f32, i32, i32, f32, f32, u32, vp],
     # ---- include/customnerf_sd.h (score-distillation primitives)
     "cnerf_sd_gemm": [vp, vp, u64, vp],
     "cnerf_sd_gemm_workspace_bytes": [vp, vp],
@@ -106,6 +109,15 @@ class SdGemmDesc(C.Structure):
                 ("mode", C.c_int32), ("Cin", u32), ("H_in", u32), ("W_in", u32), ("H_out", u32), ("W_out", u32),
                 ("KH", u32), ("KW", u32), ("stride", u32), ("pad_t", u32), ("pad_l", u32), ("ups", u32), ("tstride", u32),
                 ("gn_sums", vp), ("gn_groups", u32), ("gn_rows", u32)]
+
+ADAM_MAX_JOBS = 8
+
+
+class AdamJobs(C.Structure):
+    """struct CnerfAdamJobs of include/customnerf_hip.h"""
+    _fields_ = [("p", vp * ADAM_MAX_JOBS), ("g", vp * ADAM_MAX_JOBS), ("m", vp * ADAM_MAX_JOBS), ("v", vp * ADAM_MAX_JOBS), ("p_half", vp * ADAM_MAX_JOBS),
+                ("n", u64 * ADAM_MAX_JOBS), ("lr", f32 * ADAM_MAX_JOBS), ("n_jobs", u32)]
+
 
 F32, F16 = 0, 1
 

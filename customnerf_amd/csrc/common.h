@@ -72,3 +72,26 @@ __device__ __forceinline__ T cn_wave_sum(T v) {
     v = cn_wave_incl_scan(v);
     return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// near / far of a ray against an axis-aligned box (raymarching.cu:91-145): shared by k_near_far_from_aabb and the fused coarse sampler
+#include <float.h>
+__device__ __forceinline__ void cn_near_far(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ aabb, float min_near,
+                                            float &near_out, float &far_out) {
+    const float ox = o[0], oy = o[1], oz = o[2];
+    const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { const float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { const float c = near_y; near_y = far_y; far_y = c; }
+    bool miss = (near > far_y || near_y > far);
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { const float c = near_z; near_z = far_z; far_z = c; }
+    miss = miss || (near > far_z || near_z > far);
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    near_out = miss ? FLT_MAX : near;
+    far_out = miss ? FLT_MAX : far;
+}

@@ -229,6 +229,67 @@ __global__ void __launch_bounds__(256) k_adam_scaled(float *__restrict__ p, floa
     }
 }
 
+// The small parameter tensors of a step (the three MLPs: 22.5 k floats) in ONE single-workgroup launch — three launches of ~6 us each
+// before — which, being the last Adam launch of the step, also applies GradScaler.update() once every thread is past its state reads
+// (one more launch saved).  Same arithmetic as k_adam_scaled, element by element.
+__global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, float beta1, float beta2, float eps, float *__restrict__ state,
+                                                            float extra_inv, int zero_grad, int update_scaler, float growth, float backoff, float interval) {
+    __shared__ double s_bc1;
+    __shared__ float s_r2;
+    const bool skip = state[2] != 0.0f;
+    const float gscale = extra_inv / state[0];
+    if (threadIdx.x == 0) {                                               // the double-precision pow()s once, not once per thread
+        const double step = (double)state[3] + 1.0;
+        s_bc1 = 1.0 - pow((double)beta1, step);
+        s_r2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
+    }
+    __syncthreads();
+    const double bc1 = s_bc1;
+    const float rsqrt_bc2 = s_r2;
+    for (uint32_t j = 0; j < jobs.n_jobs; j++) {
+        float *__restrict__ p = jobs.p[j], *__restrict__ g = jobs.g[j], *__restrict__ m = jobs.m[j], *__restrict__ v = jobs.v[j];
+        __half *__restrict__ ph = reinterpret_cast<__half *>(jobs.p_half[j]);
+        const float step_size = (float)((double)jobs.lr[j] / bc1);             // (the same expression as k_adam_scaled: bit-identical updates)
+        const uint64_t n = jobs.n[j];
+        // a single workgroup is latency-bound: eight elements per thread and trip, all their loads issued before the first is used
+        for (uint64_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+            float gk[8], mk[8], vk[8], pk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = i0 + (uint64_t)u * 1024;
+                const bool in = i < n;
+                gk[u] = in ? g[i] : 0.0f; mk[u] = in ? m[i] : 0.0f; vk[u] = in ? v[i] : 0.0f; pk[u] = in ? p[i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = i0 + (uint64_t)u * 1024;
+                if (i >= n) continue;
+                if (!skip) {
+                    const float gs = gk[u] * gscale;
+                    const float mn = beta1 * mk[u] + (1.0f - beta1) * gs;
+                    const float vn = beta2 * vk[u] + (1.0f - beta2) * gs * gs;
+                    const float pn = pk[u] - step_size * mn / (sqrtf(vn) * rsqrt_bc2 + eps);
+                    m[i] = mn; v[i] = vn; p[i] = pn;
+                    if (ph) ph[i] = __float2half_rn(pn);
+                }
+                if (zero_grad) g[i] = 0;
+            }
+        }
+    }
+    if (update_scaler) {
+        __syncthreads();                                                      // every thread has read the state
+        if (threadIdx.x == 0) {
+            if (skip) { state[0] *= backoff; state[1] = 0.0f; }
+            else {
+                state[3] += 1.0f;
+                const float t = state[1] + 1.0f;
+                if (t >= interval) { state[0] *= growth; state[1] = 0.0f; } else state[1] = t;
+            }
+            state[2] = 0.0f;
+        }
+    }
+}
+
 extern "C" {
 
 int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
@@ -300,6 +361,19 @@ int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half,
     const uint32_t blocks = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
     hipLaunchKernelGGL(k_adam_scaled, dim3(blocks), dim3(256), 0, CN_STREAM(stream), p, g, m, v, (__half *)p_half, n, lr, beta1, beta2, eps, state,
                        extra_inv, zero_grad);
+    return cn_launch_status();
+}
+
+int cnerf_adam_step_scaled_multi(const CnerfAdamJobs *jobs, float beta1, float beta2, float eps, float *state, float extra_inv, int zero_grad,
+                                 int update_scaler, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream) {
+    if (!jobs || !state) return CNERF_ENULL;
+    if (jobs->n_jobs > CNERF_ADAM_MAX_JOBS) return CNERF_EINVAL;
+    if (update_scaler && (!(growth_factor >= 1.0f) || !(backoff_factor > 0.0f && backoff_factor <= 1.0f) || growth_interval == 0)) return CNERF_EINVAL;
+    for (uint32_t j = 0; j < jobs->n_jobs; j++)
+        if (!jobs->p[j] || !jobs->g[j] || !jobs->m[j] || !jobs->v[j]) return CNERF_ENULL;
+    if (jobs->n_jobs == 0 && !update_scaler) return CNERF_OK;
+    hipLaunchKernelGGL(k_adam_scaled_multi, dim3(1), dim3(1024), 0, CN_STREAM(stream), *jobs, beta1, beta2, eps, state, extra_inv, zero_grad, update_scaler,
+                       growth_factor, backoff_factor, (float)growth_interval);
     return cn_launch_status();
 }
 

@@ -52,24 +52,10 @@ __global__ void __launch_bounds__(RM_BLOCK) k_near_far_from_aabb(const float *__
                                                                  float *__restrict__ nears, float *__restrict__ fars) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
-    if (near > far) { const float c = near; near = far; far = c; }
-    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
-    if (near_y > far_y) { const float c = near_y; near_y = far_y; far_y = c; }
-    bool miss = (near > far_y || near_y > far);
-    if (near_y > near) near = near_y;
-    if (far_y < far) far = far_y;
-    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
-    if (near_z > far_z) { const float c = near_z; near_z = far_z; far_z = c; }
-    miss = miss || (near > far_z || near_z > far);
-    if (near_z > near) near = near_z;
-    if (far_z < far) far = far_z;
-    if (near < min_near) near = min_near;
-    nears[n] = miss ? FLT_MAX : near;
-    fars[n] = miss ? FLT_MAX : far;
+    float near, far;
+    cn_near_far(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, aabb, min_near, near, far);
+    nears[n] = near;
+    fars[n] = far;
 }
 
 __global__ void __launch_bounds__(RM_BLOCK) k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,

@@ -32,11 +32,18 @@ __device__ __forceinline__ void rn_point(const float *o, const float *d, float z
 __global__ void __launch_bounds__(256) k_sample_coarse(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
                                                        const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
                                                        uint32_t N, uint32_t T, float *__restrict__ z_vals, float *__restrict__ xyzs,
-                                                       float *__restrict__ unit, float bound) {
+                                                       float *__restrict__ unit, float bound, float *__restrict__ nears_out, float *__restrict__ fars_out,
+                                                       float min_near) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * T) return;
     const uint32_t n = idx / T, i = idx - n * T;
-    const float near = nears[n], far = fars[n];
+    float near, far;
+    if (nears_out) {                                          // near_far_from_aabb folded in (renderer.py:297): every thread of a ray repeats the slab test, sample 0 stores it
+        cn_near_far(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, aabb, min_near, near, far);
+        if (i == 0) { nears_out[n] = near; fars_out[n] = far; }
+    } else {
+        near = nears[n]; far = fars[n];
+    }
     float z = near + (far - near) * rn_linspace01(i, T);
     if (noise) z = z + (noise[idx] - 0.5f) * ((far - near) / (float)T);
     float p[3];
@@ -440,9 +447,11 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
 // a one-wave second launch adds them in a fixed order into loss[0].
 #define RL_BLOCKS 64
 __global__ void __launch_bounds__(256) k_recon_loss(const float *__restrict__ out_ray, const float *__restrict__ rgb_gt, const float *__restrict__ mask_gt,
-                                                    uint32_t N, float k_rgb, float k_m, float *__restrict__ partial, float *__restrict__ g_out) {
+                                                    uint32_t N, float k_rgb, float k_m, float *__restrict__ partial, float *__restrict__ g_out,
+                                                    const float *__restrict__ grad_scale) {
     __shared__ float red[2][4];
     float s_rgb = 0.0f, s_m = 0.0f;
+    const float gsc = grad_scale ? grad_scale[0] : 1.0f;          // the backward pass's seed (the loss scale), folded into the stored gradient
     for (uint32_t n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
         const float *r = out_ray + (size_t)n * 6;
         float g[6] = {0, 0, 0, 0, 0, 0};
@@ -450,12 +459,12 @@ __global__ void __launch_bounds__(256) k_recon_loss(const float *__restrict__ ou
         for (int c = 0; c < 3; c++) {
             const float d = r[c] - rgb_gt[(size_t)n * 3 + c];
             s_rgb += d * d;
-            g[c] = 2.0f * k_rgb * d;
+            g[c] = (2.0f * k_rgb * d) * gsc;
         }
         if (mask_gt) {
             const float d = r[5] - mask_gt[n];
             s_m += d * d;
-            g[5] = 2.0f * k_m * d;
+            g[5] = (2.0f * k_m * d) * gsc;
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) {
@@ -486,7 +495,7 @@ int cnerf_sample_coarse(const float *rays_o, const float *rays_d, const float *n
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs) return CNERF_ENULL;
     hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb, noise, N, T,
-                       z_vals, xyzs, (float *)nullptr, 0.0f);
+                       z_vals, xyzs, (float *)nullptr, 0.0f, (float *)nullptr, (float *)nullptr, 0.0f);
     return cn_launch_status();
 }
 
@@ -496,7 +505,17 @@ int cnerf_sample_coarse_unit(const float *rays_o, const float *rays_d, const flo
     if (N == 0) return CNERF_OK;
     if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs || !unit) return CNERF_ENULL;
     hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, nears, fars, aabb, noise, N, T,
-                       z_vals, xyzs, unit, bound);
+                       z_vals, xyzs, unit, bound, (float *)nullptr, (float *)nullptr, 0.0f);
+    return cn_launch_status();
+}
+
+int cnerf_sample_coarse_unit_aabb(const float *rays_o, const float *rays_d, const float *aabb, float min_near, const float *noise, uint32_t N, uint32_t T,
+                                  float *nears, float *fars, float *z_vals, float *xyzs, float *unit, float bound, void *stream) {
+    if (T < 2 || T > RN_MAXS || !(bound > 0.0f)) return CNERF_EINVAL;
+    if (N == 0) return CNERF_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !aabb || !z_vals || !xyzs || !unit) return CNERF_ENULL;
+    hipLaunchKernelGGL(k_sample_coarse, dim3(cn_div_up(N * T, 256)), dim3(256), 0, CN_STREAM(stream), rays_o, rays_d, (const float *)nullptr,
+                       (const float *)nullptr, aabb, noise, N, T, z_vals, xyzs, unit, bound, nears, fars, min_near);
     return cn_launch_status();
 }
 
@@ -568,17 +587,21 @@ int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas,
                                                 detach_mask_from_field, nullptr, grad_sigmas, grad_rgbc, stream);
 }
 
-int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf, float *loss,
-                     float *grad_out_ray, void *stream) {
+int cnerf_recon_loss_scaled(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf,
+                            const float *grad_scale, float *loss, float *grad_out_ray, void *stream) {
     if (N == 0) return CNERF_EINVAL;
     if (!out_ray || !rgb_gt || !loss || !grad_out_ray) return CNERF_ENULL;
-    // the tail of grad_out_ray is written last by the same launch, so its first floats can carry the partial sums until the second launch
-    // has read them?  No: keep it simple and exact — the partials live in loss[1 .. RL_BLOCKS] (loss must hold 1 + 64 floats).
+    // the partial sums live in loss[1 .. RL_BLOCKS] (loss must hold 1 + 64 floats), added in a fixed order by the second launch
     const uint32_t blocks = cn_div_up(N, 256) < RL_BLOCKS ? cn_div_up(N, 256) : RL_BLOCKS;
     hipLaunchKernelGGL(k_recon_loss, dim3(blocks), dim3(256), 0, CN_STREAM(stream), out_ray, rgb_gt, mask_gt, N, w_rgb / (3.0f * (float)N),
-                       mask_gt ? w_conf / (float)N : 0.0f, loss + 1, grad_out_ray);
+                       mask_gt ? w_conf / (float)N : 0.0f, loss + 1, grad_out_ray, grad_scale);
     hipLaunchKernelGGL(k_recon_loss_sum, dim3(1), dim3(64), 0, CN_STREAM(stream), loss + 1, blocks, loss);
     return cn_launch_status();
+}
+
+int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf, float *loss,
+                     float *grad_out_ray, void *stream) {
+    return cnerf_recon_loss_scaled(out_ray, rgb_gt, mask_gt, N, w_rgb, w_conf, nullptr, loss, grad_out_ray, stream);
 }
 
 int cnerf_sample_pdf(const float *bins, const float *weights, const float *u, uint32_t B, uint32_t n_bins, uint32_t n_samples, float *samples, void *stream) {

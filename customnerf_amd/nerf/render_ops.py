@@ -25,6 +25,21 @@ def sample_coarse(rays_o, rays_d, nears, fars, aabb, T, noise=None, xyz_out=None
     return z, xyz
 
 
+def sample_coarse_aabb(rays_o, rays_d, aabb, min_near, T, noise, xyz_out, unit_out, bound):
+    """near_far_from_aabb (renderer.py:297) + the stratified coarse samples (:310-322) + the grid's [0,1] coordinates in ONE launch
+    -> nears [N], fars [N], z_vals [N,T], xyzs [N,T,3]; nears / fars are bit-identical to raymarching.near_far_from_aabb."""
+    require_cuda(rays_o, rays_d, aabb, noise, xyz_out, unit_out)
+    N = rays_o.shape[0]
+    nears = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+    fars = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+    z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
+    assert xyz_out.is_contiguous() and xyz_out.dtype == torch.float32 and xyz_out.numel() == N * T * 3
+    assert unit_out.is_contiguous() and unit_out.dtype == torch.float32 and unit_out.numel() == N * T * 3
+    check(lib.cnerf_sample_coarse_unit_aabb(ptr(rays_o), ptr(rays_d), ptr(aabb), float(min_near), ptr(noise), N, int(T), ptr(nears), ptr(fars), ptr(z),
+                                            ptr(xyz_out), ptr(unit_out), float(bound), stream()), "sample_coarse_unit_aabb")
+    return nears, fars, z, xyz_out
+
+
 def sample_fine_merge(rays_o, rays_d, nears, fars, aabb, z_vals, sigmas, t, u=None):
     """-> z_all [N,T+t] (sorted), xyz_all [N,T+t,3]   (renderer.py:334-363; u [N,t] = the draw of sample_pdf:37, None = det)"""
     require_cuda(z_vals, sigmas, u)
@@ -152,24 +167,33 @@ class _ReconLoss(Function):
     """loss [] = w_rgb * mse(image, rgb_gt) + w_conf * mse(render_mask, mask_gt) on out_ray [3,N,6]; the gradient comes out of the same launch"""
 
     @staticmethod
-    def forward(ctx, out_ray, rgb_gt, mask_gt, w_rgb, w_conf):
-        require_cuda(out_ray, rgb_gt, mask_gt)
+    def forward(ctx, out_ray, rgb_gt, mask_gt, w_rgb, w_conf, grad_scale=None):
+        """grad_scale: the device scalar the backward pass will be seeded with (DynamicLossScaler.state[0:1]) — the stored gradient is then
+        already multiplied by it and backward() hands it on as it is (one element-wise launch per step saved)"""
+        require_cuda(out_ray, rgb_gt, mask_gt, grad_scale)
         out_ray = out_ray.contiguous().float()
         N = out_ray.shape[1]
         rgb_gt = rgb_gt.reshape(N, 3).contiguous().float()
         mask_gt = mask_gt.reshape(N).contiguous().float() if mask_gt is not None else None
         loss = torch.empty(65, dtype=torch.float32, device=out_ray.device)       # [0] = loss, [1:] = partial sums
         g = torch.empty_like(out_ray)
-        check(lib.cnerf_recon_loss(ptr(out_ray), ptr(rgb_gt), ptr(mask_gt), N, float(w_rgb), float(w_conf), ptr(loss), ptr(g), stream()), "recon_loss")
+        check(lib.cnerf_recon_loss_scaled(ptr(out_ray), ptr(rgb_gt), ptr(mask_gt), N, float(w_rgb), float(w_conf), ptr(grad_scale), ptr(loss), ptr(g),
+                                          stream()), "recon_loss")
         ctx.save_for_backward(g)
+        ctx.scale = grad_scale
         return loss[0]
 
     @staticmethod
     def backward(ctx, g_loss):
         g, = ctx.saved_tensors
-        return g * g_loss, None, None, None, None
+        sc = ctx.scale
+        if sc is None:
+            return g * g_loss, None, None, None, None, None
+        if g_loss.data_ptr() == sc.data_ptr() and g_loss.dtype == sc.dtype:         # seeded with the very scalar that is already in g
+            return g, None, None, None, None, None
+        return g * (g_loss / sc.reshape(())), None, None, None, None, None           # some other seed: correct for the folded factor
 
 
-def recon_loss(out_ray, rgb_gt, mask_gt, w_rgb, w_conf):
+def recon_loss(out_ray, rgb_gt, mask_gt, w_rgb, w_conf, grad_scale=None):
     """utils_init_nerf.py:220-234 on the fused renderer's raw composite output (results['_out_ray'])"""
-    return _ReconLoss.apply(out_ray, rgb_gt, mask_gt, w_rgb, w_conf)
+    return _ReconLoss.apply(out_ray, rgb_gt, mask_gt, w_rgb, w_conf, grad_scale)

@@ -129,6 +129,19 @@ class NeRFRenderer(nn.Module):
                              "the reference's recipe is 64 + 64)")
         return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
 
+    def _dirs_twice(self, rays_d):
+        """[d | d] for the split sample list, cached per view: a dataset's ray directions are resident tensors that come back every epoch
+        (provider.py keeps them on the GPU), so the concatenation launch is paid once per view, not once per step"""
+        cache = self.__dict__.setdefault('_dirs2_cache', {})
+        key = (rays_d.data_ptr(), rays_d._version, tuple(rays_d.shape))
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            ent = (rays_d, torch.cat([rays_d, rays_d], 0))               # the source reference pins the key's storage
+            cache[key] = ent
+        return ent[1]
+
     def _field_all(self, xyz, rays_d, S):
         """sigma [P], rgb+confidence [P, 4] of P = N*S samples (S consecutive samples share a ray direction) from a subclass forward()"""
         if getattr(self, 'supports_dir_group', False):
@@ -149,7 +162,6 @@ class NeRFRenderer(nn.Module):
         device = rays_o.device
         draws = _draws or {}
         aabb = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         S = num_steps + upsample_steps
         soft, thr = bool(getattr(self.opt, 'soft_mask', False)), float(getattr(self.opt, 'conf_thr', 0.5))
         dbg, dmask = bool(getattr(self.opt, 'detach_bg', False)), bool(getattr(self.opt, 'detach_mask_from_field', False))
@@ -157,6 +169,8 @@ class NeRFRenderer(nn.Module):
                  and not getattr(self.opt, 'eval_fine_density', False))
         grad_on = torch.is_grad_enabled()
         plan = None
+        if not split:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         with torch.no_grad():
             noise = None
             both = None
@@ -179,8 +193,9 @@ class NeRFRenderer(nn.Module):
                 xyz_list = torch.empty(P, 3, dtype=torch.float32, device=device)
                 enc, unit = self.split_buffers(P, device)
                 bnd = float(self.opt.bound)                                  # the samplers also write the grid's [0,1] coordinates (no elementwise pass)
-                z_vals, xyz_c = render_ops.sample_coarse(rays_o, rays_d, nears, fars, aabb, num_steps, noise, xyz_out=xyz_list[:Pc].view(N, num_steps, 3),
-                                                         unit_out=unit[:Pc].view(N, num_steps, 3), bound=bnd)
+                # near_far_from_aabb (:297) rides on the coarse sampler's launch
+                nears, fars, z_vals, xyz_c = render_ops.sample_coarse_aabb(rays_o, rays_d, aabb.contiguous().float(), self.min_near, num_steps, noise,
+                                                                           xyz_list[:Pc].view(N, num_steps, 3), unit[:Pc].view(N, num_steps, 3), bnd)
                 # the scatter plan's histogram in two pieces: the coarse block's rows now (beside the coarse gather), the fine block's after the
                 # importance sampling — all of it is then done before the field backward starts
                 pstate, piecewise = self.split_prepare_rows(None, unit, grad_on, 0, Pc, False)
@@ -212,7 +227,7 @@ class NeRFRenderer(nn.Module):
                     self.density(xyz_all.view(-1, 3))
         if split:
             # both blocks hold num_steps samples per ray, so "one direction per num_steps consecutive samples" covers the list with [d | d]
-            dirs2 = torch.cat([rays_d, rays_d], 0)
+            dirs2 = self._dirs_twice(rays_d)
             if blockwise:
                 sig_l, rgbc_l = self.split_attach(enc, unit, xyz_list, dirs2, num_steps, sig_all, rgbc_all, plan=plan)
             else:

@@ -3,7 +3,11 @@ NeRFNetwork.get_params; main.py:189: lr * 0.1^(iter/iters)) as one fused HIP lau
 un-scale + moments + update + fp16 shadow refresh + gradient zeroing."""
 import torch
 
-from ._lib import lib, check, ptr, stream, require_cuda
+import ctypes
+
+from ._lib import lib, check, ptr, stream, require_cuda, AdamJobs, ADAM_MAX_JOBS
+
+SMALL_PARAM_MAX = 1 << 16          # tensors up to this size go through the single-workgroup multi-tensor launch (the three MLPs: 22.5 k floats)
 
 
 def adam_step(p, g, m, v, lr, betas=(0.9, 0.99), eps=1e-15, step=1, grad_scale_inv=1.0, zero_grad=True, p_half=None):
@@ -67,9 +71,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale_inv = 1.0
         self.scaler = None              # DynamicLossScaler: gradient scale, skip decision and step count come from its device state
         self.skip_params = set()        # id(p) of parameters some other owner updates (dp.ShardedExchange: the sharded grid table)
+        self.updates_scaler = False     # set by step(): the last launch of this step also ran GradScaler.update() (the caller must not run it again)
 
     @torch.no_grad()
     def step(self, closure=None):
+        self.updates_scaler = False
+        small = []                      # (p, state, group) of the small tensors: one multi-tensor launch at the end (with a scaler)
+        betas0, eps0 = self.param_groups[0]['betas'], self.param_groups[0]['eps']
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is None or id(p) in self.skip_params:
@@ -80,6 +88,10 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
+                if (self.scaler is not None and p.numel() <= SMALL_PARAM_MAX and len(small) < ADAM_MAX_JOBS and group['betas'] == betas0
+                        and group['eps'] == eps0 and p.grad.is_contiguous() and p.is_contiguous()):
+                    small.append((p, st, group))
+                    continue
                 if self.scaler is not None:
                     require_cuda(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], self.half_shadows.get(p))
                     check(lib.cnerf_adam_step_scaled(ptr(p.data), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), ptr(self.half_shadows.get(p)),
@@ -91,6 +103,23 @@ class FusedAdam(torch.optim.Optimizer):
                 # the kernel writes through the raw pointer, which does not bump torch's version counter:
                 # advance our own epoch so caches keyed on the parameter (GridEncoder.half_table) notice.
                 p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
+        if small:
+            # the small tensors in ONE single-workgroup launch, which — being the last Adam launch of the step — also applies the scaler's
+            # update (found_inf ? back off : count the step, grow every `growth_interval`): two or three launches and the update launch saved
+            jobs = AdamJobs()
+            for j, (p, st, group) in enumerate(small):
+                sh = self.half_shadows.get(p)
+                require_cuda(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], sh)
+                jobs.p[j], jobs.g[j], jobs.m[j], jobs.v[j] = p.data.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+                jobs.p_half[j] = sh.data_ptr() if sh is not None else None
+                jobs.n[j], jobs.lr[j] = p.numel(), float(group['lr'])
+                p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
+            jobs.n_jobs = len(small)
+            sc = self.scaler
+            check(lib.cnerf_adam_step_scaled_multi(ctypes.addressof(jobs), float(betas0[0]), float(betas0[1]), float(eps0), ptr(sc.state),
+                                                   float(self.grad_scale_inv), int(self.zero_grad_in_step), 1, float(sc.growth_factor),
+                                                   float(sc.backoff_factor), int(sc.growth_interval), stream()), "adam_step_scaled_multi")
+            self.updates_scaler = True
 
     def zero_grad(self, set_to_none=False):
         if self.zero_grad_in_step and not set_to_none:

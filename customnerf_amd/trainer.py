@@ -133,14 +133,15 @@ def apply_optimizer_step(trainer):
             e1.record()
             ev.append((e0, e1))
         trainer.optimizer.step()                                     # the small (replicated) parameters; the big ones are in skip_params
-        if trainer.scaler is not None:
-            trainer.scaler.update()
+        if trainer.scaler is not None and not getattr(trainer.optimizer, 'updates_scaler', False):
+            trainer.scaler.update()                                  # (FusedAdam's multi-tensor launch of the small tensors already did it)
     else:
         trainer.allreduce_grads()
         if trainer.scaler is not None:
             check_grads_finite(trainer.scaler, list(trainer.model.parameters()), trainer._flat)      # on the all-reduced gradients: every rank takes the same skip decision
             trainer.optimizer.step()
-            trainer.scaler.update()
+            if not getattr(trainer.optimizer, 'updates_scaler', False):
+                trainer.scaler.update()                              # (FusedAdam's multi-tensor launch of the small tensors already did it)
         else:
             trainer.optimizer.step()
     refresh_half_shadow(trainer.optimizer, trainer.model)
@@ -217,8 +218,9 @@ class ReconTrainer(CheckpointMixin):
         if '_out_ray' in outputs and outputs['_out_ray'].is_cuda and getattr(self.opt, 'fused_loss', True):
             from .nerf.render_ops import recon_loss                   # loss + gradient in one launch on the fused renderer's composite output
             with_mask = bool(getattr(self.opt, 'train_conf', 0)) and 'render_mask' in outputs
+            sc = getattr(self, 'scaler', None)                        # the backward seed (DynamicLossScaler.backward) folded into the loss gradient
             return recon_loss(outputs['_out_ray'], rgbs, mask if with_mask else None, getattr(self.opt, 'train_rgb', 1.0),
-                              getattr(self.opt, 'train_conf', 0) if with_mask else 0.0)
+                              getattr(self.opt, 'train_conf', 0) if with_mask else 0.0, sc.state[0:1] if sc is not None else None)
         pred_rgb = outputs['image']
         loss = getattr(self.opt, 'train_rgb', 1.0) * F.mse_loss(pred_rgb.reshape(-1, 3).float(), rgbs.reshape(-1, 3))
         if getattr(self.opt, 'train_conf', 0) and 'render_mask' in outputs:

@@ -304,6 +304,10 @@ int cnerf_sample_fine_merge_split(const float *rays_o, const float *rays_d, cons
 int cnerf_sample_coarse_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb,
                              const float *noise, uint32_t N, uint32_t T, float *z_vals, float *xyzs, float *unit, float bound,
                              void *stream);
+/* cnerf_sample_coarse_unit with cnerf_near_far_from_aabb folded in (renderer.py:297 then :309-322: one launch instead of two): nears / fars
+ * [N] are OUTPUTS here, computed per ray against `aabb` with the arithmetic of raymarching.cu:91-145 (bit-identical to the separate call). */
+int cnerf_sample_coarse_unit_aabb(const float *rays_o, const float *rays_d, const float *aabb, float min_near, const float *noise, uint32_t N,
+                                  uint32_t T, float *nears, float *fars, float *z_vals, float *xyzs, float *unit, float bound, void *stream);
 int cnerf_sample_fine_merge_split_unit(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
                                        const float *aabb, const float *z_vals, const float *sigmas, const float *u, uint32_t N,
                                        uint32_t T, uint32_t t, float *z_all, float *xyz_fine, uint32_t *src_index,
@@ -341,6 +345,10 @@ int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float 
  * grad_out_ray [3][N][6] = d(loss)/d(out_ray), ready for cnerf_composite_run_backward. */
 int cnerf_recon_loss(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf,
                      float *loss, float *grad_out_ray, void *stream);
+/* the same with grad_out_ray multiplied by the device scalar grad_scale[0] — the seed the backward pass starts from under a loss scaler
+ * (GradScaler.scale(loss).backward()): the element-wise multiply of the autograd node disappears.  grad_scale NULL = plain. */
+int cnerf_recon_loss_scaled(const float *out_ray, const float *rgb_gt, const float *mask_gt, uint32_t N, float w_rgb, float w_conf,
+                            const float *grad_scale, float *loss, float *grad_out_ray, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step used by the reference's recipe (main.py:182: Adam betas (0.9,0.99) eps 1e-15, no weight decay),
@@ -367,6 +375,19 @@ int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream);
 int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2,
                            float eps, const float *state, float extra_inv, int zero_grad, void *stream);
 int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream);
+/* cnerf_adam_step_scaled for up to CNERF_ADAM_MAX_JOBS SMALL tensors in one single-workgroup launch (the reference's three tinycudann
+ * parameter vectors: main.py:182 gives each network its own Adam group) and, with update_scaler != 0, cnerf_scaler_update folded into
+ * its tail — call it as the LAST adam step of the iteration.  Plain pointers, no alignment demands. */
+#define CNERF_ADAM_MAX_JOBS 8
+typedef struct CnerfAdamJobs {
+    float *p[CNERF_ADAM_MAX_JOBS], *g[CNERF_ADAM_MAX_JOBS], *m[CNERF_ADAM_MAX_JOBS], *v[CNERF_ADAM_MAX_JOBS];
+    void *p_half[CNERF_ADAM_MAX_JOBS];            /* optional fp16 shadows (NULL) */
+    uint64_t n[CNERF_ADAM_MAX_JOBS];
+    float lr[CNERF_ADAM_MAX_JOBS];
+    uint32_t n_jobs;
+} CnerfAdamJobs;
+int cnerf_adam_step_scaled_multi(const CnerfAdamJobs *jobs, float beta1, float beta2, float eps, float *state, float extra_inv, int zero_grad,
+                                 int update_scaler, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data-parallel gradient exchange (customnerf_amd/dp.py; the reference has no working multi-GPU path: its DDP scaffolding

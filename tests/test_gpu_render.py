@@ -692,3 +692,26 @@ def test_field_matches_reference_glue_golden(golden, half):
             assert np.array_equal(torch.nonzero(ge.abs().sum(-1)).reshape(-1).numpy(), g["grad_emb_idx"])
     finally:
         tcnn.set_default_dtype(torch.float32)
+
+
+def test_coarse_sampler_with_the_slab_test_folded_in():
+    """cnerf_sample_coarse_unit_aabb (near_far_from_aabb + stratified samples + grid coordinates in one launch) against the two separate
+    launches: the same bits, rays that miss the box included"""
+    from customnerf_amd import raymarching
+    from customnerf_amd.nerf import render_ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    N, T = 3000, 64
+    o = (torch.rand(N, 3, device="cuda", generator=g) * 2 - 1) * 3.5
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    d[:7, 0] = 0.0                                                       # axis-parallel components: 1 / 0 in the slab test
+    aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2], device="cuda")
+    noise = torch.rand(N, T, device="cuda", generator=g)
+    nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.01)
+    xyz_a, unit_a = torch.empty(N, T, 3, device="cuda"), torch.empty(N, T, 3, device="cuda")
+    z_a, _ = render_ops.sample_coarse(o, d, nears, fars, aabb, T, noise, xyz_out=xyz_a, unit_out=unit_a, bound=2.0)
+    xyz_b, unit_b = torch.empty(N, T, 3, device="cuda"), torch.empty(N, T, 3, device="cuda")
+    n_b, f_b, z_b, _ = render_ops.sample_coarse_aabb(o, d, aabb, 0.01, T, noise, xyz_b, unit_b, 2.0)
+    assert torch.equal(n_b, nears) and torch.equal(f_b, fars)
+    same = lambda a, b: torch.equal(a, b) or torch.equal(torch.nan_to_num(a, nan=1e30), torch.nan_to_num(b, nan=1e30))
+    assert same(z_a, z_b) and same(xyz_a, xyz_b) and same(unit_a, unit_b)
+    assert int((nears > 1e30).sum()) > 0                                 # the case has rays that miss the box

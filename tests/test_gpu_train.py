@@ -107,7 +107,7 @@ def test_dynamic_loss_scaler_matches_torch_gradscaler():
     only the non-skipped steps)."""
     from customnerf_amd.optim import DynamicLossScaler, FusedAdam
     torch.manual_seed(0)
-    shapes = [(1003,), (37, 16), (8,)]
+    shapes = [(70001,), (37, 16), (8,)]           # one tensor takes the per-tensor launch, two the multi-tensor launch (which also applies update())
     p_ref = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
     p_our = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
     opt_ref = torch.optim.Adam([{'params': p_ref[:1], 'lr': 1e-2}, {'params': p_ref[1:], 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15)
@@ -134,7 +134,7 @@ def test_dynamic_loss_scaler_matches_torch_gradscaler():
         opt_ref.zero_grad()
         check_grads_finite(our, p_our, flat)
         opt_our.step()
-        our.update()
+        assert opt_our.updates_scaler                                 # the small tensors' launch applied GradScaler.update() already
         for p, q in zip(p_ref, p_our):
             assert torch.all(q.grad == 0)
             assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), (step, float((p - q).abs().max()))
@@ -162,6 +162,54 @@ def test_fused_recon_loss_matches_the_torch_formulation(with_mask):
     (la * 7.0).backward(); (lb * 7.0).backward()
     assert torch.allclose(out_a.grad, out_b.grad, atol=1e-9, rtol=1e-5)
     assert bool((out_a.grad[1:] == 0).all())
+    # the backward seed folded into the stored gradient (cnerf_recon_loss_scaled): the same bits as seeding afterwards, no multiply launch
+    scale = torch.tensor([4096.0, 0.0, 0.0, 0.0], device="cuda")
+    out_c, out_d = out_a.detach().clone().requires_grad_(True), out_a.detach().clone().requires_grad_(True)
+    lc = recon_loss(out_c, rgb, mask if with_mask else None, 1.0, 0.3 if with_mask else 0.0, grad_scale=scale[0:1])
+    lc.backward(gradient=scale[0].reshape(()))                       # DynamicLossScaler.backward's seed: the very scalar
+    ld = recon_loss(out_d, rgb, mask if with_mask else None, 1.0, 0.3 if with_mask else 0.0)
+    ld.backward(gradient=scale[0].reshape(()))
+    assert torch.equal(out_c.grad, out_d.grad) and float(lc) == float(ld)
+    out_e = out_a.detach().clone().requires_grad_(True)                # some other seed: the folded factor is corrected for
+    (recon_loss(out_e, rgb, mask if with_mask else None, 1.0, 0.3 if with_mask else 0.0, grad_scale=scale[0:1]) * 3.0).backward()
+    assert torch.allclose(out_e.grad, out_d.grad * (3.0 / 4096.0), rtol=1e-6, atol=0)
+
+
+def test_multi_tensor_adam_matches_per_tensor_launches():
+    """cnerf_adam_step_scaled_multi (the three MLP vectors in one single-workgroup launch, GradScaler.update() in its tail) against
+    cnerf_adam_step_scaled per tensor + cnerf_scaler_update: the same bits, with and without an overflow step."""
+    from customnerf_amd import optim
+    from customnerf_amd.optim import DynamicLossScaler, FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(10240,), (5120,), (7168,), (13,)]
+    for bad in (False, True):
+        runs = []
+        for small_max in (1 << 16, 0):                                # multi-tensor path on / off
+            old = optim.SMALL_PARAM_MAX
+            optim.SMALL_PARAM_MAX = small_max
+            try:
+                gg = torch.Generator(device="cuda").manual_seed(5)
+                ps = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=gg)) for s in shapes]
+                opt = FusedAdam([{'params': ps[:2], 'lr': 1e-2}, {'params': ps[2:], 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15)
+                sc = DynamicLossScaler("cuda", init_scale=256.0, growth_interval=2)
+                opt.scaler = sc
+                for step in range(5):
+                    for p in ps:
+                        p.grad = torch.randn(p.shape, device="cuda", generator=gg) * 256.0
+                    if bad and step == 2:
+                        ps[1].grad[7] = float("inf")
+                    for p in ps:
+                        sc.check(p.grad)
+                    opt.step()
+                    if not opt.updates_scaler:
+                        sc.update()
+                    assert opt.updates_scaler == (small_max > 0)
+                runs.append(([p.detach().clone() for p in ps], sc.state.clone()))
+            finally:
+                optim.SMALL_PARAM_MAX = old
+        for a, b in zip(runs[0][0], runs[1][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(runs[0][1], runs[1][1])
 
 
 def test_in_place_gradient_accumulation_matches_autograd_accumulation():
