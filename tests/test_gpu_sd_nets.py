@@ -51,8 +51,10 @@ def test_unet_forward(cfg_name, hw):
         ref2 = so.unet_forward(sd, cfg, x * 0.5, t, ctx) if cfg_name == "tiny" else None
     assert out.shape == (2, hw, hw, 4)
     emax, el2 = rel_err(out.permute(0, 3, 1, 2), ref)
-    assert emax < 3e-2 and el2 < 1e-2, (emax, el2)
-    assert rel_err(out_g, out)[0] < 1e-2          # the HIP-graph replay is the same computation (GroupNorm statistics use float atomics: not bitwise)
+    print(f"[unet {cfg_name}-{hw}] max rel {emax:.3e}, L2 rel {el2:.3e}")
+    assert emax < 5e-3 and el2 < 5e-3, (emax, el2)      # measured on MI355X (round 4): 1.4e-3 .. 1.7e-3 at every size (float16 activations vs the float32 oracle)
+    # the HIP-graph replay is the same computation, and since round 4 (fixed-point GroupNorm statistics) the same bits
+    assert torch.equal(out_g, out)
     if ref2 is not None:
         assert rel_err(out_g2.permute(0, 3, 1, 2), ref2)[1] < 1e-2
 
@@ -77,7 +79,8 @@ def test_vae_encode_forward_backward(cfg_name, size):
     lat.backward(dlat.cuda())
     assert lat.shape == lat_ref.shape and lat.dtype == torch.float32
     emax, el2 = rel_err(lat, lat_ref)
-    assert emax < 3e-2 and el2 < 1e-2, ("latents", emax, el2)
+    print(f"[vae {cfg_name}-{size}] latents max rel {emax:.3e}, L2 rel {el2:.3e}")
+    assert emax < 5e-3 and el2 < 3e-3, ("latents", emax, el2)      # measured: 0.7e-3 .. 1.3e-3 max, 0.6e-3 .. 0.7e-3 L2
     gmax, gl2 = rel_err(img_g.grad, img_ref.grad)
     assert gmax < 6e-2 and gl2 < 3e-2, ("d latents / d image", gmax, gl2)
 
