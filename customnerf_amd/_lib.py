@@ -85,6 +85,7 @@ SIGNATURES = {
     "cnerf_sd_softmax_forward": [vp, u64, u32, u32, vp],
     "cnerf_sd_softmax_backward": [vp, vp, u64, u32, u32, vp],
     "cnerf_sd_attention": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u64, u32, u64, u32, u64, u32, u64, i32, vp],
+    "cnerf_sd_attention_v": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u64, u32, u64, u32, u64, u32, u64, i32, vp],
     "cnerf_sd_geglu": [vp, u64, u32, vp, vp],
     "cnerf_sd_transpose": [vp, vp, u32, u32, u32, u32, u32, u64, u64, vp],
     "cnerf_sd_image_to_vae_input": [vp, u32, u32, u32, u32, u32, vp, vp],

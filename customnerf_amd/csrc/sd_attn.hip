@@ -4,8 +4,10 @@
 // 32 keys of the tile spread over the lane's 16 accumulator registers (x 2 half-waves), so the online-softmax row statistics are
 // per-lane scalars (one cross-half exchange per key tile for the running maximum), and the probabilities — still in their C
 // registers — are directly the B fragments of the second product O^T += V^T P^T (same K-slot permutation trick as the NeRF
-// field kernels, field_common.h).  V is consumed transposed ([C][tokens], produced by cnerf_sd_transpose) so that every
-// MFMA operand is contiguous along its contraction index.  K and V^T tiles are read through L2 (they are shared by all query
+// field kernels, field_common.h).  V is consumed either transposed ([C][tokens], produced by cnerf_sd_transpose: the cross-attention values,
+// which depend on the prompt only and are transposed once per prompt) or — round 4, VROW — as it comes out of the projection ([tokens][C]):
+// its key tile is staged row-major in LDS and the V^T fragments are transposing reads (ds_read_b64_tr_b16) of it, which removes the
+// k_transpose launch in front of every self-attention.  K and V^T tiles are read through L2 (they are shared by all query
 // blocks of a head); head dims 40 / 80 / 160 are padded to the 16- / 32-wide MFMA shapes with zero fragments.
 #include "common.h"
 #include "../../include/customnerf_sd.h"
@@ -16,8 +18,13 @@ typedef float at_f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int at_rho(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// KS = ceil(d / 16) k-steps of the score product, DT = ceil(d / 32) output tiles
-template <int KS, int DT>
+typedef short at_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+// row pitch (halves) of the row-major V tile: 32 DT channels, padded so that the pitch is 64 bytes modulo 128 — the four key rows a transposing
+// read touches then fall into four different 64-byte bank quarters (conflict-free)
+__host__ __device__ constexpr uint32_t at_vrow_halves(int dt) { return (32u * dt * 2u) % 128u == 64u ? 32u * dt : 32u * dt + 32u; }
+
+// KS = ceil(d / 16) k-steps of the score product, DT = ceil(d / 32) output tiles; VROW: V is [tokens][C] (ldv = its row pitch), else V^T [C][tokens]
+template <int KS, int DT, bool VROW>
 __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict__ Q, const _Float16 *__restrict__ K, const _Float16 *__restrict__ VT,
                                                       _Float16 *__restrict__ O, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq, uint64_t sq,
                                                       uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e, int causal) {
@@ -28,7 +35,7 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
     const bool q_ok = qi < Tq;                               // waves past the last query keep running (workgroup barriers below), results unused
     const _Float16 *qrow = Q + sq * b + (size_t)qi * ldq + h * d;
     const _Float16 *kbase = K + sk * b + h * d;
-    const _Float16 *vbase = VT + sv * b + (size_t)(h * d) * ldv;
+    const _Float16 *vbase = VROW ? VT + sv * b + h * d : VT + sv * b + (size_t)(h * d) * ldv;
 
     // Q fragments (B operand of S^T = K Q^T): lane = query, k = 16 s + 8 hi + j
     at_h8 qf[KS];
@@ -51,8 +58,11 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
     // fetched one tile ahead into registers.  (Each wave reading its own fragments from L2 cost 4x the L2 traffic: 1.8 GB per
     // 4096-token layer.)
     constexpr int NF = KS + 2 * DT;                    // fragments per key tile: KS of K, 2 per 32-channel tile of V^T
-    constexpr int PER = (NF * 64 + 255) / 256;         // staged 16-byte items per thread
-    __shared__ __attribute__((aligned(16))) at_h8 tile[2][NF * 64];
+    constexpr uint32_t VROWH = at_vrow_halves(DT), VCH = 4 * DT;                  // VROW: row pitch of the V tile, 16-byte chunks per row
+    constexpr int N_ITEMS = VROW ? KS * 64 + 32 * (int)VCH : NF * 64;
+    constexpr int PER = (N_ITEMS + 255) / 256;         // staged 16-byte items per thread
+    __shared__ __attribute__((aligned(16))) at_h8 tile[2][VROW ? KS * 64 : NF * 64];
+    __shared__ __attribute__((aligned(16))) _Float16 vtile[2][VROW ? 32 * VROWH : 8];
     // causal (CLIP text encoder): query q attends to keys <= q; the workgroup's key range ends with its last query
     const uint32_t q_end = min(blockIdx.x * 128 + 128, Tq);
     const uint32_t n_kt = causal ? min((Tk + 31) / 32, (q_end + 31) / 32) : (Tk + 31) / 32;
@@ -66,6 +76,9 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
             if (f < (uint32_t)KS) {
                 const uint32_t krow = key0 + fl, c = 16 * f + 8 * fh;
                 if (krow < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(kbase + (size_t)krow * ldk + c);
+            } else if (VROW) {
+                const uint32_t j = item - KS * 64, row = j / VCH, c = 8 * (j - row * VCH);
+                if (j < 32 * VCH && key0 + row < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(vbase + (size_t)(key0 + row) * ldv + c);
             } else if (f < (uint32_t)NF) {
                 const uint32_t g = f - KS, t = g >> 1, s2 = g & 1, dd = 32 * t + fl;
                 if (dd < d) {
@@ -81,7 +94,13 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
 #pragma unroll
         for (int it = 0; it < PER; it++) {
             const uint32_t item = it * 256 + threadIdx.x;
-            if (item < (uint32_t)NF * 64) tile[buf][item] = stage[it];
+            if (VROW) {
+                if (item < (uint32_t)KS * 64) tile[buf][item] = stage[it];
+                else if (item < (uint32_t)N_ITEMS) {
+                    const uint32_t j = item - KS * 64, row = j / VCH, c = 8 * (j - row * VCH);
+                    *reinterpret_cast<at_h8 *>(&vtile[buf][row * VROWH + c]) = stage[it];
+                }
+            } else if (item < (uint32_t)NF * 64) tile[buf][item] = stage[it];
         }
     };
     fetch(0);
@@ -142,7 +161,22 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
 #pragma unroll
         for (int t = 0; t < DT; t++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][(KS + 2 * t + s) * 64 + lane], pf[s], o[t], 0, 0, 0);
+            for (int s = 0; s < 2; s++) {
+                at_h8 vf;
+                if (VROW) {
+                    // lane (channel 32 t + (l & 31), half hi) wants keys 4 hi + 16 s + {0..3} and + 8: two transposing reads of the row-major tile.
+                    // Address role of lane i in its 16-lane group G: key row i >> 2, chunk i & 3 of the group's 16 channels.
+                    const uint32_t i16 = lane & 15, G = (lane >> 4) & 1;
+                    const _Float16 *vp = &vtile[buf][(4 * hi + 16 * s + (i16 >> 2)) * VROWH + 32 * t + 16 * G + 4 * (i16 & 3)];
+                    union { at_h8 h; at_s4 q[2]; } f;
+                    f.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)vp);
+                    f.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)(vp + 8 * VROWH));
+                    vf = f.h;
+                } else {
+                    vf = tile[buf][(KS + 2 * t + s) * 64 + lane];
+                }
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
+            }
         if (kt + 1 < n_kt) commit(buf ^ 1);
         __syncthreads();
     }
@@ -164,20 +198,22 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         }
 }
 
-extern "C" {
-
-int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
-                       uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
+template <bool VROW>
+static int at_launch(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
+                     uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
     if (B == 0 || H == 0 || Tq == 0 || Tk == 0 || d == 0 || (d & 7) || d > 160) return CNERF_EINVAL;
-    if ((ldq & 7) || (ldk & 7) || (ldv & 3) || (ldo & 3) || ldv < ((Tk + 31) / 32) * 32) return CNERF_EINVAL;     // V^T rows are read in whole 32-key tiles
+    if (VROW) {
+        if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (sv & 7)) return CNERF_EINVAL;                     // V rows are read in 16-byte chunks
+    } else if ((ldq & 7) || (ldk & 7) || (ldv & 3) || (ldo & 3) || ldv < ((Tk + 31) / 32) * 32) return CNERF_EINVAL;  // V^T rows are read in whole 32-key tiles
     if ((sq & 7) || (sk & 7) || (sv & 3) || (so & 3)) return CNERF_EINVAL;
     if (!q || !k || !vT || !out) return CNERF_ENULL;
     if ((((uintptr_t)q) | ((uintptr_t)k)) & 15 || (((uintptr_t)vT) | ((uintptr_t)out)) & 7) return CNERF_EINVAL;
+    if (VROW && (((uintptr_t)vT) & 15)) return CNERF_EINVAL;
     const dim3 grid(cn_div_up(Tq, 128), B * H), block(256);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
     hipStream_t st = CN_STREAM(stream);
 #define AT_LAUNCH(KS, DT)                                                                                                                           \
-    hipLaunchKernelGGL((k_sd_attention<KS, DT>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
+    hipLaunchKernelGGL((k_sd_attention<KS, DT, VROW>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
                        d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e, causal)
     const uint32_t ks = (d + 15) / 16, dt = (d + 31) / 32;
     if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2);
@@ -186,6 +222,18 @@ int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, 
     else AT_LAUNCH(10, 5);
 #undef AT_LAUNCH
     return cn_launch_status();
+}
+
+extern "C" {
+
+int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
+                       uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
+    return at_launch<false>(q, k, vT, out, B, H, Tq, Tk, d, ldq, sq, ldk, sk, ldv, sv, ldo, so, causal, stream);
+}
+
+int cnerf_sd_attention_v(const void *q, const void *k, const void *v, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
+                         uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
+    return at_launch<true>(q, k, v, out, B, H, Tq, Tk, d, ldq, sq, ldk, sk, ldv, sv, ldo, so, causal, stream);
 }
 
 }  // extern "C"

@@ -259,6 +259,12 @@ def attention(q, k, v, heads, causal=False):
         assert not causal
         return attention_apply(attention_scores(q, k, heads, 1.0 / float(d_) ** 0.5), v, heads)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if v.stride(1) % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0:
+        # V as the projection leaves it (e.g. the last third of a fused qkv GEMM): the kernel transposes its key tiles in LDS
+        out = torch.empty(B, Tq, C, dtype=torch.float16, device=q.device)
+        check(lib.cnerf_sd_attention_v(ptr(q), ptr(k), ptr(v), ptr(out), B, heads, Tq, Tk, d_, q.stride(1), q.stride(0), k.stride(1), k.stride(0),
+                                       v.stride(1), v.stride(0), C, Tq * C, int(causal), stream()), "sd_attention_v")
+        return out
     return attention_vt(q, k, transpose_v(v), heads, causal)
 
 

@@ -105,6 +105,11 @@ int cnerf_sd_softmax_backward(const void *P, void *dP, uint64_t rows, uint32_t c
 int cnerf_sd_attention(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk,
                        uint32_t d, uint32_t ldq, uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo,
                        uint64_t so, int causal, void *stream);
+/* The same with V as the value projection leaves it — v [B][Tk][.] (row pitch ldv, batch stride sv, head h at column h*d; 16-byte
+ * aligned rows, ldv % 8 == 0): the kernel transposes its key tiles in LDS (ds_read_b64_tr_b16), no cnerf_sd_transpose launch. */
+int cnerf_sd_attention_v(const void *q, const void *k, const void *v, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk,
+                         uint32_t d, uint32_t ldq, uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo,
+                         uint64_t so, int causal, void *stream);
 
 /* GEGLU (diffusers GEGLU): y[r][c] = x[r][c] * gelu_erf(x[r][c + C]) for x [rows, 2C] -> y [rows, C] (half). */
 int cnerf_sd_geglu(const void *x, uint64_t rows, uint32_t C, void *y, void *stream);
