@@ -23,14 +23,33 @@ typedef short at_s4 __attribute__((__vector_size__(4 * sizeof(short))));
 // read touches then fall into four different 64-byte bank quarters (conflict-free)
 __host__ __device__ constexpr uint32_t at_vrow_halves(int dt) { return (32u * dt * 2u) % 128u == 64u ? 32u * dt : 32u * dt + 32u; }
 
-// KS = ceil(d / 16) k-steps of the score product, DT = ceil(d / 32) output tiles; VROW: V is [tokens][C] (ldv = its row pitch), else V^T [C][tokens]
-template <int KS, int DT, bool VROW>
+// exchange between the two half-waves on the vector ALU (v_permlane32_swap: no LDS round trip in the middle of the softmax chain)
+__device__ __forceinline__ float at_half_max(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);          // r[0] = (low half, low half), r[1] = (high half, high half)
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+
+// KS = ceil(d / 16) k-steps of the score product, DT = ceil(d / 32) output tiles, KT = 32-key sub-tiles per iteration (one workgroup barrier, one
+// running-maximum update and one staging round per 32 KT keys); VROW: V is [tokens][C] (ldv = its row pitch), else V^T [C][tokens]
+template <int KS, int DT, int KT, bool VROW>
 __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict__ Q, const _Float16 *__restrict__ K, const _Float16 *__restrict__ VT,
                                                       _Float16 *__restrict__ O, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq, uint64_t sq,
                                                       uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e, int causal) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
-    const uint32_t b = blockIdx.y / H, h = blockIdx.y - b * H;
-    const uint32_t q0 = (blockIdx.x * 4 + wave) * 32;
+    // workgroups are dealt to the 8 XCDs round-robin by linear id: renumber so that the query blocks of one (batch, head) run on ONE XCD and its
+    // K / V stream (0.65–1.7 MB of lines at 4096 keys) is served by that XCD's 4 MB L2 instead of by every L2 at once
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    {
+        const uint32_t total = gridDim.x * gridDim.y;
+        if (total % CN_NXCD == 0) {
+            const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x, nid = (id % CN_NXCD) * (total / CN_NXCD) + id / CN_NXCD;
+            by = nid / gridDim.x;
+            bx = nid - by * gridDim.x;
+        }
+    }
+    const uint32_t b = by / H, h = by - b * H;
+    const uint32_t q0 = (bx * 4 + wave) * 32;
     const uint32_t qi = q0 + li;
     const bool q_ok = qi < Tq;                               // waves past the last query keep running (workgroup barriers below), results unused
     const _Float16 *qrow = Q + sq * b + (size_t)qi * ldq + h * d;
@@ -51,106 +70,124 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
     for (int t = 0; t < DT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
-    float m = -INFINITY, l = 0.0f;                     // running max (identical in both half-waves) and this half's partial sum
+    float m = -INFINITY, l = 0.0f;                     // running max in raw score units (identical in both half-waves) and this half's partial sum
+    // Head dims below the padded 32 DT channels (40 -> 64, 80 -> 96) leave a spare zero channel in the V tile: it carries ones, so that the softmax
+    // denominator is one more row of O^T += V^T P^T (rescaled with it) instead of 32 conversions + adds per key tile on the vector ALU.
+    const bool sum_mfma = d < 32u * DT;
 
     // The four waves of a workgroup share the K / V^T tiles of their (batch, head) through LDS, stored in MFMA fragment order
-    // ([fragment][lane] x 16 B: conflict-free ds_read_b128), double-buffered; every thread stages NF / 256 fragments-lanes per tile,
-    // fetched one tile ahead into registers.  (Each wave reading its own fragments from L2 cost 4x the L2 traffic: 1.8 GB per
-    // 4096-token layer.)
-    constexpr int NF = KS + 2 * DT;                    // fragments per key tile: KS of K, 2 per 32-channel tile of V^T
+    // ([fragment][lane] x 16 B: conflict-free ds_read_b128), double-buffered; every thread stages N_ITEMS / 256 16-byte items per tile.
+    // (Each wave reading its own fragments from L2 cost 4x the L2 traffic: 1.8 GB per 4096-token layer.)
+    constexpr int NFK = KT * KS, NFV = KT * 2 * DT;    // fragments per iteration: of K, of V^T (2 per 32-channel tile and sub-tile)
     constexpr uint32_t VROWH = at_vrow_halves(DT), VCH = 4 * DT;                  // VROW: row pitch of the V tile, 16-byte chunks per row
-    constexpr int N_ITEMS = VROW ? KS * 64 + 32 * (int)VCH : NF * 64;
+    constexpr uint32_t KEYS = 32 * KT;
+    constexpr int N_ITEMS = VROW ? NFK * 64 + (int)(KEYS * VCH) : (NFK + NFV) * 64;
     constexpr int PER = (N_ITEMS + 255) / 256;         // staged 16-byte items per thread
-    __shared__ __attribute__((aligned(16))) at_h8 tile[2][VROW ? KS * 64 : NF * 64];
-    __shared__ __attribute__((aligned(16))) _Float16 vtile[2][VROW ? 32 * VROWH : 8];
+    __shared__ __attribute__((aligned(16))) at_h8 tile[2][VROW ? NFK * 64 : (NFK + NFV) * 64];
+    __shared__ __attribute__((aligned(16))) _Float16 vtile[2][VROW ? KEYS * VROWH : 8];
     // causal (CLIP text encoder): query q attends to keys <= q; the workgroup's key range ends with its last query
-    const uint32_t q_end = min(blockIdx.x * 128 + 128, Tq);
-    const uint32_t n_kt = causal ? min((Tk + 31) / 32, (q_end + 31) / 32) : (Tk + 31) / 32;
-    at_h8 stage[PER];
-    auto fetch = [&](uint32_t kt) __attribute__((always_inline)) {
-        const uint32_t key0 = kt * 32;
+    const uint32_t q_end = min(bx * 128 + 128, Tq);
+    const uint32_t n_kt = causal ? min((Tk + KEYS - 1) / KEYS, (q_end + KEYS - 1) / KEYS) : (Tk + KEYS - 1) / KEYS;
+    // register staging two iterations deep: a tile's loads are issued two iterations before its LDS commit (one iteration is ~0.5 us of work, an
+    // L2 / MALL round trip more than that: with one tile of lookahead every iteration waited for its loads)
+    at_h8 stage_a[PER], stage_b[PER];
+    auto fetch = [&](uint32_t kt, at_h8 (&stage)[PER]) __attribute__((always_inline)) {
+        const uint32_t key0 = kt * KEYS;
 #pragma unroll
         for (int it = 0; it < PER; it++) {
             const uint32_t item = it * 256 + threadIdx.x, f = item >> 6, ln = item & 63, fl = ln & 31, fh = ln >> 5;
             at_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (f < (uint32_t)KS) {
-                const uint32_t krow = key0 + fl, c = 16 * f + 8 * fh;
+            if (f < (uint32_t)NFK) {
+                const uint32_t u = f / KS, s = f - u * KS, krow = key0 + 32 * u + fl, c = 16 * s + 8 * fh;
                 if (krow < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(kbase + (size_t)krow * ldk + c);
             } else if (VROW) {
-                const uint32_t j = item - KS * 64, row = j / VCH, c = 8 * (j - row * VCH);
-                if (j < 32 * VCH && key0 + row < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(vbase + (size_t)(key0 + row) * ldv + c);
-            } else if (f < (uint32_t)NF) {
-                const uint32_t g = f - KS, t = g >> 1, s2 = g & 1, dd = 32 * t + fl;
-                if (dd < d) {
-                    const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 4 * fh + 16 * s2;
+                const uint32_t j = item - NFK * 64, row = j / VCH, c = 8 * (j - row * VCH);
+                if (j < KEYS * VCH && key0 + row < Tk && c < d) v = *reinterpret_cast<const at_h8 *>(vbase + (size_t)(key0 + row) * ldv + c);
+                else if (sum_mfma && c == d) v[0] = (_Float16)1.0f;                       // the ones channel (masked keys have p = 0)
+            } else if (f < (uint32_t)(NFK + NFV)) {
+                const uint32_t g = f - NFK, u = g / (2 * DT), g2 = g - u * 2 * DT, t = g2 >> 1, s2 = g2 & 1, dd = 32 * t + fl;
+                if (dd < d && key0 + 32 * u < Tk) {                                    // V^T rows are padded to whole 32-key tiles (at_launch checks ldv)
+                    const _Float16 *vp = vbase + (size_t)dd * ldv + key0 + 32 * u + 4 * fh + 16 * s2;
                     const at_h4 x = *reinterpret_cast<const at_h4 *>(vp), y = *reinterpret_cast<const at_h4 *>(vp + 8);
                     v = at_h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                } else if (sum_mfma && dd == d) {
+                    v = at_h8{1, 1, 1, 1, 1, 1, 1, 1};                                  // the ones channel
                 }
             }
             stage[it] = v;
         }
     };
-    auto commit = [&](uint32_t buf) __attribute__((always_inline)) {
+    auto commit = [&](uint32_t buf, const at_h8 (&stage)[PER]) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < PER; it++) {
             const uint32_t item = it * 256 + threadIdx.x;
             if (VROW) {
-                if (item < (uint32_t)KS * 64) tile[buf][item] = stage[it];
+                if (item < (uint32_t)NFK * 64) tile[buf][item] = stage[it];
                 else if (item < (uint32_t)N_ITEMS) {
-                    const uint32_t j = item - KS * 64, row = j / VCH, c = 8 * (j - row * VCH);
+                    const uint32_t j = item - NFK * 64, row = j / VCH, c = 8 * (j - row * VCH);
                     *reinterpret_cast<at_h8 *>(&vtile[buf][row * VROWH + c]) = stage[it];
                 }
-            } else if (item < (uint32_t)NF * 64) tile[buf][item] = stage[it];
+            } else if (item < (uint32_t)(NFK + NFV) * 64) tile[buf][item] = stage[it];
         }
     };
-    fetch(0);
-    commit(0);
+    fetch(0, stage_a);
+    commit(0, stage_a);
+    if (1 < n_kt) fetch(1, stage_b);
     __syncthreads();
-    for (uint32_t kt = 0; kt < n_kt; kt++) {
-        const uint32_t key0 = kt * 32, buf = kt & 1;
-        if (kt + 1 < n_kt) fetch(kt + 1);
-        // ---- S^T tile: rows = keys (A operand: lane = key li), cols = queries
-        at_f16v sacc;
+    // one iteration: `st_same` held tile kt (committed an iteration ago) and takes tile kt + 2, `st_next` holds tile kt + 1
+    auto key_tile = [&](uint32_t kt, at_h8 (&st_same)[PER], const at_h8 (&st_next)[PER]) __attribute__((always_inline)) {
+        const uint32_t key0 = kt * KEYS, buf = kt & 1;
+        if (kt + 2 < n_kt) fetch(kt + 2, st_same);
+        // ---- S^T sub-tiles: rows = keys (A operand: lane = key li), cols = queries
+        at_f16v sacc[KT];
 #pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+        for (int u = 0; u < KT; u++) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][s * 64 + lane], qf[s], sacc, 0, 0, 0);
-        // ---- online softmax over this lane's 16 keys (+ the partner half's 16)
+            for (int r = 0; r < 16; r++) sacc[u][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; s++) sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tile[buf][(u * KS + s) * 64 + lane], qf[s], sacc[u], 0, 0, 0);
+        }
+        // ---- online softmax over this lane's 16 KT keys (+ the partner half's).  The running maximum is kept in raw score units and the
+        // 1/sqrt(d) log2(e) scale rides on the exponent's fused multiply-add: max3 + fma + exp2 + packed convert per key, nothing else.
         float tmax = -INFINITY;
-        if (!causal && key0 + 32 <= Tk) {                        // interior tile (workgroup-uniform): no masking work
+        if (!causal && key0 + KEYS <= Tk) {                      // interior tile (workgroup-uniform): no masking work
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sacc[r] *= scale_log2e;
-                tmax = fmaxf(tmax, sacc[r]);
-            }
+            for (int u = 0; u < KT; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, sacc[u][r]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t key = key0 + at_rho(r, hi);
-                sacc[r] = (key < Tk && !(causal && key > qi)) ? sacc[r] * scale_log2e : -INFINITY;
-                tmax = fmaxf(tmax, sacc[r]);
-            }
+            for (int u = 0; u < KT; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = key0 + 32 * u + at_rho(r, hi);
+                    sacc[u][r] = (key < Tk && !(causal && key > qi)) ? sacc[u][r] : -INFINITY;
+                    tmax = fmaxf(tmax, sacc[u][r]);
+                }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = at_half_max(tmax);
         const float m_new = fmaxf(fmaxf(m, tmax), -1e30f);   // stays finite even when a causal tile holds no key for this query yet
         const bool moved = m_new != m;
-        const float corr = moved ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
+        const float corr = moved ? __builtin_amdgcn_exp2f((m - m_new) * scale_log2e) : 1.0f;
         m = m_new;
+        const float nm = -m_new * scale_log2e;
         float psum = 0.0f;
-        at_h8 pf[2];
+        at_h8 pf[KT][2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            at_h8 f;
+        for (int u = 0; u < KT; u++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float p = __builtin_amdgcn_exp2f(sacc[8 * s + j] - m_new);       // v_exp_f32: exp2(-inf) = 0 for masked keys
-                const _Float16 ph = (_Float16)p;
-                f[j] = ph;
-                psum += (float)ph;                       // the denominator sums what the numerator uses
+            for (int s = 0; s < 2; s++) {
+                at_h8 f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float p = __builtin_amdgcn_exp2f(cn_fma(sacc[u][8 * s + j], scale_log2e, nm));       // v_exp_f32: exp2(-inf) = 0 for masked keys
+                    const _Float16 ph = (_Float16)p;
+                    f[j] = ph;
+                    if (!sum_mfma) psum += (float)ph;    // the denominator sums what the numerator uses
+                }
+                pf[u][s] = f;
             }
-            pf[s] = f;
-        }
-        l = l * corr + psum;
+        if (!sum_mfma) l = l * corr + psum;
         if (__any(moved)) {                                      // the running maxima settle after a few tiles: skip the rescale when no lane moved
 #pragma unroll
             for (int t = 0; t < DT; t++)
@@ -159,28 +196,44 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         }
         // ---- O^T += V^T P^T : A = V^T fragment (lane = channel row, K-slots = keys in C-register order: two runs of 4 keys)
 #pragma unroll
+        for (int u = 0; u < KT; u++)
+#pragma unroll
+            for (int t = 0; t < DT; t++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    at_h8 vf;
+                    if (VROW) {
+                        // lane (channel 32 t + (l & 31), half hi) wants keys 4 hi + 16 s + {0..3} and + 8: two transposing reads of the row-major tile.
+                        // Address role of lane i in its 16-lane group G: key row i >> 2, chunk i & 3 of the group's 16 channels.
+                        const uint32_t i16 = lane & 15, G = (lane >> 4) & 1;
+                        const _Float16 *vp = &vtile[buf][(32 * u + 4 * hi + 16 * s + (i16 >> 2)) * VROWH + 32 * t + 16 * G + 4 * (i16 & 3)];
+                        union { at_h8 h; at_s4 q[2]; } f;
+                        f.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)vp);
+                        f.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)(vp + 8 * VROWH));
+                        vf = f.h;
+                    } else {
+                        vf = tile[buf][(NFK + u * 2 * DT + 2 * t + s) * 64 + lane];
+                    }
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][s], o[t], 0, 0, 0);
+                }
+        if (kt + 1 < n_kt) commit(buf ^ 1, st_next);
+        __syncthreads();
+    };
+    for (uint32_t kt = 0; kt < n_kt; kt += 2) {
+        key_tile(kt, stage_a, stage_b);
+        if (kt + 1 < n_kt) key_tile(kt + 1, stage_b, stage_a);
+    }
+    if (sum_mfma) {                                   // channel d sits in C row d % 32 = register 4 ((d % 32) / 8) of the low half-wave, column = query
+        float ls = 0.0f;
+#pragma unroll
         for (int t = 0; t < DT; t++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                at_h8 vf;
-                if (VROW) {
-                    // lane (channel 32 t + (l & 31), half hi) wants keys 4 hi + 16 s + {0..3} and + 8: two transposing reads of the row-major tile.
-                    // Address role of lane i in its 16-lane group G: key row i >> 2, chunk i & 3 of the group's 16 channels.
-                    const uint32_t i16 = lane & 15, G = (lane >> 4) & 1;
-                    const _Float16 *vp = &vtile[buf][(4 * hi + 16 * s + (i16 >> 2)) * VROWH + 32 * t + 16 * G + 4 * (i16 & 3)];
-                    union { at_h8 h; at_s4 q[2]; } f;
-                    f.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)vp);
-                    f.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3))) *)(vp + 8 * VROWH));
-                    vf = f.h;
-                } else {
-                    vf = tile[buf][(KS + 2 * t + s) * 64 + lane];
-                }
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
-            }
-        if (kt + 1 < n_kt) commit(buf ^ 1);
-        __syncthreads();
+            for (int g = 0; g < 4; g++)
+                if ((uint32_t)(32 * t + 8 * g) == d) ls = o[t][4 * g];
+        l = __shfl(ls, li, 64);
+    } else {
+        l += __shfl_xor(l, 32, 64);
     }
-    l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     if (!q_ok) return;
     _Float16 *orow = O + so * b + (size_t)qi * ldo + h * d;
@@ -212,14 +265,15 @@ static int at_launch(const void *q, const void *k, const void *vT, void *out, ui
     const dim3 grid(cn_div_up(Tq, 128), B * H), block(256);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
     hipStream_t st = CN_STREAM(stream);
-#define AT_LAUNCH(KS, DT)                                                                                                                           \
-    hipLaunchKernelGGL((k_sd_attention<KS, DT, VROW>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
+#define AT_LAUNCH(KS, DT, KT)                                                                                                                       \
+    hipLaunchKernelGGL((k_sd_attention<KS, DT, KT, VROW>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
                        d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e, causal)
     const uint32_t ks = (d + 15) / 16, dt = (d + 31) / 32;
-    if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2);
-    else if (ks <= 4 && dt <= 2) AT_LAUNCH(4, 2);
-    else if (ks <= 5 && dt <= 3) AT_LAUNCH(5, 3);
-    else AT_LAUNCH(10, 5);
+    // 64 keys per iteration where the registers allow two waves per SIMD with it (head dims <= 64), 32 above
+    if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2, 2);
+    else if (ks <= 4 && dt <= 2) AT_LAUNCH(4, 2, 2);
+    else if (ks <= 5 && dt <= 3) AT_LAUNCH(5, 3, 1);
+    else AT_LAUNCH(10, 5, 1);
 #undef AT_LAUNCH
     return cn_launch_status();
 }
