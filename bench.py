@@ -233,6 +233,16 @@ def run_edit(args, world, rank, dev):
         ms = sum(r[0].elapsed_time(r[1]) for r in prof)
         fl = sum(r[2] for r in prof)
         ach = fl / (ms * 1e-3) / 1e12
+        if getattr(args, "gemm_table", None):                            # per-shape table of the step's GEMM launches (tuning aid)
+            import collections
+            tab = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for r in prof:
+                t = tab[r[3]]
+                t[0] += 1; t[1] += r[0].elapsed_time(r[1]); t[2] += r[2]
+            with open(args.gemm_table, "w") as fh:
+                fh.write("M N K mode batch H_in Cin tstride ups : launches  ms  TFLOP/s\n")
+                for k, t in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"{k} : {t[0]:4d} {t[1]:8.3f} {t[2] / (t[1] * 1e-3) / 1e12:8.1f}\n")
         result["roofline"] = {"kernel": "k_sd_gemm (implicit-GEMM conv / linear / attention GEMMs of the UNet + VAE)", "bound": "mfma", "achieved": ach,
                               "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "launches": len(prof),
                               "gemm_ms_per_step": ms, "algorithmic_tflop_per_step": fl / 1e12,
@@ -476,6 +486,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` sub-records (bear table, march path, trained field; strong scaling at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-table", default=None, help="edit leg: write the per-shape table of one step's GEMM launches to this file (tuning aid)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` (no torchrun): this process becomes the launcher — before anything here touches the GPU runtime

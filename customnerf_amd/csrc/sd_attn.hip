@@ -251,6 +251,256 @@ __global__ void __launch_bounds__(256) k_sd_attention(const _Float16 *__restrict
         }
 }
 
+// ---- LDS-DMA form for row-major V and the head dims the UNet / CLIP encoder use (40, 64, 80, 160: compile-time D) -----------------------------
+// The register-staged loop above spends a third of its time in its fetch: per-item bounds branches, and a compiler-placed vmcnt(0) in front of the
+// first MFMA of every iteration (the two-deep staging registers are written under exec masks, so every load is waited for where it is issued).
+// Here K fragments and V rows go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write pass): every wave issues NIW
+// branch-free instructions per iteration — a lane whose source lies outside the problem (key >= Tk, pad channels) reads a 16-byte constant of zeros,
+// the lane of the ones channel reads {1, 0, ...} — into a ring of three LDS buffers, two iterations ahead, with a counted vmcnt before the iteration's
+// one barrier.  The V tile is row-major with a pitch of D / 8 (+ 1: the ones channel) 16-byte chunks; the transposing fragment reads of channels
+// beyond the pitch run into the next key row — finite values in accumulator rows that are never stored.
+// compile-time loops (immediate offsets of the inline-assembly LDS reads below)
+#include <utility>
+template <typename F, int... Is>
+__device__ __forceinline__ void at_static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void at_static_for(F &&f) { at_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
+
+// The transposing reads of the DMA kernel are inline assembly: the compiler orders every LDS read it can see behind ALL outstanding LDS-DMA
+// (s_waitcnt vmcnt(0) — it cannot tell the ring's buffers apart), which would make each iteration wait for the batch it has just issued.
+template <int OFF>
+__device__ __forceinline__ at_s4 at_tr_read(uint32_t addr) {
+    at_s4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void at_lds_wait(at_s4 &a, at_s4 &b, at_s4 &c, at_s4 &d) {      // the reads have landed before anything consumes them
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+__device__ __attribute__((aligned(16))) const _Float16 at_const[16] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+
+template <int D, int KT>
+__global__ void __launch_bounds__(256) k_sd_attention_dma(const _Float16 *__restrict__ Q, const _Float16 *__restrict__ K, const _Float16 *__restrict__ V,
+                                                          _Float16 *__restrict__ O, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t ldq, uint64_t sq,
+                                                          uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, float scale_log2e, int causal) {
+    constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
+    constexpr bool ONES = D < 32 * DT;                          // spare channel: the softmax denominator rides on the PV product
+    constexpr uint32_t PCH = D / 8 + (ONES ? 1 : 0);            // 16-byte chunks per V row in LDS
+    constexpr uint32_t KEYS = 32 * KT;
+    constexpr int NFK = KT * KS;                                // K fragments (1 KiB each) per iteration
+    constexpr int NVI = (KEYS * PCH + 63) / 64;                 // DMA instructions of the V tile
+    constexpr int NI = NFK + NVI, NIW = (NI + 3) / 4;           // per iteration, per wave (slots beyond NI write zeros to a dump area)
+    constexpr uint32_t KB = NFK * 1024, VB = NVI * 1024 + 128;  // bytes per buffer (V: whole instructions + over-read slack)
+    constexpr uint32_t BUF = KB + VB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * BUF + 1024];
+    unsigned char *dump = lds + 3 * BUF;
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, li = lane & 31;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;                  // one (batch, head) per XCD at a time (see k_sd_attention)
+    {
+        const uint32_t total = gridDim.x * gridDim.y;
+        if (total % CN_NXCD == 0) {
+            const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x, nid = (id % CN_NXCD) * (total / CN_NXCD) + id / CN_NXCD;
+            by = nid / gridDim.x;
+            bx = nid - by * gridDim.x;
+        }
+    }
+    const uint32_t b = by / H, h = by - b * H;
+    const uint32_t q0 = (bx * 4 + wave) * 32;
+    const uint32_t qi = q0 + li;
+    const bool q_ok = qi < Tq;
+    const _Float16 *qrow = Q + sq * b + (size_t)qi * ldq + h * D;
+    const _Float16 *kbase = K + sk * b + h * D;
+    const _Float16 *vbase = V + sv * b + h * D;
+
+    at_h8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const uint32_t c = 16 * s + 8 * hi;
+        at_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q_ok && c < (uint32_t)D) v = *reinterpret_cast<const at_h8 *>(qrow + c);
+        qf[s] = v;
+    }
+    at_f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+
+    // ---- this wave's DMA slots: item = wave + 4 i.  Per lane: source pointer at key tile 0, its advance per iteration, the key row it reads (for
+    // the Tk test), the constant it reads instead when the source is outside the problem; per slot (uniform): the LDS destination inside a buffer.
+    const _Float16 *src[NIW];
+    const _Float16 *alt[NIW];
+    uint32_t rowk[NIW], step[NIW], dst[NIW];
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int i = 0; i < NIW; i++) {
+        const uint32_t item = wave_u + 4 * i;
+        alt[i] = at_const;
+        if (item < (uint32_t)NFK) {                              // K fragment f = u KS + s: lane (fl, fh) holds K[32 u + fl][16 s + 8 fh ..]
+            const uint32_t u = item / KS, sfrag = item - u * KS, c = 16 * sfrag + 8 * hi;
+            rowk[i] = c < (uint32_t)D ? 32 * u + li : 0xFFFFFFFFu;
+            src[i] = kbase + (size_t)(32 * u + li) * ldk + c;
+            step[i] = KEYS * ldk;
+            dst[i] = item * 1024;
+        } else if (item < (uint32_t)NI) {                        // V rows: 16-byte chunk idx = row PCH + ch of the row-major tile
+            const uint32_t idx = (item - NFK) * 64 + lane, row = idx / PCH, ch = idx - row * PCH;
+            const bool data = row < KEYS && ch < (uint32_t)D / 8;
+            rowk[i] = data ? row : 0xFFFFFFFFu;
+            if (ONES && row < KEYS && ch == (uint32_t)D / 8) alt[i] = at_const + 8;
+            src[i] = vbase + (size_t)row * ldv + 8 * ch;
+            step[i] = KEYS * ldv;
+            dst[i] = KB + (item - NFK) * 1024;
+        } else {                                                 // filler slot: every wave issues NIW instructions per iteration (counted vmcnt)
+            rowk[i] = 0xFFFFFFFFu;
+            src[i] = at_const;
+            step[i] = 0;
+            dst[i] = 0xFFFFFFFFu;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < 3 * 128 / 4; i += 256) {  // the over-read slack behind each V tile
+        const uint32_t bsel = i / 32, w = i - bsel * 32;
+        reinterpret_cast<uint32_t *>(lds + bsel * BUF + KB + NVI * 1024)[w] = 0;
+    }
+    auto issue = [&](uint32_t kt, uint32_t boff) __attribute__((always_inline)) {
+        const uint32_t key0 = kt * KEYS;
+#pragma unroll
+        for (int i = 0; i < NIW; i++) {
+            const bool ok = rowk[i] != 0xFFFFFFFFu && key0 + rowk[i] < Tk;
+            const _Float16 *p = ok ? src[i] + (size_t)kt * step[i] : alt[i];
+            unsigned char *dp = dst[i] == 0xFFFFFFFFu ? dump : lds + boff + dst[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)dp, 16, 0, 0);
+        }
+    };
+    const uint32_t q_end = min(bx * 128 + 128, Tq);
+    const uint32_t n_kt = causal ? min((Tk + KEYS - 1) / KEYS, (q_end + KEYS - 1) / KEYS) : (Tk + KEYS - 1) / KEYS;
+    // per-lane bases of the fragment reads
+    const uint32_t i16 = lane & 15, G = (lane >> 4) & 1;
+    const uint32_t vlane = (4 * hi + (i16 >> 2)) * PCH * 16 + (16 * G + 4 * (i16 & 3)) * 2;
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    issue(0, 0);
+    if (1 < n_kt) issue(1, BUF);
+    uint32_t b_cur = 0, b_nxt = BUF, b_nx2 = 2 * BUF;
+    for (uint32_t kt = 0; kt < n_kt; kt++) {
+        // tile kt has landed (this wave's share: at most the newest batch is still in flight), then everybody's; the barrier also says that
+        // every wave is done reading tile kt - 1, whose buffer the next batch overwrites
+        if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < n_kt) issue(kt + 2, b_nx2);
+        const uint32_t key0 = kt * KEYS;
+        const at_h8 *ktile = reinterpret_cast<const at_h8 *>(lds + b_cur);
+        // ---- S^T sub-tiles
+        at_f16v sacc[KT];
+#pragma unroll
+        for (int u = 0; u < KT; u++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[u][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; s++) sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktile[(u * KS + s) * 64 + lane], qf[s], sacc[u], 0, 0, 0);
+        }
+        // ---- online softmax (as in k_sd_attention)
+        float tmax = -INFINITY;
+        if (!causal && key0 + KEYS <= Tk) {
+#pragma unroll
+            for (int u = 0; u < KT; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, sacc[u][r]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < KT; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = key0 + 32 * u + at_rho(r, hi);
+                    sacc[u][r] = (key < Tk && !(causal && key > qi)) ? sacc[u][r] : -INFINITY;
+                    tmax = fmaxf(tmax, sacc[u][r]);
+                }
+        }
+        tmax = at_half_max(tmax);
+        const float m_new = fmaxf(fmaxf(m, tmax), -1e30f);
+        const bool moved = m_new != m;
+        const float corr = moved ? __builtin_amdgcn_exp2f((m - m_new) * scale_log2e) : 1.0f;
+        m = m_new;
+        const float nm = -m_new * scale_log2e;
+        float psum = 0.0f;
+        at_h8 pf[KT][2];
+#pragma unroll
+        for (int u = 0; u < KT; u++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                at_h8 f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float p = __builtin_amdgcn_exp2f(cn_fma(sacc[u][8 * s + j], scale_log2e, nm));
+                    const _Float16 ph = (_Float16)p;
+                    f[j] = ph;
+                    if (!ONES) psum += (float)ph;
+                }
+                pf[u][s] = f;
+            }
+        if (!ONES) l = l * corr + psum;
+        if (__any(moved)) {
+#pragma unroll
+            for (int t = 0; t < DT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[t][r] *= corr;
+        }
+        // ---- O^T += V^T P^T: transposing reads of the row-major tile (lane i of its 16-lane group: key row i >> 2, chunk i & 3 of 16 channels)
+        const uint32_t va = lds_addr + b_cur + KB + vlane;
+        at_static_for<KT>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            at_s4 fr[DT][2][2];
+            at_static_for<DT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                at_static_for<2>([&](auto S2) {
+                    constexpr int s2 = decltype(S2)::value;
+                    constexpr int off = (32 * u + 16 * s2) * (int)PCH * 16 + 64 * t;
+                    fr[t][s2][0] = at_tr_read<off>(va);
+                    fr[t][s2][1] = at_tr_read<off + 8 * (int)PCH * 16>(va);
+                });
+            });
+#pragma unroll
+            for (int t = 0; t < DT; t++) {
+                at_lds_wait(fr[t][0][0], fr[t][0][1], fr[t][1][0], fr[t][1][1]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    union { at_h8 h; at_s4 q[2]; } f;
+                    f.q[0] = fr[t][s2][0];
+                    f.q[1] = fr[t][s2][1];
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, pf[u][s2], o[t], 0, 0, 0);
+                }
+            }
+        });
+        const uint32_t tb = b_cur;
+        b_cur = b_nxt; b_nxt = b_nx2; b_nx2 = tb;
+    }
+    if (ONES) {                                       // channel D sits in C row D % 32 = register 4 ((D % 32) / 8) of the low half-wave, column = query
+        l = __shfl(o[D / 32][4 * ((D % 32) / 8)], li, 64);
+    } else {
+        l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    if (!q_ok) return;
+    _Float16 *orow = O + so * b + (size_t)qi * ldo + h * D;
+#pragma unroll
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t dd = 32 * t + 8 * g + 4 * hi;
+            if (dd < (uint32_t)D) {
+                at_h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (_Float16)(o[t][4 * g + e] * inv);
+                *reinterpret_cast<at_h4 *>(orow + dd) = v;
+            }
+        }
+}
+
+static bool at_use_dma() { static const int v = cn_tune_env("CNERF_ATTN_DMA", 1); return v != 0; }
+
 template <bool VROW>
 static int at_launch(const void *q, const void *k, const void *vT, void *out, uint32_t B, uint32_t H, uint32_t Tq, uint32_t Tk, uint32_t d, uint32_t ldq,
                      uint64_t sq, uint32_t ldk, uint64_t sk, uint32_t ldv, uint64_t sv, uint32_t ldo, uint64_t so, int causal, void *stream) {
@@ -268,6 +518,16 @@ static int at_launch(const void *q, const void *k, const void *vT, void *out, ui
 #define AT_LAUNCH(KS, DT, KT)                                                                                                                       \
     hipLaunchKernelGGL((k_sd_attention<KS, DT, KT, VROW>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
                        d, ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e, causal)
+#define AT_LAUNCH_DMA(D, KT)                                                                                                                         \
+    hipLaunchKernelGGL((k_sd_attention_dma<D, KT>), grid, block, 0, st, (const _Float16 *)q, (const _Float16 *)k, (const _Float16 *)vT, (_Float16 *)out, H, Tq, Tk, \
+                       ldq, sq, ldk, sk, ldv, sv, ldo, so, scale_log2e, causal)
+    if (VROW && at_use_dma()) {                                  // row-major V at the head dims of the UNet / the text encoder: the LDS-DMA form
+        if (d == 40) { AT_LAUNCH_DMA(40, 2); return cn_launch_status(); }
+        if (d == 64) { AT_LAUNCH_DMA(64, 2); return cn_launch_status(); }
+        if (d == 80) { AT_LAUNCH_DMA(80, 1); return cn_launch_status(); }
+        if (d == 160) { AT_LAUNCH_DMA(160, 1); return cn_launch_status(); }
+    }
+#undef AT_LAUNCH_DMA
     const uint32_t ks = (d + 15) / 16, dt = (d + 31) / 32;
     // 64 keys per iteration where the registers allow two waves per SIMD with it (head dims <= 64), 32 above
     if (ks <= 3 && dt <= 2) AT_LAUNCH(3, 2, 2);
