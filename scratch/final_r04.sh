@@ -8,11 +8,11 @@ mkdir -p $out
 timeout 900 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json; echo
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_recon -o bench -- python3 bench.py --task recon --steps 20 --warmup 5 --no-cpu-baseline > $out/prof_recon.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_edit -o bench -- python3 bench.py --task edit --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_edit.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_recon -o bench -- python3 bench.py --task recon --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $out/prof_recon.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_edit -o bench -- python3 bench.py --task edit --steps 10 --warmup 3 --no-cpu-baseline --no-variants > $out/prof_edit.log 2>&1
 rm -f $out/prof_recon/bench_kernel_trace.csv $out/prof_edit/bench_kernel_trace.csv
 for c in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o b -- python3 bench.py --task recon --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $out/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o b -- python3 bench.py --task recon --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants > $out/pmc_$c.log 2>&1
   python3 - <<E
 import csv, collections
 try:
@@ -30,7 +30,7 @@ E
   rm -rf $out/pmc_$c
 done
 for c in MfmaUtil LdsUtil; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmce_$c -o b -- python3 bench.py --task edit --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/pmce_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmce_$c -o b -- python3 bench.py --task edit --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-variants > $out/pmce_$c.log 2>&1
   python3 - <<E
 import csv, collections, json
 try:
