@@ -353,7 +353,9 @@ __global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict_
 // Sums stay 64-bit fixed point with 24 fractional bits (order-independent, so bit-deterministic wherever one workgroup owns a chunk);
 // the per-corner products are rounded to that grid instead of to binary16 (the reference rounds w*g to half, gridencoder.cu:328: the
 // difference is below one half ulp of each product).
+#ifndef B2_THREADS
 #define B2_THREADS 1024
+#endif
 #define B2_SEG_MIN ((1u << 16) + (1u << 13))       // records per accumulate workgroup, see b2_seg()
 #define B2_SINGLE 15u
 
