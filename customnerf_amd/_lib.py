@@ -81,6 +81,7 @@ SIGNATURES = {
     "cnerf_sd_gemm_workspace_bytes": [vp, vp],
     "cnerf_sd_groupnorm_forward": [vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, i32, vp, vp],
     "cnerf_sd_groupnorm_backward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, vp, vp],
+    "cnerf_sd_groupnorm_backward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, i32, vp, vp, vp],
     "cnerf_sd_layernorm_forward": [vp, vp, vp, u32, u32, f32, vp, vp],
     "cnerf_sd_softmax_forward": [vp, u64, u32, u32, vp],
     "cnerf_sd_softmax_backward": [vp, vp, u64, u32, u32, vp],

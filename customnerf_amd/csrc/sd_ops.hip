@@ -118,7 +118,8 @@ template <int MODE>
 __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restrict__ x, const _Float16 *__restrict__ dy, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, const long long *__restrict__ fsums, const long long *__restrict__ bsums,
                                                          uint32_t HW, uint32_t C, uint32_t G, float eps, int silu, uint32_t rows_per_block,
-                                                         _Float16 *__restrict__ out) {
+                                                         _Float16 *__restrict__ out, const _Float16 *__restrict__ res = nullptr) {
+    // res (MODE 1): a second gradient arriving at x — the skip connection of a residual block — added before the one rounding to half
     const GnGeom q = gn_geom(C, G);
     const uint32_t b = blockIdx.y, r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
     const uint32_t tcol = threadIdx.x % q.cols_per_pass, trow = threadIdx.x / q.cols_per_pass;
@@ -146,8 +147,9 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restr
         for (uint32_t r = r0 + trow; r < r1; r += q.rows_per_pass) {
             const size_t off = ((size_t)b * HW + r) * C + c0;
             const so_h8 xv = so_ld8(x + off);
-            so_h8 dv, o;
+            so_h8 dv, o, rv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (MODE == 1) dv = so_ld8(dy + off);
+            if (MODE == 1 && res) rv = so_ld8(res + off);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float xh = ((float)xv[e] - mean[e]) * rstd[e];
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restr
                         gq *= sg * (1.0f + z * (1.0f - sg));
                     }
                     gq *= ga[e];
-                    o[e] = (_Float16)(rstd[e] * (gq - s1[e] - xh * s2[e]));
+                    o[e] = (_Float16)(rstd[e] * (gq - s1[e] - xh * s2[e]) + (float)rv[e]);
                 }
             }
             so_st8(out + off, o);
@@ -601,20 +603,31 @@ int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *b
     return cn_launch_status();
 }
 
-int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
-                                float eps, int silu, const int64_t *sums, int64_t *scratch, void *dx, void *stream) {
+static int gn_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, float eps,
+                       int silu, const int64_t *sums, int64_t *scratch, int scratch_is_zero, const void *residual, void *dx, void *stream) {
     int rc = gn_check(B, HW, C, G);
     if (rc) return rc;
     if (!x || !dy || !gamma || !beta || !sums || !scratch || !dx) return CNERF_ENULL;
     hipStream_t st = CN_STREAM(stream);
-    so_zero(reinterpret_cast<float *>(scratch), (size_t)B * G * 4, st);
+    if (!scratch_is_zero) so_zero(reinterpret_cast<float *>(scratch), (size_t)B * G * 4, st);
     const uint32_t rpb = gn_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_stats<1>), dim3(cn_div_up(HW, rpb), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta,
                        (const long long *)sums, HW, C, G, eps, silu, rpb, reinterpret_cast<long long *>(scratch));
     const uint32_t rpa = gn_apply_rows_per_block(B, HW, C);
     hipLaunchKernelGGL((k_gn_apply<1>), dim3(cn_div_up(HW, rpa), B), dim3(GN_THREADS), 0, st, (const _Float16 *)x, (const _Float16 *)dy, gamma, beta,
-                       (const long long *)sums, (const long long *)scratch, HW, C, G, eps, silu, rpa, (_Float16 *)dx);
+                       (const long long *)sums, (const long long *)scratch, HW, C, G, eps, silu, rpa, (_Float16 *)dx, (const _Float16 *)residual);
     return cn_launch_status();
+}
+
+int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                float eps, int silu, const int64_t *sums, int64_t *scratch, void *dx, void *stream) {
+    return gn_backward(x, dy, gamma, beta, B, HW, C, G, eps, silu, sums, scratch, 0, nullptr, dx, stream);
+}
+
+int cnerf_sd_groupnorm_backward_ex(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                   float eps, int silu, const int64_t *sums, int64_t *scratch, int scratch_is_zero, const void *residual, void *dx,
+                                   void *stream) {
+    return gn_backward(x, dy, gamma, beta, B, HW, C, G, eps, silu, sums, scratch, scratch_is_zero, residual, dx, stream);
 }
 
 int cnerf_sd_layernorm_forward(const void *x, const float *gamma, const float *beta, uint32_t rows, uint32_t C, float eps, void *y, void *stream) {

@@ -159,14 +159,21 @@ def groupnorm(x, gamma, beta, groups, eps, silu, pool=None, sums=None, sums_read
     return y, sums
 
 
-def groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums):
+def groupnorm_backward(x, dy, gamma, beta, groups, eps, silu, sums, residual=None, scratch=None):
+    """dx of groupnorm() for frozen gamma / beta.  residual (x's shape, half): a second gradient arriving at x (a skip connection), added inside
+    the apply kernel; scratch: a pre-zeroed [B, G, 2] int64 slice (SumsPool.take()) instead of a fresh buffer + its zero-fill launch."""
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    scratch = torch.empty(B, groups, 2, dtype=torch.int64, device=x.device)
-    check(lib.cnerf_sd_groupnorm_backward(ptr(x), ptr(dy), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(scratch), ptr(dx), stream()),
-          "sd_groupnorm_backward")
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == x.shape and residual.dtype == torch.float16
+    zeroed = scratch is not None
+    if scratch is None:
+        scratch = torch.empty(B, groups, 2, dtype=torch.int64, device=x.device)
+    check(lib.cnerf_sd_groupnorm_backward_ex(ptr(x), ptr(dy), ptr(gamma), ptr(beta), B, HW, C, groups, eps, int(silu), ptr(sums), ptr(scratch), int(zeroed),
+                                             ptr(residual), ptr(dx), stream()), "sd_groupnorm_backward")
     return dx
 
 

@@ -81,10 +81,11 @@ class _Transformer:
         return k in sd
 
     def context_kv(self, ctx):
-        """cross-attention keys / transposed values of a text embedding: they depend on the prompt only, not on the latents or t"""
+        """cross-attention keys / values of a text embedding: they depend on the prompt only, not on the latents or t (views of the fused
+        k|v projection: the attention kernel reads V row-major since round 4)"""
         C = self.q2.shape[0]
         kv = ops.linear(ctx, self.kv2)                                                   # [B, 77, 2C]
-        return kv[..., :C], ops.transpose_v(kv[..., C:])
+        return kv[..., :C], kv[..., C:]
 
     def __call__(self, x, ctx, groups, pool, x_sums=None, out_gn=False, kv=None):
         """-> (y, y_sums | None), see _Resnet.__call__.  kv: this block's context_kv(ctx) when the caller caches it per prompt."""
@@ -102,7 +103,7 @@ class _Transformer:
         q = ops.linear(n, self.q2)
         if kv is None:
             kv = self.context_kv(ctx)
-        a = ops.attention_vt(q, kv[0], kv[1], self.heads)
+        a = ops.attention(q, kv[0], kv[1], self.heads)
         h = ops.linear(a, self.o2w, bias=self.o2b, residual=h)
         n = ops.layernorm(h, *self.ln[2])
         f = ops.linear(n, self.f1w, bias=self.f1b, act=ops.ACT_GEGLU)                     # [B, T, 4C]

@@ -146,6 +146,53 @@ class _LinW:
         return _Linear.apply(x, self.w, self.wT, self.b, residual)
 
 
+class _ResnetFn(Function):
+    """A whole residual block (norm1 + SiLU -> conv1 -> norm2 + SiLU -> conv2 + shortcut) with a hand-written backward for frozen weights.
+    Against the per-op Functions autograd chains (round 4): the skip gradient joins the branch gradient INSIDE norm1's backward apply kernel
+    (one rounding to half, no add launch), and both backward norms take their scratch statistics pre-zeroed from the pass's pool (no
+    zero-fill launches).  Outputs: y, the statistics of y for the next norm (or None), a 0 / 1 flag tensor: statistics ready."""
+
+    @staticmethod
+    def forward(ctx, x, blk, groups, eps, pool, x_sums, x_ready, out_gn):
+        B, H, W, _ = x.shape
+        if x_sums is not None:
+            h, s1 = ops.groupnorm(x, *blk.n1, groups, eps, True, sums=x_sums, sums_ready=x_ready)
+        else:
+            h, s1 = ops.groupnorm(x, *blk.n1, groups, eps, True, pool)
+        c1w, c2w = blk.c1, blk.c2
+        s2 = pool.take()
+        c1, ok1 = ops.conv2d(h, c1w.w, c1w.b, c1w.k, stride=1, pad=c1w.k // 2, gn=(s2, groups, H * W))
+        h, _ = ops.groupnorm(c1, *blk.n2, groups, eps, True, sums=s2, sums_ready=ok1)
+        res = ops.linear(x, blk.sc.w, bias=blk.sc.b) if blk.sc is not None else x
+        so, ok = None, False
+        if out_gn:
+            so = pool.take()
+            y, ok = ops.conv2d(h, c2w.w, c2w.b, c2w.k, stride=1, pad=c2w.k // 2, residual=res, gn=(so, groups, H * W))
+        else:
+            y = ops.conv2d(h, c2w.w, c2w.b, c2w.k, stride=1, pad=c2w.k // 2, residual=res)
+        ctx.save_for_backward(x, s1, c1, s2, pool.take(), pool.take())       # + two pre-zeroed scratch slices for the backward norms
+        ctx.blk, ctx.cfg = blk, (groups, eps, H, W)
+        flag = torch.tensor(1 if ok else 0)
+        ctx.mark_non_differentiable(flag)
+        if so is not None:
+            ctx.mark_non_differentiable(so)
+        return y, so, flag
+
+    @staticmethod
+    def backward(ctx, dy, _so=None, _flag=None):
+        x, s1, c1, s2, scr2, scr1 = ctx.saved_tensors
+        blk = ctx.blk
+        groups, eps, H, W = ctx.cfg
+        dy = dy.contiguous()
+        c1w, c2w = blk.c1, blk.c2
+        d = ops.conv2d(dy, c2w.wd, None, c2w.k, stride=1, pad=c2w.k - 1 - c2w.k // 2, out_hw=(H, W))
+        d = ops.groupnorm_backward(c1, d, *blk.n2, groups, eps, True, s2, scratch=scr2)
+        d = ops.conv2d(d, c1w.wd, None, c1w.k, stride=1, pad=c1w.k - 1 - c1w.k // 2, out_hw=(H, W))
+        skip = ops.linear(dy, blk.sc.wT) if blk.sc is not None else dy
+        dx = ops.groupnorm_backward(x, d, *blk.n1, groups, eps, True, s1, residual=skip, scratch=scr1)
+        return dx, None, None, None, None, None, None, None
+
+
 class _Resnet:
     def __init__(self, sd, p, dev):
         self.n1 = (pack.f32(sd[p + "norm1.weight"].to(dev)), pack.f32(sd[p + "norm1.bias"].to(dev)))
@@ -154,14 +201,10 @@ class _Resnet:
         self.sc = _LinW(sd, p + "conv_shortcut", dev) if (p + "conv_shortcut.weight") in sd else None
 
     def __call__(self, x, groups, eps, pool, x_sums=None, out_gn=False):
-        """x_sums = (sums, ready) of x from its producer (or None); out_gn: also return the statistics of the output"""
-        h = _GroupNorm.apply(x, *self.n1, groups, eps, True, *(x_sums if x_sums is not None else (None, False)))
-        h, hs = self.c1(h, gn=(pool, groups))
-        h = _GroupNorm.apply(h, *self.n2, groups, eps, True, *hs)
-        res = self.sc(x) if self.sc is not None else x
-        if out_gn:
-            return self.c2(h, residual=res, gn=(pool, groups))
-        return self.c2(h, residual=res), None
+        """x_sums = (sums, ready) of x from its producer (or None); out_gn: also return the statistics of the output -> (y, (sums, ready) | None)"""
+        xs, xr = x_sums if x_sums is not None else (None, False)
+        y, so, flag = _ResnetFn.apply(x, self, groups, eps, pool, xs, xr, out_gn)
+        return y, ((so, bool(flag)) if out_gn else None)
 
 
 class VAEEncoder:
@@ -193,7 +236,7 @@ class VAEEncoder:
         """x [B, H, W, 8] half NHWC in [-1, 1] (3 channels + zero padding) -> [B, H/8, W/8, 2*latent] half (mean | logvar)"""
         G, eps = self.cfg["groups"], self.cfg["eps"]
         n_res = sum(len(res) for res, _ in self.down) + 2
-        pool = ops.SumsPool(2 * n_res + 8, x.shape[0], G, x.device)          # one zero-fill; the producing GEMMs fill the statistics
+        pool = ops.SumsPool(5 * n_res + 8, x.shape[0], G, x.device)          # one zero-fill: forward statistics (filled by the producing GEMMs) + backward scratch
         h, hs = self.conv_in(x, gn=(pool, G))
         for bi, (res, ds) in enumerate(self.down):
             for j, r in enumerate(res):

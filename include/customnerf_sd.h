@@ -87,6 +87,12 @@ int cnerf_sd_groupnorm_forward(const void *x, const float *gamma, const float *b
 int cnerf_sd_groupnorm_backward(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW,
                                 uint32_t C, uint32_t G, float eps, int silu, const int64_t *sums, int64_t *scratch, void *dx,
                                 void *stream);
+/* The same with two savings for residual blocks (round 4): scratch_is_zero != 0 — the caller hands over zeros (one fill for all the norms of a
+ * backward pass, as zero_sums == 0 does for the forward); residual (nullable, x's shape) — a second gradient arriving at x (the block's skip
+ * connection) is added before the one rounding to half: dx = groupnorm_backward(dy) + residual, no separate add launch. */
+int cnerf_sd_groupnorm_backward_ex(const void *x, const void *dy, const float *gamma, const float *beta, uint32_t B, uint32_t HW,
+                                   uint32_t C, uint32_t G, float eps, int silu, const int64_t *sums, int64_t *scratch,
+                                   int scratch_is_zero, const void *residual, void *dx, void *stream);
 
 /* LayerNorm over the last dimension of x [rows, C] (half), float32 statistics, eps inside the sqrt. */
 int cnerf_sd_layernorm_forward(const void *x, const float *gamma, const float *beta, uint32_t rows, uint32_t C, float eps,
