@@ -137,6 +137,15 @@ def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
     n = HW * (C // G)
     mean_ref = x.detach().half().float().view(B, G, -1).mean(-1)
     assert float((ops.gn_sums_to_float(sums)[..., 0].cpu() / n - mean_ref.double()).abs().max()) < 1e-4
+    # (round 4) residual blocks: a second gradient arriving at x is added inside the apply kernel (one rounding instead of two), with the
+    # scratch statistics handed over pre-zeroed — the same dx + r up to that rounding, and the same bits whether the scratch is passed or not
+    r = h(torch.randn(B, HW, C, generator=g)).half().cuda()
+    scratch = torch.zeros(B, G, 2, dtype=torch.int64, device="cuda")
+    dxr = ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums, residual=r, scratch=scratch)
+    two_roundings = (dx.float() + r.float())
+    assert float((dxr.float() - two_roundings).abs().max()) <= float(two_roundings.abs().max()) * 2 ** -10
+    assert torch.equal(dxr, ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums, residual=r))
+    assert torch.equal(ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums, scratch=torch.zeros_like(scratch)), dx)
 
 
 @pytest.mark.parametrize("rows,C", [(100, 320), (77, 640), (513, 1280), (3, 768)])
