@@ -181,6 +181,9 @@ class _ResnetFn(Function):
     @staticmethod
     def backward(ctx, dy, _so=None, _flag=None):
         x, s1, c1, s2, scr2, scr1 = ctx.saved_tensors
+        if getattr(ctx, "scratch_used", False):       # a second backward through the same graph (retain_graph): the pooled slices hold the first
+            scr2 = scr1 = None                        # pass's sums — let the calls allocate and zero their own
+        ctx.scratch_used = True
         blk = ctx.blk
         groups, eps, H, W = ctx.cfg
         dy = dy.contiguous()
