@@ -125,6 +125,7 @@ class NeRFRenderer(nn.Module):
         if not getattr(self.opt, 'train_conf', 0):
             return {}
         if not (3 <= num_steps <= 128 and 2 <= upsample_steps <= 128):
+            # (upsample_steps == 0 fails in the reference as well: `weights` is bound only inside `if upsample_steps > 0`, renderer.py:333-384)
             raise ValueError(f"run(): the sampling kernels take 3..128 coarse and 2..128 importance samples per ray (got {num_steps} + {upsample_steps}; "
                              "the reference's recipe is 64 + 64)")
         return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
