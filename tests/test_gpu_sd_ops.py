@@ -178,7 +178,9 @@ def test_geglu_add_silu_concat_transpose():
 # the last two rows are the shapes the SD-1.5 UNet runs at 64x64 latents (nerf/sd.py:140): 4096-token self-attention (the most expensive
 # instantiation, k_sd_attention<3,2>: head dim 40) and its cross-attention against the 77 text tokens
 @pytest.mark.parametrize("B,Tq,Tk,C,heads", [(2, 256, 256, 320, 8), (2, 64, 77, 1280, 8), (1, 300, 300, 512, 1), (2, 1024, 77, 640, 8), (1, 100, 1100, 80, 2),
-                                             (2, 4096, 4096, 320, 8), (2, 4096, 77, 320, 8), (3, 200, 333, 512, 8), (1, 130, 70, 96, 2)])
+                                             (2, 4096, 4096, 320, 8), (2, 4096, 77, 320, 8), (3, 200, 333, 512, 8), (1, 130, 70, 96, 2),
+                                             # edges of the LDS-DMA kernel's tiling (64- / 32-key iterations, ring of three buffers, partial query blocks)
+                                             (1, 1, 1, 40, 1), (1, 33, 65, 80, 1), (1, 31, 129, 160, 1), (2, 257, 63, 128, 2), (1, 64, 192, 40, 1), (1, 5, 64, 64, 1)])
 def test_attention(B, Tq, Tk, C, heads):
     from customnerf_amd.sd import ops
     g = torch.Generator().manual_seed(Tq + Tk)
