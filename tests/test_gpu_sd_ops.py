@@ -148,6 +148,21 @@ def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
     assert torch.equal(ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums, scratch=torch.zeros_like(scratch)), dx)
 
 
+@pytest.mark.parametrize("B,T,C,heads", [(2, 77, 768, 12), (1, 200, 80, 2), (1, 130, 160, 2), (2, 65, 320, 2), (1, 100, 96, 2)])
+def test_attention_causal(B, T, C, heads):
+    """causal = 1 (the CLIP text tower's mask): query i attends to keys <= i, in both kernel forms (LDS-DMA at head dims 64 / 40 / 80 / 160,
+    register-staged at 48) and through the pre-transposed-V entry"""
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(T + C)
+    q, k, v = (h(torch.randn(B, T, C, generator=g)) for _ in range(3))
+    o = ops.attention(q.half().cuda(), k.half().cuda(), v.half().cuda(), heads, causal=True)
+    qh, kh, vh = (t.view(B, T, heads, C // heads).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(B, T, C)
+    close(o, ref, 5e-3, 5e-3)
+    o_vt = ops.attention_vt(q.half().cuda(), k.half().cuda(), ops.transpose_v(v.half().cuda()), heads, causal=True)
+    assert torch.equal(o, o_vt)
+
+
 @pytest.mark.parametrize("rows,C", [(100, 320), (77, 640), (513, 1280), (3, 768)])
 def test_layernorm(rows, C):
     from customnerf_amd.sd import ops
