@@ -10,11 +10,11 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
-from ..trainer import (CheckpointMixin, allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
+from ..trainer import (CheckpointMixin, EvalMixin, allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
                        setup_sharded_dp)
 
 
-class EditTrainer(CheckpointMixin):
+class EditTrainer(CheckpointMixin, EvalMixin):
     def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale='dynamic', seed=0,
                  clip_guidance=None, clip_match_text=None, dp_mode='allreduce'):
         """text_z / text_z_fg: the [2, 77, 768] (uncond, cond) embeddings of the global / local prompt; with `opt.clip_view` they are

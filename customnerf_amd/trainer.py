@@ -173,7 +173,53 @@ class CheckpointMixin:
                                           scaler=self.scaler)
 
 
-class ReconTrainer(CheckpointMixin):
+class EvalMixin:
+    """Trainer_Nerf.eval_step / test_step (nerf/utils_init_nerf.py:396-434, 436-485): one full view rendered without perturbation and the image
+    panels the reference's evaluate_one_epoch / test loops write out.  The reference passes `**vars(self.opt)` to render(); the sampling keys
+    run() / run_cuda() read are forwarded here.  (Its render() ignores `staged` — renderer.py:1719-1733 — as this package's does.)"""
+
+    def _render_eval(self, model, rays_o, rays_d, perturb=False):
+        opt = self.opt
+        kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=getattr(opt, 'dt_gamma', 0), max_steps=opt.max_steps)
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+            return model.render(rays_o, rays_d, staged=True, perturb=perturb, force_all_rays=True, **kw)
+
+    def eval_step(self, data):
+        """-> (panel [B, H, n W, 3] = gt | prediction | depth (| gt mask | predicted mask | foreground | background under opt.train_conf), None, None,
+        loss = tensor([0])), as utils_init_nerf.py:396-434"""
+        rgbs, mask, rays_o, rays_d, H, W, _ = data
+        dev = next(self.model.parameters()).device
+        rgbs, mask, rays_o, rays_d = rgbs.to(dev), mask.to(dev), rays_o.to(dev), rays_d.to(dev)
+        B = rays_o.shape[0]
+        outputs = self._render_eval(self.model, rays_o, rays_d)
+        ims = [rgbs.reshape(B, H, W, 3).float(), outputs['image'].reshape(B, H, W, 3).float(), outputs['depth'].reshape(B, H, W, 1).float().repeat(1, 1, 1, 3)]
+        if getattr(self.opt, 'train_conf', 0):
+            ims += [mask.reshape(B, H, W, 1).float().repeat(1, 1, 1, 3),
+                    outputs['render_mask'].reshape(B, H, W, -1).float().mean(-1, keepdim=True).repeat(1, 1, 1, 3),
+                    outputs['fg']['image'].reshape(B, H, W, 3).float(), outputs['bg']['image'].reshape(B, H, W, 3).float()]
+        return torch.cat(ims, dim=2), None, None, torch.tensor([0])
+
+    def test_step(self, data, bg_color=None, perturb=False, if_gui=False):
+        """-> (pred_rgb [B, H, W, 3] — the panel prediction | mask | foreground | background under opt.train_conf and opt.render_all —,
+        pred_depth [B, H, W], dir), as utils_init_nerf.py:436-485.  (The reference also renders model_pretrained there and drops the result.)"""
+        direction = torch.tensor(0)
+        if if_gui:
+            rays_o, rays_d, H, W, direction = data['rays_o'], data['rays_d'], data['H'], data['W'], data['dir']
+        else:
+            _, _, rays_o, rays_d, H, W, _ = data
+        dev = next(self.model.parameters()).device
+        rays_o, rays_d = rays_o.to(dev), rays_d.to(dev)
+        B = rays_o.shape[0]
+        outputs = self._render_eval(self.model, rays_o, rays_d, perturb=perturb)
+        pred_rgb = outputs['image'].reshape(B, H, W, 3).float()
+        pred_depth = outputs['depth'].reshape(B, H, W).float()
+        if getattr(self.opt, 'train_conf', 0) and getattr(self.opt, 'render_all', False):
+            pred_rgb = torch.cat([pred_rgb, outputs['render_mask'].reshape(B, H, W, 1).float().repeat(1, 1, 1, 3),
+                                  outputs['fg']['image'].reshape(B, H, W, 3).float(), outputs['bg']['image'].reshape(B, H, W, 3).float()], dim=2)
+        return pred_rgb, pred_depth, direction
+
+
+class ReconTrainer(CheckpointMixin, EvalMixin):
     def __init__(self, model, opt, lr=None, fp16=False, world_size=1, fused_adam=True, loss_scale='dynamic', dp_mode='allreduce'):
         """dp_mode (world_size > 1): 'allreduce' = one in-place fp32 all-reduce of the flat gradient buffer; 'sharded' = customnerf_amd.dp.ShardedExchange
         (fp16 all-to-all payload summed in fp32 on arrival, sharded Adam, all-gather of the fp16 shadow; MLP groups all-reduced in fp32).

@@ -99,6 +99,23 @@ def test_train_one_epoch_on_a_disk_scene(tmp_path):
     before = tr.global_step
     train_one_epoch(tr, views, shard=(1, 2))
     assert tr.global_step - before == len(range(1, len(views), 2))
+    # eval_step / test_step (utils_init_nerf.py:396-485): one unperturbed full-view render and the panels the reference writes out
+    rgbs, mask, rays_o, rays_d, H, W, path = views[0]
+    model.eval()
+    panel, _, _, loss0 = tr.eval_step(views[0])
+    n = 7 if opt.train_conf else 3
+    assert panel.shape == (1, H, n * W, 3) and panel.dtype == torch.float32 and float(loss0) == 0.0
+    assert torch.equal(panel[:, :, :W], rgbs.reshape(1, H, W, 3).float())
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        out = model.render(rays_o, rays_d, staged=True, perturb=False, force_all_rays=True, num_steps=16, upsample_steps=16, dt_gamma=0, max_steps=opt.max_steps)
+    assert torch.equal(panel[:, :, W:2 * W], out['image'].reshape(1, H, W, 3).float())
+    assert torch.equal(panel[:, :, 2 * W:3 * W, 0], out['depth'].reshape(1, H, W).float())
+    rgb_t, depth_t, d_t = tr.test_step(views[0])
+    assert torch.equal(rgb_t, out['image'].reshape(1, H, W, 3).float()) and torch.equal(depth_t, out['depth'].reshape(1, H, W).float()) and int(d_t) == 0
+    opt.render_all = True
+    rgb_all, _, _ = tr.test_step(dict(rays_o=rays_o, rays_d=rays_d, H=H, W=W, dir=torch.tensor(2)), if_gui=True)
+    assert rgb_all.shape == (1, H, (4 if opt.train_conf else 1) * W, 3)
+    model.train()
 
 
 def test_dynamic_loss_scaler_matches_torch_gradscaler():
