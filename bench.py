@@ -300,9 +300,13 @@ def run_recon(args, world, rank, dev):
         n_rays = H * W
         rays_per_step = n_rays * world
 
+    # --graph (one GPU, run() path): render + loss + backward of each view replayed as one hipGraph, eager optimiser step (ReconTrainer.train_step_graphed)
+    use_graph = bool(getattr(args, "graph", False)) and world == 1 and args.path == "run" and fp16
+
     def step(i):
         v = (i % V) if strong else (i * world + rank) % V      # weak: each rank renders its own view (view-parallel data parallelism)
-        return trainer.train_step(rays_o[v], rays_d[v], rgb[v], mask[v], **render_kw)
+        f = trainer.train_step_graphed if use_graph else trainer.train_step
+        return f(rays_o[v], rays_d[v], rgb[v], mask[v], **render_kw)
 
     if args.prefit > 0:
         # `trained_field`: the benchmark's random-initialised field spreads its importance samples almost uniformly; a fitted field clusters them
@@ -311,9 +315,9 @@ def run_recon(args, world, rank, dev):
         rgb, mask = sc.sphere_targets(rays_o.reshape(V, -1, 3), rays_d.reshape(V, -1, 3))          # (this rank's rays: already the chunk under --scaling strong)
         for i in range(args.prefit):
             step(i)
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, V) if use_graph else args.warmup):       # (graph mode: every view is captured before the timed region)
         step(i)
-    prof = [] if not args.no_roofline else None
+    prof = [] if (not args.no_roofline and not use_graph) else None            # per-launch event brackets need eager launches
     ge.set_profile(prof)
     xev = [] if trainer._dp is not None else None
     trainer._exchange_events = xev
@@ -341,6 +345,8 @@ def run_recon(args, world, rank, dev):
         }
         if args.path == "march":
             result["config"]["samples_per_ray"] = out.get('num_points', 0) / n_rays
+        if use_graph:
+            result["config"]["graph"] = "render + loss + backward replayed as one hipGraph per view; optimiser step eager"
         if args.prefit > 0:
             result["config"]["prefit_steps"] = args.prefit
             result["config"]["workload"] += f", field pre-fitted for {args.prefit} steps to the analytic sphere scene (targets of the timed steps too)"
@@ -482,6 +488,7 @@ def main():
     ap.add_argument("--prefit", type=int, default=0,
                     help="recon leg: fit the field to the analytic sphere scene for this many untimed steps first, so that the importance samples cluster around a surface")
     ap.add_argument("--dp-selftest", action="store_true", help="one GPU: force the sharded gradient exchange on over a one-rank RCCL group (no link time)")
+    ap.add_argument("--graph", action="store_true", help="recon leg (one GPU, run() path): forward + backward of each view as one hipGraph (ReconTrainer.train_step_graphed)")
     ap.add_argument("--dry-launch", action="store_true", help="print the child environments `--gpus N` would spawn and exit (no GPU needed)")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` sub-records (bear table, march path, trained field; strong scaling at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -535,7 +542,7 @@ def main():
         if r is None or "error" in r:
             return r
         out = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"]}
-        for k in ("samples_per_ray", "prefit_steps", "exchange_ms"):
+        for k in ("samples_per_ray", "prefit_steps", "exchange_ms", "graph"):
             if k in r["config"]:
                 out[k] = r["config"][k]
         if "roofline" in r:
@@ -545,13 +552,14 @@ def main():
     result = None
     if args.task in ("both", "recon"):
         result = run_recon(args, world, rank, dev)
-        plain = args.path == "run" and args.grid == "synthetic" and args.prefit == 0 and not args.no_variants       # rank-independent conditions only
+        plain = args.path == "run" and args.grid == "synthetic" and args.prefit == 0 and not args.no_variants and not args.graph   # rank-independent conditions only
         if plain and world == 1 and not args.dp_selftest:
             # the claims that used to live in builder-run profiles/, under the driver's clock: the reference field's own table
             # (network_grid.py:89-96), the occupancy-march path (renderer.py:597-718) and the gather on a FITTED field
             v = {"bear_table": brief(variant(run_recon, grid="bear")),
                  "march_path": brief(variant(run_recon, path="march", no_roofline=True)),
-                 "trained_field": brief(variant(run_recon, prefit=300))}
+                 "trained_field": brief(variant(run_recon, prefit=300)),
+                 "graphed_step": brief(variant(run_recon, graph=True, no_roofline=True))}
             if rank == 0:
                 result["variants"] = v
         if plain and world > 1 and args.scaling == "weak":

@@ -316,6 +316,40 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         self.global_step += 1
         return loss.detach(), outputs
 
+    def train_step_graphed(self, rays_o, rays_d, rgbs, mask, **render_kw):
+        """train_step with render + loss + backward replayed as ONE hipGraph per view (opt-in).  A view is recognised by the addresses of its four
+        resident tensors (a dataset keeps its rays on the GPU and hands the same tensors out every epoch); the first visit runs two eager steps
+        (allocations, workspaces) and captures the third, later visits replay it.  The optimiser step stays eager: its learning rate is a host-side
+        scalar that changes every step.  The GPU time is the eager step's (the step is GPU-bound: DESIGN.md section 6); what the graph buys is the
+        host — 0.18 instead of 0.79 ms of enqueue per step (scratch/graph_probe.py) — i.e. immunity against a slow or shared host.
+        One GPU, fused Adam with the on-device loss scaler, no --batch_rays subsampling.  -> (loss, None): the loss is a static tensor that the
+        next replay of the same view overwrites; the per-ray outputs stay inside the graph's memory pool."""
+        if not (self.fused_adam and self.scaler is not None and self.world_size == 1) or int(getattr(self.opt, 'batch_rays', -1) or -1) > 0:
+            raise ValueError("train_step_graphed: one GPU, fused Adam with the dynamic loss scaler, no batch_rays")
+        tensors = (rays_o, rays_d, rgbs, mask)
+        key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors) + (tuple(sorted(render_kw.items())),)
+        cache = self.__dict__.setdefault('_graphs', {})
+        ent = cache.get(key)
+        if ent is None:
+            for _ in range(2):
+                self.train_step(rays_o, rays_d, rgbs, mask, **render_kw)
+            torch.cuda.synchronize()
+            self.model.train()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')):
+                with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+                    outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
+                    loss = self.loss(outputs, rgbs, mask)
+                self.scaler.backward(loss)
+                loss = loss.detach()
+            self._graph_pool = graph.pool()
+            ent = cache[key] = (graph, loss, tensors)                # (the tensors keep the captured addresses alive)
+        self.model.train()
+        ent[0].replay()
+        apply_optimizer_step(self)
+        self.global_step += 1
+        return ent[1], None
+
 
 def train_one_epoch(trainer, views, shard=None, log=None):
     """Loop body of Trainer_Nerf.train_one_epoch (nerf/utils_init_nerf.py:577-671) over an indexable of view tuples

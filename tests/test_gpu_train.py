@@ -510,3 +510,43 @@ def test_recon_step_matches_reference_golden(tag):
     np.testing.assert_allclose(float(loss.detach()), float(g[f"pre_{tag}__loss"]), rtol=2e-4)
     want = g[f"pre_{tag}__grad_theta"]
     assert np.abs(model.theta.grad.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max(), (model.theta.grad.cpu().numpy(), want)
+
+
+def test_train_step_graphed_follows_the_eager_trainer():
+    """ReconTrainer.train_step_graphed (render + loss + backward as one hipGraph per view, eager optimiser step): the same training as train_step —
+    different random jitter, so the comparison is the loss trajectory — and bit-reproducible from run to run"""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    H = W = 64                                      # >= 2^20 (sample, level) pairs per backward: the bit-reproducible binned scatter, not the float-atomic kernel
+    V = 2
+    c2w = torch.from_numpy(sc.poses(V)).cuda()
+    ro, rd = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+    ro, rd = ro.view(V, 1, H * W, 3), rd.view(V, 1, H * W, 3)
+    rgb, mask = sc.targets(V, H, W)
+    rgb, mask = rgb.cuda(), mask.cuda()
+    views = [(ro[v].contiguous(), rd[v].contiguous(), rgb[v].contiguous(), mask[v].contiguous()) for v in range(V)]
+
+    def run(graphed, steps=12):
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True, num_steps=16, upsample_steps=16, iters=100)
+        model = NeRFNetwork(opt).cuda()
+        tr = ReconTrainer(model, opt, fp16=True)
+        kw = dict(num_steps=16, upsample_steps=16, dt_gamma=0, max_steps=opt.max_steps)
+        losses = []
+        for i in range(steps):
+            step = tr.train_step_graphed if graphed else tr.train_step
+            loss, _ = step(*views[i % V], **kw)
+            losses.append(float(loss))
+        return losses, [p.detach().clone() for p in model.parameters()], tr
+    le, _, _ = run(False, steps=16)                     # (the graphed trainer spends two eager steps + the captured one per view on its first visit)
+    lg, pg, trg = run(True)
+    lg2, pg2, _ = run(True)
+    assert trg.global_step == 12 + 2 * V and len(trg._graphs) == V
+    assert all(np.isfinite(lg)) and lg[-1] < lg[0] and abs(lg[-1] - le[-1]) < 0.15 * le[-1], (le, lg)
+    assert lg == lg2 and all(torch.equal(a, b) for a, b in zip(pg, pg2))
+    with pytest.raises(ValueError):
+        opt2 = sc.make_opt(fp16=False, num_levels=8)
+        ReconTrainer(NeRFNetwork(opt2).cuda(), opt2, fp16=False).train_step_graphed(*views[0], num_steps=16, upsample_steps=16, dt_gamma=0, max_steps=1024)
