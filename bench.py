@@ -396,9 +396,30 @@ def child_envs(n, port):
              "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")} for r in range(n)]
 
 
+def visible_gpu_count(env=None, kfd_root="/sys/class/kfd/kfd/topology/nodes"):
+    """Number of GPUs a child process would see, WITHOUT touching the HIP / HSA runtime: KFD topology nodes with simd_count > 0 (CPU nodes carry 0),
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None = cannot tell (no sysfs): the caller skips the check
+    and lets the children fail."""
+    env = os.environ if env is None else env
+    try:
+        n = 0
+        for node in sorted(os.listdir(kfd_root)):
+            with open(os.path.join(kfd_root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv, child_cmd=None, check_devices=True):
     """`python bench.py --gpus N` without torchrun: spawn N fresh worker processes (one per device) BEFORE this process makes any GPU call —
-    the parent never initialises HIP, the children are new processes (no exec from a process that touched the GPU) — forward rank 0's record,
+    the parent never initialises HIP (devices are counted from the KFD sysfs topology, not through torch / HIP), the children are new processes (no exec from a process that touched the GPU) — forward rank 0's record,
     exit non-zero if any child fails or if the record does not show N RCCL ranks.  --dry-launch prints the N child environments instead."""
     import subprocess
     n = args.gpus
@@ -407,8 +428,8 @@ def launch_ranks(args, argv, child_cmd=None, check_devices=True):
     if args.dry_launch:
         print(json.dumps({"dry_launch": True, "n_ranks": n, "argv": child_argv, "env": envs}))
         return 0
-    have = torch.cuda.device_count() if check_devices else n      # counting devices does not initialise the GPU runtime
-    if have < n:
+    have = visible_gpu_count() if check_devices else n            # sysfs only: the torch query may fall back to hipGetDeviceCount (HSA init)
+    if have is not None and have < n:
         sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible\n")
         return 3
     procs = []

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcustomnerf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
 
@@ -179,6 +179,20 @@ def scratch_key(device):
     trainer.ReconTrainer runs two half-batches on two streams): (device, stream handle)."""
     import torch
     return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
+_SCRATCH_GENERATION = [0]
+
+
+def scratch_reallocated():
+    """Call whenever a cached grow-on-demand scratch buffer (scatter workspaces, field / MLP partial-gradient rows, the march's probe list)
+    is replaced: captured hipGraphs hold the OLD buffer's address, so their owners (trainer.ReconTrainer.train_step_graphed) compare
+    scratch_generation() with the value at capture and drop every cached graph when it moved."""
+    _SCRATCH_GENERATION[0] += 1
+
+
+def scratch_generation():
+    return _SCRATCH_GENERATION[0]
 
 
 _GRAD_CHAIN = {}

@@ -386,12 +386,6 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
               uint32_t max_partials, hipStream_t st);
 
-// field_bwd_w8.hip (round 4): the same pipeline on four waves per tile stream, 16-sample tiles, two waves per SIMD
-bool w8_eligible(const FieldDims &dm);
-int w8_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
-              const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
-              uint32_t max_partials, hipStream_t st);
-
 void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
                         hipStream_t st) {
     hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(total, 64)), dim3(256), 0, st, partials, n_partials, total, n_net, n_den, g_net, g_den, g_rgb);
@@ -400,9 +394,6 @@ void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t tot
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
               float *g_rgb, void *workspace, hipStream_t st) {
-    if (w8_eligible(dm)) {
-        return w8_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
-    }
     if (x2_eligible(dm)) {
         return x2_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, st);
     }

@@ -769,91 +769,6 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
     *dst = g;
 }
 
-// ------------------------------------------------------------------------------------------------ direct accumulation of the small dense levels
-// Round 4.  The coarsest levels are a few thousand entries each: their whole table (or half / a third of it) fits in LDS as the same 64-bit
-// fixed-point image the accumulate kernel builds per bin — so for them the radix partition is pure overhead: 32 B of records written and
-// read per (sample, level), the crowded bins split into a dozen accumulate workgroups whose partial images are summed again, and the
-// wave-aggregated tickets in histogram and emit (a dense level cost 15.7 + 29.6 + 32 us against 6.8 + 25 + 14.6 us of a hashed one).
-// Here a workgroup owns a "pass" (a contiguous entry range of one level, <= DD_ENTRIES entries) and a contiguous range of the sample list,
-// re-derives the corners of its samples (the very arithmetic of the emit / accumulate pair: same weights, same 16-bit x fraction, same
-// chunk-border rule for unpaired corners — bit-identical sums), adds into its LDS image and parks the image; k_dd_reduce sums the images
-// of a pass exactly and rounds once into the gradient table, as k_bin2_reduce_split does for split bins.
-#define DD_ENTRIES 6912u                           // table entries per pass (x 2 channels x 8 B = 108 KiB of LDS)
-#define DD_MAX_PASSES 3u                           // per level: levels of up to 20 736 entries qualify
-#define DD_MAX_JOBS 8u
-#define DD_THREADS 1024
-#define DD_WGS 256u                                // one resident workgroup per CU
-struct DdJob { uint32_t level, e0, e1, wg0, nwg; };
-struct DdPlan { uint32_t n_jobs, n_wg; DdJob job[DD_MAX_JOBS]; };
-
-__device__ __forceinline__ void dd_add(long long *acc, uint32_t e, uint32_t e0, uint32_t e1, float a, float b) {
-    if (e >= e0 && e < e1) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e - e0]), b2_fix(a));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[DD_ENTRIES + e - e0]), b2_fix(b));
-    }
-}
-
-__global__ void __launch_bounds__(DD_THREADS) k_dd_accum(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv, const DdPlan plan,
-                                                         uint32_t B, uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid,
-                                                         long long *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dd_lds[];
-    long long *acc = reinterpret_cast<long long *>(dd_lds);                        // [2][DD_ENTRIES]: channels in separate halves (lds_atomic_peak)
-    uint32_t j = 0;
-    while (j + 1 < plan.n_jobs && blockIdx.x >= plan.job[j + 1].wg0) j++;
-    const DdJob jb = plan.job[j];
-    for (uint32_t i = threadIdx.x; i < DD_ENTRIES * 2 * 8 / 16; i += DD_THREADS) reinterpret_cast<uint4 *>(dd_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t w = blockIdx.x - jb.wg0;
-    const uint32_t ppw = (B + jb.nwg - 1) / jb.nwg;
-    const uint32_t p0 = w * ppw, p1 = min(p0 + ppw, B);
-    const uint32_t level = jb.level;
-    // (measured and dropped: a contiguous run of samples per thread, so that same-cell neighbours become successive instructions of one lane
-    // instead of same-address lanes of one atomic — the uncoalesced coordinate loads cost more than the conflicts: 218 against 164 us)
-    for (uint32_t b = p0 + threadIdx.x; b < p1; b += DD_THREADS) {
-        float in[3];
-        if (!bn_load_point(inputs, b, B, in)) continue;
-        uint32_t i0[4], i1[4];
-        float wyz[4], fx;
-        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
-        const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
-        const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
-        if (jb.e0 == 0) b2_poison(g0, g1, grad_grid, lv, level, i0[0]);            // (once per level: the first pass)
-        const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (b2_paired(i0[q], i1[q])) {                                          // what a pair record carries and b2_add_record rebuilds
-                const float2 f = __half22float2(__floats2half2_rn(wyz[q] * g0, wyz[q] * g1));
-                const float w1 = (float)fxq * (1.0f / 65536.0f), w0 = 1.0f - w1;
-                const float w1s = w1 * 16777216.0f, w0s = w0 * 16777216.0f;
-                dd_add(acc, i0[q], jb.e0, jb.e1, w0s * f.x, w0s * f.y);
-                dd_add(acc, i1[q], jb.e0, jb.e1, w1s * f.x, w1s * f.y);
-            } else {                                                                // the two single records of a pair that straddles a chunk border
-                const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
-                const float2 f0 = __half22float2(__floats2half2_rn(w0 * g0, w0 * g1)), f1 = __half22float2(__floats2half2_rn(w1 * g0, w1 * g1));
-                dd_add(acc, i0[q], jb.e0, jb.e1, f0.x * 16777216.0f, f0.y * 16777216.0f);
-                dd_add(acc, i1[q], jb.e0, jb.e1, f1.x * 16777216.0f, f1.y * 16777216.0f);
-            }
-        }
-    }
-    __syncthreads();
-    long long *__restrict__ img = partial + (size_t)blockIdx.x * (DD_ENTRIES * 2);
-    const uint32_t ne = jb.e1 - jb.e0;
-    for (uint32_t i = threadIdx.x; i < ne * 2; i += DD_THREADS) img[i] = acc[(i & 1) * DD_ENTRIES + (i >> 1)];      // interleaved (entry, channel) order
-}
-
-// exact sum of a pass's images, one rounding into the gradient table (grid: passes x entry tiles)
-__global__ void __launch_bounds__(256) k_dd_reduce(const long long *__restrict__ partial, const GridLevels lv, const DdPlan plan, float *__restrict__ grad_grid) {
-    const DdJob jb = plan.job[blockIdx.y];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;                             // (entry, channel) index inside the pass
-    if (i >= (jb.e1 - jb.e0) * 2) return;
-    long long sum = 0;
-    const long long *__restrict__ src = partial + (size_t)jb.wg0 * (DD_ENTRIES * 2) + i;
-#pragma unroll 8
-    for (uint32_t w = 0; w < jb.nwg; w++) sum += src[(size_t)w * (DD_ENTRIES * 2)];
-    float *dst = grad_grid + ((size_t)lv.offset[jb.level] + jb.e0) * 2 + i;
-    *dst += bn_acc_to_float<__half>(sum);
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 static inline uint64_t bn_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
 
@@ -918,56 +833,6 @@ static uint32_t b2_max_chunks(const Bin2Plan &plan, uint32_t nl) {
 }
 
 
-// Which levels take the direct path (k_dd_accum) and which the radix partition.  A level qualifies when it is dense whatever align_corners says
-// ((resolution + 1)^3 entries fit) and needs at most DD_MAX_PASSES passes; what remains keeps its relative order in a reduced level list.
-// Derived from (lv, nl) alone, so that every entry point (workspace size, histogram pieces, scans, backward) arrives at the same split.
-struct B2Split { GridLevels lvb; uint32_t nlb; DdPlan dd; };
-static void b2_split(const GridLevels &lv, uint32_t nl, B2Split &sp) {
-    // OFF in the release library (tuning builds: CNERF_B2_DD=1).  Measured on the benchmark step (levels 0 and 1 direct, three passes, 256 workgroups,
-    // cost-weighted shares): k_dd_accum 142 us + k_dd_reduce 12.5 us against 147 us saved in emit (444 -> 374), accumulate (375 -> 318) and the
-    // split reduction (36 -> 16) — 2.164 / 2.181 ms per step with it, 2.171 / 2.176 ms without.  The direct kernel pays what the crowded bins pay:
-    // neighbouring samples of a ray hit the same few thousand entries, and same-address lanes of an LDS atomic serialise (profiles/r04_scatter_dd.txt).
-    static const int on = b2_env("CNERF_B2_DD", 0);
-    sp.lvb = lv;
-    sp.dd.n_jobs = 0; sp.dd.n_wg = 0;
-    uint8_t rest[GE_MAX_LEVELS];
-    uint32_t n_rest = 0, n_pass = 0;
-    bool is_dd[GE_MAX_LEVELS];
-    for (uint32_t l = 0; l < nl; l++) {
-        const uint64_t r1 = (uint64_t)lv.resolution[l] + 1;
-        const uint32_t passes = cn_div_up(lv.size[l], DD_ENTRIES);
-        is_dd[l] = on && r1 * r1 * r1 <= lv.size[l] && passes <= DD_MAX_PASSES && n_pass + passes <= DD_MAX_JOBS;
-        if (is_dd[l]) n_pass += passes; else rest[n_rest++] = (uint8_t)l;
-    }
-    if (n_pass) {
-        // workgroups per pass in proportion to its cost: every pass walks the whole sample list (corner arithmetic), a pass of a P-pass level
-        // applies ~1/P of the level's LDS atomics (the larger share of the time: neighbouring samples collide on the same entries)
-        static const double w_atom = b2_env("CNERF_DD_WATOM", 30) / 10.0;
-        double wsum = 0, wacc = 0;
-        for (uint32_t l = 0; l < nl; l++)
-            if (is_dd[l]) { const uint32_t P = cn_div_up(lv.size[l], DD_ENTRIES); wsum += P * (1.0 + w_atom / P); }
-        uint32_t wg = 0, k = 0;
-        for (uint32_t l = 0; l < nl; l++) {
-            if (!is_dd[l]) continue;
-            const uint32_t passes = cn_div_up(lv.size[l], DD_ENTRIES);
-            for (uint32_t q = 0; q < passes; q++, k++) {
-                DdJob &jb = sp.dd.job[k];
-                jb.level = l; jb.e0 = q * DD_ENTRIES; jb.e1 = lv.size[l] < (q + 1) * DD_ENTRIES ? lv.size[l] : (q + 1) * DD_ENTRIES;
-                jb.wg0 = wg;
-                wacc += 1.0 + w_atom / passes;
-                const uint32_t end = k + 1 == n_pass ? DD_WGS : (uint32_t)(DD_WGS * wacc / wsum + 0.5);
-                jb.nwg = end > wg ? end - wg : 1;
-                wg += jb.nwg;
-            }
-        }
-        sp.dd.n_jobs = n_pass; sp.dd.n_wg = wg;
-    }
-    sp.nlb = n_rest;
-    uint32_t lo = 0, hi = n_rest;                                               // coarse / fine interleave of the remaining levels (as ge_levels orders them)
-    for (uint32_t i = 0; i < n_rest; i++) sp.lvb.order[i] = (i & 1) ? rest[--hi] : rest[lo++];
-}
-static uint64_t dd_bytes(const DdPlan &dd) { return dd.n_wg ? bn_align((uint64_t)dd.n_wg * DD_ENTRIES * 2 * 8) : 0; }
-
 static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &plan) {
     plan.nb = cn_div_up(B, b2_pts());
     uint32_t acc = 0;
@@ -1003,12 +868,8 @@ static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws 
 }
 
 // histogram of the point blocks that cover rows [row0, row0 + rows) (row0 a multiple of the block size; the range ends on a block border or at B)
-static int b2_hist_rows(const float *inputs, const GridLevels &lv_in, uint32_t B, uint32_t nl_in, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
+static int b2_hist_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
                         hipStream_t st, uint32_t row0, uint32_t rows) {
-    B2Split sp;
-    b2_split(lv_in, nl_in, sp);
-    const GridLevels &lv = sp.lvb;
-    const uint32_t nl = sp.nlb;
     if (nl == 0) return CNERF_OK;
     Bin2Plan plan;
     b2_plan(lv, nl, B, plan);
@@ -1025,11 +886,7 @@ static int b2_hist_rows(const float *inputs, const GridLevels &lv_in, uint32_t B
     return cn_launch_status();
 }
 
-static int b2_scans(const GridLevels &lv_in, uint32_t B, uint32_t nl_in, void *workspace, hipStream_t st) {
-    B2Split sp;
-    b2_split(lv_in, nl_in, sp);
-    const GridLevels &lv = sp.lvb;
-    const uint32_t nl = sp.nlb;
+static int b2_scans(const GridLevels &lv, uint32_t B, uint32_t nl, void *workspace, hipStream_t st) {
     if (nl == 0) return CNERF_OK;
     Bin2Plan plan;
     b2_plan(lv, nl, B, plan);
@@ -1046,28 +903,13 @@ static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint
     return rc ? rc : b2_scans(lv, B, nl, workspace, st);
 }
 
-static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &lv_in, float *gemb, uint32_t B, uint32_t nl_in, uint32_t gridtype, int ac,
+static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                      uint32_t interp, void *workspace, hipStream_t st) {
-    B2Split sp;
-    b2_split(lv_in, nl_in, sp);
-    const GridLevels &lv = sp.lvb;
-    const uint32_t nl = sp.nlb;
+    if (nl == 0) return CNERF_OK;
     Bin2Plan plan;
     b2_plan(lv, nl, B, plan);
     Bin2Ws ws;
-    const uint64_t dd_off = b2_layout(plan, B, nl, &ws, workspace);
-    if (sp.dd.n_jobs) {
-        // the small dense levels: straight into LDS images, no records (the images live behind the partition's workspace)
-        long long *dd_part = reinterpret_cast<long long *>(reinterpret_cast<char *>(workspace) + dd_off);
-        static bool dd_attr = false;
-        if (!dd_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dd_accum), hipFuncAttributeMaxDynamicSharedMemorySize, DD_ENTRIES * 2 * 8);
-            dd_attr = true;
-        }
-        hipLaunchKernelGGL(k_dd_accum, dim3(sp.dd.n_wg), dim3(DD_THREADS), DD_ENTRIES * 2 * 8, st, grad, inputs, lv_in, sp.dd, B, gridtype, ac, interp, gemb, dd_part);
-        hipLaunchKernelGGL(k_dd_reduce, dim3(cn_div_up(DD_ENTRIES * 2, 256), sp.dd.n_jobs), dim3(256), 0, st, (const long long *)dd_part, lv_in, sp.dd, gemb);
-        if (nl == 0) return cn_launch_status();
-    }
+    b2_layout(plan, B, nl, &ws, workspace);
     const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(long long) + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1105,11 +947,9 @@ bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLeve
 
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
     if (b2_enabled(dtype)) {
-        B2Split sp;
-        b2_split(lv, nl, sp);
         Bin2Plan p2;
-        b2_plan(sp.lvb, sp.nlb, B, p2);
-        return b2_layout(p2, B, sp.nlb, nullptr, nullptr) + dd_bytes(sp.dd);
+        b2_plan(lv, nl, B, p2);
+        return b2_layout(p2, B, nl, nullptr, nullptr);
     }
     BinPlan plan;
     bn_plan(lv, nl, B, plan);

@@ -3,7 +3,7 @@ cnerf_field_forward / cnerf_field_backward.  Mirrors NeRFNetwork.forward/.densit
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, check, ptr, stream, F16, F32, require_cuda, scratch_key, grad_chain_wait, grad_chain_record
+from ._lib import lib, check, ptr, stream, F16, F32, require_cuda, scratch_key, grad_chain_wait, grad_chain_record, scratch_reallocated
 
 
 def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, with_rgb=True):
@@ -49,6 +49,7 @@ def _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, device):
     if buf is None or buf.numel() < need.value:
         buf = torch.empty(int(need.value * 1.1) + 256, dtype=torch.uint8, device=device)
         _WS[key] = buf
+        scratch_reallocated()
     return buf
 
 

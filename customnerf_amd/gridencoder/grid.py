@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .._lib import lib, check, ptr, stream, dtype_id, require_cuda, scratch_key, grad_chain_wait, grad_chain_record
+from .._lib import lib, check, ptr, stream, dtype_id, require_cuda, scratch_key, grad_chain_wait, grad_chain_record, scratch_reallocated
 
 # Optional in-stream timing of the gather kernel (bench.py's roofline leg): when a list is installed with
 # set_profile(), every forward launch is bracketed by a pair of events recorded on the launch stream.
@@ -69,6 +69,7 @@ def _bwd_workspace(offsets_host, B, D, C, L, max_level, S, H, dt, device):
     if buf is None or buf.numel() < need.value:
         buf = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
         _WS_CACHE[key] = buf
+        scratch_reallocated()
     return buf, buf.numel()
 
 
@@ -173,6 +174,7 @@ def _prepare_plan(inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corner
         return None
     if side['ws'] is None or side['ws'].numel() < need.value:
         side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
+        scratch_reallocated()
     ws = side['ws']
     cur = torch.cuda.current_stream()
     side['stream'].wait_stream(cur)                              # the coordinates were produced on the current stream
@@ -207,6 +209,8 @@ def _plan_rows(state, inputs, offsets_host, B, D, C, L, S, H, gridtype, align_co
             return None
         if side['ws'] is None or side['ws'].numel() < need.value:
             side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
+            scratch_reallocated()
+        scratch_reallocated()
         state = {'ws': side['ws'], 'token': _Plan(side['ws'], None)}
         state['token'].inputs_ptr, state['token'].rows = inputs.data_ptr(), B
         side['owner'] = weakref.ref(state['token'])                  # the side stream's workspace is taken from the first piece on

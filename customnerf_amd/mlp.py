@@ -9,7 +9,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, check, ptr, stream, F16, F32, require_cuda
+from ._lib import lib, check, ptr, stream, F16, F32, require_cuda, scratch_reallocated
 
 _ACT = {"None": 0, "Sigmoid": 1}
 _WS = {}
@@ -23,6 +23,7 @@ def _workspace(P, cfg, dt, device):
     if buf is None or buf.numel() < need.value:
         buf = torch.empty(int(need.value * 1.1) + 256, dtype=torch.uint8, device=device)
         _WS[device] = buf
+        scratch_reallocated()
     return buf
 
 

@@ -133,6 +133,10 @@ class NeRFRenderer(nn.Module):
     def _dirs_twice(self, rays_d):
         """[d | d] for the split sample list, cached per view: a dataset's ray directions are resident tensors that come back every epoch
         (provider.py keeps them on the GPU), so the concatenation launch is paid once per view, not once per step"""
+        if torch.cuda.is_current_stream_capturing():
+            # hipGraph capture (trainer.train_step_graphed): the concatenation becomes a node of the graph and its result lives in the graph's
+            # own memory pool — a cached tensor's address would be baked into the graph and outlive its eviction from the 64-entry cache
+            return torch.cat([rays_d, rays_d], 0)
         cache = self.__dict__.setdefault('_dirs2_cache', {})
         key = (rays_d.data_ptr(), rays_d._version, tuple(rays_d.shape))
         ent = cache.get(key)

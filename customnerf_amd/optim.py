@@ -24,6 +24,7 @@ class DynamicLossScaler:
     def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._update_consumed = False       # FusedAdam.step() already applied this step's update() in its last launch
 
     def scale(self, loss):
         return loss * self.state[0]
@@ -39,6 +40,11 @@ class DynamicLossScaler:
         check(lib.cnerf_scaler_check(ptr(flat_grads), flat_grads.numel(), ptr(self.state), stream()), "scaler_check")
 
     def update(self):
+        """GradScaler.update().  A no-op for the step whose FusedAdam.step() already applied it in the tail of its multi-tensor launch, so the
+        standard idiom `opt.step(); scaler.update()` (the reference's Trainer, the drop-in flows) counts every step exactly once."""
+        if self._update_consumed:
+            self._update_consumed = False
+            return
         check(lib.cnerf_scaler_update(ptr(self.state), float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval), stream()), "scaler_update")
 
     def get_scale(self):
@@ -76,6 +82,8 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self.updates_scaler = False
+        if self.scaler is not None:
+            self.scaler._update_consumed = False      # (a caller that skipped update() after the previous step, as the trainers used to)
         small = []                      # (p, state, group) of the small tensors: one multi-tensor launch at the end (with a scaler)
         betas0, eps0 = self.param_groups[0]['betas'], self.param_groups[0]['eps']
         for group in self.param_groups:
@@ -120,6 +128,7 @@ class FusedAdam(torch.optim.Optimizer):
                                                    float(self.grad_scale_inv), int(self.zero_grad_in_step), 1, float(sc.growth_factor),
                                                    float(sc.backoff_factor), int(sc.growth_interval), stream()), "adam_step_scaled_multi")
             self.updates_scaler = True
+            sc._update_consumed = True                # ... so the caller's scaler.update() for this step does nothing
 
     def zero_grad(self, set_to_none=False):
         if self.zero_grad_in_step and not set_to_none:

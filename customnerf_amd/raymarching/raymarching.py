@@ -15,7 +15,7 @@ Differences that are deliberate:
 import torch
 from torch.autograd import Function
 
-from .._lib import lib, check, ptr, stream, scratch_key
+from .._lib import lib, check, ptr, stream, scratch_key, scratch_reallocated
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "composite_rays_train_sdf", "march_rays", "composite_rays", "compact_rays_alive"]
@@ -97,13 +97,15 @@ def _hits_scratch(N, max_steps, device):
     need = N * max_steps * 2
     key = scratch_key(device)
     if need * 4 > _HITS_MAX_BYTES:
-        _HITS.pop(key, None)
+        if _HITS.pop(key, None) is not None:
+            scratch_reallocated()
         return None
     buf = _HITS.get(key)
     if buf is None or buf.numel() < need or buf.numel() > 4 * need:
         _HITS.pop(key, None)
         buf = None                                                  # drop the old block before asking for the new one
         buf = _HITS[key] = torch.empty(need, dtype=torch.float32, device=device)
+        scratch_reallocated()
     return buf
 
 

@@ -124,8 +124,10 @@ GN_FRAC_BITS = 20        # include/customnerf_sd.h CNERF_SD_GN_FRAC_BITS: GroupN
 
 
 def gn_sums_to_float(sums):
-    """the fixed-point statistics [B, G, 2] as float64 (sum, sum of squares)"""
-    return sums.double() * (1.0 / (1 << GN_FRAC_BITS))
+    """the fixed-point statistics [B, G, 2] as float64 (sum, sum of squares); NaN where the sum is poisoned / out of range (csrc/sd_gn_fix.h:
+    bits 63..60 not all equal)"""
+    top = sums >> 60
+    return torch.where((top == 0) | (top == -1), sums.double() * (1.0 / (1 << GN_FRAC_BITS)), torch.full((), float('nan'), dtype=torch.float64, device=sums.device))
 
 
 class SumsPool:

@@ -133,15 +133,14 @@ def apply_optimizer_step(trainer):
             e1.record()
             ev.append((e0, e1))
         trainer.optimizer.step()                                     # the small (replicated) parameters; the big ones are in skip_params
-        if trainer.scaler is not None and not getattr(trainer.optimizer, 'updates_scaler', False):
-            trainer.scaler.update()                                  # (FusedAdam's multi-tensor launch of the small tensors already did it)
+        if trainer.scaler is not None:
+            trainer.scaler.update()                                  # (a no-op when FusedAdam's multi-tensor launch of the small tensors already did it)
     else:
         trainer.allreduce_grads()
         if trainer.scaler is not None:
             check_grads_finite(trainer.scaler, list(trainer.model.parameters()), trainer._flat)      # on the all-reduced gradients: every rank takes the same skip decision
             trainer.optimizer.step()
-            if not getattr(trainer.optimizer, 'updates_scaler', False):
-                trainer.scaler.update()                              # (FusedAdam's multi-tensor launch of the small tensors already did it)
+            trainer.scaler.update()                                  # (a no-op when FusedAdam's multi-tensor launch of the small tensors already did it)
         else:
             trainer.optimizer.step()
     refresh_half_shadow(trainer.optimizer, trainer.model)
@@ -317,7 +316,11 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         return loss.detach(), outputs
 
     def train_step_graphed(self, rays_o, rays_d, rgbs, mask, **render_kw):
-        """train_step with render + loss + backward replayed as ONE hipGraph per view (opt-in).  A view is recognised by the addresses of its four
+        """Buffer ownership: everything a captured graph reads is either one of the view's four resident tensors (pinned by the cache entry), a
+        parameter / its .grad / optimiser state (never reallocated), an allocation made during capture (graph pool), or a cached scratch buffer
+        — and the cache is flushed whenever one of those is reallocated (_lib.scratch_generation).
+
+        train_step with render + loss + backward replayed as ONE hipGraph per view (opt-in).  A view is recognised by the addresses of its four
         resident tensors (a dataset keeps its rays on the GPU and hands the same tensors out every epoch); the first visit runs two eager steps
         (allocations, workspaces) and captures the third, later visits replay it.  The optimiser step stays eager: its learning rate is a host-side
         scalar that changes every step.  The GPU time is the eager step's (the step is GPU-bound: DESIGN.md section 6); what the graph buys is the
@@ -326,9 +329,15 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         next replay of the same view overwrites; the per-ray outputs stay inside the graph's memory pool."""
         if not (self.fused_adam and self.scaler is not None and self.world_size == 1) or int(getattr(self.opt, 'batch_rays', -1) or -1) > 0:
             raise ValueError("train_step_graphed: one GPU, fused Adam with the dynamic loss scaler, no batch_rays")
+        from ._lib import scratch_generation
         tensors = (rays_o, rays_d, rgbs, mask)
         key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors) + (tuple(sorted(render_kw.items())),)
         cache = self.__dict__.setdefault('_graphs', {})
+        if cache and self.__dict__.get('_graphs_generation') != scratch_generation():
+            # a grow-on-demand workspace (scatter plan, partial-gradient rows) was reallocated since these graphs were captured — e.g. by an
+            # eval_step on a larger view: they hold the freed buffer's address.  Drop them all (and their pool); every view recaptures.
+            cache.clear()
+            self.__dict__.pop('_graph_pool', None)
         ent = cache.get(key)
         if ent is None:
             for _ in range(2):
@@ -344,6 +353,7 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
                 loss = loss.detach()
             self._graph_pool = graph.pool()
             ent = cache[key] = (graph, loss, tensors)                # (the tensors keep the captured addresses alive)
+            self._graphs_generation = scratch_generation()           # (the two eager steps above did every allocation: capture moves nothing)
         self.model.train()
         ent[0].replay()
         apply_optimizer_step(self)

@@ -30,8 +30,9 @@ extern "C" {
 #define CNERF_F32 0
 #define CNERF_F16 1
 
-/* ABI version of this header; cnerf_abi_version() of the loaded library must match. */
-#define CNERF_ABI_VERSION 1
+/* ABI version of this header; cnerf_abi_version() of the loaded library must match.
+ * 2: the GroupNorm / GEMM-epilogue statistics buffers of customnerf_sd.h are int64[B][G][2] fixed point (were float[B][G][2]). */
+#define CNERF_ABI_VERSION 2
 int cnerf_abi_version(void);
 /* name of the code object's target ("gfx950") */
 const char *cnerf_target_arch(void);

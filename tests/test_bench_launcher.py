@@ -26,9 +26,29 @@ def test_gpus_gt_1_without_devices_fails_loudly():
     """no GPU in the build container: asking for 2 ranks must exit non-zero, not fall back to one GPU and report n_gpus 1"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                          env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
-    import torch
-    if torch.cuda.device_count() < 2:
-        assert out.returncode != 0 and "device" in out.stderr
+    import bench
+    have = bench.visible_gpu_count()
+    if have is None or have < 2:
+        assert out.returncode != 0 and ("device" in out.stderr or "GPU" in out.stderr)
+
+
+def test_visible_gpu_count_reads_sysfs_only(tmp_path):
+    """the launcher's parent counts devices from the KFD topology (simd_count > 0), narrowed by the *_VISIBLE_DEVICES variables — never through
+    torch / HIP: a missing sysfs tree answers None and the check is skipped"""
+    import bench
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):                    # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    root = str(tmp_path)
+    assert bench.visible_gpu_count(env={}, kfd_root=root) == 3
+    assert bench.visible_gpu_count(env={"HIP_VISIBLE_DEVICES": "0,2"}, kfd_root=root) == 2
+    assert bench.visible_gpu_count(env={"ROCR_VISIBLE_DEVICES": "1"}, kfd_root=root) == 1
+    assert bench.visible_gpu_count(env={"HIP_VISIBLE_DEVICES": ""}, kfd_root=root) == 0
+    assert bench.visible_gpu_count(env={}, kfd_root=str(tmp_path / "absent")) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def main") if "def main" in src else len(src)]
+    assert "device_count(" not in body
 
 
 def _launch(tmp_path, body, n=2):

@@ -148,6 +148,40 @@ def test_groupnorm_forward_backward(B, HW, C, G, eps, silu):
     assert torch.equal(ops.groupnorm_backward(xg, dyg, gamma.cuda(), beta.cuda(), G, eps, silu, sums, scratch=torch.zeros_like(scratch)), dx)
 
 
+
+def test_groupnorm_statistics_surface_overflow_and_non_finite_inputs():
+    """integer sums cannot carry Inf / NaN and wrap silently — a non-finite element, a thread partial >= 2^30 or a total >= 2^40 must
+    poison the (image, group) statistics (sd_gn_fix.h) so that the normalised group is NaN, as the float sums it replaced would have been; the
+    other groups are untouched."""
+    from customnerf_amd.sd import ops
+    B, HW, C, G = 2, 4096, 128, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, HW, C, generator=g).half().cuda()
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    y0, s0 = ops.groupnorm(x, gamma, beta, G, 1e-5, False)
+    assert bool(torch.isfinite(y0).all()) and bool(torch.isfinite(ops.gn_sums_to_float(s0)).all())
+    cg = C // G
+    for bad, what in ((float("inf"), "inf element"), (float("nan"), "nan element")):
+        xb = x.clone()
+        xb[1, 77, 5 * cg + 1] = bad
+        y, s = ops.groupnorm(xb, gamma, beta, G, 1e-5, False)
+        f = ops.gn_sums_to_float(s)
+        assert bool(torch.isnan(f[1, 5]).any()) and bool(torch.isfinite(f[0]).all()) and bool(torch.isfinite(f[1, :5]).all()) and bool(torch.isfinite(f[1, 6:]).all()), what
+        yg = y.view(B, HW, G, cg)
+        assert bool(torch.isnan(yg[1, :, 5]).all()) and bool(torch.isfinite(yg[0]).all()) and bool(torch.isfinite(yg[1, :, :5]).all()), what
+    # a finite tensor whose sum of squares leaves the representable range (16384 elements of 60000^2 = 5.9e13 > 2^40): NaN, not a wrapped finite value
+    xb = x.clone()
+    xb[0, :, 2 * cg:3 * cg] = 60000.0
+    y, s = ops.groupnorm(xb, gamma, beta, G, 1e-5, False)
+    f = ops.gn_sums_to_float(s)
+    assert bool(torch.isnan(f[0, 2, 1])) and bool(torch.isnan(y.view(B, HW, G, cg)[0, :, 2]).all()) and bool(torch.isfinite(y.view(B, HW, G, cg)[0, :, 3:]).all())
+    # the backward statistics: a non-finite dy poisons the group's dx
+    dy = torch.randn(B, HW, C, generator=g).half().cuda()
+    dy[1, 9, 7 * cg] = float("inf")
+    dx = ops.groupnorm_backward(x, dy, gamma, beta, G, 1e-5, False, s0)
+    dxg = dx.view(B, HW, G, cg)
+    assert bool(torch.isnan(dxg[1, :, 7]).all()) and bool(torch.isfinite(dxg[0]).all()) and bool(torch.isfinite(dxg[1, :, :7]).all())
+
 @pytest.mark.parametrize("B,T,C,heads", [(2, 77, 768, 12), (1, 200, 80, 2), (1, 130, 160, 2), (2, 65, 320, 2), (1, 100, 96, 2)])
 def test_attention_causal(B, T, C, heads):
     """causal = 1 (the CLIP text tower's mask): query i attends to keys <= i, in both kernel forms (LDS-DMA at head dims 64 / 40 / 80 / 160,

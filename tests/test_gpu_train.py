@@ -152,6 +152,7 @@ def test_dynamic_loss_scaler_matches_torch_gradscaler():
         check_grads_finite(our, p_our, flat)
         opt_our.step()
         assert opt_our.updates_scaler                                 # the small tensors' launch applied GradScaler.update() already
+        our.update()                                                  # the standard idiom `opt.step(); scaler.update()` must not count the step twice
         for p, q in zip(p_ref, p_our):
             assert torch.all(q.grad == 0)
             assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), (step, float((p - q).abs().max()))
@@ -218,8 +219,7 @@ def test_multi_tensor_adam_matches_per_tensor_launches():
                     for p in ps:
                         sc.check(p.grad)
                     opt.step()
-                    if not opt.updates_scaler:
-                        sc.update()
+                    sc.update()                                       # applies it, or does nothing when the step's last launch already has
                     assert opt.updates_scaler == (small_max > 0)
                 runs.append(([p.detach().clone() for p in ps], sc.state.clone()))
             finally:
@@ -550,3 +550,64 @@ def test_train_step_graphed_follows_the_eager_trainer():
     with pytest.raises(ValueError):
         opt2 = sc.make_opt(fp16=False, num_levels=8)
         ReconTrainer(NeRFNetwork(opt2).cuda(), opt2, fp16=False).train_step_graphed(*views[0], num_steps=16, upsample_steps=16, dt_gamma=0, max_steps=1024)
+
+@pytest.mark.gpu
+def test_graphed_step_owns_its_buffers():
+    """a captured graph must not read buffers whose lifetime it does not control.  (1) more views than the renderer's 64-entry
+    [d | d] cache holds: the concatenation is a node of the graph (its result lives in the graph pool), so replaying view 0 after 70 other views is
+    still the training the eager trainer does, run after run bit-identical; (2) a grow-on-demand workspace reallocated by an interleaved larger
+    eager step (scratch generation) drops every cached graph and the next visit recaptures."""
+    from customnerf_amd import scene as sc, tcnn, _lib
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    H = W = 16
+    V = 70
+
+    def make_views(V, H, W):
+        c2w = torch.from_numpy(sc.poses(V)).cuda()
+        ro, rd = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+        ro, rd = ro.view(V, 1, H * W, 3), rd.view(V, 1, H * W, 3)
+        rgb, mask = sc.targets(V, H, W)
+        rgb, mask = rgb.cuda(), mask.cuda()
+        return [(ro[v].contiguous(), rd[v].contiguous(), rgb[v].contiguous(), mask[v].contiguous()) for v in range(V)]
+    views = make_views(V, H, W)
+    kw = dict(num_steps=8, upsample_steps=8, dt_gamma=0, max_steps=1024)
+
+    def run(graphed):
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True, num_levels=8, num_steps=8, upsample_steps=8, iters=1000)
+        model = NeRFNetwork(opt).cuda()
+        tr = ReconTrainer(model, opt, fp16=True)
+        losses = []
+        for epoch in range(2):
+            for v in range(V):
+                loss, _ = (tr.train_step_graphed if graphed else tr.train_step)(*views[v], **kw)
+                losses.append(float(loss))
+        return losses, tr, model
+    lg, trg, model = run(True)
+    le, _, _ = run(False)
+    assert len(trg._graphs) == V and len(model._dirs2_cache) <= 64
+    assert all(np.isfinite(lg))                                          # (float-atomic scatter at this size: not bit-reproducible, so compare with the eager trainer)
+    assert abs(np.mean(lg[V:]) - np.mean(le[V:])) < 0.1 * np.mean(le[V:]), (np.mean(lg[V:]), np.mean(le[V:]))
+    # under capture the [d | d] concatenation is a graph node with its result in the graph pool, not a cache entry
+    n_cached = len(model._dirs2_cache)
+    fresh = views[0][1].view(-1, 3).clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        d2 = model._dirs_twice(fresh)
+    g.replay()
+    torch.cuda.synchronize()
+    assert len(model._dirs2_cache) == n_cached and torch.equal(d2, torch.cat([fresh, fresh], 0))
+    # (2) an eager step on a larger view grows the backward workspaces: the graphs captured before it are dropped, not replayed
+    gen = _lib.scratch_generation()
+    big = make_views(1, 48, 48)[0]
+    trg.train_step(*big, **kw)
+    assert _lib.scratch_generation() > gen
+    step0 = trg.global_step
+    loss, _ = trg.train_step_graphed(*views[0], **kw)
+    assert len(trg._graphs) == 1 and trg.global_step == step0 + 3 and np.isfinite(float(loss))
+    loss, _ = trg.train_step_graphed(*views[0], **kw)                    # and the recaptured graph replays
+    assert len(trg._graphs) == 1 and trg.global_step == step0 + 4 and np.isfinite(float(loss))
+
