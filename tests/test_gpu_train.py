@@ -602,7 +602,7 @@ def test_graphed_step_owns_its_buffers():
     assert len(model._dirs2_cache) == n_cached and torch.equal(d2, torch.cat([fresh, fresh], 0))
     # (2) an eager step on a larger view grows the backward workspaces: the graphs captured before it are dropped, not replayed
     gen = _lib.scratch_generation()
-    big = make_views(1, 48, 48)[0]
+    big = make_views(1, 128, 128)[0]                                    # >= 2^20 (sample, level) pairs: the binned scatter's workspaces (side-stream plan + records)
     trg.train_step(*big, **kw)
     assert _lib.scratch_generation() > gen
     step0 = trg.global_step
