@@ -40,6 +40,7 @@ SIGNATURES = {
     "cnerf_grid_encode_backward_prepared": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp],
     "cnerf_grid_encode_backward_workspace_bytes": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grid_encode_backward_prepare_block": [i32, vp],
+    "cnerf_grid_encode_backward_needs_plan": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grid_encode_backward_prepare_rows": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, u32, u32, vp, u64, vp, vp],
     "cnerf_grid_encode_backward_prepare_finish": [vp, u32, u32, u32, u32, f32, u32, u32, u32, i32, vp, u64, vp, vp],
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
@@ -47,6 +48,7 @@ SIGNATURES = {
     "cnerf_field_forward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, vp],
     "cnerf_field_forward_strided": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, u32, vp],
     "cnerf_field_backward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp],
+    "cnerf_field_backward_ex": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp, vp],
     "cnerf_field_backward_workspace_bytes": [u32, u32, u32, u32, i32, vp],
     "cnerf_mlp_forward": [vp, u32, vp, u32, u32, u32, u32, u32, i32, vp, u32, i32, vp],
     "cnerf_mlp_backward": [vp, u32, vp, vp, u32, u32, u32, u32, u32, u32, i32, vp, u32, vp, vp, u64, i32, vp],
@@ -69,6 +71,7 @@ SIGNATURES = {
     "cnerf_sample_coarse_unit_aabb": [vp, vp, vp, f32, vp, u32, u32, vp, vp, vp, vp, vp, f32, vp],
     "cnerf_composite_run_indexed": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp, vp, vp, vp],
     "cnerf_composite_run_backward_indexed": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, vp],
+    "cnerf_composite_run_backward_indexed_flush": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, i32, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
     "cnerf_scaler_check": [vp, u64, vp, vp],
     "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],

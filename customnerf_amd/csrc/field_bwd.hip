@@ -294,7 +294,7 @@ static int fb_launch(const void *enc, const float *xyz, const float *dirs, uint3
 uint64_t ff_workspace_bytes(const FieldDims &dm);
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
-              float *g_rgb, void *workspace, hipStream_t st);
+              float *g_rgb, void *workspace, const uint8_t *tile_live, hipStream_t st);
 static bool fb_use_fused(const FieldDims &dm, int dtype) {
     static const int env = cn_tune_env("CNERF_FIELD_FUSED_BWD", 1);
     return env && dtype == CNERF_F16 && dm.enc_pad <= 32;           // 92 KiB weight fragments + 64 KiB staging must fit the 160 KiB LDS
@@ -318,6 +318,14 @@ int cnerf_field_backward(const void *enc, const float *xyz, const float *dirs, u
                          uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
                          const float *grad_sigma, const float *grad_rgbc, void *grad_enc, float *grad_params_net, float *grad_params_den,
                          float *grad_params_rgb, void *workspace, uint64_t workspace_bytes, int dtype, void *stream) {
+    return cnerf_field_backward_ex(enc, xyz, dirs, dir_group, P_, enc_dim, n_hidden_geo, n_rgb_out, params_net, params_den, params_rgb, grad_sigma, grad_rgbc,
+                                   grad_enc, grad_params_net, grad_params_den, grad_params_rgb, workspace, workspace_bytes, dtype, nullptr, stream);
+}
+
+int cnerf_field_backward_ex(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
+                            uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
+                            const float *grad_sigma, const float *grad_rgbc, void *grad_enc, float *grad_params_net, float *grad_params_den,
+                            float *grad_params_rgb, void *workspace, uint64_t workspace_bytes, int dtype, const uint8_t *tile_live, void *stream) {
     FieldDims dm;
     int rc = fb_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
     if (rc) return rc;
@@ -332,7 +340,7 @@ int cnerf_field_backward(const void *enc, const float *xyz, const float *dirs, u
     if (workspace_bytes < need) return CNERF_EINVAL;
     if (fb_use_fused(dm, dtype))
         return ff_launch(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, grad_sigma, grad_rgbc, grad_enc, grad_params_net,
-                         grad_params_den, grad_params_rgb, workspace, CN_STREAM(stream));
+                         grad_params_den, grad_params_rgb, workspace, tile_live, CN_STREAM(stream));
     if (dtype == CNERF_F16)
         return fb_launch<true>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, grad_sigma, grad_rgbc, grad_enc,
                                grad_params_net, grad_params_den, grad_params_rgb, workspace, CN_STREAM(stream));

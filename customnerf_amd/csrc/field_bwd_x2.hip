@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                                                               uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                               const float *__restrict__ pden, const float *__restrict__ prgb,
                                                               const float *__restrict__ g_sigma, const float *__restrict__ g_rgbc,
-                                                              void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate_arg) {
+                                                              void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate_arg,
+                                                              const uint8_t *__restrict__ tile_live) {
 #ifdef CNERF_TUNING
     const uint32_t ablate = ablate_arg;                       // measurement aid, tuning builds only
 #else
@@ -332,13 +333,13 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
 #pragma unroll
             for (int b = 0; b < 2; b++) { x4_zero(wn2[a][b]); x4_zero(wn1[a][b]); }
         }
-        struct ASet { frag_t x0[SENC], h1[4], h2[4]; uint32_t p; bool v; };
+        struct ASet { frag_t x0[SENC], h1[4], h2[4]; uint32_t p; bool v, live; };
         ASet S0, S1;                                          // activations of the tiles with even / odd phase index (forward at p, backward at p+2)
 #pragma unroll
         for (int s = 0; s < SENC; s++) S0.x0[s] = S1.x0[s] = PR::zero();
 #pragma unroll
         for (int s = 0; s < 4; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = PR::zero();
-        S0.p = S1.p = 0; S0.v = S1.v = false;
+        S0.p = S1.p = 0; S0.v = S1.v = false; S0.live = S1.live = false;
         frag_t N0[SENC], N1[SENC];                            // grid features requested one phase ahead (even / odd tiles)
         x4_enc_request<SENC>(enc, P_, dm.L, gp * FLD_TILE + li, hi, N0);
 #pragma unroll
@@ -349,7 +350,18 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             asm volatile("" ::: "memory");
             x4_enc_request<SENC>(enc, P_, dm.L, (gp + (p + 1) * G) * FLD_TILE + li, hi, xnext);
             // ---- backward of tile p-2 (dz_3 was published by wave B in phase p-1); S still holds that tile
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 1)) {
+            if (p >= 2 && p - 2 < n_iter && !(ablate & 1) && !S.live) {
+                // a dead tile (cnerf_composite_run_backward_indexed_flush: every row's output gradient is exactly zero): nothing to add to any
+                // weight gradient; its rows of d(loss)/d(grid features) are zeros
+                if (S.v) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const uint32_t level = (uint32_t)fld_rho(r, (int)hi) >> 1;
+                        if (level < dm.L) reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + S.p] = 0u;
+                    }
+                }
+            }
+            if (p >= 2 && p - 2 < n_iter && !(ablate & 1) && S.live) {
                 const unsigned char *z3i = xch + X2_Z3 + ((p - 2) & 1) * 4 * X4_K;
                 frag_t z3[4];
                 x4_fetch<4>(z3i, lane, z3);
@@ -406,6 +418,11 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                 const uint32_t tile = gp + p * G;
                 S.p = tile * FLD_TILE + li;
                 S.v = S.p < P_;
+                S.live = tile < n_tiles && (!tile_live || tile_live[tile] != 0);           // (wave-uniform)
+            } else {
+                S.live = false;
+            }
+            if (p < n_iter && !(ablate & 2) && S.live) {
                 x4_enc_mask<SENC>(xcur, dm.L, S.v, hi, S.x0);
                 cn_f16v acc[2];
                 fb_zero(acc);
@@ -421,7 +438,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                 x4_gemm<2, S64>(wl + lo.off[2], S64, 0, (NGEO == 2) ? S.h2 : S.h1, lane, acc);
                 x4_c_to_b<false>(acc, fea);
                 x4_publish<4>(xch + X2_FEA + (p & 1) * 4 * X4_K, lane, fea);
-            } else {
+            } else if (!(p < n_iter && !(ablate & 2))) {
                 S.v = false;
             }
             X4_T1();
@@ -467,7 +484,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             X4_T0();
             asm volatile("" ::: "memory");
             if (p >= 1) nxt = load_in(gp + p * G);
-            if (p >= 1 && p - 1 < n_iter && !(ablate & 4)) {
+            if (p >= 1 && p - 1 < n_iter && !(ablate & 4) && (gp + (p - 1) * G) < n_tiles && (!tile_live || tile_live[gp + (p - 1) * G] != 0)) {
                 const uint32_t i = p - 1;
                 const uint32_t tile = gp + i * G;
                 const bool valid = tile * FLD_TILE + li < P_;
@@ -608,7 +625,7 @@ bool x2_eligible(const FieldDims &dm) {
 
 int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
-              uint32_t max_partials, hipStream_t st) {
+              uint32_t max_partials, const uint8_t *tile_live, hipStream_t st) {
     const FieldLds lo = fld_lds_layout<true>(dm);
     if (lo.off[7] > FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID) return CNERF_EINVAL;
     const uint32_t lds_bytes = 2 * X2_PAIR_BYTES;                               // dynamic part; the weight fragments are a 48 KiB static array
@@ -628,7 +645,7 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
         auto kern = KERN;                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
-                           grad_enc, partials, (uint32_t)ablate);                                                                          \
+                           grad_enc, partials, (uint32_t)ablate, tile_live);                                                               \
     }
     if (dm.n_hidden_geo == 2) X2_LAUNCH(k_field_bwd_x2<2>) else X2_LAUNCH(k_field_bwd_x2<1>)
     int rc = cn_launch_status();

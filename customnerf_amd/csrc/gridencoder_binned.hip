@@ -769,6 +769,396 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
     *dst = g;
 }
 
+// ================================================================================================ fp16 records, third form (round 5)
+// The second form needs the EXACT record count of every (point block, bin) pair before the first record is written: a histogram pass over
+// all 16 levels (the corner arithmetic of the emit, a second time) plus two scans, issued on a side stream beside the forward.  Measured with
+// the plan frozen (scratch/stale_plan.py, profiles/r05_stale_plan_control.json): that "hidden" pre-pass costs the step 113 us — its 1.1 ms of
+// side-stream kernel time takes CUs from the gathers and the field backward.  It also fixes the record count before the gradients exist, so
+// samples whose gradient is exactly zero still travel as records.  Since the sums became exact fixed point the ORDER of a bin's records is
+// free, so nothing has to be counted ahead of time — the emit counts for itself:
+//   k_bin3_emit   a block (2048 points of one level) derives its corner pairs ONCE, takes an LDS ticket per record against per-bin counters
+//                 that start at zero, scans the 128 counters (the block's own histogram) and sorts the records by bin into the LDS staging area.
+//                 Samples whose gradient is exactly zero on this level emit nothing (they add exactly zero to every fixed-point sum).
+//     hashed levels (bin loads near-uniform): every bin owns a slab region of fixed capacity (1.5 x its expected load); the block reserves its
+//                 run in each bin with ONE returning atomic per (block, bin) on the bin's cursor — issued right after the scan, consumed at
+//                 copy-out — and copies its runs there: bin-major, densely packed, exactly the layout the accumulate kernel streams.  A bin
+//                 whose cursor passes its capacity (a sample distribution that defeats the hash) is flagged by that very cursor and recomputed
+//                 from the samples by k_bin3_redo: exact, only slower.
+//     dense levels (a few crowded, uneven bins): the staging area leaves as ONE contiguous run into the block's private region, and the run
+//                 table gets {count, offset} per (bin, block); the accumulate workgroup of a bin segment walks the runs (thousands of records each).
+//   k_bin3_totals per bin: dense — exclusive prefix of the run counts over the blocks + total; hashed — the clamped cursor
+//   k_bin_scan_bins, k_bin3_accum, k_bin3_redo, k_bin2_reduce_split
+// Same 8-byte pair records, same exact 64-bit fixed-point sums, same split-bin reduction: the gradient is bit-identical to the second form's.
+#define B3_PTS 2048
+#define B3_CAP (B3_PTS * 4 + 256)                 // staging capacity in records
+#define B3_REGION (B3_PTS * 8)                    // records a block may emit on one level (8 single records per sample): its region on a dense level
+
+struct Bin3Plan {
+    Bin2Plan p;
+    uint32_t capb;                                 // record capacity of a hashed bin's region
+    uint32_t dense_slot[GE_MAX_LEVELS];            // slot -> index among the dense slots (block-major regions), or 0xFFFFFFFF for a hashed level
+};
+
+__global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+                                                          const Bin3Plan plan, uint32_t *__restrict__ runs, uint32_t *__restrict__ cursor,
+                                                          uint2 *__restrict__ hslab, uint2 *__restrict__ dslab, uint32_t B,
+                                                          uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];        // one LDS object: staged records, bin ids, counters, run starts, run destinations
+    uint2 *s_rec = reinterpret_cast<uint2 *>(b3_lds);
+    uint8_t *s_bin = b3_lds + (size_t)B3_CAP * 8;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(b3_lds + (size_t)B3_CAP * 9);
+    uint32_t *start = cnt + B2S_MAX_CHUNKS;
+    uint32_t *gdst = start + B2S_MAX_CHUNKS;                                        // hashed: first record of the block's run inside the bin's region
+    uint32_t *s_total = gdst + B2S_MAX_CHUNKS;
+    const uint32_t nb = plan.p.nb;
+    const uint32_t slot = blockIdx.x / nb, pb = blockIdx.x % nb;
+    const uint32_t level = lv.order[slot];
+    const uint32_t bin0 = plan.p.bin_first[slot], nch = plan.p.bin_first[slot + 1] - bin0;
+    const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu;
+    if (threadIdx.x < B2S_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int PPT = B3_PTS / B2_THREADS;
+    bool ok[PPT];
+    uint32_t i0[PPT][4], i1[PPT][4], tk[PPT][4];
+    float wyz[PPT][4], fx[PPT], g0[PPT], g1[PPT];
+    // ---- phase 1: corner pairs, gradients, one LDS ticket per record (ticket = rank of the record inside the block's run for its bin)
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const uint32_t b = pb * B3_PTS + i * B2_THREADS + threadIdx.x;
+        float in[3];
+        ok[i] = bn_load_point(inputs, b, B, in);
+        g0[i] = g1[i] = fx[i] = 0.0f;
+        if (ok[i]) {
+            b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
+            const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
+            g0[i] = __half2float(g.v[0]); g1[i] = __half2float(g.v[1]);
+            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
+            ok[i] = g0[i] != 0.0f || g1[i] != 0.0f;                              // a zero gradient adds zero to every sum: no records
+        }
+        if (ok[i]) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t c0 = i0[i][q] >> BN_CHUNK_LOG2;
+                if (b2_paired(i0[i][q], i1[i][q])) {
+                    tk[i][q] = dense_lvl ? b2_ticket(cnt, c0) : atomicAdd(&cnt[c0], 1u);
+                } else {
+                    const uint32_t t0 = atomicAdd(&cnt[c0], 1u);
+                    const uint32_t t1 = atomicAdd(&cnt[i1[i][q] >> BN_CHUNK_LOG2], 1u);
+                    tk[i][q] = t0 | (t1 << 16);                                  // (a block emits at most 16384 records per level)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the block's histogram is complete: run starts (two bins per lane of the first wave); dense: the run table; hashed: the reservations
+    uint32_t res_a = 0, res_b = 0;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t ca = cnt[lane], cb = cnt[lane + 64];
+        const uint32_t ia = cn_wave_incl_scan(ca);
+        const uint32_t tot_a = __shfl(ia, 63, 64);
+        const uint32_t ib = cn_wave_incl_scan(cb);
+        const uint32_t oa = ia - ca, ob = tot_a + ib - cb;
+        start[lane] = oa; start[lane + 64] = ob;
+        if (lane == 63) *s_total = tot_a + ib;
+        if (dense_lvl) {
+            if (lane < nch) runs[(size_t)(bin0 + lane) * nb + pb] = ca | (oa << 16);
+            if (lane + 64 < nch) runs[(size_t)(bin0 + lane + 64) * nb + pb] = cb | (ob << 16);
+        } else {
+            // records the staging area cannot hold (more than 256 chunk-straddling pairs in a block: practically never on a hashed level) are
+            // not stored at all — the bin's cursor is pushed past its capacity instead, which hands the bin to k_bin3_redo
+            const uint32_t tot = tot_a + ib;
+            const uint32_t bump_a = (ca && oa + ca > B3_CAP && tot > B3_CAP) ? plan.capb : 0u, bump_b = (cb && ob + cb > B3_CAP && tot > B3_CAP) ? plan.capb : 0u;
+            if (lane < nch && ca) res_a = atomicAdd(&cursor[bin0 + lane], ca + bump_a);
+            if (lane + 64 < nch && cb) res_b = atomicAdd(&cursor[bin0 + lane + 64], cb + bump_b);
+        }
+    }
+    // bare barrier: only the LDS writes above (start[], *s_total) must have landed; __syncthreads() would also wait for the returning atomics
+    // (vmcnt(0)) — they have all of phase 2 to come back
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- phase 2: the records, sorted by bin, into the staging area
+    uint2 *__restrict__ region = dense_lvl ? dslab + ((size_t)plan.dense_slot[slot] * nb + pb) * B3_REGION : nullptr;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        if (!ok[i]) continue;
+        const uint32_t fxq = min((uint32_t)(fx[i] * 65536.0f), 65535u);
+        union { __half2 h; uint32_t u; } v;
+        auto put = [&](uint32_t c, uint32_t ticket, uint32_t word, uint32_t val) {
+            const uint32_t sl = start[c] + ticket;
+            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
+            else if (dense_lvl) region[sl] = make_uint2(word, val);                 // beyond the staging capacity: straight to its final place
+        };
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a0 = i0[i][q], a1 = i1[i][q];
+            const uint32_t c0 = a0 >> BN_CHUNK_LOG2;
+            if (b2_paired(a0, a1)) {
+                const uint32_t t = 31u - (uint32_t)__clz((int)(a0 ^ a1));
+                v.h = __floats2half2_rn(wyz[i][q] * g0[i], wyz[i][q] * g1[i]);
+                put(c0, tk[i][q], (a0 & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
+            } else {
+                const float w0 = (1 - fx[i]) * wyz[i][q], w1 = fx[i] * wyz[i][q];
+                v.h = __floats2half2_rn(w0 * g0[i], w0 * g1[i]);
+                put(c0, tk[i][q] & 0xFFFFu, (a0 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+                v.h = __floats2half2_rn(w1 * g0[i], w1 * g1[i]);
+                put(a1 >> BN_CHUNK_LOG2, tk[i][q] >> 16, (a1 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+            }
+        }
+    }
+    if (!dense_lvl && threadIdx.x < 64) {                                           // the reservations have had phase 2 to come back
+        gdst[threadIdx.x] = res_a - start[threadIdx.x];                             // staging slot -> position in the bin's region (wrapping arithmetic)
+        gdst[threadIdx.x + 64] = res_b - start[threadIdx.x + 64];
+    }
+    __syncthreads();
+    const uint32_t total = min(*s_total, (uint32_t)B3_CAP);
+    if (dense_lvl) {
+        for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) region[sl] = s_rec[sl];
+    } else {
+        const uint32_t capb = plan.capb;
+        for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) {
+            const uint32_t c = s_bin[sl];
+            const uint32_t pos = gdst[c] + sl;
+            if (pos < capb) hslab[(size_t)(bin0 + c) * capb + pos] = s_rec[sl];     // (a run that does not fit marks its bin for k_bin3_redo: cursor > capb)
+        }
+    }
+}
+
+// per bin — dense level: exclusive prefix of the run counts (low half of the run-table words) over the point blocks -> pre, and the bin total;
+// hashed level: the total is the bin's cursor (0 for a bin that overflowed its region: k_bin3_redo serves it)
+__global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t *__restrict__ runs, uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor,
+                                                                 uint32_t *__restrict__ bin_total, const Bin3Plan plan, uint32_t n_slots) {
+    constexpr uint32_t NW = BN_SCAN_THREADS / 64;
+    __shared__ uint32_t wave_tot[NW];
+    __shared__ uint32_t carry;
+    const uint32_t bin = blockIdx.x, nb = plan.p.nb;
+    uint32_t slot = 0;
+    while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
+    if (plan.dense_slot[slot] == 0xFFFFFFFFu) {
+        if (threadIdx.x == 0) { const uint32_t c = cursor[bin]; bin_total[bin] = c > plan.capb ? 0u : c; }
+        return;
+    }
+    const uint32_t *h = runs + (size_t)bin * nb;
+    uint32_t *o = pre + (size_t)bin * nb;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < nb; s0 += BN_SCAN_THREADS * 4) {
+        const uint32_t i = s0 + tid * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < nb ? (h[i + k] & 0xFFFFu) : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = cn_wave_incl_scan(mine);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) {
+            const uint32_t t = wave_tot[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        const uint32_t base = carry;
+        uint32_t run = base + wbase + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < nb) o[i + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 0) carry = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) bin_total[bin] = carry;
+}
+
+// flush of a finished LDS image: sole owner -> read-modify-write of the gradient table; a split bin parks its fixed-point image
+__device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels &lv, const Bin2Plan &plan, uint32_t slot, uint32_t bin, uint32_t nseg, uint32_t gseg,
+                                         float *__restrict__ grad_grid, long long *__restrict__ partial) {
+    const uint32_t level = lv.order[slot];
+    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
+    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
+    float *__restrict__ dst = grad_grid + ((size_t)lv.offset[level] + e0) * 2;
+    if (nseg == 1) {
+        for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024) {             // two entries x two channels per thread
+            float4 g = reinterpret_cast<float4 *>(dst)[j];
+            g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
+            g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
+            reinterpret_cast<float4 *>(dst)[j] = g;
+        }
+    } else {
+        long long *__restrict__ img = partial + (size_t)gseg * (BN_CHUNK * 2);
+        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) img[j] = acc[(j & 1) * BN_CHUNK + (j >> 1)];      // interleaved (entry, channel) order
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ hslab, const uint2 *__restrict__ dslab, const uint32_t *__restrict__ runs,
+                                                     const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bin_base,
+                                                     const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin3Plan plan,
+                                                     float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin,
+                                                     uint32_t n_slots, uint32_t seg_records) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [2][BN_CHUNK] accumulators, then two uint32 (one LDS object)
+    long long *acc = reinterpret_cast<long long *>(bn_lds);
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
+    const uint32_t gseg = blockIdx.x;
+    if (gseg >= seg_first[plan.p.total_bins]) return;
+    const uint32_t nb = plan.p.nb;
+    if (threadIdx.x == 0) {
+        const uint32_t bin = seg_bin[gseg];
+        uint32_t slot = 0;
+        while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
+        uint32_t lo = 0;
+        if (plan.dense_slot[slot] != 0xFFFFFFFFu) {
+            // first run that reaches into [begin, ...): the last block whose prefix is <= begin
+            const uint32_t begin = (gseg - seg_first[bin]) * seg_records;
+            const uint32_t *p = pre + (size_t)bin * nb;
+            uint32_t hi = nb;                                                  // invariant: p[lo] <= begin (p[0] = 0)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p[mid] <= begin) lo = mid; else hi = mid;
+            }
+        }
+        s_w[0] = bin; s_w[1] = lo; s_w[2] = slot;
+    }
+    for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t bin = s_w[0], pb_first = s_w[1], slot = s_w[2];
+    const uint32_t seg = gseg - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
+    const uint32_t total = bin_base[bin + 1] - bin_base[bin];
+    const uint32_t begin = seg * seg_records, end = min(begin + seg_records, total);
+    if (plan.dense_slot[slot] == 0xFFFFFFFFu) {
+        // ---- hashed level: the bin's records are one contiguous range of its region (the second form's stream: 16-byte loads, two records per lane)
+        const uint2 *__restrict__ slab = hslab + (size_t)bin * plan.capb;           // (capb is even: the region starts 16-byte aligned)
+        uint32_t b2 = begin, e2 = end;
+        if ((b2 & 1u) && b2 < e2) { if (threadIdx.x == 0) b2_add_record(acc, slab[b2]); b2++; }
+        if ((e2 & 1u) && b2 < e2) { e2--; if (threadIdx.x == 0) b2_add_record(acc, slab[e2]); }
+        const uint4 *__restrict__ slab2 = reinterpret_cast<const uint4 *>(slab);
+        const uint32_t pend = e2 >> 1;
+        constexpr int UNR = 4;
+        const bool crowded = nseg > 1;
+        uint32_t ib = b2 >> 1;
+        for (; ib + UNR * 1024 <= pend; ib += UNR * 1024) {
+            uint4 r[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) r[u] = slab2[crowded ? ib + threadIdx.x * UNR + u : ib + u * 1024 + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                b2_add_record(acc, make_uint2(r[u].x, r[u].y));
+                b2_add_record(acc, make_uint2(r[u].z, r[u].w));
+            }
+        }
+        for (uint32_t i = ib + threadIdx.x; i < pend; i += 1024) {
+            const uint4 r = slab2[i];
+            b2_add_record(acc, make_uint2(r.x, r.y));
+            b2_add_record(acc, make_uint2(r.z, r.w));
+        }
+    } else {
+        // ---- dense level: walk the runs of the point blocks.  Waves take chunks of 64 consecutive runs round-robin; a lane fetches the metadata of
+        // one run, the wave then walks the 64 runs together, eight at a time: the first 64 records of eight runs are requested back to back, the
+        // rest of each run (thousands of records on these levels) in a second loop.  Loads are unconditional on a clamped index and masked at use
+        // (a `valid ? load : 0` becomes a branch with the wait right behind the load).
+        const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t *__restrict__ rt = runs + (size_t)bin * nb, *__restrict__ pt = pre + (size_t)bin * nb;
+        const uint2 *__restrict__ lvl_slab = dslab + (size_t)plan.dense_slot[slot] * nb * B3_REGION;
+        constexpr int RU = 8;
+        for (uint32_t pb0 = pb_first + wave * 64; pb0 < nb; pb0 += 16 * 64) {
+            const uint32_t pbl = pb0 + lane;
+            uint32_t m_pre = 0xFFFFFFFFu, m_run = 0;
+            if (pbl < nb) { m_pre = pt[pbl]; m_run = rt[pbl]; }
+            if (__builtin_amdgcn_readfirstlane(m_pre) >= end) break;               // the prefix is monotone: nothing further belongs to this segment
+            bool done = false;
+            for (uint32_t j0 = 0; j0 < 64 && !done; j0 += RU) {
+                uint32_t base[RU], lo[RU], hi[RU];
+                uint2 v[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const uint32_t p_j = __builtin_amdgcn_readlane(m_pre, j0 + u), r_j = __builtin_amdgcn_readlane(m_run, j0 + u);
+                    const bool in = p_j < end;                                      // (wave-uniform)
+                    const uint32_t c_j = in ? (r_j & 0xFFFFu) : 0u;
+                    const uint32_t pj = in ? p_j : 0u;
+                    lo[u] = max(pj, begin) - pj;
+                    hi[u] = max(min(pj + c_j, end), pj) - pj;                       // the part of the run inside the segment: [lo, hi)
+                    if (hi[u] < lo[u]) hi[u] = lo[u];
+                    base[u] = (pb0 + j0 + u) * B3_REGION + (r_j >> 16);
+                    if (!in) { done = true; base[u] = 0; }
+                    const uint32_t r = lo[u] + lane;
+                    v[u] = lvl_slab[r < hi[u] ? base[u] + r : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < RU; u++)
+                    if (lo[u] + lane < hi[u]) b2_add_record(acc, v[u]);
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    if (hi[u] - lo[u] <= 64) continue;                              // (wave-uniform)
+                    const uint2 *__restrict__ src = lvl_slab + base[u];
+                    uint32_t r = lo[u] + 64 + lane;
+                    for (; r + 192 < hi[u]; r += 256) {
+                        const uint2 a = src[r], b = src[r + 64], c = src[r + 128], d = src[r + 192];
+                        b2_add_record(acc, a); b2_add_record(acc, b); b2_add_record(acc, c); b2_add_record(acc, d);
+                    }
+                    for (; r < hi[u]; r += 64) b2_add_record(acc, src[r]);
+                }
+            }
+            if (done) break;
+        }
+    }
+    __syncthreads();
+    b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial);
+}
+
+// A hashed bin whose cursor passed the capacity of its region (cursor > capb: records were dropped): recompute its sums from the samples — every
+// sample of the level, the very records the emit builds, those that fall into this bin — exact like everything else here, only slower (one sweep
+// over the level's points per such bin).  Grid = the bins; a workgroup whose bin did not overflow exits on its first load.
+__global__ void __launch_bounds__(1024) k_bin3_redo(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv, const Bin3Plan plan,
+                                                    const uint32_t *__restrict__ cursor, uint32_t B, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                    float *__restrict__ grad_grid, uint32_t n_slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];
+    long long *acc = reinterpret_cast<long long *>(bn_lds);
+    const uint32_t bin = blockIdx.x;
+    uint32_t slot = 0;
+    while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
+    if (plan.dense_slot[slot] != 0xFFFFFFFFu || cursor[bin] <= plan.capb) return;
+    for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t level = lv.order[slot], chunk = bin - plan.p.bin_first[slot];
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) {
+        float in[3];
+        if (!bn_load_point(inputs, b, B, in)) continue;
+        uint32_t i0[4], i1[4];
+        float wyz[4], fx;
+        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
+        const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
+        const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
+        if (g0 == 0.0f && g1 == 0.0f) continue;
+        const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
+        union { __half2 h; uint32_t u; } v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a0 = i0[q], a1 = i1[q];
+            if (b2_paired(a0, a1)) {
+                if ((a0 >> BN_CHUNK_LOG2) != chunk) continue;
+                const uint32_t t = 31u - (uint32_t)__clz((int)(a0 ^ a1));
+                v.h = __floats2half2_rn(wyz[q] * g0, wyz[q] * g1);
+                b2_add_record(acc, make_uint2((a0 & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u));
+            } else {
+                const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
+                if ((a0 >> BN_CHUNK_LOG2) == chunk) {
+                    v.h = __floats2half2_rn(w0 * g0, w0 * g1);
+                    b2_add_record(acc, make_uint2((a0 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u));
+                }
+                if ((a1 >> BN_CHUNK_LOG2) == chunk) {
+                    v.h = __floats2half2_rn(w1 * g0, w1 * g1);
+                    b2_add_record(acc, make_uint2((a1 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    b3_flush(acc, lv, plan.p, slot, bin, 1u, 0u, grad_grid, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline uint64_t bn_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
 
@@ -937,6 +1327,121 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     return cn_launch_status();
 }
 
+// ---- third form, host side
+struct Bin3Ws {
+    uint32_t *runs, *pre, *cursor, *bin_base, *seg_first, *seg_bin;
+    uint2 *hslab, *dslab;
+    long long *partial;
+    uint64_t max_seg, cursor_bytes;
+};
+
+static bool b3_is_dense(const GridLevels &lv, uint32_t level) {                  // (every dimension's stride fits the table: see ge_level_mode; align_corners only shrinks the grid)
+    const uint64_t r1 = (uint64_t)lv.resolution[level] + 1;
+    return r1 * r1 * r1 <= lv.size[level];
+}
+
+static void b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense) {
+    b2_plan(lv, nl, B, plan.p);
+    plan.p.nb = cn_div_up(B, B3_PTS);
+    n_dense = 0;
+    uint64_t cap = 0;
+    for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) plan.dense_slot[s] = 0xFFFFFFFFu;
+    for (uint32_t s = 0; s < nl; s++) {
+        if (b3_is_dense(lv, lv.order[s])) { plan.dense_slot[s] = n_dense++; continue; }
+        const uint32_t nch = plan.p.bin_first[s + 1] - plan.p.bin_first[s];
+        const uint64_t mean = (uint64_t)B * 4 / nch;                               // four pair records per sample, spread by the hash
+        const uint64_t c = mean + mean / 2 + 8192;
+        cap = cap > c ? cap : c;
+    }
+    plan.capb = (uint32_t)((cap + 1) & ~(uint64_t)1);
+}
+
+// the third form serves float16 records on tables of at most B2S_MAX_CHUNKS bins per level (the staging area's counters); larger tables
+// (T = 2^20, 2^21: the reference's bear table) keep the second form with its histogram
+static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype) {
+    static const int on = b2_env("CNERF_B3", 1);
+    if (!on || !b2_enabled(dtype)) return false;
+    Bin3Plan plan;
+    uint32_t nd;
+    b3_plan(lv, nl, B, plan, nd);
+    return b2_max_chunks(plan.p, nl) <= B2S_MAX_CHUNKS && (uint64_t)nd * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
+}
+
+static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, uint32_t nl, Bin3Ws *ws, void *base) {
+    const Bin2Plan &p2 = plan.p;
+    uint64_t off = 0;
+    const uint64_t o_runs = off; off = bn_align(off + (uint64_t)p2.total_bins * p2.nb * 4);
+    const uint64_t o_pre = off; off = bn_align(off + (uint64_t)p2.total_bins * p2.nb * 4);
+    const uint64_t o_cur = off; off = bn_align(off + (uint64_t)p2.total_bins * 4);
+    const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
+    const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
+    const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
+    const uint64_t d_records = (uint64_t)n_dense * p2.nb * B3_REGION;              // block-major regions of the dense levels
+    const uint64_t o_h = off; off = bn_align(off + h_records * 8);
+    const uint64_t o_d = off; off = bn_align(off + d_records * 8);
+    const uint64_t max_seg = (uint64_t)p2.total_bins + cn_div_up64((uint64_t)B * nl * 8, b2_seg(B, b2_max_chunks(p2, nl)));
+    const uint64_t o_segbin = off; off = bn_align(off + max_seg * 4);
+    const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);
+    if (ws) {
+        char *p = (char *)base;
+        ws->runs = (uint32_t *)(p + o_runs);
+        ws->pre = (uint32_t *)(p + o_pre);
+        ws->cursor = (uint32_t *)(p + o_cur);
+        ws->cursor_bytes = (uint64_t)p2.total_bins * 4;
+        ws->bin_base = (uint32_t *)(p + o_base);
+        ws->seg_first = (uint32_t *)(p + o_seg);
+        ws->hslab = (uint2 *)(p + o_h);
+        ws->dslab = (uint2 *)(p + o_d);
+        ws->seg_bin = (uint32_t *)(p + o_segbin);
+        ws->partial = (long long *)(p + o_part);
+        ws->max_seg = max_seg;
+    }
+    return off;
+}
+
+__global__ void __launch_bounds__(256) k_bin3_zero(uint32_t *__restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+static int b3_backward(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
+                       uint32_t interp, void *workspace, hipStream_t st) {
+    if (nl == 0) return CNERF_OK;
+    Bin3Plan plan;
+    uint32_t n_dense;
+    b3_plan(lv, nl, B, plan, n_dense);
+    Bin3Ws ws;
+    b3_layout(plan, n_dense, B, nl, &ws, workspace);
+    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_emit), hipFuncAttributeMaxDynamicSharedMemorySize, emit_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_accum), hipFuncAttributeMaxDynamicSharedMemorySize, acc_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_redo), hipFuncAttributeMaxDynamicSharedMemorySize, acc_lds);
+        attr_set = true;
+    }
+    const Bin2Plan &p2 = plan.p;
+    const uint32_t seg = b2_seg(B, b2_max_chunks(p2, nl));
+    hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
+    hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B2_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
+                       interp, gemb);
+    hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
+                       plan, nl);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin);
+    hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
+                       (const uint32_t *)ws.pre, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
+                       (const uint32_t *)ws.seg_bin, nl, seg);
+    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(p2.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, p2,
+                       gemb, nl);
+    if (n_dense < nl)
+        hipLaunchKernelGGL(k_bin3_redo, dim3(p2.total_bins), dim3(1024), acc_lds, st, grad, inputs, lv, plan, (const uint32_t *)ws.cursor, B, gridtype, ac, interp, gemb, nl);
+    return cn_launch_status();
+}
+
+// does the binned backward of this shape use a plan prepared ahead of time (histogram + scans on the sample coordinates)?  The third form
+// counts inside its emit kernel: nothing to prepare.
+bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) { return !b3_enabled(lv, nl, B, dtype); }
+
 // used by gridencoder.hip
 bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv) {
     if (D != 3 || C != 2 || nl == 0) return false;
@@ -946,6 +1451,12 @@ bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLeve
 }
 
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
+    if (b3_enabled(lv, nl, B, dtype)) {
+        Bin3Plan p3;
+        uint32_t nd;
+        b3_plan(lv, nl, B, p3, nd);
+        return b3_layout(p3, nd, B, nl, nullptr, nullptr);
+    }
     if (b2_enabled(dtype)) {
         Bin2Plan p2;
         b2_plan(lv, nl, B, p2);
@@ -1014,6 +1525,7 @@ int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t n
 
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
+    if (b3_enabled(lv, nl, B, dtype)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
     if (b2_enabled(dtype)) {
         if (!prepared) {
             const int rc = b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);

@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
                                                                   const float *__restrict__ nears, const float *__restrict__ fars, uint32_t N, uint32_t S,
                                                                   uint32_t num_steps, int soft, float thr, int detach_bg, int detach_mask,
                                                                   float *__restrict__ g_sigma, float *__restrict__ g_rgbc,
-                                                                  const uint32_t *__restrict__ src_index) {
+                                                                  const uint32_t *__restrict__ src_index, float flush_thr, uint8_t *__restrict__ tile_live,
+                                                                  uint32_t T_coarse) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
     if (n >= N) return;
@@ -361,6 +362,13 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
     const float sd = (far - near) / (float)num_steps;
     const float *zr = z_vals + (size_t)n * S;
     const float4 *c4 = reinterpret_cast<const float4 *>(rgbc);
+    // early termination (flush_thr > 0: the consumer is the half-precision fused field): a sample whose gradients, as k_field_bwd_x2 will
+    // consume them — half(g_sigma * exp'), half(g_c * sigmoid') — are all zero contributes exactly nothing to any weight or table entry;
+    // behind an opaque surface (T underflows) and in empty space (sigma -> 0) that is most of a fitted scene's samples.  Such rows are
+    // written as exact zeros here, and the ray's 32-sample tiles of the sample list that hold nothing else are reported dead (tile_live),
+    // so that the field backward skips them and the scatter emits no records for them — bit-identical gradients, less work.
+    const float e_lo = __expf(-15.0f), e_hi = __expf(15.0f);
+    uint32_t live_bits = 0;                                 // bit k: local tile k of this ray (T_coarse / 32 coarse tiles, then the fine ones) has a live row
     float go[3][6];
 #pragma unroll
     for (int v = 0; v < 3; v++)
@@ -433,9 +441,30 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
             if (v == 2) ge -= dsv * sigma;
         }
         if (soft) gc.w += ge * 100.0f * e * (1.0f - e);                                    // edit = sigmoid((conf - thr) * 100), renderer.py:387
+        if (flush_thr > 0.0f) {
+            // conservative by a factor of two against the half rounding threshold 2^-25 (last-bit differences between the forward's values
+            // and the backward kernel's recomputation cannot revive a row); NaN / Inf gradients compare false and stay
+            const float sc = fminf(fmaxf(sigma, e_lo), e_hi);                                // exp(clamp(., -15, 15)) of provider_utils.py:26-29
+            const bool dead = fabsf(gs) * sc < flush_thr && fabsf(gc.x) * (c.x * (1.0f - c.x)) < flush_thr && fabsf(gc.y) * (c.y * (1.0f - c.y)) < flush_thr &&
+                              fabsf(gc.z) * (c.z * (1.0f - c.z)) < flush_thr && fabsf(gc.w) * (c.w * (1.0f - c.w)) < flush_thr;
+            if (dead) { gs = 0.0f; gc = make_float4(0, 0, 0, 0); }
+            else if (ok && tile_live) {
+                const uint32_t Pc = N * T_coarse, t_f = S - T_coarse;
+                const uint32_t lt = row < Pc ? ((uint32_t)row - n * T_coarse) >> 5 : (T_coarse >> 5) + (((uint32_t)row - Pc - n * t_f) >> 5);
+                live_bits |= 1u << lt;
+            }
+        }
         if (ok) {
             g_sigma[row] = gs;
             reinterpret_cast<float4 *>(g_rgbc)[row] = gc;
+        }
+    }
+    if (tile_live) {
+        // the ray owns its tiles (T_coarse and S - T_coarse are multiples of 32: checked by the host): one byte each, written once — no atomics
+        const uint32_t Pc = N * T_coarse, t_f = S - T_coarse, ntc = T_coarse >> 5, ntf = t_f >> 5;
+        for (uint32_t k = 0; k < ntc + ntf; k++) {
+            const bool any = __ballot((live_bits >> k) & 1u) != 0;
+            if (lane == 0) tile_live[k < ntc ? (n * T_coarse >> 5) + k : ((Pc + n * t_f) >> 5) + (k - ntc)] = any ? 1 : 0;
         }
     }
 }
@@ -568,16 +597,27 @@ int cnerf_composite_run(const float *sigmas, const float *rgbc, const float *z_v
                                        nullptr, stream);
 }
 
-int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
-                                         const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
-                                         int detach_mask_from_field, const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream) {
+int cnerf_composite_run_backward_indexed_flush(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
+                                               const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
+                                               int detach_mask_from_field, const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, int flush_half_zero,
+                                               uint8_t *tile_live, void *stream) {
     if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
     if (!grad_out_ray || !sigmas || !rgbc || !z_vals || !nears || !fars || !grad_sigmas || !grad_rgbc) return CNERF_ENULL;
     if ((((uintptr_t)rgbc) | ((uintptr_t)grad_rgbc)) & 15) return CNERF_EINVAL;
+    // tile flags need the split sample list ([coarse N * num_steps | fine N * (S - num_steps)], src_index) with whole 32-sample tiles per ray
+    if (tile_live && (!flush_half_zero || !src_index || num_steps >= S || (num_steps & 31u) || ((S - num_steps) & 31u) || S > 256)) return CNERF_EINVAL;
     hipLaunchKernelGGL(k_composite_run_bwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), grad_out_ray, sigmas, rgbc, z_vals, nears,
-                       fars, N, S, num_steps, soft_mask, conf_thr, detach_bg, detach_mask_from_field, grad_sigmas, grad_rgbc, src_index);
+                       fars, N, S, num_steps, soft_mask, conf_thr, detach_bg, detach_mask_from_field, grad_sigmas, grad_rgbc, src_index,
+                       flush_half_zero ? 1.4901161193847656e-08f /* 2^-26 */ : 0.0f, tile_live, num_steps);
     return cn_launch_status();
+}
+
+int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,
+                                         const float *fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, int detach_bg,
+                                         int detach_mask_from_field, const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream) {
+    return cnerf_composite_run_backward_indexed_flush(grad_out_ray, sigmas, rgbc, z_vals, nears, fars, N, S, num_steps, soft_mask, conf_thr, detach_bg,
+                                                      detach_mask_from_field, src_index, grad_sigmas, grad_rgbc, 0, nullptr, stream);
 }
 
 int cnerf_composite_run_backward(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals, const float *nears,

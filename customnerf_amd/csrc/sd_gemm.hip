@@ -60,6 +60,173 @@ __device__ __forceinline__ bool sg_coord(int32_t num, uint32_t tstride, uint32_t
     return out < n_in;
 }
 
+// ---- epilogue phase 2 (shared by the 128-row kernel and the 256-row kernel of sd_gemm_big.hip): the fp32 tile sits in LDS as ct[BM][BN + 4];
+// every thread takes 8 consecutive columns of NIT rows: bias / per-image bias / activation / residual / GroupNorm statistics / 16-byte stores.
+// gn_lds: [GI = 4][36][2] 64-bit fixed-point scratch (images a tile can touch x (32 groups + 4) x {sum, sum of squares}).
+template <int BM, int BN, int NTHREADS, bool SPLIT>
+__device__ __forceinline__ void sg_epilogue_phase2(const CnerfSdGemm &g, const float *ct, long long (*gn_lds)[36][2], uint32_t tid, uint32_t m0, uint32_t n0,
+                                                   uint32_t zo, uint32_t zi, uint32_t split, float *__restrict__ partial) {
+    constexpr uint32_t LDC = BN + 4;
+    constexpr int SG_EPI_THREADS = NTHREADS;
+    // ---- phase 2: 8 consecutive columns per lane
+    // optional: GroupNorm statistics of the output for the norm that reads it next.  A thread's column chunk is fixed over its rows, so
+    // the (<= 2) groups' sums live in registers; flushed per image into a small LDS table, then one global atomic per (image, group) and tile.
+    const bool do_gn = !SPLIT && g.gn_sums != nullptr;
+    constexpr int GI = 4;                                // images a tile can touch (gn_rows >= 64)
+    const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u;
+    const uint32_t gn_g0 = n0 / gn_cg, gn_i0 = do_gn ? m0 / g.gn_rows : 0u;
+    if (do_gn) {
+        for (uint32_t i = tid; i < GI * 36 * 2; i += SG_EPI_THREADS) (&gn_lds[0][0][0])[i] = 0;
+        __syncthreads();
+    }
+    float gs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    uint32_t gn_img = 0xFFFFFFFFu;
+    _Float16 *C = (!SPLIT && g.C) ? reinterpret_cast<_Float16 *>(g.C) + g.sc_o * zo + g.sc_i * zi : nullptr;
+    float *C32 = SPLIT ? partial + (size_t)split * g.M * g.N : (g.C32 ? g.C32 + g.sc_o * zo + g.sc_i * zi : nullptr);
+    const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
+    const uint32_t ldc32 = SPLIT ? g.N : g.ldc;
+    constexpr uint32_t CPR = BN / 8;                    // column chunks per row
+    // The epilogue of a tile used to take 9.4 k cycles — 4 us, two thirds of a single-K-step launch and ~13 % of a large convolution's tile
+    // time (cycle stamps) — almost all of it instruction issue: every element of every item went through its own `n + e < N` exec-mask
+    // branch (three times), the activation switch and, for SiLU, an IEEE division.  Tiles that lie inside the problem (tile-uniform test)
+    // take a guard-free instantiation; the bias of a thread's column chunk (the same for all its items) is read once; the activation is
+    // selected once per item; the sigmoid forms use the hardware reciprocal (their result is rounded to half right after).
+    float bias8[8];
+    {
+        const uint32_t nb_ = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) bias8[e] = (!SPLIT && g.bias && nb_ + e < g.N) ? g.bias[nb_ + e] : 0.0f;
+    }
+    auto phase2 = [&](auto inside_c) __attribute__((always_inline)) {
+    constexpr bool INSIDE = decltype(inside_c)::value;   // the whole tile is inside [M, N]
+    constexpr int NIT = BM * CPR / SG_EPI_THREADS;            // items per thread (8 | 4): fixed trip count, unrolled — the LDS reads of all items
+#pragma unroll                                           // are in flight together instead of one read -> convert -> store chain per item
+    for (int k = 0; k < NIT; k++) {
+        const uint32_t c = tid + k * SG_EPI_THREADS;
+        const uint32_t row = c / CPR, cc = (c % CPR) * 8;
+        const uint32_t m = m0 + row, n = n0 + cc;
+        if (!INSIDE && (m >= g.M || n >= g.N)) continue;
+        const sd_f4 v0 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc), v1 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bool full = INSIDE || n + 8 <= g.N;
+        if (!SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = v[e] * g.alpha + bias8[e];            // (columns beyond N are never stored)
+            if (g.bias_rows) {
+                const float *brow_ = g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N);
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] += brow_[n + e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        if (INSIDE || n + e < g.N) v[e] += brow_[n + e];
+                }
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            } else if (g.act == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[e]));
+            }
+            if (R) {
+                const _Float16 *rp = R + (size_t)m * g.ldr + n;
+                if (full && ((g.ldr | n) & 7) == 0) {
+                    const sd_h8 rv = *reinterpret_cast<const sd_h8 *>(rp);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] += (float)rv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        if (INSIDE || n + e < g.N) v[e] += (float)rp[e];
+                }
+            }
+        }
+        if (!SPLIT && g.act == 4) {
+            // GEGLU on interleaved (value, gate) column pairs: out[m][n / 2 + e] = v[2e] * gelu(v[2e + 1]); the output is N / 2 wide
+            _Float16 *cp = C + (size_t)m * g.ldc + n / 2;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (INSIDE || n + 2 * e + 1 < g.N) {
+                    const float gt = v[2 * e + 1];
+                    cp[e] = (_Float16)(v[2 * e] * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752f))));
+                }
+            }
+            continue;
+        }
+        if (do_gn) {
+            const uint32_t img = m / g.gn_rows;
+            const uint32_t g_lo = n / gn_cg, split_c = (g_lo + 1) * gn_cg - n;      // columns [0, split_c) of the chunk belong to g_lo
+            if (img != gn_img) {
+                if (gn_img != 0xFFFFFFFFu) {
+                    const uint32_t gl = n / gn_cg - gn_g0;
+                    gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+                    gs[0][0] = gs[0][1] = gs[1][0] = gs[1][1] = 0.0f;
+                }
+                gn_img = img;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (INSIDE || n + e < g.N) {
+                    const float xf = (float)(_Float16)v[e];                         // what the consumer will read
+                    const int k = ((uint32_t)e < split_c) ? 0 : 1;
+                    gs[k][0] += xf;
+                    gs[k][1] += xf * xf;
+                }
+            }
+        }
+        if (C) {
+            _Float16 *cp = C + (size_t)m * g.ldc + n;
+            if (full && ((g.ldc | n) & 7) == 0 && ((((uintptr_t)C) & 15) == 0)) {
+                sd_h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (_Float16)v[e];
+                *reinterpret_cast<sd_h8 *>(cp) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (INSIDE || n + e < g.N) cp[e] = (_Float16)v[e];
+            }
+        }
+        if (C32) {
+            float *cp = C32 + (size_t)m * ldc32 + n;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (INSIDE || n + e < g.N) cp[e] = v[e];
+        }
+    }
+    };
+    if (m0 + BM <= g.M && n0 + BN <= g.N) phase2(std::true_type{});
+    else phase2(std::false_type{});
+    if (do_gn) {
+        if (gn_img != 0xFFFFFFFFu) {
+            const uint32_t gl = (n0 + (tid % CPR) * 8) / gn_cg - gn_g0;
+            gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
+            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+        }
+        __syncthreads();
+        const uint32_t n_img = g.M / g.gn_rows;
+        for (uint32_t i = tid; i < GI * 36; i += SG_EPI_THREADS) {
+            const uint32_t im = i / 36, gl = i % 36, img = gn_i0 + im, grp = gn_g0 + gl;
+            const long long a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
+            if (img < n_img && grp < g.gn_groups) {
+                long long *dst = reinterpret_cast<long long *>(g.gn_sums) + ((size_t)img * g.gn_groups + grp) * 2;
+                gn_add_fixed(dst, a);
+                gn_add_fixed(dst + 1, b2);
+            }
+        }
+    }
+}
+
 // AMODE 0: dense A.  1: implicit conv, tap resolved per 16-byte chunk.  2: implicit conv with Cin % 64 == 0 (tap uniform per K step).
 // row r of a [rows][64 halfs] LDS stage, 16-byte chunk c: XOR swizzle keyed on (row >> 1) & 7 — every ds_read_b128 lane group (16 lanes,
 // consecutive-ish rows, one chunk column) then covers all sixteen 16-byte slots of the 256-byte bank row: conflict-free.
@@ -366,164 +533,197 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
 #pragma unroll
             for (int r = 0; r < 16; r++) ct[(wm * 32 * MT + i * 32 + sg_rho(r, hi)) * LDC + wn * 32 * NT + j * 32 + li] = acc[i][j][r];
     __syncthreads();
-    // ---- phase 2: 8 consecutive columns per lane
-    // optional: GroupNorm statistics of the output for the norm that reads it next.  A thread's column chunk is fixed over its rows, so
-    // the (<= 2) groups' sums live in registers; flushed per image into a small LDS table, then one global atomic per (image, group) and tile.
-    const bool do_gn = !SPLIT && g.gn_sums != nullptr;
-    constexpr int GI = 4;                                // images a tile can touch (gn_rows >= 64)
-    __shared__ long long gn_lds[GI][36][2];           // 64-bit fixed point (sd_gn_fix.h): exact, order-independent sums
-    const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u;
-    const uint32_t gn_g0 = n0 / gn_cg, gn_i0 = do_gn ? m0 / g.gn_rows : 0u;
-    if (do_gn) {
-        for (uint32_t i = tid; i < GI * 36 * 2; i += SG_THREADS) (&gn_lds[0][0][0])[i] = 0;
-        __syncthreads();
-    }
-    float gs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-    uint32_t gn_img = 0xFFFFFFFFu;
-    _Float16 *C = (!SPLIT && g.C) ? reinterpret_cast<_Float16 *>(g.C) + g.sc_o * zo + g.sc_i * zi : nullptr;
-    float *C32 = SPLIT ? partial + (size_t)split * g.M * g.N : (g.C32 ? g.C32 + g.sc_o * zo + g.sc_i * zi : nullptr);
-    const _Float16 *R = (!SPLIT && g.residual) ? reinterpret_cast<const _Float16 *>(g.residual) + g.sc_o * zo + g.sc_i * zi : nullptr;
-    const uint32_t ldc32 = SPLIT ? g.N : g.ldc;
-    constexpr uint32_t CPR = BN / 8;                    // column chunks per row
-    // The epilogue of a tile used to take 9.4 k cycles — 4 us, two thirds of a single-K-step launch and ~13 % of a large convolution's tile
-    // time (cycle stamps) — almost all of it instruction issue: every element of every item went through its own `n + e < N` exec-mask
-    // branch (three times), the activation switch and, for SiLU, an IEEE division.  Tiles that lie inside the problem (tile-uniform test)
-    // take a guard-free instantiation; the bias of a thread's column chunk (the same for all its items) is read once; the activation is
-    // selected once per item; the sigmoid forms use the hardware reciprocal (their result is rounded to half right after).
-    float bias8[8];
+    // ---- phase 2: 8 consecutive columns per lane (sg_epilogue_phase2)
+    __shared__ long long gn_lds[4][36][2];            // 64-bit fixed point (sd_gn_fix.h): exact, order-independent sums
+    sg_epilogue_phase2<BM, BN, SG_THREADS, SPLIT>(g, ct, gn_lds, tid, m0, n0, zo, zi, split, partial);
+}
+
+// ================================================================================================ 256-row tile, eight waves, three stages (round 5)
+// The 128 x {64, 128} kernel above fills 24-32 KiB of LDS per 2.1 MFLOP K step and drains its single step of prefetch at every barrier
+// (`vmcnt(0)` + `__syncthreads()`): on the large-M convolutions of the VAE (M = 16 K ... 262 K rows, N = 128 ... 512) its matrix pipe is busy
+// 28 % of the time (profiles/r04_sd_mfma_pmc.json).  This kernel takes a 256 x 128 tile with EIGHT waves (4 x 2, each the same 64 x 64 wave
+// tile and the same 32x32x16 MFMA sequence per K step as above: the accumulation order, hence every output bit, is unchanged):
+//   * the B tile (weights) is shared by 256 rows instead of 128: 48 KiB of LDS fill per 4.2 MFLOP instead of 64;
+//   * THREE 48 KiB stages as a ring, two K steps in flight: `s_waitcnt vmcnt(6)` (the six LDS-DMA instructions of the newest step may still be
+//     in flight) + a bare `s_barrier` per K step — the DMA queue never drains inside the loop (the guide's counted-vmcnt rule; the 128-row
+//     kernel cannot afford a third stage without losing its second resident workgroup);
+//   * one workgroup per CU = two waves per SIMD, as before (two four-wave workgroups), but they now share one barrier domain and one B tile;
+//   * consecutive M tiles go to the same XCD (bijective swizzle): the 3 x 3 halo rows of neighbouring tiles are served by one L2.
+// Dense / implicit-conv (Cin % 64 == 0) operands through the same buffer-descriptor LDS-DMA rounds (64 rows per round with 512 threads), the
+// same XOR swizzle on the source chunk and on the fragment reads, the same epilogue (sg_epilogue_phase2), no split-K (the launches it serves have
+// >= one workgroup per CU by themselves).
+#define SGB_BM 256
+#define SGB_BN 128
+#define SGB_THREADS 512
+#define SGB_STAGE ((SGB_BM + SGB_BN) * SG_BK * 2)                 // bytes
+#define SGB_STAGES 3
+__host__ __device__ constexpr uint32_t sgb_lds_bytes() {
+    return (SGB_STAGES * SGB_STAGE > SGB_BM * (SGB_BN + 4) * 4 ? SGB_STAGES * SGB_STAGE : SGB_BM * (SGB_BN + 4) * 4) + 4 * 36 * 2 * 8;
+}
+
+template <int AMODE, bool SIMPLE>
+__global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g) {
+    constexpr int BM = SGB_BM, BN = SGB_BN, MT = 2, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sgb_lds[];          // the ONLY LDS object (a second one makes hipcc drain the DMA queue before every ds_read)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+    const uint32_t wm = wave >> 1, wn = wave & 1;
+    // XCD-aware M-tile order: workgroup b runs on XCD b % 8; XCD x takes a contiguous run of M tiles
+    uint32_t mt;
     {
-        const uint32_t nb_ = n0 + (tid % CPR) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; e++) bias8[e] = (!SPLIT && g.bias && nb_ + e < g.N) ? g.bias[nb_ + e] : 0.0f;
+        const uint32_t n = gridDim.x, q = n / CN_NXCD, r = n % CN_NXCD, xcd = blockIdx.x % CN_NXCD, k = blockIdx.x / CN_NXCD;
+        mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    auto phase2 = [&](auto inside_c) __attribute__((always_inline)) {
-    constexpr bool INSIDE = decltype(inside_c)::value;   // the whole tile is inside [M, N]
-    constexpr int NIT = BM * CPR / SG_THREADS;            // items per thread (8 | 4): fixed trip count, unrolled — the LDS reads of all items
-#pragma unroll                                           // are in flight together instead of one read -> convert -> store chain per item
-    for (int k = 0; k < NIT; k++) {
-        const uint32_t c = tid + k * SG_THREADS;
-        const uint32_t row = c / CPR, cc = (c % CPR) * 8;
-        const uint32_t m = m0 + row, n = n0 + cc;
-        if (!INSIDE && (m >= g.M || n >= g.N)) continue;
-        const sd_f4 v0 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc), v1 = *reinterpret_cast<const sd_f4 *>(ct + row * LDC + cc + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const bool full = INSIDE || n + 8 <= g.N;
-        if (!SPLIT) {
+    const uint32_t m0 = mt * BM, n0 = blockIdx.y * BN;
+    const uint32_t z = blockIdx.z;
+    const uint32_t zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
+    const _Float16 *A = reinterpret_cast<const _Float16 *>(g.A) + g.sa_o * zo + g.sa_i * zi;
+    const _Float16 *B = reinterpret_cast<const _Float16 *>(g.B) + g.sb_o * zo + g.sb_i * zi;
+    const uint32_t n_k = (g.K + SG_BK - 1) / SG_BK;
+
+    sd_f16v acc[MT][NT];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = v[e] * g.alpha + bias8[e];            // (columns beyond N are never stored)
-            if (g.bias_rows) {
-                const float *brow_ = g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N);
-                if (full) {
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] += brow_[n + e];
-                } else {
+        for (int j = 0; j < NT; j++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        if (INSIDE || n + e < g.N) v[e] += brow_[n + e];
-                }
-            }
-            if (g.act == 1) {
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    constexpr int RA = BM / 64, RB = BN / 64;                                      // LDS-DMA rounds per K step (64 rows x 128 bytes per round)
+    constexpr uint32_t OOB = 0xFFFFFF00u;
+    const uint32_t grow = tid >> 3, gch = tid & 7u;
+    const uint32_t a_batch = AMODE == 0 ? 1u : g.M / (g.H_out * g.W_out);
+    const uint32_t a_bytes = AMODE == 0 ? (uint32_t)(((size_t)(g.M - 1) * g.lda + g.K) * 2) : (uint32_t)((size_t)a_batch * g.H_in * g.W_in * g.Cin * 2);
+    const uint32_t b_bytes = (uint32_t)(((size_t)(g.N - 1) * g.ldb + g.K) * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(B), 0, b_bytes, 0x00020000);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t a_sc0 = sg_swz(grow, gch) * 8;                                   // (row >> 1) & 7 is the same for rows 64 r + grow
+    uint32_t a_off[RA];
+    int32_t a_oh[RA], a_ow[RA];
+    bool a_ok[RA];
 #pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
-            } else if (g.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
-            } else if (g.act == 3) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[e]));
-            }
-            if (R) {
-                const _Float16 *rp = R + (size_t)m * g.ldr + n;
-                if (full && ((g.ldr | n) & 7) == 0) {
-                    const sd_h8 rv = *reinterpret_cast<const sd_h8 *>(rp);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] += (float)rv[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        if (INSIDE || n + e < g.N) v[e] += (float)rp[e];
-                }
-            }
+    for (int r = 0; r < RA; r++) {
+        const uint32_t row = 64 * r + grow, m = m0 + row;
+        a_ok[r] = m < g.M;
+        a_oh[r] = a_ow[r] = 0;
+        const uint32_t mm = a_ok[r] ? m : 0;
+        if (AMODE == 0) a_off[r] = (mm * g.lda + a_sc0) * 2;
+        else {
+            const uint32_t hw = g.H_out * g.W_out;
+            const uint32_t img = mm / hw, rem = mm - img * hw, oh = rem / g.W_out, ow = rem - oh * g.W_out;
+            a_oh[r] = (int32_t)(oh * g.stride) - (int32_t)g.pad_t;
+            a_ow[r] = (int32_t)(ow * g.stride) - (int32_t)g.pad_l;
+            a_off[r] = ((img * g.H_in + (uint32_t)a_oh[r]) * g.W_in + (uint32_t)a_ow[r]) * g.Cin * 2 + a_sc0 * 2;      // wrapping 32-bit arithmetic (see k_sd_gemm)
+            if (!SIMPLE) a_off[r] = img * g.H_in * g.W_in * g.Cin * 2 + a_sc0 * 2;
         }
-        if (!SPLIT && g.act == 4) {
-            // GEGLU on interleaved (value, gate) column pairs: out[m][n / 2 + e] = v[2e] * gelu(v[2e + 1]); the output is N / 2 wide
-            _Float16 *cp = C + (size_t)m * g.ldc + n / 2;
+    }
+    uint32_t b_off[RB];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (INSIDE || n + 2 * e + 1 < g.N) {
-                    const float gt = v[2 * e + 1];
-                    cp[e] = (_Float16)(v[2 * e] * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752f))));
-                }
-            }
-            continue;
-        }
-        if (do_gn) {
-            const uint32_t img = m / g.gn_rows;
-            const uint32_t g_lo = n / gn_cg, split_c = (g_lo + 1) * gn_cg - n;      // columns [0, split_c) of the chunk belong to g_lo
-            if (img != gn_img) {
-                if (gn_img != 0xFFFFFFFFu) {
-                    const uint32_t gl = n / gn_cg - gn_g0;
-                    gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
-                    gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
-                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
-                    gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
-                    gs[0][0] = gs[0][1] = gs[1][0] = gs[1][1] = 0.0f;
-                }
-                gn_img = img;
-            }
+    for (int r = 0; r < RB; r++) {
+        const uint32_t row = 64 * r + grow, n = n0 + row;
+        b_off[r] = n < g.N ? (n * g.ldb + sg_swz(row, gch) * 8) * 2 : OOB;
+    }
+    uint32_t t_kh = 0, t_kw = 0, t_c0 = 0;                                         // uniform tap state (AMODE 2), advanced once per issued K step
+    auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+        const uint32_t i_k = kt * SG_BK;
+        unsigned char *sA = sgb_lds + (size_t)stage * SGB_STAGE, *sB = sA + BM * SG_BK * 2;
+        const bool kin = i_k + a_sc0 < g.K;
+        const uint32_t tap = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : i_k * 2;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                if (INSIDE || n + e < g.N) {
-                    const float xf = (float)(_Float16)v[e];                         // what the consumer will read
-                    const int k = ((uint32_t)e < split_c) ? 0 : 1;
-                    gs[k][0] += xf;
-                    gs[k][1] += xf * xf;
-                }
-            }
-        }
-        if (C) {
-            _Float16 *cp = C + (size_t)m * g.ldc + n;
-            if (full && ((g.ldc | n) & 7) == 0 && ((((uintptr_t)C) & 15) == 0)) {
-                sd_h8 o;
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = (_Float16)v[e];
-                *reinterpret_cast<sd_h8 *>(cp) = o;
+        for (int r = 0; r < RA; r++) {
+            uint32_t voff;
+            if (AMODE == 0) {
+                voff = (a_off[r] + tap) | ((a_ok[r] && kin) ? 0u : OOB);
+            } else if (SIMPLE) {
+                const bool ok = a_ok[r] && (uint32_t)(a_oh[r] + (int32_t)t_kh) < g.H_in && (uint32_t)(a_ow[r] + (int32_t)t_kw) < g.W_in;
+                voff = (a_off[r] + tap) | (ok ? 0u : OOB);
             } else {
+                uint32_t ih = 0, iw = 0;
+                const bool ok = a_ok[r] && sg_coord(a_oh[r] + (int32_t)t_kh, g.tstride, g.ups, g.H_in, ih) &&
+                                sg_coord(a_ow[r] + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
+                voff = ok ? a_off[r] + ((ih * g.W_in + iw) * g.Cin + t_c0) * 2 : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(sA + (64 * r + 8 * wave_u) * 128), 16, voff, 0, 0, 0);
+        }
 #pragma unroll
-                for (int e = 0; e < 8; e++)
-                    if (INSIDE || n + e < g.N) cp[e] = (_Float16)v[e];
+        for (int r = 0; r < RB; r++) {
+            const uint32_t voff = b_off[r] | (kin ? 0u : OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(sB + (64 * r + 8 * wave_u) * 128), 16, voff, i_k * 2, 0, 0);
+        }
+        if (AMODE == 2) {
+            t_c0 += SG_BK;
+            if (t_c0 >= g.Cin) {
+                t_c0 = 0;
+                if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
             }
         }
-        if (C32) {
-            float *cp = C32 + (size_t)m * ldc32 + n;
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                if (INSIDE || n + e < g.N) cp[e] = v[e];
-        }
-    }
     };
-    if (m0 + BM <= g.M && n0 + BN <= g.N) phase2(std::true_type{});
-    else phase2(std::false_type{});
-    if (do_gn) {
-        if (gn_img != 0xFFFFFFFFu) {
-            const uint32_t gl = (n0 + (tid % CPR) * 8) / gn_cg - gn_g0;
-            gn_add(&gn_lds[gn_img - gn_i0][gl][0], gs[0][0]);
-            gn_add(&gn_lds[gn_img - gn_i0][gl][1], gs[0][1]);
-            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][0], gs[1][0]);
-            gn_add(&gn_lds[gn_img - gn_i0][gl + 1][1], gs[1][1]);
+    uint32_t a_rd[MT][4], b_rd[NT][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const uint32_t row = wm * 64 + i * 32 + li;
+            a_rd[i][s2] = row * 128 + sg_swz(row, 2 * s2 + hi) * 16;
         }
-        __syncthreads();
-        const uint32_t n_img = g.M / g.gn_rows;
-        for (uint32_t i = tid; i < GI * 36; i += SG_THREADS) {
-            const uint32_t im = i / 36, gl = i % 36, img = gn_i0 + im, grp = gn_g0 + gl;
-            const long long a = gn_lds[im][gl][0], b2 = gn_lds[im][gl][1];
-            if (img < n_img && grp < g.gn_groups) {
-                long long *dst = reinterpret_cast<long long *>(g.gn_sums) + ((size_t)img * g.gn_groups + grp) * 2;
-                gn_add_fixed(dst, a);
-                gn_add_fixed(dst + 1, b2);
-            }
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const uint32_t row = wn * 64 + j * 32 + li;
+            b_rd[j][s2] = row * 128 + sg_swz(row, 2 * s2 + hi) * 16;
         }
     }
+    // ---- ring of three stages, two K steps in flight
+    issue(0, 0);
+    if (n_k > 1) issue(1, 1);
+    uint32_t stage = 0;
+    for (uint32_t it = 0; it < n_k; it++) {
+        // this wave's share of step `it` has landed (the newer step's six DMA instructions may still be in flight) ...
+        if (it + 1 < n_k) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and after the barrier everybody's has, and everybody is done reading the stage that step it + 2 overwrites (read in step it - 1)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < n_k) issue(it + 2, stage >= 1 ? stage - 1 : 2);                // (it + 2) % 3
+        const unsigned char *sA = sgb_lds + (size_t)stage * SGB_STAGE, *sB = sA + BM * SG_BK * 2;
+        sd_h8 a[2][MT], b[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][0]);
+#pragma unroll
+        for (int j = 0; j < NT; j++) b[0][j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][0]);
+#pragma unroll
+        for (int s2 = 0; s2 < SG_BK / 16; s2++) {
+            const int cur = s2 & 1, nxt = cur ^ 1;
+            if (s2 + 1 < SG_BK / 16) {
+#pragma unroll
+                for (int i = 0; i < MT; i++) a[nxt][i] = *reinterpret_cast<const sd_h8 *>(sA + a_rd[i][s2 + 1]);
+#pragma unroll
+                for (int j = 0; j < NT; j++) b[nxt][j] = *reinterpret_cast<const sd_h8 *>(sB + b_rd[j][s2 + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    __syncthreads();                                                               // every wave is done with the last stage: the tile may take its place
+    // ---- epilogue phase 1: fp32 tile -> LDS [256][BN + 4]
+    constexpr uint32_t LDC = BN + 4;
+    float *ct = reinterpret_cast<float *>(sgb_lds);
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ct[(wm * 64 + i * 32 + sg_rho(r, hi)) * LDC + wn * 64 + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    constexpr uint32_t CT_BYTES = SGB_STAGES * SGB_STAGE > BM * LDC * 4 ? SGB_STAGES * SGB_STAGE : BM * LDC * 4;
+    long long (*gn_lds)[36][2] = reinterpret_cast<long long (*)[36][2]>(sgb_lds + CT_BYTES);
+    sg_epilogue_phase2<BM, BN, SGB_THREADS, false>(g, ct, gn_lds, tid, m0, n0, zo, zi, 0u, nullptr);
 }
 
 // split-K tail: sum the partials, apply the epilogue
@@ -685,6 +885,34 @@ static bool sg_use_glds(const CnerfSdGemm *g) {
     return v != 0 && sg_glds_fits(g);
 }
 
+// Which problems take the 256 x 128 eight-wave kernel: LDS-DMA-able operands (dense, or a convolution with Cin % 64 == 0), no split-K, and enough
+// tiles to give every CU a workgroup (below that the 128-row tiles fill the chip better); a GroupNorm-statistics request needs images of at
+// least 128 rows (a 256-row tile then touches at most three: the epilogue's table holds four).
+static bool sg_use_big(const CnerfSdGemm *g, const SgPlan &plan) {
+    static const int on = cn_tune_env("CNERF_SG_BIG", 1);
+    static const int min_tiles = cn_tune_env("CNERF_SG_BIG_TILES", 224), min_k = cn_tune_env("CNERF_SG_BIG_K", 512);
+    if (!on || plan.splits > 1 || !sg_use_glds(g)) return false;
+    if (g->mode != 0 && (g->Cin % SG_BK) != 0) return false;
+    if (g->gn_sums && g->gn_rows < 128) return false;
+    if (g->K < (uint32_t)min_k || (g->N % SGB_BN) > 0 && (g->N % SGB_BN) <= 64 && g->N < 1024) return false;      // (a ragged last N tile that is mostly padding)
+    const uint64_t tiles = (uint64_t)cn_div_up(g->M, SGB_BM) * cn_div_up(g->N, SGB_BN) * g->batch_outer * g->batch_inner;
+    return tiles >= (uint64_t)min_tiles;
+}
+
+static void sgb_launch(const CnerfSdGemm *g, hipStream_t st) {
+    const dim3 grid(cn_div_up(g->M, SGB_BM), cn_div_up(g->N, SGB_BN), g->batch_outer * g->batch_inner);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        attr_set = true;
+    }
+    if (g->mode == 0) hipLaunchKernelGGL((k_sd_gemm_big<0, false>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+    else if (g->tstride == 1 && g->ups == 1) hipLaunchKernelGGL((k_sd_gemm_big<2, true>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+    else hipLaunchKernelGGL((k_sd_gemm_big<2, false>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+}
+
 template <int AMODE, int NT, bool SPLIT, bool GLDS, bool SIMPLE = false>
 static void sg_launch_g(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
     if constexpr (GLDS && AMODE == 2 && !SIMPLE) {
@@ -749,6 +977,10 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
         kps = cn_div_up(g->K, SG_BK);
     }
     const bool split = splits > 1;
+    if (!split && sg_use_big(g, plan)) {
+        sgb_launch(g, st);
+        return cn_launch_status();
+    }
     const dim3 grid(cn_div_up(g->M, SG_BM), cn_div_up(g->N, 64 * nt), split ? splits : g->batch_outer * g->batch_inner);
     const int amode = g->mode == 0 ? 0 : ((g->Cin % SG_BK) == 0 ? 2 : 1);
     float *partial = reinterpret_cast<float *>(workspace);

@@ -73,6 +73,12 @@ class FieldFunction(Function):
         dir_group, enc_dim, n_hidden_geo, n_rgb_out = ctx.cfg
         P = xyz.shape[0]
         dt = F16 if enc.dtype == torch.float16 else F32
+        # early termination: the compositing backward (render_ops._CompositeRunIndexed with flush_half_zero) hands over, on the gradient tensor itself,
+        # one byte per 32-row tile of the sample list — 0 = every output gradient of the tile is exactly zero (autograd passes the very tensor
+        # object on; a gradient that was accumulated or copied on the way simply arrives without the attribute and nothing is skipped)
+        tile_live = getattr(g_sigma, '_cnerf_tile_live', None)
+        if tile_live is not None and not (g_sigma.is_contiguous() and g_sigma.dtype == torch.float32 and tile_live.numel() * 32 == P and tile_live.is_cuda):
+            tile_live = None
         g_sigma = g_sigma.contiguous().float()
         g_rgbc = g_rgbc.contiguous().float()
         g_enc = torch.empty_like(enc)
@@ -88,9 +94,9 @@ class FieldFunction(Function):
         ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
         if in_place:
             grad_chain_wait(xyz.device)                                # the partial reduction adds into the shared .grad buffers
-        check(lib.cnerf_field_backward(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
-                                       ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
-                                       ptr(ws), ws.numel(), dt, stream()), "field_backward")
+        check(lib.cnerf_field_backward_ex(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
+                                          ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
+                                          ptr(ws), ws.numel(), dt, ptr(tile_live), stream()), "field_backward")
         if in_place:
             grad_chain_record(xyz.device)
             return g_enc, None, None, None, None, None, None, None, None, None, None

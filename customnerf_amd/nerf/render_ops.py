@@ -78,10 +78,11 @@ class _CompositeRunIndexed(Function):
     what it needs from sigma / rgbc, and the result dict asks for them lazily (composite_run_indexed_aux)."""
 
     @staticmethod
-    def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask):
+    def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero=False):
         sigmas = sigmas.contiguous().float()
         rgbc = rgbc.contiguous().float()
         N, S = z_vals.shape
+        ctx.flush = bool(flush_half_zero)
         out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=z_vals.device)
         check(lib.cnerf_composite_run_indexed(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
                                               ptr(src_index), ptr(out_ray), None, None, None, stream()), "composite_run_indexed")
@@ -92,21 +93,35 @@ class _CompositeRunIndexed(Function):
     @staticmethod
     def backward(ctx, g_ray):
         if g_ray is None:
-            return (None,) * 11
+            return (None,) * 12
         sigmas, rgbc, z_vals, src_index, nears, fars = ctx.saved_tensors
         num_steps, soft, thr, dbg, dmask = ctx.cfg
         N, S = z_vals.shape
         g_ray = g_ray.contiguous().float()
         g_sigma = torch.empty_like(sigmas)                      # src_index is a permutation of the rows: every element is written
         g_rgbc = torch.empty_like(rgbc)
-        check(lib.cnerf_composite_run_backward_indexed(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr,
-                                                       dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward_indexed")
-        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None, None
+        if ctx.flush:
+            # early termination for the half-precision fused field: rows whose gradients round to zero in the form its backward consumes them are
+            # written as exact zeros (bit-identical parameter gradients), and — when every ray owns whole 32-row tiles of the sample list — one
+            # byte per tile says whether anything is left in it; the flags travel on the gradient tensor (field.FieldFunction.backward)
+            tiles = (num_steps % 32 == 0 and (S - num_steps) % 32 == 0 and 0 < num_steps < S and S <= 256 and g_sigma.numel() == N * S)
+            tile_live = torch.empty(N * S // 32, dtype=torch.uint8, device=g_sigma.device) if tiles else None
+            check(lib.cnerf_composite_run_backward_indexed_flush(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft,
+                                                                 thr, dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), 1, ptr(tile_live), stream()),
+                  "composite_run_backward_indexed_flush")
+            if tile_live is not None:
+                g_sigma._cnerf_tile_live = tile_live
+        else:
+            check(lib.cnerf_composite_run_backward_indexed(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr,
+                                                           dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward_indexed")
+        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None, None, None
 
 
-def composite_run_indexed(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False):
-    """sigmas [P], rgbc [P,4] in sample-list order -> out_ray [3,N,6] (differentiable in sigmas / rgbc)"""
-    return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask)
+def composite_run_indexed(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False,
+                          flush_half_zero=False):
+    """sigmas [P], rgbc [P,4] in sample-list order -> out_ray [3,N,6] (differentiable in sigmas / rgbc).
+    flush_half_zero: the producer of sigmas / rgbc is the half-precision fused field (cnerf_composite_run_backward_indexed_flush)."""
+    return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero)
 
 
 @torch.no_grad()

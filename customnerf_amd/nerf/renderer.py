@@ -237,7 +237,10 @@ class NeRFRenderer(nn.Module):
                 sig_l, rgbc_l = self.split_attach(enc, unit, xyz_list, dirs2, num_steps, sig_all, rgbc_all, plan=plan)
             else:
                 sig_l, rgbc_l = self.split_forward(enc, unit, xyz_list, dirs2, num_steps, plan=plan)
-            out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask)
+            # early termination of the backward (north_star; the reference's own is `T < T_thresh` on its march path): only where the gradients
+            # go into the half-precision fused field, whose backward rounds them to half anyway
+            flush = bool(grad_on and getattr(self.opt, 'early_termination', True) and self._fused_cfg() and self._half())
+            out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask, flush_half_zero=flush)
             # per-sample by-products (weights, sorted-order sigma / rgbc copies, detached): a second launch, only if somebody reads them
             aux = _Lazy(lambda: render_ops.composite_run_indexed_aux(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr))
             weights_of = lambda v: _Lazy(lambda: aux.get()[0][v])

@@ -178,6 +178,12 @@ int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offse
  * row0 must be a multiple of *block_points (cnerf_grid_encode_backward_prepare_block) and the range must end on a block border or at B;
  * ..._finish runs the scans once every row has been counted.  *prepared = 0: nothing launched (the shape takes the atomic kernel / float32 records). */
 int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points);
+/* *needs_plan = 1 when cnerf_grid_encode_backward of this shape profits from a plan prepared ahead of time (the forms that need the exact record
+ * counts before the emit: float16 records on tables of more than 128 chunks per level, e.g. T = 2^21; float32 records); 0 when there is nothing to
+ * prepare — the atomic kernel, or (round 5) the scatter that counts inside its emit kernel: float16 records, <= 128 chunks of 4096 entries per level.
+ * The _prepare* entry points report *prepared = 0 for such shapes; this query lets a caller skip them (and their workspace) altogether. */
+int cnerf_grid_encode_backward_needs_plan(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
+                                          uint32_t H, int dtype, int *needs_plan);
 int cnerf_grid_encode_backward_prepare_rows(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                             float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, uint32_t row0,
                                             uint32_t rows, void *workspace, uint64_t workspace_bytes, int *prepared, void *stream);
@@ -233,6 +239,14 @@ int cnerf_field_backward(const void *enc, const float *xyz, const float *dirs, u
                          const float *params_rgb, const float *grad_sigma, const float *grad_rgbc, void *grad_enc,
                          float *grad_params_net, float *grad_params_den, float *grad_params_rgb, void *workspace,
                          uint64_t workspace_bytes, int dtype, void *stream);
+/* cnerf_field_backward with early termination: tile_live (optional) = the uint8 [ceil(P / 32)] flags of
+ * cnerf_composite_run_backward_indexed_flush — a zero byte promises that grad_sigma / grad_rgbc of rows 32 k .. 32 k + 31 are exactly zero; the
+ * kernel then skips the tile (its rows of grad_enc are written as zeros, the weight gradients are bit-identical: skipped tiles add exact zeros). */
+int cnerf_field_backward_ex(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                            uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                            const float *params_rgb, const float *grad_sigma, const float *grad_rgbc, void *grad_enc,
+                            float *grad_params_net, float *grad_params_den, float *grad_params_rgb, void *workspace,
+                            uint64_t workspace_bytes, int dtype, const uint8_t *tile_live, void *stream);
 int cnerf_field_backward_workspace_bytes(uint32_t P, uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, int dtype,
                                          uint64_t *bytes);
 
@@ -338,6 +352,17 @@ int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float 
                                          const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
                                          int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
                                          const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, void *stream);
+/* The same with early termination for a half-precision consumer (round 5; the reference's own early-out is `T < T_thresh` in
+ * raymarching.cu:691-772, its run() path has none).  flush_half_zero: a sample whose gradients AS THE FUSED FIELD BACKWARD CONSUMES THEM —
+ * half(g_sigma * exp'(raw)), half(g_c * sigmoid'(c)) — are all zero (|g_sigma| sigma < 2^-26 and |g_c| c (1 - c) < 2^-26: behind an opaque
+ * surface, in empty space) gets exact zeros in grad_sigmas / grad_rgbc: every parameter gradient computed downstream is bit-identical, and the
+ * field backward / grid scatter can skip the row.  tile_live (optional, uint8 [N * S / 32]; needs src_index and num_steps, S - num_steps
+ * multiples of 32): byte k = 1 when rows 32 k .. 32 k + 31 of the sample list hold at least one live row (cnerf_field_backward_ex). */
+int cnerf_composite_run_backward_indexed_flush(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals,
+                                               const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
+                                               int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,
+                                               const uint32_t *src_index, float *grad_sigmas, float *grad_rgbc, int flush_half_zero,
+                                               uint8_t *tile_live, void *stream);
 
 /* Loss of the reconstruction step (Trainer_Nerf.train_step_pretrain, utils_init_nerf.py:220-234) with its gradient, one launch:
  *   loss = w_rgb * mean((image - rgb_gt)^2) + w_conf * mean((render_mask - mask_gt)^2)

@@ -209,6 +209,53 @@ def test_backward_binned_no_atomics(name, kw, half):
         assert torch.equal(gc, gd)
 
 
+def test_scatter_skips_zero_rows_and_recomputes_overflowing_bins():
+    """Round 5 scatter (no histogram pre-pass: block-local counting, one run reservation per (block, bin) in fixed-capacity bin regions on the
+    hashed levels, run tables on the dense ones).  (a) Rows whose gradient is exactly zero emit no records: the table gradient is BIT-identical to
+    the scatter of the list with those rows removed.  (b) A sample distribution that defeats the hash — every sample in one tiny cube, so a few bins
+    of each hashed level receive all records and overflow their regions — is recomputed exactly by the fallback sweep: same result as the atomic
+    kernel, and the same bits on every run."""
+    from customnerf_amd._lib import lib, ptr, stream, check
+    import ctypes
+    enc = build(CONFIGS[0][1])
+    L, C = enc.num_levels, enc.level_dim
+    S = float(np.log2(enc.per_level_scale))
+
+    def scatter(x, g_lbc, binned=True):
+        B = x.shape[0]
+        need = ctypes.c_uint64(0)
+        lib.cnerf_grid_encode_backward_workspace_bytes(enc._offsets_host.ctypes.data, B, 3, C, L, L, S, enc.base_resolution, 1, ctypes.addressof(need))
+        assert need.value > 0
+        ws = torch.empty(int(need.value) + 256, dtype=torch.uint8, device='cuda') if binned else None
+        out = torch.zeros(enc.embeddings.shape, device='cuda')
+        check(lib.cnerf_grid_encode_backward(ptr(g_lbc), ptr(x), enc._offsets_host.ctypes.data, ptr(out), B, 3, C, L, L, S, enc.base_resolution, None, None,
+                                             enc.gridtype_id, int(enc.align_corners), enc.interp_id, 1, ptr(ws), ws.numel() if binned else 0, stream()))
+        return out
+    # (a)
+    B = 150001
+    rng = np.random.default_rng(21)
+    x = cuda(make_inputs(B, 3, seed=22))
+    g = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32)).cuda().half()
+    dead = torch.from_numpy(rng.random(B) < 0.7).cuda()
+    g[:, dead] = 0
+    full = scatter(x, g.contiguous())
+    keep = (~dead).nonzero().squeeze(1)
+    compact = scatter(x[keep].contiguous(), g[:, keep].contiguous())
+    assert int(keep.numel()) * L >= (1 << 20)                     # the compacted list still takes the binned path
+    assert torch.equal(full, compact)
+    assert float(full.abs().max()) > 1.0
+    # (b)
+    B = 120001
+    xb = (torch.rand(B, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * (1.0 / 2048) + 0.3137).contiguous()
+    gb = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32)).cuda().half().contiguous()
+    r1 = scatter(xb, gb)
+    r2 = scatter(xb, gb)
+    ra = scatter(xb, gb, binned=False)                             # float atomics: order-dependent rounding, so a tolerance scaled to the sums
+    assert torch.equal(r1, r2)
+    scale = float(ra.abs().max())
+    assert scale > 100.0 and float((r1 - ra).abs().max()) < 2e-3 * scale
+
+
 def test_grad_total_variation():
     kw = CONFIGS[0][1]
     enc = build(kw, scale=0.5, seed=7)

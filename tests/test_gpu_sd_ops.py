@@ -314,7 +314,8 @@ def test_image_front_end_and_sds_tail():
     close(gr, ref_g, 1e-5, 1e-6)
 
 
-@pytest.mark.parametrize("B,C,H,Co", [(2, 320, 64, 320), (1, 128, 96, 128), (2, 64, 8, 128), (2, 320, 16, 640)])
+@pytest.mark.parametrize("B,C,H,Co", [(2, 320, 64, 320), (1, 128, 96, 128), (2, 64, 8, 128), (2, 320, 16, 640),
+                                      (1, 128, 256, 128), (2, 256, 128, 256)])                       # the 256-row eight-wave kernel (>= 224 tiles)
 def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     """the producing conv accumulates the next GroupNorm's statistics in its epilogue (gn=): same normalised output as the two-pass norm"""
     from customnerf_amd.sd import ops, pack
@@ -339,6 +340,46 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     ops.conv2d(x, w, b, 3, gn=(sums2, 32, H * H))
     _, s_ref2 = ops.groupnorm(y_ref, gamma, beta, 32, 1e-5, True)
     assert torch.equal(sums, sums2) and torch.equal(s_ref, s_ref2)
+
+
+def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
+    """Round 5: launches with at least one 256 x 128 tile per CU take k_sd_gemm_big (eight waves, three-stage LDS-DMA ring, counted vmcnt).  Its
+    waves run the same 64 x 64 tile and the same MFMA sequence per K step as k_sd_gemm, so the same problem cut into row blocks small enough to
+    take the 128-row kernel must give the same BITS — dense with bias / activation / residual, a 3 x 3 convolution (against the CPU reference:
+    a row block of a convolution has other borders), the transposed-stride input gradient of the VAE's downsampling convolutions, ragged M."""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(77)
+    # dense: M = 65536 + 77 (ragged), N = 256, K = 1152 -> 257 x 2 tiles; row blocks of 8192 -> 32 x 2 tiles: the 128-row kernel
+    M, N, K = 65536 + 77, 256, 1152
+    x = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).half().cuda()
+    for kw in (dict(bias=b, residual=r), dict(act=ops.ACT_SILU, alpha=0.5), dict(bias=b, act=ops.ACT_GELU)):
+        big = ops.linear(x, w, **kw)
+        parts = []
+        for m0 in range(0, M, 8192):
+            kws = dict(kw)
+            if 'residual' in kws:
+                kws['residual'] = r[m0:m0 + 8192]
+            parts.append(ops.linear(x[m0:m0 + 8192], w, **kws))
+        assert torch.equal(big, torch.cat(parts, 0)), kw.keys()
+    y = ops.linear(x[:4096], w, bias=b).float().cpu()
+    close(y, x[:4096].float().cpu() @ w.float().cpu().t() + b.cpu(), 2e-3, 4e-3)
+    # convolutions against the CPU reference: 3 x 3 stride 1 (plain), and the stride-2 input gradient (transposed-stride loader)
+    B, C, H, Co = 1, 128, 256, 128
+    xc = h(torch.randn(B, C, H, H, generator=g))
+    wc = h(torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    bc = torch.randn(Co, generator=g)
+    yc = ops.conv2d(nhwc(xc).half().cuda(), pack.pack_conv(wc).cuda(), bc.cuda(), 3)
+    close(nchw(yc), F.conv2d(xc, wc, bc, padding=1), 2e-3, 5e-3)
+    x2 = h(torch.randn(1, 128, 256, 256, generator=g)).requires_grad_(True)
+    w2 = h(torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(9 * 128))
+    ref = F.conv2d(F.pad(x2, (0, 1, 0, 1)), w2, None, stride=2)
+    dy = h(torch.randn_like(ref))
+    ref.backward(dy)
+    dx = ops.conv2d(nhwc(dy).half().cuda(), pack.pack_conv_dgrad(w2).cuda(), None, 3, stride=1, pad=2, tstride=2, out_hw=(256, 256))
+    close(nchw(dx), x2.grad, 3e-3, 5e-3, "stride-2 dgrad, big tile")
 
 
 @pytest.mark.parametrize("M,C", [(8192, 320), (128, 1280), (77, 64)])

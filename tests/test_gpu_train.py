@@ -562,6 +562,9 @@ def test_graphed_step_owns_its_buffers():
     from customnerf_amd.nerf.provider_utils import generate_rays
     from customnerf_amd.trainer import ReconTrainer
     tcnn.set_default_dtype(torch.float16)
+    from customnerf_amd import field as fld
+    from customnerf_amd.gridencoder import grid as ge
+    ge._WS_CACHE.clear(); ge._SIDE.clear(); fld._WS.clear()              # earlier tests of the session may have left large workspaces: (2) needs a real growth
     H = W = 16
     V = 70
 
@@ -610,4 +613,67 @@ def test_graphed_step_owns_its_buffers():
     assert len(trg._graphs) == 1 and trg.global_step == step0 + 3 and np.isfinite(float(loss))
     loss, _ = trg.train_step_graphed(*views[0], **kw)                    # and the recaptured graph replays
     assert len(trg._graphs) == 1 and trg.global_step == step0 + 4 and np.isfinite(float(loss))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fitted", [False, True], ids=["random_init", "fitted_sphere"])
+def test_early_termination_leaves_every_gradient_bit_identical(fitted):
+    """VERDICT r4 item 2 (north_star: "wavefront ballot/scan for ray compaction and early termination").  With the half-precision fused field the
+    compositing backward writes exact zeros for rows whose gradients round to zero in the form k_field_bwd_x2 consumes them, reports the ray's dead
+    32-row tiles by wave ballot, the field backward skips those tiles in place and the scatter emits no records for zero rows.  Skipped work adds
+    exact zeros, so the table gradient (exact fixed-point sums) and the three MLP gradients (same tiles, same pipelines, same order) must be
+    torch.equal to the run without it — on a random-initialised field (nothing to skip) and on a field fitted to the sphere scene (most of it)."""
+    from customnerf_amd import scene as sc, tcnn, field as fld
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    H = W = 64
+    V = 4
+    torch.manual_seed(0)
+    opt = sc.make_opt(fp16=True, num_steps=32, upsample_steps=32, iters=1000)
+    model = NeRFNetwork(opt).cuda()
+    c2w = torch.from_numpy(sc.poses(V)).cuda()
+    ro, rd = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+    ro, rd = ro.view(V, 1, H * W, 3), rd.view(V, 1, H * W, 3)
+    rgb, mask = sc.sphere_targets(ro.reshape(V, -1, 3), rd.reshape(V, -1, 3))
+    kw = dict(num_steps=32, upsample_steps=32, dt_gamma=0, max_steps=1024)
+    tr = ReconTrainer(model, opt, fp16=True)
+    if fitted:
+        for i in range(200):
+            tr.train_step(ro[i % V], rd[i % V], rgb[i % V], mask[i % V], **kw)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    draws = dict(z=torch.rand(H * W, 32, device="cuda", generator=g), u=torch.rand(H * W, 32, device="cuda", generator=g))
+    seen = []
+    orig = fld.FieldFunction.backward
+
+    def spy(ctx, g_sigma, g_rgbc):
+        tl = getattr(g_sigma, '_cnerf_tile_live', None)
+        seen.append((None if tl is None else float(tl.float().mean()), float((g_sigma == 0).float().mean())))
+        return orig(ctx, g_sigma, g_rgbc)
+    fld.FieldFunction.backward = staticmethod(spy)
+    try:
+        grads = {}
+        for et in (True, False):
+            model.opt.early_termination = et
+            for p in model.parameters():
+                p.grad.zero_()
+            model.train()
+            with torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(ro[1], rd[1], staged=False, perturb=True, force_all_rays=True, _draws=draws, **kw)
+                loss = tr.loss(out, rgb[1], mask[1])
+            tr.scaler.backward(loss)
+            grads[et] = [p.grad.detach().clone() for p in model.parameters()]
+    finally:
+        fld.FieldFunction.backward = orig
+        model.opt.early_termination = True
+    (live_on, zero_on), (live_off, zero_off) = seen
+    assert live_off is None and live_on is not None
+    if fitted:
+        assert live_on < 0.7 and zero_on > 0.4 and zero_off < 0.05, seen           # most tiles dead, most rows flushed; without it hardly any exact zero
+    else:
+        assert live_on > 0.95, seen
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
+    assert all(bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0 for a in grads[True])
 
