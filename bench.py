@@ -144,8 +144,9 @@ def _timed(step, args, world, dist):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
+        from customnerf_amd import _coll
         tt = torch.tensor([dt], device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        _coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, out
 
@@ -201,8 +202,8 @@ def run_edit(args, world, rank, dev):
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
     dt, (loss, ld) = _timed(step, args, world, dist)
     skipped = args.steps - (trainer.scaler.good_steps() - good0) if trainer.scaler is not None else 0
-    if rank != 0:
-        return None
+    # (every rank goes on: the roofline leg below runs two more steps, i.e. two more gradient exchanges — a rank that returned here left its
+    # peers waiting in the all-to-all: found by tests/test_gpu_dp_two_ranks.py in round 5, before any multi-GPU hardware saw it)
     result = {"metric": "SDS edit-steps/s", "value": world * args.steps / dt, "unit": "edit-steps/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
               "config": {"workload": f"cfg3 synthetic: {nv} {H}x{W} view(s)/step/GPU of the L16 T2^19 hash-grid field (run() path), SD-1.5-shaped UNet (859.5M params, random weights) on "
@@ -255,7 +256,7 @@ def run_edit(args, world, rank, dev):
             result["cpu_baseline"] = {"value": None, "unit": "edit-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
     del trainer, guidance, model, pretrained
     torch.cuda.empty_cache()
-    return result
+    return result if rank == 0 else None
 
 
 def run_recon(args, world, rank, dev):
@@ -428,6 +429,8 @@ def launch_ranks(args, argv, child_cmd=None, check_devices=True):
     if args.dry_launch:
         print(json.dumps({"dry_launch": True, "n_ranks": n, "argv": child_argv, "env": envs}))
         return 0
+    if os.environ.get("CNERF_SINGLE_DEVICE") == "1":
+        check_devices = False                                      # test mode: every rank on device 0 (tests/test_gpu_dp_two_ranks.py)
     have = visible_gpu_count() if check_devices else n            # sysfs only: the torch query may fall back to hipGetDeviceCount (HSA init)
     if have is not None and have < n:
         sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible\n")
@@ -527,18 +530,30 @@ def main():
     record_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if os.environ.get("CNERF_BENCH_WATCHDOG"):
+        # a rank that sits in a collective its peer never enters would wait forever: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CNERF_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test-only switches (tests/test_gpu_dp_two_ranks.py: the N > 1 code path end to end on a one-GPU box): CNERF_DP_BACKEND=gloo stages every
+    # collective through host memory (customnerf_amd/_coll.py), CNERF_SINGLE_DEVICE=1 puts every rank on device 0
+    backend = os.environ.get("CNERF_DP_BACKEND", "nccl")
+    if os.environ.get("CNERF_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1 or args.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != world:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
@@ -581,6 +596,19 @@ def main():
                  "march_path": brief(variant(run_recon, path="march", no_roofline=True)),
                  "trained_field": brief(variant(run_recon, prefit=300)),
                  "graphed_step": brief(variant(run_recon, graph=True, no_roofline=True))}
+            # the N > 1 code path on this one GPU: the sharded gradient exchange forced on over a ONE-rank RCCL group (pack, all-to-all, fp32 sum,
+            # sharded Adam, shadow all-gather — the collectives are self-copies, everything else is what an 8-GPU run executes): its local cost
+            # (`exchange_ms`, event pairs) under the driver's clock
+            try:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ["MASTER_PORT"] = str(_free_port())
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                v["dp_selftest"] = brief(variant(run_recon, dp_selftest=True, no_roofline=True))
+            except Exception as e:
+                v["dp_selftest"] = {"error": repr(e)}
+            finally:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
             if rank == 0:
                 result["variants"] = v
         if plain and world > 1 and args.scaling == "weak":
@@ -609,6 +637,8 @@ def main():
             result["secondary"] = edit
     if rank == 0:
         result["rccl_ranks"] = rccl_ranks
+        if backend != "nccl":
+            result["collective_backend"] = backend + " (host-staged: test mode, no links)"
         os.write(record_fd, (json.dumps(result) + "\n").encode())
     os.close(record_fd)
     if world > 1:

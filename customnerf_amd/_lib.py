@@ -40,7 +40,7 @@ SIGNATURES = {
     "cnerf_grid_encode_backward_prepared": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp],
     "cnerf_grid_encode_backward_workspace_bytes": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
     "cnerf_grid_encode_backward_prepare_block": [i32, vp],
-    "cnerf_grid_encode_backward_needs_plan": [vp, u32, u32, u32, u32, u32, f32, u32, i32, vp],
+    "cnerf_grid_encode_backward_needs_plan": [vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, vp],
     "cnerf_grid_encode_backward_prepare_rows": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, u32, u32, vp, u64, vp, vp],
     "cnerf_grid_encode_backward_prepare_finish": [vp, u32, u32, u32, u32, f32, u32, u32, u32, i32, vp, u64, vp, vp],
     "cnerf_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, vp],

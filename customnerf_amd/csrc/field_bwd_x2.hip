@@ -262,7 +262,9 @@ __device__ __forceinline__ void x4_zero(cn_f16v &a) {
 #define X2_B_BDO (20 * X4_K)
 #define X2_PAIR_BYTES (X2_B + 22 * X4_K)      // 56 KiB per pair
 
-template <int NGEO>
+// SKIP: tile_live is given (one byte per 32-sample tile, 0 = every output gradient of the tile is exactly zero: cnerf_field_backward_ex) — the
+// flags are requested one phase ahead, like every other input of the pipeline, so the decision costs no memory round trip
+template <int NGEO, bool SKIP>
 __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
                                                               uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                               const float *__restrict__ pden, const float *__restrict__ prgb,
@@ -341,14 +343,17 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
         for (int s = 0; s < 4; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = PR::zero();
         S0.p = S1.p = 0; S0.v = S1.v = false; S0.live = S1.live = false;
         frag_t N0[SENC], N1[SENC];                            // grid features requested one phase ahead (even / odd tiles)
+        uint32_t LV0 = 1u, LV1 = 1u;                          // ... and the liveness flag of the tile
+        if (SKIP) LV0 = tile_live[min(gp, n_tiles - 1)];
         x4_enc_request<SENC>(enc, P_, dm.L, gp * FLD_TILE + li, hi, N0);
 #pragma unroll
         for (int s = 0; s < SENC; s++) N1[s] = PR::zero();
         unsigned char *my = xch + X2_A;
-        auto phase = [&](uint32_t p, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC]) __attribute__((always_inline)) {
+        auto phase = [&](uint32_t p, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC], const uint32_t &lcur, uint32_t &lnext) __attribute__((always_inline)) {
             X4_T0();
             asm volatile("" ::: "memory");
             x4_enc_request<SENC>(enc, P_, dm.L, (gp + (p + 1) * G) * FLD_TILE + li, hi, xnext);
+            if (SKIP) lnext = tile_live[min(gp + (p + 1) * G, n_tiles - 1)];
             // ---- backward of tile p-2 (dz_3 was published by wave B in phase p-1); S still holds that tile
             if (p >= 2 && p - 2 < n_iter && !(ablate & 1) && !S.live) {
                 // a dead tile (cnerf_composite_run_backward_indexed_flush: every row's output gradient is exactly zero): nothing to add to any
@@ -418,7 +423,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                 const uint32_t tile = gp + p * G;
                 S.p = tile * FLD_TILE + li;
                 S.v = S.p < P_;
-                S.live = tile < n_tiles && (!tile_live || tile_live[tile] != 0);           // (wave-uniform)
+                S.live = tile < n_tiles && (!SKIP || lcur != 0);                           // (wave-uniform)
             } else {
                 S.live = false;
             }
@@ -444,8 +449,8 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             X4_T1();
         };
         for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, S0, N0, N1);
-            phase(p + 1, S1, N1, N0);
+            phase(p, S0, N0, N1, LV0, LV1);
+            phase(p + 1, S1, N1, N0, LV1, LV0);
         }
 #pragma unroll
         for (int a = 0; a < 2; a++) {
@@ -466,7 +471,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             for (int b = 0; b < 2; b++) { x4_zero(wrf[a][b]); x4_zero(wd0[a][b]); }
         }
         // per-sample inputs, requested unconditionally (clamped index) and masked at use: see x4_enc_request
-        struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; };
+        struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; uint32_t live; };
         auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
             BIn r;
             const uint32_t p = min(tile * FLD_TILE + li, P_ - 1);
@@ -475,6 +480,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             r.gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
             const float *dp = dirs + (size_t)(p / dir_group) * 3;
             r.dx = dp[0]; r.dy = dp[1]; r.dz = dp[2];
+            r.live = SKIP ? (uint32_t)tile_live[min(tile, n_tiles - 1)] : 1u;
             return r;
         };
         BIn I0 = load_in(gp), I1 = I0;
@@ -484,7 +490,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             X4_T0();
             asm volatile("" ::: "memory");
             if (p >= 1) nxt = load_in(gp + p * G);
-            if (p >= 1 && p - 1 < n_iter && !(ablate & 4) && (gp + (p - 1) * G) < n_tiles && (!tile_live || tile_live[gp + (p - 1) * G] != 0)) {
+            if (p >= 1 && p - 1 < n_iter && !(ablate & 4) && (gp + (p - 1) * G) < n_tiles && (!SKIP || cur.live != 0)) {
                 const uint32_t i = p - 1;
                 const uint32_t tile = gp + i * G;
                 const bool valid = tile * FLD_TILE + li < P_;
@@ -647,7 +653,11 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
                            grad_enc, partials, (uint32_t)ablate, tile_live);                                                               \
     }
-    if (dm.n_hidden_geo == 2) X2_LAUNCH(k_field_bwd_x2<2>) else X2_LAUNCH(k_field_bwd_x2<1>)
+    if (tile_live) {
+        if (dm.n_hidden_geo == 2) X2_LAUNCH((k_field_bwd_x2<2, true>)) else X2_LAUNCH((k_field_bwd_x2<1, true>))
+    } else {
+        if (dm.n_hidden_geo == 2) X2_LAUNCH((k_field_bwd_x2<2, false>)) else X2_LAUNCH((k_field_bwd_x2<1, false>))
+    }
     int rc = cn_launch_status();
     if (rc) return rc;
     ff_reduce_partials(partials, blocks * 2, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);

@@ -476,7 +476,7 @@ int bn_prepare_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint3
                     void *workspace, hipStream_t st, uint32_t row0, uint32_t rows);
 int bn_prepare_finish(const GridLevels &lv, uint32_t B, uint32_t nl, int dtype, void *workspace, hipStream_t st);
 uint32_t bn_hist_block_points(int dtype);
-bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype);
+bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype, uint32_t gridtype);
 #define BN_MIN_UPDATES (1u << 20)        // below this many (point, level) pairs the plain atomic kernel is cheaper than five launches
 
 extern "C" {
@@ -567,7 +567,7 @@ int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offse
     if (!(workspace && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) && workspace_bytes >= bn_workspace_bytes(B, nl, lv, dtype) &&
           !(((uintptr_t)workspace) & 255)))
         return CNERF_OK;
-    if (!bn_needs_plan(B, nl, lv, dtype)) return CNERF_OK;                    // (the scatter counts inside its emit kernel: *prepared = 0, nothing launched)
+    if (!bn_needs_plan(B, nl, lv, dtype, gridtype)) return CNERF_OK;          // (the scatter counts inside its emit kernel: *prepared = 0, nothing launched)
     rc = bn_prepare(inputs, lv, B, nl, gridtype, align_corners, interp, dtype, workspace, CN_STREAM(stream));
     if (rc == 0) *prepared = 1;
     return rc;
@@ -584,7 +584,7 @@ int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points) 
 }
 
 int cnerf_grid_encode_backward_needs_plan(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
-                                          uint32_t H, int dtype, int *needs_plan) {
+                                          uint32_t H, uint32_t gridtype, int dtype, int *needs_plan) {
     if (!needs_plan) return CNERF_ENULL;
     *needs_plan = 0;
     GridLevels lv;
@@ -592,7 +592,7 @@ int cnerf_grid_encode_backward_needs_plan(const int32_t *offsets_host, uint32_t 
     int rc = ge_levels(offsets_host, L, nl, S, H, lv);
     if (rc) return rc;
     if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
-    if (B && nl && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) && bn_needs_plan(B, nl, lv, dtype)) *needs_plan = 1;
+    if (B && nl && (uint64_t)B * nl >= BN_MIN_UPDATES && bn_eligible(B, D, C, nl, lv) && bn_needs_plan(B, nl, lv, dtype, gridtype)) *needs_plan = 1;
     return CNERF_OK;
 }
 
@@ -605,7 +605,7 @@ static int ge_prepare_common(const int32_t *offsets_host, uint32_t B, uint32_t D
     if (dtype != CNERF_F32 && dtype != CNERF_F16) return CNERF_EINVAL;
     go = dtype == CNERF_F16 && B && workspace && (uint64_t)B * L >= BN_MIN_UPDATES && bn_eligible(B, D, C, L, lv) &&
          workspace_bytes >= bn_workspace_bytes(B, L, lv, dtype) && !(((uintptr_t)workspace) & 255) && bn_hist_block_points(dtype) != 0 &&
-         bn_needs_plan(B, L, lv, dtype);
+         bn_needs_plan(B, L, lv, dtype, gridtype);
     return CNERF_OK;
 }
 

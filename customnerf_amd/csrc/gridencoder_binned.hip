@@ -779,30 +779,62 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 //   k_bin3_emit   a block (2048 points of one level) derives its corner pairs ONCE, takes an LDS ticket per record against per-bin counters
 //                 that start at zero, scans the 128 counters (the block's own histogram) and sorts the records by bin into the LDS staging area.
 //                 Samples whose gradient is exactly zero on this level emit nothing (they add exactly zero to every fixed-point sum).
-//     hashed levels (bin loads near-uniform): every bin owns a slab region of fixed capacity (1.5 x its expected load); the block reserves its
-//                 run in each bin with ONE returning atomic per (block, bin) on the bin's cursor — issued right after the scan, consumed at
-//                 copy-out — and copies its runs there: bin-major, densely packed, exactly the layout the accumulate kernel streams.  A bin
-//                 whose cursor passes its capacity (a sample distribution that defeats the hash) is flagged by that very cursor and recomputed
-//                 from the samples by k_bin3_redo: exact, only slower.
+//     hashed levels (interleaved bins, loads near-uniform): every bin owns a slab region of fixed capacity (1.5 x its expected load); the block
+//                 reserves its run in each bin with ONE returning atomic per (block, bin) on the bin's cursor — issued right after the scan,
+//                 consumed at copy-out — and copies its runs there: bin-major, densely packed, exactly the layout the accumulate kernel streams.
+//                 What does not fit (importance samples crowding a few hundred entries of a coarse hashed level) SPILLS: it stays in the block's
+//                 private region and the run table says so.
 //     dense levels (a few crowded, uneven bins): the staging area leaves as ONE contiguous run into the block's private region, and the run
-//                 table gets {count, offset} per (bin, block); the accumulate workgroup of a bin segment walks the runs (thousands of records each).
-//   k_bin3_totals per bin: dense — exclusive prefix of the run counts over the blocks + total; hashed — the clamped cursor
-//   k_bin_scan_bins, k_bin3_accum, k_bin3_redo, k_bin2_reduce_split
+//                 table gets {count, offset} per (bin, block).
+//   k_bin3_totals per bin: dense (and overflowed hashed) — exclusive prefix of the run counts over the blocks; the bin's record total
+//   k_bin_scan_bins   segments per bin (as before)
+//   k_bin3_accum      a segment of a hashed bin streams its range of the bin's region; a segment of a dense bin (and the first segment of an
+//                     overflowed hashed bin, for the spill) walks the runs of the point blocks through a tile list in LDS
+//   k_bin3_reduce_split
 // Same 8-byte pair records, same exact 64-bit fixed-point sums, same split-bin reduction: the gradient is bit-identical to the second form's.
 #define B3_PTS 2048
-#define B3_CAP (B3_PTS * 4 + 256)                 // staging capacity in records
+// staging capacity in records: a hashed level emits 4.125 records per sample on average (one x-pair in 32 leaves as two singles: 8448 +- 31 per
+// block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
+#define B3_CAP (B3_PTS * 4 + 640)
+#define B3_MAXT 72                               // LDS words pairs of the run walk: 65 prefix words + 64 run positions
 #define B3_REGION (B3_PTS * 8)                    // records a block may emit on one level (8 single records per sample): its region on a dense level
 
 struct Bin3Plan {
     Bin2Plan p;
     uint32_t capb;                                 // record capacity of a hashed bin's region
     uint32_t dense_slot[GE_MAX_LEVELS];            // slot -> index among the dense slots (block-major regions), or 0xFFFFFFFF for a hashed level
+    uint8_t hbits[GE_MAX_LEVELS];                  // hashed slot: log2(bins of the level)
 };
 
-__global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+// Hashed levels: INTERLEAVED bins.  The hash is x ^ h(y, z): with contiguous 4096-entry chunks the bin of a record is a function of the (y, z)
+// row alone (x < 4096 never reaches the chunk bits), so on the coarser hashed levels — a few thousand rows — the bin loads follow the scene (bins
+// at twice the mean load on the benchmark's level 5).  A bin here owns the entries whose index bits [B3_K, B3_K + log2 bins) equal the bin id:
+// x spreads every row over the bins, the loads are uniform wherever the samples are spread, and a bin is still 4096 entries = one 64 KiB LDS
+// image, written back as 256-byte granules (2^B3_K entries x 2 channels x float32).  An x-pair stays one record while x ^ (x + 1) < 2^B3_K
+// (31 pairs in 32); the others travel as two single records: 4.125 records per sample and level, 8448 +- 31 per block (the four pairs of a sample
+// share x, so the unpaired ones come in fours) against a staging capacity of 8832.
+#define B3_K 5u
+__device__ __forceinline__ uint32_t b3_bin_of(uint32_t e, uint32_t hbits) { return (e >> B3_K) & ((1u << hbits) - 1u); }
+__device__ __forceinline__ uint32_t b3_local_of(uint32_t e, uint32_t hbits) { return ((e >> (B3_K + hbits)) << B3_K) | (e & ((1u << B3_K) - 1u)); }
+__device__ __forceinline__ uint32_t b3_entry_of(uint32_t local, uint32_t bin, uint32_t hbits) {
+    return ((local >> B3_K) << (B3_K + hbits)) | (bin << B3_K) | (local & ((1u << B3_K) - 1u));
+}
+__device__ __forceinline__ bool b3_paired_h(uint32_t i0, uint32_t i1) {
+    const uint32_t m = i0 ^ i1;
+    return m != 0 && m < (1u << B3_K) && (m & (m + 1)) == 0;
+}
+
+__global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                           const Bin3Plan plan, uint32_t *__restrict__ runs, uint32_t *__restrict__ cursor,
                                                           uint2 *__restrict__ hslab, uint2 *__restrict__ dslab, uint32_t B,
-                                                          uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
+                                                          uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
+                                                          uint32_t abl_arg) {
+#ifdef CNERF_TUNING
+    const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores
+#else
+    constexpr uint32_t abl = 0;
+    (void)abl_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];        // one LDS object: staged records, bin ids, counters, run starts, run destinations
     uint2 *s_rec = reinterpret_cast<uint2 *>(b3_lds);
     uint8_t *s_bin = b3_lds + (size_t)B3_CAP * 8;
@@ -811,10 +843,17 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restri
     uint32_t *gdst = start + B2S_MAX_CHUNKS;                                        // hashed: first record of the block's run inside the bin's region
     uint32_t *s_total = gdst + B2S_MAX_CHUNKS;
     const uint32_t nb = plan.p.nb;
-    const uint32_t slot = blockIdx.x / nb, pb = blockIdx.x % nb;
+    // level fastest: the workgroups resident at one time cover all levels of a few point blocks — their reservations spread over every bin
+    // cursor of the table instead of hammering the 128 of one level (same-address atomics serialise at the memory side), and the blocks that
+    // share a point block's coordinates run together
+    const uint32_t slot = blockIdx.x % n_slots, pb = blockIdx.x / n_slots;
     const uint32_t level = lv.order[slot];
     const uint32_t bin0 = plan.p.bin_first[slot], nch = plan.p.bin_first[slot + 1] - bin0;
     const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu;
+    const uint32_t hb = plan.hbits[slot];
+    auto bin_of = [&](uint32_t e) { return dense_lvl ? e >> BN_CHUNK_LOG2 : b3_bin_of(e, hb); };
+    auto local_of = [&](uint32_t e) { return dense_lvl ? e & (BN_CHUNK - 1) : b3_local_of(e, hb); };
+    auto paired = [&](uint32_t a, uint32_t b) { return dense_lvl ? b2_paired(a, b) : b3_paired_h(a, b); };
     if (threadIdx.x < B2S_MAX_CHUNKS) cnt[threadIdx.x] = 0;
     __syncthreads();
     constexpr int PPT = B3_PTS / B2_THREADS;
@@ -838,12 +877,12 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restri
         if (ok[i]) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t c0 = i0[i][q] >> BN_CHUNK_LOG2;
-                if (b2_paired(i0[i][q], i1[i][q])) {
+                const uint32_t c0 = bin_of(i0[i][q]);
+                if (paired(i0[i][q], i1[i][q])) {
                     tk[i][q] = dense_lvl ? b2_ticket(cnt, c0) : atomicAdd(&cnt[c0], 1u);
                 } else {
                     const uint32_t t0 = atomicAdd(&cnt[c0], 1u);
-                    const uint32_t t1 = atomicAdd(&cnt[i1[i][q] >> BN_CHUNK_LOG2], 1u);
+                    const uint32_t t1 = atomicAdd(&cnt[bin_of(i1[i][q])], 1u);
                     tk[i][q] = t0 | (t1 << 16);                                  // (a block emits at most 16384 records per level)
                 }
             }
@@ -862,15 +901,13 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restri
         start[lane] = oa; start[lane + 64] = ob;
         if (lane == 63) *s_total = tot_a + ib;
         if (dense_lvl) {
-            if (lane < nch) runs[(size_t)(bin0 + lane) * nb + pb] = ca | (oa << 16);
-            if (lane + 64 < nch) runs[(size_t)(bin0 + lane + 64) * nb + pb] = cb | (ob << 16);
-        } else {
-            // records the staging area cannot hold (more than 256 chunk-straddling pairs in a block: practically never on a hashed level) are
-            // not stored at all — the bin's cursor is pushed past its capacity instead, which hands the bin to k_bin3_redo
-            const uint32_t tot = tot_a + ib;
-            const uint32_t bump_a = (ca && oa + ca > B3_CAP && tot > B3_CAP) ? plan.capb : 0u, bump_b = (cb && ob + cb > B3_CAP && tot > B3_CAP) ? plan.capb : 0u;
-            if (lane < nch && ca) res_a = atomicAdd(&cursor[bin0 + lane], ca + bump_a);
-            if (lane + 64 < nch && cb) res_b = atomicAdd(&cursor[bin0 + lane + 64], cb + bump_b);
+            if (lane < nch && !(abl & 8)) runs[(size_t)(bin0 + lane) * nb + pb] = ca | (oa << 16);
+            if (lane + 64 < nch && !(abl & 8)) runs[(size_t)(bin0 + lane + 64) * nb + pb] = cb | (ob << 16);
+        } else if (!(abl & 1)) {
+            // reserve room in the bin's region for what the staging area holds of the run (the rest, if any, is already in the block's region)
+            const uint32_t sa = oa >= B3_CAP ? 0u : min(ca, (uint32_t)B3_CAP - oa), sb = ob >= B3_CAP ? 0u : min(cb, (uint32_t)B3_CAP - ob);
+            if (lane < nch && sa) res_a = atomicAdd(&cursor[bin0 + lane], sa) & 0x7FFFFFFFu;
+            if (lane + 64 < nch && sb) res_b = atomicAdd(&cursor[bin0 + lane + 64], sb) & 0x7FFFFFFFu;
         }
     }
     // bare barrier: only the LDS writes above (start[], *s_total) must have landed; __syncthreads() would also wait for the returning atomics
@@ -879,54 +916,70 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin3_emit(const __half *__restri
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // ---- phase 2: the records, sorted by bin, into the staging area
-    uint2 *__restrict__ region = dense_lvl ? dslab + ((size_t)plan.dense_slot[slot] * nb + pb) * B3_REGION : nullptr;
+    uint2 *__restrict__ region = dslab + ((size_t)slot * nb + pb) * B3_REGION;        // the block's private region on this level
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
-        if (!ok[i]) continue;
+        if (!ok[i] || (abl & 4)) continue;
         const uint32_t fxq = min((uint32_t)(fx[i] * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t ticket, uint32_t word, uint32_t val) {
             const uint32_t sl = start[c] + ticket;
             if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
-            else if (dense_lvl) region[sl] = make_uint2(word, val);                 // beyond the staging capacity: straight to its final place
+            else region[sl] = make_uint2(word, val);                                // beyond the staging capacity: straight into the block's region
         };
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t a0 = i0[i][q], a1 = i1[i][q];
-            const uint32_t c0 = a0 >> BN_CHUNK_LOG2;
-            if (b2_paired(a0, a1)) {
+            const uint32_t c0 = bin_of(a0);
+            if (paired(a0, a1)) {
                 const uint32_t t = 31u - (uint32_t)__clz((int)(a0 ^ a1));
                 v.h = __floats2half2_rn(wyz[i][q] * g0[i], wyz[i][q] * g1[i]);
-                put(c0, tk[i][q], (a0 & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
+                put(c0, tk[i][q], local_of(a0) | (t << 12) | (fxq << 16), v.u);
             } else {
                 const float w0 = (1 - fx[i]) * wyz[i][q], w1 = fx[i] * wyz[i][q];
                 v.h = __floats2half2_rn(w0 * g0[i], w0 * g1[i]);
-                put(c0, tk[i][q] & 0xFFFFu, (a0 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+                put(c0, tk[i][q] & 0xFFFFu, local_of(a0) | (B2_SINGLE << 12), v.u);
                 v.h = __floats2half2_rn(w1 * g0[i], w1 * g1[i]);
-                put(a1 >> BN_CHUNK_LOG2, tk[i][q] >> 16, (a1 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
+                put(bin_of(a1), tk[i][q] >> 16, local_of(a1) | (B2_SINGLE << 12), v.u);
             }
         }
     }
     if (!dense_lvl && threadIdx.x < 64) {                                           // the reservations have had phase 2 to come back
-        gdst[threadIdx.x] = res_a - start[threadIdx.x];                             // staging slot -> position in the bin's region (wrapping arithmetic)
-        gdst[threadIdx.x + 64] = res_b - start[threadIdx.x + 64];
+        // what of the run fits the bin's region goes there; the rest SPILLS: it stays in the block's region (where the staging order puts it anyway)
+        // and the run table says so — the accumulate workgroup of an overflowed bin walks those runs after its region.  Records beyond the staging
+        // capacity (already in the block's region) count as spilled whatever the cursor says.
+        const uint32_t capb = plan.capb;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t c = threadIdx.x + 64 * h;
+            const uint32_t n = cnt[c], st0 = start[c], res = h ? res_b : res_a;
+            const uint32_t staged = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
+            const uint32_t room = res >= capb ? 0u : capb - res;
+            const uint32_t fit = min(min(n, room), staged);
+            gdst[c] = res - st0;                                                    // staging slot -> position in the bin's region (wrapping arithmetic)
+            cnt[c] = fit;                                                           // (the counts are not needed any more: records of the run that go to the region)
+            if (c < nch && !(abl & 8)) runs[(size_t)(bin0 + c) * nb + pb] = (n - fit) | ((st0 + fit) << 16);
+            if (c < nch && n > fit) atomicOr(&cursor[bin0 + c], 0x80000000u);       // the bin has spilled runs: its accumulate workgroup must walk the run table
+        }
     }
     __syncthreads();
-    const uint32_t total = min(*s_total, (uint32_t)B3_CAP);
+    const uint32_t total = (abl & 2) ? 0u : min(*s_total, (uint32_t)B3_CAP);
     if (dense_lvl) {
         for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) region[sl] = s_rec[sl];
     } else {
         const uint32_t capb = plan.capb;
         for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) {
             const uint32_t c = s_bin[sl];
-            const uint32_t pos = gdst[c] + sl;
-            if (pos < capb) hslab[(size_t)(bin0 + c) * capb + pos] = s_rec[sl];     // (a run that does not fit marks its bin for k_bin3_redo: cursor > capb)
+            const uint32_t pos = gdst[c] + sl;                                      // (wrapping 32-bit arithmetic: gdst = reservation - run start)
+            if (sl - start[c] < cnt[c]) hslab[(size_t)(bin0 + c) * capb + pos] = s_rec[sl];
+            else region[sl] = s_rec[sl];
         }
     }
 }
 
-// per bin — dense level: exclusive prefix of the run counts (low half of the run-table words) over the point blocks -> pre, and the bin total;
-// hashed level: the total is the bin's cursor (0 for a bin that overflowed its region: k_bin3_redo serves it)
+// per bin: dense level — exclusive prefix of the run counts (low half of the run-table words) over the point blocks -> pre, and the bin total;
+// hashed level — the total is what the bin's region holds (its cursor, capped), and only a bin that overflowed (cursor > capacity) needs the
+// prefix of its SPILLED runs
 __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t *__restrict__ runs, uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ bin_total, const Bin3Plan plan, uint32_t n_slots) {
     constexpr uint32_t NW = BN_SCAN_THREADS / 64;
@@ -935,9 +988,13 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t 
     const uint32_t bin = blockIdx.x, nb = plan.p.nb;
     uint32_t slot = 0;
     while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
-    if (plan.dense_slot[slot] == 0xFFFFFFFFu) {
-        if (threadIdx.x == 0) { const uint32_t c = cursor[bin]; bin_total[bin] = c > plan.capb ? 0u : c; }
-        return;
+    const bool hashed = plan.dense_slot[slot] == 0xFFFFFFFFu;
+    if (hashed) {
+        const uint32_t cw = cursor[bin], c = cw & 0x7FFFFFFFu;                      // bit 31: some block spilled a run of this bin
+        if (!(cw >> 31)) {
+            if (threadIdx.x == 0) bin_total[bin] = min(c, plan.capb);
+            return;
+        }
     }
     const uint32_t *h = runs + (size_t)bin * nb;
     uint32_t *o = pre + (size_t)bin * nb;
@@ -971,48 +1028,155 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t 
         if (tid == 0) carry = base + tot;
         __syncthreads();
     }
-    if (tid == 0) bin_total[bin] = carry;
+    // (a hashed bin's record index space: what its region holds, then its spilled runs)
+    if (tid == 0) bin_total[bin] = hashed ? min(cursor[bin] & 0x7FFFFFFFu, plan.capb) + carry : carry;
 }
 
-// flush of a finished LDS image: sole owner -> read-modify-write of the gradient table; a split bin parks its fixed-point image
+// flush of a finished LDS image: sole owner -> read-modify-write of the gradient table; a split bin parks its fixed-point image.
+// hbits = 0xFF: dense level (the bin is a contiguous chunk); else a hashed level's interleaved bin.
 __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels &lv, const Bin2Plan &plan, uint32_t slot, uint32_t bin, uint32_t nseg, uint32_t gseg,
-                                         float *__restrict__ grad_grid, long long *__restrict__ partial) {
+                                         float *__restrict__ grad_grid, long long *__restrict__ partial, uint32_t hbits) {
     const uint32_t level = lv.order[slot];
-    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
-    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
-    float *__restrict__ dst = grad_grid + ((size_t)lv.offset[level] + e0) * 2;
+    const uint32_t cb = bin - plan.bin_first[slot];
+    const uint32_t e0 = hbits == 0xFFu ? cb << BN_CHUNK_LOG2 : 0u;
+    const uint32_t n_entries = hbits == 0xFFu ? min(BN_CHUNK, lv.size[level] - e0) : min(BN_CHUNK, lv.size[level] >> hbits);
+    float *__restrict__ dst = grad_grid + (size_t)lv.offset[level] * 2;
     if (nseg == 1) {
         for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024) {             // two entries x two channels per thread
-            float4 g = reinterpret_cast<float4 *>(dst)[j];
+            const uint32_t e = hbits == 0xFFu ? e0 + 2 * j : b3_entry_of(2 * j, cb, hbits);
+            float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)e * 2);
+            float4 g = *d4;
             g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
             g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
-            reinterpret_cast<float4 *>(dst)[j] = g;
+            *d4 = g;
         }
     } else {
         long long *__restrict__ img = partial + (size_t)gseg * (BN_CHUNK * 2);
-        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) img[j] = acc[(j & 1) * BN_CHUNK + (j >> 1)];      // interleaved (entry, channel) order
+        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) img[j] = acc[(j & 1) * BN_CHUNK + (j >> 1)];      // interleaved (local entry, channel) order
+    }
+}
+
+// sum the fixed-point partial images of the split bins into the gradient table (k_bin2_reduce_split with the interleaved bins of the hashed levels)
+__global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
+                                                           const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
+    const uint32_t bin = blockIdx.x;
+    const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
+    if (nseg <= 1) return;
+    uint32_t slot = 0;
+    while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
+    const uint32_t level = lv.order[slot];
+    const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu;
+    const uint32_t hb = plan.hbits[slot], cb = bin - plan.p.bin_first[slot];
+    const uint32_t e0 = dense_lvl ? cb << BN_CHUNK_LOG2 : 0u;
+    const uint32_t n_entries = dense_lvl ? min(BN_CHUNK, lv.size[level] - e0) : min(BN_CHUNK, lv.size[level] >> hb);
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // group of four values (two local entries x two channels)
+    if (j >= n_entries / 2) return;
+    long long sum[4] = {0, 0, 0, 0};
+    const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
+#pragma unroll 4
+    for (uint32_t s = 0; s < nseg; s++) {
+        const longlong2 v0 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[0];
+        const longlong2 v1 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[1];
+        sum[0] += v0.x; sum[1] += v0.y; sum[2] += v1.x; sum[3] += v1.y;
+    }
+    const uint32_t e = dense_lvl ? e0 + 2 * j : b3_entry_of(2 * j, cb, hb);
+    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e) * 2);
+    float4 g = *dst;
+    g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
+    g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
+    *dst = g;
+}
+
+// The records of a bin segment that live in RUNS of the point blocks' private regions (a dense level's bins; the spill of a hashed bin): the
+// part [begin, end) of the bin's run index space, starting at block pb_first.  Runs are anything from a handful of records (a block that grazes
+// the chunk's slab of a level-4 table) to thousands, so the runs of 64 blocks at a time are flattened: the first wave clips each run to the
+// segment and leaves its source position and the exclusive prefix of the clipped lengths in LDS; thread t then takes records 4 t .. 4 t + 3 of
+// every 4096 of the flat index space (a 6-step search in the 64 prefix words for the first, a short walk for the next three) — four loads in
+// flight per thread, full lanes whatever the run lengths, and runs of same-entry records (neighbouring samples of a ray on a coarse level)
+// become successive atomics of one lane instead of same-address lanes of one instruction.
+__device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint32_t *tiles, const uint32_t *__restrict__ rt, const uint32_t *__restrict__ pt,
+                                             const uint2 *__restrict__ lvl_slab, uint32_t nb, uint32_t pb_first, uint32_t begin, uint32_t end) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *s_pre = tiles, *s_base = tiles + 65;                                  // [65] exclusive prefix of the clipped run lengths (+ total), [64] first record of each
+    for (uint32_t pb0 = pb_first; pb0 < nb; pb0 += 64) {
+        if (threadIdx.x < 64) {
+            const uint32_t pbl = pb0 + lane;
+            uint32_t p_j = 0xFFFFFFFFu, r_j = 0;
+            if (pbl < nb) { p_j = pt[pbl]; r_j = rt[pbl]; }
+            uint32_t lo = 0, hi = 0;
+            if (p_j < end) {
+                const uint32_t c_j = r_j & 0xFFFFu;
+                lo = max(p_j, begin) - p_j;
+                hi = max(min(p_j + c_j, end), p_j) - p_j;
+                if (hi < lo) hi = lo;
+            }
+            const uint32_t len = hi - lo;
+            const uint32_t incl = cn_wave_incl_scan(len);
+            s_pre[lane] = incl - len;
+            s_base[lane] = pbl * B3_REGION + (r_j >> 16) + lo;
+            if (lane == 63) { s_pre[64] = incl; s_c[1] = p_j >= end ? 1u : 0u; }    // 1 = the segment ends inside this chunk
+        }
+        __syncthreads();
+        const uint32_t total = s_pre[64], last = s_c[1];
+        for (uint32_t f0 = threadIdx.x * 4; f0 < total; f0 += 4096) {
+            uint32_t j = 0;                                                         // largest j with s_pre[j] <= f0
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1)
+                if (s_pre[j + step] <= f0) j += step;
+            uint32_t idx[4];
+            bool ok4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t f = f0 + u;
+                ok4[u] = f < total;
+                while (ok4[u] && f >= s_pre[j + 1]) j++;                            // (empty runs are stepped over; j stays < 64 while f < total)
+                idx[u] = ok4[u] ? s_base[j] + (f - s_pre[j]) : s_base[0];
+            }
+            uint2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = lvl_slab[idx[u]];                    // (unconditional on a valid index: masked at use)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ok4[u]) b2_add_record(acc, v[u]);
+        }
+        __syncthreads();
+        if (last) break;
     }
 }
 
 __global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ hslab, const uint2 *__restrict__ dslab, const uint32_t *__restrict__ runs,
-                                                     const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bin_base,
+                                                     const uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin3Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin,
-                                                     uint32_t n_slots, uint32_t seg_records) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [2][BN_CHUNK] accumulators, then two uint32 (one LDS object)
+                                                     uint32_t n_slots, uint32_t seg_records, uint32_t only) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [2][BN_CHUNK] accumulators, scratch words, the tile list (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t *s_w = reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
     const uint32_t gseg = blockIdx.x;
     if (gseg >= seg_first[plan.p.total_bins]) return;
+#ifdef CNERF_TUNING
+    if (only) {                                                          // timing aid (results wrong): 1 = hashed bins only, 2 = dense bins only
+        uint32_t sl_ = 0;
+        const uint32_t b_ = seg_bin[gseg];
+        while (sl_ + 1 < n_slots && plan.p.bin_first[sl_ + 1] <= b_) sl_++;
+        if ((plan.dense_slot[sl_] == 0xFFFFFFFFu) != (only == 1)) return;
+    }
+#else
+    (void)only;
+#endif
     const uint32_t nb = plan.p.nb;
     if (threadIdx.x == 0) {
         const uint32_t bin = seg_bin[gseg];
         uint32_t slot = 0;
         while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
         uint32_t lo = 0;
-        if (plan.dense_slot[slot] != 0xFFFFFFFFu) {
+        const bool hashed = plan.dense_slot[slot] == 0xFFFFFFFFu;
+        const uint32_t cw = hashed ? cursor[bin] : 0u;
+        const uint32_t treg = hashed ? min(cw & 0x7FFFFFFFu, plan.capb) : 0u;      // records in the bin's region (hashed); the run space starts behind them
+        uint32_t begin = (gseg - seg_first[bin]) * seg_records;
+        if (!hashed || ((cw >> 31) && begin > treg)) {
             // first run that reaches into [begin, ...): the last block whose prefix is <= begin
-            const uint32_t begin = (gseg - seg_first[bin]) * seg_records;
+            begin -= treg;
             const uint32_t *p = pre + (size_t)bin * nb;
             uint32_t hi = nb;                                                  // invariant: p[lo] <= begin (p[0] = 0)
             while (hi - lo > 1) {
@@ -1020,18 +1184,21 @@ __global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ h
                 if (p[mid] <= begin) lo = mid; else hi = mid;
             }
         }
-        s_w[0] = bin; s_w[1] = lo; s_w[2] = slot;
+        s_w[0] = bin; s_w[1] = lo; s_w[2] = slot; s_w[3] = treg;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const uint32_t bin = s_w[0], pb_first = s_w[1], slot = s_w[2];
+    const uint32_t bin = s_w[0], pb_first = s_w[1], slot = s_w[2], treg = s_w[3];
     const uint32_t seg = gseg - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
     const uint32_t total = bin_base[bin + 1] - bin_base[bin];
     const uint32_t begin = seg * seg_records, end = min(begin + seg_records, total);
+    uint32_t *s_c = s_w + 4, *tiles = s_w + 8;                                // {tiles in the chunk, segment ends here}; [B3_MAXT][2]: first record, count
+    const uint32_t *__restrict__ rt = runs + (size_t)bin * nb, *__restrict__ pt = pre + (size_t)bin * nb;
+    const uint2 *__restrict__ lvl_slab = dslab + (size_t)slot * nb * B3_REGION;
     if (plan.dense_slot[slot] == 0xFFFFFFFFu) {
         // ---- hashed level: the bin's records are one contiguous range of its region (the second form's stream: 16-byte loads, two records per lane)
         const uint2 *__restrict__ slab = hslab + (size_t)bin * plan.capb;           // (capb is even: the region starts 16-byte aligned)
-        uint32_t b2 = begin, e2 = end;
+        uint32_t b2 = min(begin, treg), e2 = min(end, treg);                          // the segment's part of the region
         if ((b2 & 1u) && b2 < e2) { if (threadIdx.x == 0) b2_add_record(acc, slab[b2]); b2++; }
         if ((e2 & 1u) && b2 < e2) { e2--; if (threadIdx.x == 0) b2_add_record(acc, slab[e2]); }
         const uint4 *__restrict__ slab2 = reinterpret_cast<const uint4 *>(slab);
@@ -1054,109 +1221,17 @@ __global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ h
             b2_add_record(acc, make_uint2(r.x, r.y));
             b2_add_record(acc, make_uint2(r.z, r.w));
         }
+        // some runs of this bin did not fit — its region is full (a sample distribution that crowds a few entries of a coarse hashed level) or a
+        // block's staging area was: the bin's record index space continues behind the region with the spilled runs, where the point blocks left them
+        if (end > treg) {                                                            // (block-uniform)
+            __syncthreads();
+            b3_walk_runs(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, max(begin, treg) - treg, end - treg);
+        }
     } else {
-        // ---- dense level: walk the runs of the point blocks.  Waves take chunks of 64 consecutive runs round-robin; a lane fetches the metadata of
-        // one run, the wave then walks the 64 runs together, eight at a time: the first 64 records of eight runs are requested back to back, the
-        // rest of each run (thousands of records on these levels) in a second loop.  Loads are unconditional on a clamped index and masked at use
-        // (a `valid ? load : 0` becomes a branch with the wait right behind the load).
-        const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t *__restrict__ rt = runs + (size_t)bin * nb, *__restrict__ pt = pre + (size_t)bin * nb;
-        const uint2 *__restrict__ lvl_slab = dslab + (size_t)plan.dense_slot[slot] * nb * B3_REGION;
-        constexpr int RU = 8;
-        for (uint32_t pb0 = pb_first + wave * 64; pb0 < nb; pb0 += 16 * 64) {
-            const uint32_t pbl = pb0 + lane;
-            uint32_t m_pre = 0xFFFFFFFFu, m_run = 0;
-            if (pbl < nb) { m_pre = pt[pbl]; m_run = rt[pbl]; }
-            if (__builtin_amdgcn_readfirstlane(m_pre) >= end) break;               // the prefix is monotone: nothing further belongs to this segment
-            bool done = false;
-            for (uint32_t j0 = 0; j0 < 64 && !done; j0 += RU) {
-                uint32_t base[RU], lo[RU], hi[RU];
-                uint2 v[RU];
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const uint32_t p_j = __builtin_amdgcn_readlane(m_pre, j0 + u), r_j = __builtin_amdgcn_readlane(m_run, j0 + u);
-                    const bool in = p_j < end;                                      // (wave-uniform)
-                    const uint32_t c_j = in ? (r_j & 0xFFFFu) : 0u;
-                    const uint32_t pj = in ? p_j : 0u;
-                    lo[u] = max(pj, begin) - pj;
-                    hi[u] = max(min(pj + c_j, end), pj) - pj;                       // the part of the run inside the segment: [lo, hi)
-                    if (hi[u] < lo[u]) hi[u] = lo[u];
-                    base[u] = (pb0 + j0 + u) * B3_REGION + (r_j >> 16);
-                    if (!in) { done = true; base[u] = 0; }
-                    const uint32_t r = lo[u] + lane;
-                    v[u] = lvl_slab[r < hi[u] ? base[u] + r : 0u];
-                }
-#pragma unroll
-                for (int u = 0; u < RU; u++)
-                    if (lo[u] + lane < hi[u]) b2_add_record(acc, v[u]);
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    if (hi[u] - lo[u] <= 64) continue;                              // (wave-uniform)
-                    const uint2 *__restrict__ src = lvl_slab + base[u];
-                    uint32_t r = lo[u] + 64 + lane;
-                    for (; r + 192 < hi[u]; r += 256) {
-                        const uint2 a = src[r], b = src[r + 64], c = src[r + 128], d = src[r + 192];
-                        b2_add_record(acc, a); b2_add_record(acc, b); b2_add_record(acc, c); b2_add_record(acc, d);
-                    }
-                    for (; r < hi[u]; r += 64) b2_add_record(acc, src[r]);
-                }
-            }
-            if (done) break;
-        }
+        b3_walk_runs(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end);
     }
     __syncthreads();
-    b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial);
-}
-
-// A hashed bin whose cursor passed the capacity of its region (cursor > capb: records were dropped): recompute its sums from the samples — every
-// sample of the level, the very records the emit builds, those that fall into this bin — exact like everything else here, only slower (one sweep
-// over the level's points per such bin).  Grid = the bins; a workgroup whose bin did not overflow exits on its first load.
-__global__ void __launch_bounds__(1024) k_bin3_redo(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv, const Bin3Plan plan,
-                                                    const uint32_t *__restrict__ cursor, uint32_t B, uint32_t gridtype, int align_corners, uint32_t interp,
-                                                    float *__restrict__ grad_grid, uint32_t n_slots) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];
-    long long *acc = reinterpret_cast<long long *>(bn_lds);
-    const uint32_t bin = blockIdx.x;
-    uint32_t slot = 0;
-    while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
-    if (plan.dense_slot[slot] != 0xFFFFFFFFu || cursor[bin] <= plan.capb) return;
-    for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t level = lv.order[slot], chunk = bin - plan.p.bin_first[slot];
-    for (uint32_t b = threadIdx.x; b < B; b += 1024) {
-        float in[3];
-        if (!bn_load_point(inputs, b, B, in)) continue;
-        uint32_t i0[4], i1[4];
-        float wyz[4], fx;
-        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
-        const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
-        const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
-        if (g0 == 0.0f && g1 == 0.0f) continue;
-        const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
-        union { __half2 h; uint32_t u; } v;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t a0 = i0[q], a1 = i1[q];
-            if (b2_paired(a0, a1)) {
-                if ((a0 >> BN_CHUNK_LOG2) != chunk) continue;
-                const uint32_t t = 31u - (uint32_t)__clz((int)(a0 ^ a1));
-                v.h = __floats2half2_rn(wyz[q] * g0, wyz[q] * g1);
-                b2_add_record(acc, make_uint2((a0 & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u));
-            } else {
-                const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
-                if ((a0 >> BN_CHUNK_LOG2) == chunk) {
-                    v.h = __floats2half2_rn(w0 * g0, w0 * g1);
-                    b2_add_record(acc, make_uint2((a0 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u));
-                }
-                if ((a1 >> BN_CHUNK_LOG2) == chunk) {
-                    v.h = __floats2half2_rn(w1 * g0, w1 * g1);
-                    b2_add_record(acc, make_uint2((a1 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u));
-                }
-            }
-        }
-    }
-    __syncthreads();
-    b3_flush(acc, lv, plan.p, slot, bin, 1u, 0u, grad_grid, nullptr);
+    b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot]);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1340,31 +1415,41 @@ static bool b3_is_dense(const GridLevels &lv, uint32_t level) {                 
     return r1 * r1 * r1 <= lv.size[level];
 }
 
-static void b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense) {
+// -> false when a level is neither dense nor a power-of-two hashed level of at least 2^(12 + B3_K) ... entries (tiled levels that wrap, odd sizes):
+// such tables keep the second form
+static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense) {
     b2_plan(lv, nl, B, plan.p);
     plan.p.nb = cn_div_up(B, B3_PTS);
     n_dense = 0;
     uint64_t cap = 0;
-    for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) plan.dense_slot[s] = 0xFFFFFFFFu;
+    bool ok = true;
+    for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) { plan.dense_slot[s] = 0xFFFFFFFFu; plan.hbits[s] = 0; }
     for (uint32_t s = 0; s < nl; s++) {
-        if (b3_is_dense(lv, lv.order[s])) { plan.dense_slot[s] = n_dense++; continue; }
+        const uint32_t level = lv.order[s], size = lv.size[level];
+        if (b3_is_dense(lv, level)) { plan.dense_slot[s] = n_dense++; continue; }
         const uint32_t nch = plan.p.bin_first[s + 1] - plan.p.bin_first[s];
-        const uint64_t mean = (uint64_t)B * 4 / nch;                               // four pair records per sample, spread by the hash
+        if ((size & (size - 1)) != 0 || (nch & (nch - 1)) != 0 || size != nch * BN_CHUNK) ok = false;      // interleaved bins need 2^k bins of exactly 4096 entries
+        uint32_t hb = 0;
+        while ((1u << hb) < nch) hb++;
+        plan.hbits[s] = (uint8_t)hb;
+        const uint64_t mean = (uint64_t)B * 17 / 4 / nch;                          // four pair records per sample (one in 16 travels as two singles), spread evenly by the interleave
         const uint64_t c = mean + mean / 2 + 8192;
         cap = cap > c ? cap : c;
     }
     plan.capb = (uint32_t)((cap + 1) & ~(uint64_t)1);
+    return ok;
 }
 
 // the third form serves float16 records on tables of at most B2S_MAX_CHUNKS bins per level (the staging area's counters); larger tables
 // (T = 2^20, 2^21: the reference's bear table) keep the second form with its histogram
-static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype) {
+// (gridtype 1 = tiled: its wrapping levels are x-contiguous, the interleave does not balance them — second form)
+static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype, uint32_t gridtype) {
     static const int on = b2_env("CNERF_B3", 1);
-    if (!on || !b2_enabled(dtype)) return false;
+    if (!on || !b2_enabled(dtype) || gridtype != 0) return false;
     Bin3Plan plan;
     uint32_t nd;
-    b3_plan(lv, nl, B, plan, nd);
-    return b2_max_chunks(plan.p, nl) <= B2S_MAX_CHUNKS && (uint64_t)nd * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
+    if (!b3_plan(lv, nl, B, plan, nd)) return false;
+    return b2_max_chunks(plan.p, nl) <= B2S_MAX_CHUNKS && (uint64_t)nl * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
 }
 
 static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, uint32_t nl, Bin3Ws *ws, void *base) {
@@ -1376,7 +1461,8 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
     const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
-    const uint64_t d_records = (uint64_t)n_dense * p2.nb * B3_REGION;              // block-major regions of the dense levels
+    const uint64_t d_records = (uint64_t)nl * p2.nb * B3_REGION;                   // the point blocks' private regions: every record of a dense level, the spill of a hashed one
+    (void)n_dense;
     const uint64_t o_h = off; off = bn_align(off + h_records * 8);
     const uint64_t o_d = off; off = bn_align(off + d_records * 8);
     const uint64_t max_seg = (uint64_t)p2.total_bins + cn_div_up64((uint64_t)B * nl * 8, b2_seg(B, b2_max_chunks(p2, nl)));
@@ -1409,38 +1495,35 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     if (nl == 0) return CNERF_OK;
     Bin3Plan plan;
     uint32_t n_dense;
-    b3_plan(lv, nl, B, plan, n_dense);
+    if (!b3_plan(lv, nl, B, plan, n_dense)) return CNERF_EINVAL;
     Bin3Ws ws;
     b3_layout(plan, n_dense, B, nl, &ws, workspace);
-    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 16;
+    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 32 + B3_MAXT * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_emit), hipFuncAttributeMaxDynamicSharedMemorySize, emit_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_accum), hipFuncAttributeMaxDynamicSharedMemorySize, acc_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_redo), hipFuncAttributeMaxDynamicSharedMemorySize, acc_lds);
         attr_set = true;
     }
     const Bin2Plan &p2 = plan.p;
     const uint32_t seg = b2_seg(B, b2_max_chunks(p2, nl));
     hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
     hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B2_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
-                       interp, gemb);
+                       interp, gemb, nl, (uint32_t)b2_env("CNERF_B3_EMIT_ABL", 0));
     hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
                        plan, nl);
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
-                       (const uint32_t *)ws.pre, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
-                       (const uint32_t *)ws.seg_bin, nl, seg);
-    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(p2.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, p2,
+                       (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
+                       (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0));
+    hipLaunchKernelGGL(k_bin3_reduce_split, dim3(p2.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);
-    if (n_dense < nl)
-        hipLaunchKernelGGL(k_bin3_redo, dim3(p2.total_bins), dim3(1024), acc_lds, st, grad, inputs, lv, plan, (const uint32_t *)ws.cursor, B, gridtype, ac, interp, gemb, nl);
     return cn_launch_status();
 }
 
 // does the binned backward of this shape use a plan prepared ahead of time (histogram + scans on the sample coordinates)?  The third form
 // counts inside its emit kernel: nothing to prepare.
-bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) { return !b3_enabled(lv, nl, B, dtype); }
+bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype, uint32_t gridtype) { return !b3_enabled(lv, nl, B, dtype, gridtype); }
 
 // used by gridencoder.hip
 bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv) {
@@ -1450,17 +1533,20 @@ bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLeve
     return (uint64_t)B * nl * 8 < 0xF0000000ull;          // record positions are 32-bit
 }
 
+// (the size does not depend on the grid type — the entry point that asks has none — so it covers whichever form the launch will take)
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
-    if (b3_enabled(lv, nl, B, dtype)) {
+    uint64_t b3 = 0;
+    if (b3_enabled(lv, nl, B, dtype, 0u)) {
         Bin3Plan p3;
         uint32_t nd;
         b3_plan(lv, nl, B, p3, nd);
-        return b3_layout(p3, nd, B, nl, nullptr, nullptr);
+        b3 = b3_layout(p3, nd, B, nl, nullptr, nullptr);
     }
     if (b2_enabled(dtype)) {
         Bin2Plan p2;
         b2_plan(lv, nl, B, p2);
-        return b2_layout(p2, B, nl, nullptr, nullptr);
+        const uint64_t b2 = b2_layout(p2, B, nl, nullptr, nullptr);
+        return b2 > b3 ? b2 : b3;
     }
     BinPlan plan;
     bn_plan(lv, nl, B, plan);
@@ -1525,7 +1611,7 @@ int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t n
 
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
-    if (b3_enabled(lv, nl, B, dtype)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
+    if (b3_enabled(lv, nl, B, dtype, gridtype)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
     if (b2_enabled(dtype)) {
         if (!prepared) {
             const int rc = b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);

@@ -561,7 +561,12 @@ __host__ __device__ constexpr uint32_t sgb_lds_bytes() {
     return (SGB_STAGES * SGB_STAGE > SGB_BM * (SGB_BN + 4) * 4 ? SGB_STAGES * SGB_STAGE : SGB_BM * (SGB_BN + 4) * 4) + 4 * 36 * 2 * 8;
 }
 
-template <int AMODE, bool SIMPLE>
+// SCHED (how the six LDS-DMA instructions of a K step sit beside its sixteen MFMAs; measured: DESIGN.md B.11):
+//   0  all waves: DMA, then the MFMAs
+//   1  waves 0-3: DMA then MFMAs; waves 4-7 (the second wave of each SIMD): MFMAs then DMA — while one wave of a SIMD issues memory instructions
+//      its partner has the matrix pipe (the guide's staggered wave groups, with one barrier per K step)
+//   2  the DMA rounds slotted between the four MFMA groups of the K step (2, 2, 1, 1)
+template <int AMODE, bool SIMPLE, int SCHED>
 __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g) {
     constexpr int BM = SGB_BM, BN = SGB_BN, MT = 2, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char sgb_lds[];          // the ONLY LDS object (a second one makes hipcc drain the DMA queue before every ds_read)
@@ -624,13 +629,19 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
         b_off[r] = n < g.N ? (n * g.ldb + sg_swz(row, gch) * 8) * 2 : OOB;
     }
     uint32_t t_kh = 0, t_kw = 0, t_c0 = 0;                                         // uniform tap state (AMODE 2), advanced once per issued K step
-    auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
-        const uint32_t i_k = kt * SG_BK;
-        unsigned char *sA = sgb_lds + (size_t)stage * SGB_STAGE, *sB = sA + BM * SG_BK * 2;
-        const bool kin = i_k + a_sc0 < g.K;
-        const uint32_t tap = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : i_k * 2;
-#pragma unroll
-        for (int r = 0; r < RA; r++) {
+    uint32_t i_k = 0, tap = 0;
+    unsigned char *isA = sgb_lds, *isB = sgb_lds;
+    bool kin = true;
+    auto issue_begin = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+        i_k = kt * SG_BK;
+        isA = sgb_lds + (size_t)stage * SGB_STAGE;
+        isB = isA + BM * SG_BK * 2;
+        kin = i_k + a_sc0 < g.K;
+        tap = AMODE == 2 ? ((t_kh * g.W_in + t_kw) * g.Cin + t_c0) * 2 : i_k * 2;
+    };
+    auto issue_round = [&](int q) __attribute__((always_inline)) {
+        if (q < RA) {
+            const int r = q;
             uint32_t voff;
             if (AMODE == 0) {
                 voff = (a_off[r] + tap) | ((a_ok[r] && kin) ? 0u : OOB);
@@ -643,13 +654,14 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
                                 sg_coord(a_ow[r] + (int32_t)t_kw, g.tstride, g.ups, g.W_in, iw);
                 voff = ok ? a_off[r] + ((ih * g.W_in + iw) * g.Cin + t_c0) * 2 : OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(sA + (64 * r + 8 * wave_u) * 128), 16, voff, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < RB; r++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(isA + (64 * r + 8 * wave_u) * 128), 16, voff, 0, 0, 0);
+        } else {
+            const int r = q - RA;
             const uint32_t voff = b_off[r] | (kin ? 0u : OOB);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(sB + (64 * r + 8 * wave_u) * 128), 16, voff, i_k * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(isB + (64 * r + 8 * wave_u) * 128), 16, voff, i_k * 2, 0, 0);
         }
+    };
+    auto issue_end = [&]() __attribute__((always_inline)) {
         if (AMODE == 2) {
             t_c0 += SG_BK;
             if (t_c0 >= g.Cin) {
@@ -657,6 +669,12 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
                 if (++t_kw == g.KW) { t_kw = 0; ++t_kh; }
             }
         }
+    };
+    auto issue = [&](uint32_t kt, uint32_t stage) __attribute__((always_inline)) {
+        issue_begin(kt, stage);
+#pragma unroll
+        for (int q = 0; q < RA + RB; q++) issue_round(q);
+        issue_end();
     };
     uint32_t a_rd[MT][4], b_rd[NT][4];
 #pragma unroll
@@ -683,7 +701,11 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
         // ... and after the barrier everybody's has, and everybody is done reading the stage that step it + 2 overwrites (read in step it - 1)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < n_k) issue(it + 2, stage >= 1 ? stage - 1 : 2);                // (it + 2) % 3
+        const bool more = it + 2 < n_k;
+        const uint32_t nstage = stage >= 1 ? stage - 1 : 2;                          // (it + 2) % 3
+        const bool late = SCHED == 1 && wave_u >= 4;
+        if (SCHED == 2) { if (more) issue_begin(it + 2, nstage); }
+        else if (more && !late) issue(it + 2, nstage);
         const unsigned char *sA = sgb_lds + (size_t)stage * SGB_STAGE, *sB = sA + BM * SG_BK * 2;
         sd_h8 a[2][MT], b[2][NT];
 #pragma unroll
@@ -707,7 +729,15 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
                 for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if (SCHED == 2 && more) {
+                if (s2 == 0) { issue_round(0); issue_round(1); }
+                else if (s2 == 1) { issue_round(2); issue_round(3); }
+                else if (s2 == 2) issue_round(4);
+                else { issue_round(5); issue_end(); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (SCHED == 1 && more && late) issue(it + 2, nstage);
         stage = stage == 2 ? 0 : stage + 1;
     }
     __syncthreads();                                                               // every wave is done with the last stage: the tile may take its place
@@ -899,18 +929,27 @@ static bool sg_use_big(const CnerfSdGemm *g, const SgPlan &plan) {
     return tiles >= (uint64_t)min_tiles;
 }
 
-static void sgb_launch(const CnerfSdGemm *g, hipStream_t st) {
+template <int SCHED>
+static void sgb_launch_s(const CnerfSdGemm *g, hipStream_t st) {
     const dim3 grid(cn_div_up(g->M, SGB_BM), cn_div_up(g->N, SGB_BN), g->batch_outer * g->batch_inner);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<0, false, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, false, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sd_gemm_big<2, true, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, sgb_lds_bytes());
         attr_set = true;
     }
-    if (g->mode == 0) hipLaunchKernelGGL((k_sd_gemm_big<0, false>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
-    else if (g->tstride == 1 && g->ups == 1) hipLaunchKernelGGL((k_sd_gemm_big<2, true>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
-    else hipLaunchKernelGGL((k_sd_gemm_big<2, false>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+    if (g->mode == 0) hipLaunchKernelGGL((k_sd_gemm_big<0, false, SCHED>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+    else if (g->tstride == 1 && g->ups == 1) hipLaunchKernelGGL((k_sd_gemm_big<2, true, SCHED>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+    else hipLaunchKernelGGL((k_sd_gemm_big<2, false, SCHED>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
+}
+static void sgb_launch(const CnerfSdGemm *g, hipStream_t st) {
+#ifdef CNERF_TUNING
+    static const int sched = cn_tune_env("CNERF_SGB_SCHED", 1);
+    if (sched == 0) { sgb_launch_s<0>(g, st); return; }
+    if (sched == 2) { sgb_launch_s<2>(g, st); return; }
+#endif
+    sgb_launch_s<1>(g, st);
 }
 
 template <int AMODE, int NT, bool SPLIT, bool GLDS, bool SIMPLE = false>

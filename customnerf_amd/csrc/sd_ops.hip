@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const _Float16 *__restr
                     const float m = gn_unfix(fsums[((size_t)b * G + g) * 2]) * inv_n;
                     const float v = gn_unfix(fsums[((size_t)b * G + g) * 2 + 1]) * inv_n - m * m;
                     mean[k] = m;
-                    rstd[k] = rsqrtf(fmaxf(v, 0.0f) + eps);
+                    rstd[k] = (v != v) ? v : rsqrtf(fmaxf(v, 0.0f) + eps);              // (a poisoned sum of squares must not vanish in fmaxf)
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) { gam[e] = gamma[c0 + e]; bet[e] = beta[c0 + e]; }
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply(const _Float16 *__restr
             const float m = gn_unfix(fsums[((size_t)b * G + g) * 2]) * inv_n;
             const float v = gn_unfix(fsums[((size_t)b * G + g) * 2 + 1]) * inv_n - m * m;
             mean[e] = m;
-            rstd[e] = rsqrtf(fmaxf(v, 0.0f) + eps);
+            rstd[e] = (v != v) ? v : rsqrtf(fmaxf(v, 0.0f) + eps);              // (a poisoned sum of squares must not vanish in fmaxf)
             ga[e] = gamma[c0 + e];
             be[e] = beta[c0 + e];
             s1[e] = s2[e] = 0.0f;

@@ -30,6 +30,8 @@ code on host tensors, where the Adam arithmetic is spelled out in torch — CUDA
 import torch
 import torch.distributed as dist
 
+from . import _coll
+
 BIG_PARAM_MIN = 1 << 20
 ALIGN = 64                      # shard boundaries in elements (float4 / half8 vector accesses of the Adam kernel, 128-byte lines)
 
@@ -106,7 +108,7 @@ class ShardedExchange:
     # ---- called from the backward pass, between the field backward and the grid scatter
     def start_small(self):
         if self.small_seg is not None and self._small_work is None:
-            self._small_work = dist.all_reduce(self.small_seg, op=dist.ReduceOp.SUM, group=self.group, async_op=self.async_ops)
+            self._small_work = _coll.all_reduce(self.small_seg, op=dist.ReduceOp.SUM, group=self.group, async_op=self.async_ops)
             if self._small_work is None:
                 self._small_work = True
 
@@ -123,7 +125,7 @@ class ShardedExchange:
             else:
                 torch.mul(src, inv_world, out=st['send'][:st['n']])      # pre-scaled so that the sum stays in range
                 src.zero_()                                              # the scatter of the next step accumulates into it
-            works.append(dist.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=self.async_ops))
+            works.append(_coll.all_to_all_single(st['recv'].view(-1), st['send'], group=self.group, async_op=self.async_ops))
         self.start_small()
         for st, w in zip(self.state, works):
             if w is not None:
@@ -147,7 +149,7 @@ class ShardedExchange:
                 self.scaler.check(st['g32'])
         if self.small_seg is not None:
             self.scaler.check(self.small_seg)
-        dist.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=self.group)
+        _coll.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=self.group)
 
     def step(self, lr_factor, loss_scale=1.0):
         """steps 4-5 for the big parameters.  The gradients in g32 are MEANS over ranks of loss_scale-scaled gradients (the 1/world factor went
@@ -170,10 +172,10 @@ class ShardedExchange:
             else:
                 _adam_host(st['master'], st['g32'], st['m'], st['v'], half_out, lr, self.betas, self.eps, st['step'], 1.0 / loss_scale)
             if 'shadow' in st:
-                dist.all_gather_into_tensor(st['shadow'], st['shadow'][lo:lo + s], group=self.group)          # in place: 2 bytes per parameter
+                _coll.all_gather_into_tensor(st['shadow'], st['shadow'][lo:lo + s], group=self.group)          # in place: 2 bytes per parameter
                 p._cnerf_stale = True            # the float32 nn.Parameter now lags the owners' master shards until consolidate() (checkpoint.py refuses it)
             else:
-                dist.all_gather_into_tensor(st['gather32'], st['master'], group=self.group)
+                _coll.all_gather_into_tensor(st['gather32'], st['master'], group=self.group)
                 p.data.reshape(-1).copy_(st['gather32'][:n])
             p._cnerf_epoch = getattr(p, '_cnerf_epoch', 0) + 1
 
@@ -189,7 +191,7 @@ class ShardedExchange:
             full = torch.empty(self.world * st['shard'], dtype=torch.float32, device=dev)
             entry = optimizer.state[p]
             for key, src in (('exp_avg', st['m']), ('exp_avg_sq', st['v'])):
-                dist.all_gather_into_tensor(full, src, group=self.group)
+                _coll.all_gather_into_tensor(full, src, group=self.group)
                 entry[key] = full[:n].clone().view(p.shape)
             entry['step'] = st['step']
 
@@ -222,6 +224,6 @@ class ShardedExchange:
             if 'shadow' not in st:
                 continue                                                 # float32 mode keeps the parameter current in step()
             full = torch.empty(self.world * st['shard'], dtype=torch.float32, device=st['p'].device)
-            dist.all_gather_into_tensor(full, st['master'], group=self.group)
+            _coll.all_gather_into_tensor(full, st['master'], group=self.group)
             st['p'].data.reshape(-1).copy_(full[:st['n']])
             st['p']._cnerf_stale = False

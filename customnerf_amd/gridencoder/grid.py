@@ -163,15 +163,16 @@ def _side_busy(side):
 _NEEDS_PLAN = {}
 
 
-def _needs_plan(offsets_host, B, D, C, L, S, H, dt):
+def _needs_plan(offsets_host, B, D, C, L, S, H, dt, gridtype):
     """does the backward scatter of this shape use a plan prepared ahead of time?  (cnerf_grid_encode_backward_needs_plan, cached per shape: the
     round-5 scatter counts inside its emit kernel, so the run() path of the benchmark configuration prepares nothing)"""
     import ctypes
-    key = (offsets_host.ctypes.data, B, D, C, L, S, H, dt)
+    key = (offsets_host.ctypes.data, B, D, C, L, S, H, dt, gridtype)
     v = _NEEDS_PLAN.get(key)
     if v is None:
         n = ctypes.c_int(0)
-        check(lib.cnerf_grid_encode_backward_needs_plan(offsets_host.ctypes.data, B, D, C, L, L, S, H, dt, ctypes.addressof(n)), "grid_encode_backward_needs_plan")
+        check(lib.cnerf_grid_encode_backward_needs_plan(offsets_host.ctypes.data, B, D, C, L, L, S, H, gridtype, dt, ctypes.addressof(n)),
+              "grid_encode_backward_needs_plan")
         if len(_NEEDS_PLAN) > 256:
             _NEEDS_PLAN.clear()
         v = _NEEDS_PLAN[key] = (bool(n.value), offsets_host)             # (the array reference pins the key's address)
@@ -182,7 +183,7 @@ def _prepare_plan(inputs, offsets_host, B, D, C, L, S, H, gridtype, align_corner
     """Issue the coordinate-only half of the binned backward scatter (histogram + scans) for `inputs` [B, D] on the side stream of the
     current compute stream -> _Plan, or None when the side stream still holds an earlier plan / the problem takes the atomic kernel."""
     import ctypes
-    if not _needs_plan(offsets_host, B, D, C, L, S, H, dt):
+    if not _needs_plan(offsets_host, B, D, C, L, S, H, dt, gridtype):
         return None
     side = _side(device)
     if _side_busy(side):
@@ -218,7 +219,7 @@ def _plan_rows(state, inputs, offsets_host, B, D, C, L, S, H, gridtype, align_co
     coordinates of ITS rows must exist).  -> state (a dict) while pieces are pending, a _Plan once `finish`, or None when the shape takes the
     atomic kernel / the side stream is busy (then nothing was issued and attach_backward plans by itself)."""
     import ctypes
-    if state is None and not _needs_plan(offsets_host, B, D, C, L, S, H, dt):
+    if state is None and not _needs_plan(offsets_host, B, D, C, L, S, H, dt, gridtype):
         return None
     side = _side(device)
     if state is None:

@@ -418,7 +418,8 @@ class NeRFRenderer(nn.Module):
         tot = self.step_counter[:total_step, 0].sum().float()
         import torch.distributed as dist
         if getattr(self.opt, 'sync_mean_count', True) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(tot)
+            from .. import _coll
+            _coll.all_reduce(tot)
             tot = tot / dist.get_world_size()
         return int(tot.item() / total_step)
 

@@ -7,6 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _coll
 from .optim import DynamicLossScaler, FusedAdam
 
 
@@ -55,13 +56,13 @@ def allreduce_grads_flat(parameters, flat, world_size):
         return flat
     grads = [p.grad for p in parameters if p.grad is not None]
     if flat is not None and _grads_alias_flat(grads, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _coll.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
     n = sum(g.numel() for g in grads)
     if flat is None or flat.numel() != n:
         flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)       # staging buffer (the caller keeps it for the next step)
     torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _coll.all_reduce(flat, op=dist.ReduceOp.SUM)
     torch._foreach_copy_([g.reshape(-1) for g in grads], list(flat.split([g.numel() for g in grads])))
     return flat
 

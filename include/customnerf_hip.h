@@ -180,10 +180,10 @@ int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offse
 int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points);
 /* *needs_plan = 1 when cnerf_grid_encode_backward of this shape profits from a plan prepared ahead of time (the forms that need the exact record
  * counts before the emit: float16 records on tables of more than 128 chunks per level, e.g. T = 2^21; float32 records); 0 when there is nothing to
- * prepare — the atomic kernel, or (round 5) the scatter that counts inside its emit kernel: float16 records, <= 128 chunks of 4096 entries per level.
+ * prepare — the atomic kernel, or (round 5) the scatter that counts inside its emit kernel: float16 records on a hash grid (gridtype 0) of <= 128 chunks of 4096 entries per level.
  * The _prepare* entry points report *prepared = 0 for such shapes; this query lets a caller skip them (and their workspace) altogether. */
 int cnerf_grid_encode_backward_needs_plan(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
-                                          uint32_t H, int dtype, int *needs_plan);
+                                          uint32_t H, uint32_t gridtype, int dtype, int *needs_plan);
 int cnerf_grid_encode_backward_prepare_rows(const float *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                             float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, uint32_t row0,
                                             uint32_t rows, void *workspace, uint64_t workspace_bytes, int *prepared, void *stream);

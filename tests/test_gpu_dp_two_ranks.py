@@ -1,0 +1,88 @@
+"""the N > 1 code path on a ONE-GPU box.  Two fresh child ranks share device 0; their process group is gloo with every
+collective staged through host memory (customnerf_amd/_coll.py) — same call order and arithmetic as the RCCL run, no links.  (1) two
+data-parallel steps of the sharded exchange end in exactly the table / MLPs a single process reaches from the two views' mean gradient;
+(2) `bench.py --gpus 2` runs end to end through its own launcher — every leg, the variants, the strong-scaling and multi-view sub-records — which
+is what catches collective-order hangs (a rank that skips a leg leaves its peer waiting: ADVICE r3)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_on_one_device_match_the_mean_gradient_step(tmp_path):
+    from dp_two_ranks_common import build, view_draws, KW
+    steps, world = 2, 2
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CNERF_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_two_ranks_child.py"), str(tmp_path), str(steps)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    got = torch.load(os.path.join(tmp_path, "rank0.pt"))
+
+    # the same two steps in ONE process: per step the two views' scaled gradients g0, g1 -> table gradient float(half(g0 / 2)) + float(half(g1 / 2))
+    # (the fp16 all-to-all payload, summed in float32 on arrival), MLP gradients g0 + g1 (float32 all-reduce), Adam with 1 / (scale * world)
+    from customnerf_amd.trainer import ReconTrainer, apply_optimizer_step
+    model, opt, views = build()
+    tr = ReconTrainer(model, opt, fp16=True)
+    tr.world_size = world                                          # un-scale by 1 / (scale * 2); no process group: the "all-reduce" is done by hand below
+    tr.allreduce_grads = lambda: None
+    params = list(model.parameters())
+    table = model.pos_en.embeddings
+    for s in range(steps):
+        per_rank = []
+        for r in range(world):
+            v = s * world + r
+            for p in params:
+                p.grad.zero_()
+            model.train()
+            with torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(views[v][0], views[v][1], staged=False, perturb=True, force_all_rays=True, _draws=view_draws(v), **KW)
+                loss = tr.loss(out, views[v][2], views[v][3])
+            tr.scaler.backward(loss)
+            per_rank.append([p.grad.detach().clone() for p in params])
+        for i, p in enumerate(params):
+            if p is table:
+                g = (per_rank[0][i] * 0.5).half().float() + (per_rank[1][i] * 0.5).half().float()
+                p.grad.copy_(g * 2.0)                                # (exact: the optimiser's 1 / (scale * world) then gives g / scale)
+            else:
+                p.grad.copy_(per_rank[0][i] + per_rank[1][i])
+        apply_optimizer_step(tr)
+        tr.global_step += 1
+    for a, b in zip(got["params"], params):
+        assert torch.equal(a, b.detach().cpu()), float((a - b.detach().cpu()).abs().max())
+    assert torch.equal(got["shadow"], model.pos_en.half_table().detach().cpu())
+    assert torch.equal(got["scale"], tr.scaler.state.detach().cpu())
+
+
+def test_bench_two_ranks_on_one_device_runs_every_leg():
+    env = dict(os.environ, CNERF_DP_BACKEND="gloo", CNERF_SINGLE_DEVICE="1", CNERF_BENCH_WATCHDOG="420")      # (a hang ends in stack dumps, not in the suite's timeout)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and "gloo" in rec["collective_backend"]
+    assert rec["value"] > 0 and rec["config"]["exchange_ms"] > 0 and "dp2" in rec["config"]["parallelism"]
+    assert rec["strong"]["value"] > 0                                   # one view's rays split over the two ranks
+    sec = rec["secondary"]
+    assert sec["value"] > 0 and sec["n_gpus"] == 2 and sec["multi_view"]["views_per_s"] > 0

@@ -232,7 +232,7 @@ def test_scatter_skips_zero_rows_and_recomputes_overflowing_bins():
                                              enc.gridtype_id, int(enc.align_corners), enc.interp_id, 1, ptr(ws), ws.numel() if binned else 0, stream()))
         return out
     # (a)
-    B = 150001
+    B = 300001
     rng = np.random.default_rng(21)
     x = cuda(make_inputs(B, 3, seed=22))
     g = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32)).cuda().half()

@@ -349,8 +349,9 @@ def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
     a row block of a convolution has other borders), the transposed-stride input gradient of the VAE's downsampling convolutions, ragged M."""
     from customnerf_amd.sd import ops, pack
     g = torch.Generator().manual_seed(77)
-    # dense: M = 65536 + 77 (ragged), N = 256, K = 1152 -> 257 x 2 tiles; row blocks of 8192 -> 32 x 2 tiles: the 128-row kernel
-    M, N, K = 65536 + 77, 256, 1152
+    # dense: M = 65536, N = 128, K = 1152 -> 256 x 1 tiles of 256 x 128: the eight-wave kernel; row blocks of 32768 -> 128 such tiles: the 128-row
+    # kernel, with >= 256 of its own tiles, i.e. without split-K (whose float32 partial sums round differently)
+    M, N, K = 65536, 128, 1152
     x = torch.randn(M, K, generator=g).half().cuda()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
     b = torch.randn(N, generator=g).cuda()
@@ -358,14 +359,20 @@ def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
     for kw in (dict(bias=b, residual=r), dict(act=ops.ACT_SILU, alpha=0.5), dict(bias=b, act=ops.ACT_GELU)):
         big = ops.linear(x, w, **kw)
         parts = []
-        for m0 in range(0, M, 8192):
+        for m0 in range(0, M, 32768):
             kws = dict(kw)
             if 'residual' in kws:
-                kws['residual'] = r[m0:m0 + 8192]
-            parts.append(ops.linear(x[m0:m0 + 8192], w, **kws))
+                kws['residual'] = r[m0:m0 + 32768]
+            parts.append(ops.linear(x[m0:m0 + 32768], w, **kws))
         assert torch.equal(big, torch.cat(parts, 0)), kw.keys()
-    y = ops.linear(x[:4096], w, bias=b).float().cpu()
-    close(y, x[:4096].float().cpu() @ w.float().cpu().t() + b.cpu(), 2e-3, 4e-3)
+    # ragged M and N on the eight-wave kernel against the CPU reference
+    Mr, Nr = 65536 + 77, 328
+    xr = torch.randn(Mr, K, generator=g).half().cuda()
+    wr = (torch.randn(Nr, K, generator=g) / math.sqrt(K)).half().cuda()
+    br = torch.randn(Nr, generator=g).cuda()
+    yr = ops.linear(xr, wr, bias=br)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(Mr - 300, Mr)])
+    close(yr[rows.cuda()].float().cpu(), xr[rows.cuda()].float().cpu() @ wr.float().cpu().t() + br.cpu(), 2e-3, 4e-3)
     # convolutions against the CPU reference: 3 x 3 stride 1 (plain), and the stride-2 input gradient (transposed-stride loader)
     B, C, H, Co = 1, 128, 256, 128
     xc = h(torch.randn(B, C, H, H, generator=g))
