@@ -539,6 +539,12 @@ __global__ void __launch_bounds__(SG_THREADS) k_sd_gemm(const CnerfSdGemm g, flo
 }
 
 // ================================================================================================ 256-row tile, eight waves, three stages (round 5)
+// TUNING BUILDS ONLY (`make TUNING=1`, CNERF_SG_BIG=1): measured slower than the 128-row kernel on every shape it was built for — 652 / 655-683 /
+// 756-810 TFLOP/s against 689 / 728-764 / 840-845 on the VAE's 512^2 x 128, 256^2 x 256 and 128^2 x 512 convolutions, whatever the schedule of the
+// DMA rounds (profiles/r05_gemm_big_tile.txt).  Reading: 144 KiB of stages leave ONE workgroup per CU, so the prologue (two stages of DMA latency)
+// and the epilogue (135 KiB of fp32 through LDS, 8 items per thread) of a tile are no longer hidden behind a second resident workgroup's main loop —
+// with K = 1152 ... 4608 (18 ... 72 K steps) that is 10-30 % of a tile's time, more than the shared B tile and the deeper ring buy.
+#ifdef CNERF_TUNING
 // The 128 x {64, 128} kernel above fills 24-32 KiB of LDS per 2.1 MFLOP K step and drains its single step of prefetch at every barrier
 // (`vmcnt(0)` + `__syncthreads()`): on the large-M convolutions of the VAE (M = 16 K ... 262 K rows, N = 128 ... 512) its matrix pipe is busy
 // 28 % of the time (profiles/r04_sd_mfma_pmc.json).  This kernel takes a 256 x 128 tile with EIGHT waves (4 x 2, each the same 64 x 64 wave
@@ -755,6 +761,7 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
     long long (*gn_lds)[36][2] = reinterpret_cast<long long (*)[36][2]>(sgb_lds + CT_BYTES);
     sg_epilogue_phase2<BM, BN, SGB_THREADS, false>(g, ct, gn_lds, tid, m0, n0, zo, zi, 0u, nullptr);
 }
+#endif  // CNERF_TUNING
 
 // split-K tail: sum the partials, apply the epilogue
 __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGemm g, const float *__restrict__ partial, uint32_t splits) {
@@ -915,11 +922,12 @@ static bool sg_use_glds(const CnerfSdGemm *g) {
     return v != 0 && sg_glds_fits(g);
 }
 
+#ifdef CNERF_TUNING
 // Which problems take the 256 x 128 eight-wave kernel: LDS-DMA-able operands (dense, or a convolution with Cin % 64 == 0), no split-K, and enough
 // tiles to give every CU a workgroup (below that the 128-row tiles fill the chip better); a GroupNorm-statistics request needs images of at
 // least 128 rows (a 256-row tile then touches at most three: the epilogue's table holds four).
 static bool sg_use_big(const CnerfSdGemm *g, const SgPlan &plan) {
-    static const int on = cn_tune_env("CNERF_SG_BIG", 1);
+    static const int on = cn_tune_env("CNERF_SG_BIG", 0);
     static const int min_tiles = cn_tune_env("CNERF_SG_BIG_TILES", 224), min_k = cn_tune_env("CNERF_SG_BIG_K", 512);
     if (!on || plan.splits > 1 || !sg_use_glds(g)) return false;
     if (g->mode != 0 && (g->Cin % SG_BK) != 0) return false;
@@ -944,13 +952,12 @@ static void sgb_launch_s(const CnerfSdGemm *g, hipStream_t st) {
     else hipLaunchKernelGGL((k_sd_gemm_big<2, false, SCHED>), grid, dim3(SGB_THREADS), sgb_lds_bytes(), st, *g);
 }
 static void sgb_launch(const CnerfSdGemm *g, hipStream_t st) {
-#ifdef CNERF_TUNING
-    static const int sched = cn_tune_env("CNERF_SGB_SCHED", 1);
+    static const int sched = cn_tune_env("CNERF_SGB_SCHED", 2);
     if (sched == 0) { sgb_launch_s<0>(g, st); return; }
-    if (sched == 2) { sgb_launch_s<2>(g, st); return; }
-#endif
-    sgb_launch_s<1>(g, st);
+    if (sched == 1) { sgb_launch_s<1>(g, st); return; }
+    sgb_launch_s<2>(g, st);
 }
+#endif  // CNERF_TUNING
 
 template <int AMODE, int NT, bool SPLIT, bool GLDS, bool SIMPLE = false>
 static void sg_launch_g(const CnerfSdGemm *g, dim3 grid, hipStream_t st, float *partial, uint32_t kps) {
@@ -1016,10 +1023,12 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
         kps = cn_div_up(g->K, SG_BK);
     }
     const bool split = splits > 1;
+#ifdef CNERF_TUNING
     if (!split && sg_use_big(g, plan)) {
         sgb_launch(g, st);
         return cn_launch_status();
     }
+#endif
     const dim3 grid(cn_div_up(g->M, SG_BM), cn_div_up(g->N, 64 * nt), split ? splits : g->batch_outer * g->batch_inner);
     const int amode = g->mode == 0 ? 0 : ((g->Cin % SG_BK) == 0 ? 2 : 1);
     float *partial = reinterpret_cast<float *>(workspace);

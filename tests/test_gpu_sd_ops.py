@@ -315,7 +315,7 @@ def test_image_front_end_and_sds_tail():
 
 
 @pytest.mark.parametrize("B,C,H,Co", [(2, 320, 64, 320), (1, 128, 96, 128), (2, 64, 8, 128), (2, 320, 16, 640),
-                                      (1, 128, 256, 128), (2, 256, 128, 256)])                       # the 256-row eight-wave kernel (>= 224 tiles)
+                                      (1, 128, 256, 128), (2, 256, 128, 256)])                       # the VAE's large-M shapes
 def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     """the producing conv accumulates the next GroupNorm's statistics in its epilogue (gn=): same normalised output as the two-pass norm"""
     from customnerf_amd.sd import ops, pack
@@ -342,15 +342,12 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     assert torch.equal(sums, sums2) and torch.equal(s_ref, s_ref2)
 
 
-def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
-    """Round 5: launches with at least one 256 x 128 tile per CU take k_sd_gemm_big (eight waves, three-stage LDS-DMA ring, counted vmcnt).  Its
-    waves run the same 64 x 64 tile and the same MFMA sequence per K step as k_sd_gemm, so the same problem cut into row blocks small enough to
-    take the 128-row kernel must give the same BITS — dense with bias / activation / residual, a 3 x 3 convolution (against the CPU reference:
-    a row block of a convolution has other borders), the transposed-stride input gradient of the VAE's downsampling convolutions, ragged M."""
+def test_large_m_gemms_match_the_reference_and_their_row_blocks():
+    """The VAE's shapes (M = 64 K ... 262 K rows): the same problem cut into row blocks must give the same BITS (a tile's K loop does not depend on
+    where the tile sits; both sizes run without split-K) — dense with bias / activation / residual; ragged M and N, a 3 x 3 convolution and the
+    transposed-stride input gradient of the downsampling convolutions against the CPU reference."""
     from customnerf_amd.sd import ops, pack
     g = torch.Generator().manual_seed(77)
-    # dense: M = 65536, N = 128, K = 1152 -> 256 x 1 tiles of 256 x 128: the eight-wave kernel; row blocks of 32768 -> 128 such tiles: the 128-row
-    # kernel, with >= 256 of its own tiles, i.e. without split-K (whose float32 partial sums round differently)
     M, N, K = 65536, 128, 1152
     x = torch.randn(M, K, generator=g).half().cuda()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
@@ -365,7 +362,6 @@ def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
                 kws['residual'] = r[m0:m0 + 32768]
             parts.append(ops.linear(x[m0:m0 + 32768], w, **kws))
         assert torch.equal(big, torch.cat(parts, 0)), kw.keys()
-    # ragged M and N on the eight-wave kernel against the CPU reference
     Mr, Nr = 65536 + 77, 328
     xr = torch.randn(Mr, K, generator=g).half().cuda()
     wr = (torch.randn(Nr, K, generator=g) / math.sqrt(K)).half().cuda()
@@ -373,7 +369,6 @@ def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
     yr = ops.linear(xr, wr, bias=br)
     rows = torch.cat([torch.arange(0, 300), torch.arange(Mr - 300, Mr)])
     close(yr[rows.cuda()].float().cpu(), xr[rows.cuda()].float().cpu() @ wr.float().cpu().t() + br.cpu(), 2e-3, 4e-3)
-    # convolutions against the CPU reference: 3 x 3 stride 1 (plain), and the stride-2 input gradient (transposed-stride loader)
     B, C, H, Co = 1, 128, 256, 128
     xc = h(torch.randn(B, C, H, H, generator=g))
     wc = h(torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C))
@@ -386,7 +381,7 @@ def test_big_tile_gemm_is_bit_identical_to_the_128_row_kernel():
     dy = h(torch.randn_like(ref))
     ref.backward(dy)
     dx = ops.conv2d(nhwc(dy).half().cuda(), pack.pack_conv_dgrad(w2).cuda(), None, 3, stride=1, pad=2, tstride=2, out_hw=(256, 256))
-    close(nchw(dx), x2.grad, 3e-3, 5e-3, "stride-2 dgrad, big tile")
+    close(nchw(dx), x2.grad, 3e-3, 5e-3, "stride-2 dgrad at 256 x 256")
 
 
 @pytest.mark.parametrize("M,C", [(8192, 320), (128, 1280), (77, 64)])
