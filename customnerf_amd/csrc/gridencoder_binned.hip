@@ -868,13 +868,13 @@ __global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__res
         ok[i] = bn_load_point(inputs, b, B, in);
         g0[i] = g1[i] = fx[i] = 0.0f;
         if (ok[i]) {
-            b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
             const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
             g0[i] = __half2float(g.v[0]); g1[i] = __half2float(g.v[1]);
-            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
-            ok[i] = g0[i] != 0.0f || g1[i] != 0.0f;                              // a zero gradient adds zero to every sum: no records
-        }
+            ok[i] = g0[i] != 0.0f || g1[i] != 0.0f;                              // a zero gradient adds zero to every sum: no records,
+        }                                                                        // and no corner arithmetic either (a NaN is not zero)
         if (ok[i]) {
+            b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
+            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t c0 = bin_of(i0[i][q]);

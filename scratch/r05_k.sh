@@ -1,0 +1,21 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+out=gpurun_out/r05k
+mkdir -p $out
+prof() {
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $out/prof_$1 -o bench -- python3 bench.py --task recon --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-roofline $2 > $out/prof_$1.log 2>&1
+  python3 - <<E
+import csv, glob, collections
+f = glob.glob('$out/prof_$1/**/bench_kernel_trace.csv', recursive=True)[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    d[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+rows = sorted(((sum(v[-10:]) / len(v[-10:]) / 1e3, k, len(v)) for k, v in d.items()), reverse=True)
+print('--- $1 (mean of the last 10 launches, us)')
+for t, k, n in rows[:14]: print(f'   {t:8.1f}  {n:5d}  {k[:60]}')
+E
+  rm -rf $out/prof_$1
+}
+prof release ""
+prof release_fit "--prefit 300"
