@@ -319,7 +319,6 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     const uint32_t n_tiles = (P_ + FLD_TILE - 1) / FLD_TILE;
     const uint32_t G = gridDim.x * 2, gp = blockIdx.x * 2 + pair;                   // tile pipelines of the whole launch / this one
     const uint32_t n_iter = (n_tiles + G - 1) / G;                                  // workgroup-uniform: same barrier count for every wave
-    const uint32_t n_phase = (n_iter + 3) & ~1u;                                    // n_iter + 2 phases drain the pipeline; even: unrolled by two
     // Phase p of the launch works on tiles [p G, (p + 1) G): G consecutive tiles, two per workgroup.  WHICH two rotates with the phase: workgroup b
     // takes pair (b + 97 p) mod gridDim.x of the window.  With the plain assignment (pair b in every phase) a workgroup walks tiles 2b, 2b + 1
     // (+ k G): on the run() path (G = 512 tiles = two image rows of coarse samples) always the same image columns, and with early termination
@@ -331,18 +330,58 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     // assignment does not depend on which tiles are live: the weight-gradient sums of a pipeline add the same tiles in the same order with
     // and without the flags.
     auto tile_at = [&](uint32_t p) { return 2 * (p * gridDim.x + (blockIdx.x + p * 97u) % gridDim.x) + pair; };
-    // Liveness of this pipeline's tiles, 64 phases at a time in a scalar register pair: lane l fetches the flag of phase base + l, one ballot.
-    // (A flag fetched one phase ahead, the first version, put one memory latency into every dead phase — there is no arithmetic to hide it
-    // behind — and a run of dead tiles cost almost what live ones do: 401 us against 437 with half the tiles dead.)
-    auto live_mask = [&](uint32_t base) -> uint64_t {
-        if (!SKIP) return ~0ull;
+    // Early termination (SKIP): a window whose two tiles in this workgroup are both dead (cnerf_composite_run_backward_indexed_flush: every row's
+    // output gradient exactly zero) is not a step of the pipelines at all.  The liveness of the workgroup's tile pairs is held 64 windows at a
+    // time in a scalar register pair (lane l fetches the two flags of window base + l, one ballot), and every wave walks the set bits: step k of
+    // the software pipeline works on the k-th LIVE window p_k.  All four waves build the same masks, so they agree on the sequence and on the
+    // number of barriers.  What a dead pair still owes — zero rows of d(loss)/d(grid features) — wave A stores when it loads the mask.
+    // History, fitted field (55 % of the tiles dead), 437 us without flags: a flag fetched one phase ahead and dead tiles skipped IN PLACE
+    // 401 us (one exposed memory latency per dead phase), flags as masks 352 us, + rotation 328 us — in place, a dead tile between two live
+    // ones empties one wave's slot of the phase but not the phase (profiles/r05_field_bwd_dead_phase.json: alternating live / dead windows cost
+    // 0.8 of all-live); compacted, the pipeline only ever sees live windows.  A dead tile whose neighbour lives is processed like a live one
+    // (all its products are zeros: same sums, same rows).  Without flags every window is live: the same code, the same order of additions.
+    constexpr uint32_t END = 0xFFFFFFFFu;
+    struct LiveIt { uint32_t base; uint64_t m; };
+    auto pair_mask = [&](uint32_t base, bool fill) -> uint64_t {
         const uint32_t ph = base + lane;
         uint32_t f = 0;
         if (ph < n_iter) {
-            const uint32_t t = tile_at(ph);
-            if (t < n_tiles) f = tile_live[t];
+            if (SKIP) {
+                const uint32_t t0 = tile_at(ph) - pair;                             // the pair's first tile
+                if (t0 < n_tiles) f = tile_live[t0];
+                if (t0 + 1 < n_tiles) f |= tile_live[t0 + 1];
+            } else {
+                f = 1;
+            }
         }
-        return __ballot(f != 0);
+        const uint64_t m = __ballot(f != 0);
+        if (SKIP && fill) {
+            const uint32_t nv = min(64u, n_iter - base);
+            uint64_t dead = ~m & (nv == 64 ? ~0ull : (1ull << nv) - 1);
+            while (dead) {
+                const uint32_t tile = tile_at(base + (uint32_t)__builtin_ctzll(dead));
+                dead &= dead - 1;
+                const uint32_t row = tile * FLD_TILE + li;
+                if (row < P_) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const uint32_t level = (uint32_t)fld_rho(r, (int)hi) >> 1;
+                        if (level < dm.L) reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + row] = 0u;
+                    }
+                }
+            }
+        }
+        return m;
+    };
+    auto it_next = [&](LiveIt &it, bool fill) -> uint32_t {                         // the next live window, END when there is none (and from then on)
+        while (it.m == 0) {
+            if (it.base + 64 >= n_iter) return END;
+            it.base += 64;
+            it.m = pair_mask(it.base, fill);
+        }
+        const uint32_t b = (uint32_t)__builtin_ctzll(it.m);
+        it.m &= it.m - 1;
+        return it.base + b;
     };
     float *part = partials + (size_t)gp * po.total;
     const uint32_t off_n0 = lo.off[0] * 2, off_n1 = lo.off[1] * 2, off_n2 = lo.off[2] * 2, off_d0 = lo.off[3] * 2, off_dO = lo.off[4] * 2,
@@ -367,30 +406,23 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
         for (int s = 0; s < 4; s++) S0.h1[s] = S1.h1[s] = S0.h2[s] = S1.h2[s] = PR::zero();
         S0.p = S1.p = 0; S0.v = S1.v = false; S0.live = S1.live = false;
         frag_t N0[SENC], N1[SENC];                            // grid features requested one phase ahead (even / odd tiles)
-        uint64_t lmask = ~0ull;                               // liveness of the tiles of phases [p & ~63, +64)
-        x4_enc_request<SENC>(enc, P_, dm.L, tile_at(0) * FLD_TILE + li, hi, N0);
+        LiveIt it;
+        it.base = 0; it.m = pair_mask(0, true);
+        uint32_t pk = it_next(it, true);                      // window of step k (forward), END beyond the last
+        uint32_t kend = pk == END ? 0u : END;                 // number of live windows, once known
+        x4_enc_request<SENC>(enc, P_, dm.L, (pk == END ? 0u : tile_at(pk)) * FLD_TILE + li, hi, N0);
 #pragma unroll
         for (int s = 0; s < SENC; s++) N1[s] = PR::zero();
         unsigned char *my = xch + X2_A;
-        auto phase = [&](uint32_t p, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC]) __attribute__((always_inline)) {
+        auto phase = [&](uint32_t k, ASet &S, frag_t (&xcur)[SENC], frag_t (&xnext)[SENC]) __attribute__((always_inline)) {
             X4_T0();
             asm volatile("" ::: "memory");
-            const uint32_t tile_n = tile_at(p + 1);                      // (beyond the last phase: some tile, requested and never used)
-            x4_enc_request<SENC>(enc, P_, dm.L, tile_n * FLD_TILE + li, hi, xnext);
-            // ---- backward of tile p-2 (dz_3 was published by wave B in phase p-1); S still holds that tile
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 1) && !S.live) {
-                // a dead tile (cnerf_composite_run_backward_indexed_flush: every row's output gradient is exactly zero): nothing to add to any
-                // weight gradient; its rows of d(loss)/d(grid features) are zeros
-                if (S.v) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const uint32_t level = (uint32_t)fld_rho(r, (int)hi) >> 1;
-                        if (level < dm.L) reinterpret_cast<uint32_t *>(grad_enc)[(size_t)level * P_ + S.p] = 0u;
-                    }
-                }
-            }
-            if (p >= 2 && p - 2 < n_iter && !(ablate & 1) && S.live) {
-                const unsigned char *z3i = xch + X2_Z3 + ((p - 2) & 1) * 4 * X4_K;
+            const uint32_t pn = pk == END ? END : it_next(it, true);                // window of step k + 1
+            if (pn == END && kend == END) kend = k + 1;
+            x4_enc_request<SENC>(enc, P_, dm.L, (pn == END ? 0u : tile_at(pn)) * FLD_TILE + li, hi, xnext);   // (beyond the last: some tile, never used)
+            // ---- backward of the tile of step k-2 (dz_3 was published by wave B in step k-1); S still holds that tile
+            if (!(ablate & 1) && S.live) {
+                const unsigned char *z3i = xch + X2_Z3 + (k & 1) * 4 * X4_K;
                 frag_t z3[4];
                 x4_fetch<4>(z3i, lane, z3);
                 x4_publish<SENC>(my + X2_A_X0, lane, S.x0);
@@ -441,17 +473,16 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                     }
                 }
             }
-            // ---- forward of tile p (overwrites S)
-            if (p < n_iter && !(ablate & 2)) {
-                const uint32_t tile = tile_at(p);
+            // ---- forward of the tile of step k (overwrites S)
+            if (pk != END && !(ablate & 2)) {
+                const uint32_t tile = tile_at(pk);
                 S.p = tile * FLD_TILE + li;
                 S.v = S.p < P_;
-                if (SKIP && (p & 63) == 0) lmask = live_mask(p);
-                S.live = tile < n_tiles && ((lmask >> (p & 63)) & 1) != 0;                 // (wave-uniform, scalar)
+                S.live = tile < n_tiles;                                                   // (wave-uniform)
             } else {
-                S.live = false;
+                S.live = false; S.v = false;
             }
-            if (p < n_iter && !(ablate & 2) && S.live) {
+            if (S.live) {
                 x4_enc_mask<SENC>(xcur, dm.L, S.v, hi, S.x0);
                 cn_f16v acc[2];
                 fb_zero(acc);
@@ -466,15 +497,14 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                 fb_zero(acc);
                 x4_gemm<2, S64>(wl + lo.off[2], S64, 0, (NGEO == 2) ? S.h2 : S.h1, lane, acc);
                 x4_c_to_b<false>(acc, fea);
-                x4_publish<4>(xch + X2_FEA + (p & 1) * 4 * X4_K, lane, fea);
-            } else if (!(p < n_iter && !(ablate & 2))) {
-                S.v = false;
+                x4_publish<4>(xch + X2_FEA + (k & 1) * 4 * X4_K, lane, fea);
             }
+            pk = pn;
             X4_T1();
         };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, S0, N0, N1);
-            phase(p + 1, S1, N1, N0);
+        for (uint32_t k = 0; kend == END || k < kend + 2; k += 2) {                 // kend live windows + 2 steps to drain, in pairs
+            phase(k, S0, N0, N1);
+            phase(k + 1, S1, N1, N0);
         }
 #pragma unroll
         for (int a = 0; a < 2; a++) {
@@ -495,11 +525,11 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             for (int b = 0; b < 2; b++) { x4_zero(wrf[a][b]); x4_zero(wd0[a][b]); }
         }
         // per-sample inputs, requested unconditionally (clamped index) and masked at use: see x4_enc_request
-        struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; };
-        uint64_t lmask = ~0ull;                               // liveness of the tiles of phases [(p - 1) & ~63, +64)
-        auto load_in = [&](uint32_t tile) __attribute__((always_inline)) {
+        struct BIn { float x, y, z, gs, dx, dy, dz; float4 gc; uint32_t tile; };
+        auto load_in = [&](uint32_t window) __attribute__((always_inline)) {
             BIn r;
-            const uint32_t p = min(tile * FLD_TILE + li, P_ - 1);
+            r.tile = window == END ? END : tile_at(window);
+            const uint32_t p = min((window == END ? 0u : r.tile) * FLD_TILE + li, P_ - 1);
             r.x = xyz[(size_t)p * 3]; r.y = xyz[(size_t)p * 3 + 1]; r.z = xyz[(size_t)p * 3 + 2];
             r.gs = g_sigma[p];
             r.gc = *reinterpret_cast<const float4 *>(g_rgbc + (size_t)p * 4);
@@ -507,17 +537,24 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             r.dx = dp[0]; r.dy = dp[1]; r.dz = dp[2];
             return r;
         };
-        BIn I0 = load_in(tile_at(0)), I1 = I0;
+        LiveIt it;
+        it.base = 0; it.m = pair_mask(0, false);
+        uint32_t pk = it_next(it, false);                     // window of step k (this wave works on step k-1's tile)
+        uint32_t kend = pk == END ? 0u : END;
+        BIn I0 = load_in(pk), I1 = I0;
         unsigned char *my = xch + X2_B;
         const bool dir_uniform = (dir_group % FLD_TILE) == 0;
-        auto phase = [&](uint32_t p, const BIn &cur, BIn &nxt) __attribute__((always_inline)) {
+        auto phase = [&](uint32_t k, const BIn &cur, BIn &nxt) __attribute__((always_inline)) {
             X4_T0();
             asm volatile("" ::: "memory");
-            if (p >= 1) nxt = load_in(tile_at(p));
-            if (SKIP && p >= 1 && ((p - 1) & 63) == 0) lmask = live_mask(p - 1);
-            if (p >= 1 && p - 1 < n_iter && !(ablate & 4) && tile_at(p - 1) < n_tiles && ((lmask >> ((p - 1) & 63)) & 1) != 0) {
-                const uint32_t i = p - 1;
-                const uint32_t tile = tile_at(i);
+            if (k >= 1) {
+                if (pk != END) pk = it_next(it, false);
+                if (pk == END && kend == END) kend = k;
+                nxt = load_in(pk);
+            }
+            if (k >= 1 && !(ablate & 4) && cur.tile < n_tiles) {
+                const uint32_t i = k - 1;
+                const uint32_t tile = cur.tile;
                 const bool valid = tile * FLD_TILE + li < P_;
                 const unsigned char *fe = xch + X2_FEA + (i & 1) * 4 * X4_K;
                 frag_t fea[4], dfr[SDIR];
@@ -609,9 +646,9 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
             }
             X4_T1();
         };
-        for (uint32_t p = 0; p < n_phase; p += 2) {
-            phase(p, I1, I0);
-            phase(p + 1, I0, I1);
+        for (uint32_t k = 0; kend == END || k < kend + 2; k += 2) {
+            phase(k, I1, I0);
+            phase(k + 1, I0, I1);
         }
 #pragma unroll
         for (int b = 0; b < 2; b++) {

@@ -16,7 +16,7 @@ from ..trainer import (CheckpointMixin, EvalMixin, allreduce_grads_flat, apply_o
 
 class EditTrainer(CheckpointMixin, EvalMixin):
     def __init__(self, model, model_pretrained, guidance, opt, text_z, text_z_fg, lr=None, fp16=True, world_size=1, loss_scale='dynamic', seed=0,
-                 clip_guidance=None, clip_match_text=None, dp_mode='allreduce'):
+                 clip_guidance=None, clip_match_text=None, dp_mode='allreduce', init_scale=65536.0):
         """text_z / text_z_fg: the [2, 77, 768] (uncond, cond) embeddings of the global / local prompt; with `opt.clip_view` they are
         LISTS of three such tensors for the ", front view" / ", side view" / ", back view" prompts (prepare_text_embeddings,
         utils_init_nerf.py:318-336), `clip_guidance` is a customnerf_amd.sd.clip_view.CLIP and `clip_match_text` the token ids [3, 77] of
@@ -31,7 +31,8 @@ class EditTrainer(CheckpointMixin, EvalMixin):
             if not (isinstance(text_z, (list, tuple)) and isinstance(text_z_fg, (list, tuple)) and len(text_z) == len(text_z_fg) == clip_match_text.shape[0]):
                 raise ValueError("opt.clip_view needs one (text_z, text_z_fg) pair per view prompt")
         self.fp16, self.world_size = fp16, world_size
-        self.scaler = DynamicLossScaler(next(model.parameters()).device) if (fp16 and loss_scale == 'dynamic') else None     # GradScaler policy, on device
+        # GradScaler policy, on device; init_scale = torch.cuda.amp.GradScaler's default unless the caller knows where the policy settles
+        self.scaler = DynamicLossScaler(next(model.parameters()).device, init_scale=init_scale) if (fp16 and loss_scale == 'dynamic') else None
         self.loss_scale = 1.0 if (not fp16 or self.scaler is not None) else float(loss_scale)
         lr = opt.lr if lr is None else lr
         groups = model.get_params(lr)

@@ -1,0 +1,54 @@
+"""Every aten op of one timed edit step (forward AND autograd-engine backward), with shapes and the innermost repo frame that issued it.
+usage: python scratch/edit_ops.py [out.txt]"""
+import collections, copy, os, sys, traceback, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch.utils._python_dispatch import TorchDispatchMode
+from customnerf_amd import scene as sc, tcnn
+from customnerf_amd.nerf.network_grid import NeRFNetwork
+from customnerf_amd.nerf.provider_utils import generate_rays
+from customnerf_amd.sd import StableDiffusion
+from customnerf_amd.sd.editing import EditTrainer
+dev = torch.device('cuda')
+tcnn.set_default_dtype(torch.float16)
+torch.manual_seed(0)
+opt = sc.make_opt(cuda_ray=False, fp16=True, keep_bg=1000.0, lambda_sd=0.01, cfg=100.0, log_loss_item=False)
+model = NeRFNetwork(opt).to(dev)
+pre = copy.deepcopy(model).eval()
+guidance = StableDiffusion(dev, '1.5', opt, seed=0)
+H = W = 128; V = 8
+c2w = torch.from_numpy(sc.poses(V)).to(dev)
+o, d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+o, d = o.view(V, 1, H * W, 3), d.view(V, 1, H * W, 3)
+rgb, mask = sc.targets(V, H, W); rgb, mask = rgb.to(dev), mask.to(dev)
+tr = EditTrainer(model, pre, guidance, opt, guidance.synthetic_text_embeds(0), guidance.synthetic_text_embeds(1), fp16=True, init_scale=32768.0)
+view = lambda j: (rgb[j % V], mask[j % V], o[j % V], d[j % V], H, W, f"view{j % V}")
+for i in range(2 * V + 2):
+    tr.train_step(view(i))
+torch.cuda.synchronize()
+SKIP = {'aten::view', 'aten::_unsafe_view', 'aten::reshape', 'aten::permute', 'aten::select', 'aten::slice', 'aten::detach', 'aten::alias', 'aten::as_strided',
+        'aten::t', 'aten::transpose', 'aten::expand', 'aten::unsqueeze', 'aten::squeeze', 'aten::split', 'aten::chunk', 'aten::empty', 'aten::empty_like',
+        'aten::empty_strided', 'aten::unbind', 'aten::narrow', 'aten::_local_scalar_dense', 'aten::split_with_sizes', 'aten::view_as', 'aten::lift_fresh',
+        'aten::is_same_size', 'aten::unfold', 'aten::new_empty', 'aten::new_empty_strided', 'aten::sym_size', 'aten::sym_stride', 'aten::sym_numel', 'aten::stride', 'aten::size'}
+log = []
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.name().split('.')[0]
+        if name not in SKIP:
+            where = 'autograd engine'
+            for fr in reversed(traceback.extract_stack()[:-1]):
+                if ('customnerf_amd' in fr.filename or 'bench.py' in fr.filename) and 'scratch' not in fr.filename:
+                    where = f"{fr.filename.split('customnerf_amd/')[-1]}:{fr.lineno} {fr.name}"
+                    break
+            sh = [f"{tuple(a.shape)}{str(a.dtype).replace('torch.', ':')}{'' if a.is_contiguous() else ':nc'}{':cpu' if not a.is_cuda else ''}" for a in args if isinstance(a, torch.Tensor)]
+            log.append((name, ' '.join(sh), where))
+        return func(*args, **(kwargs or {}))
+N = 2
+with Log():
+    for i in range(N):
+        tr.train_step(view(i))
+torch.cuda.synchronize()
+acc = collections.Counter(log)
+out = open(sys.argv[1], 'w') if len(sys.argv) > 1 else sys.stdout
+out.write(f"{len(log) / N:.1f} aten ops per edit step (views / metadata ops not counted)\n")
+for (name, sh, where), n in sorted(acc.items(), key=lambda kv: (kv[0][2], kv[0][0])):
+    out.write(f"{n / N:5.1f}  {name:26s} {sh:70s} {where}\n")

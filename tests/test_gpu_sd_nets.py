@@ -89,7 +89,9 @@ def test_vae_encode_forward_backward(cfg_name, size):
     print(f"[vae {cfg_name}-{size}] latents max rel {emax:.3e}, L2 rel {el2:.3e}")
     assert emax < 5e-3 and el2 < 3e-3, ("latents", emax, el2)      # measured: 0.7e-3 .. 1.3e-3 max, 0.6e-3 .. 0.7e-3 L2
     gmax, gl2 = rel_err(img_g.grad, img_ref.grad)
-    assert gmax < 6e-2 and gl2 < 3e-2, ("d latents / d image", gmax, gl2)
+    print(f"[vae {cfg_name}-{size}] d latents / d image max rel {gmax:.3e}, L2 rel {gl2:.3e}")
+    # measured (round 5, MI355X): max 1.9e-3 / 2.1e-3 / 2.4e-3, L2 2.0e-3 / 1.9e-3 / 1.9e-3 for the three cases; bound = 3 x the largest
+    assert gmax < 7.5e-3 and gl2 < 6e-3, ("d latents / d image", gmax, gl2)
 
 
 def test_sds_train_step_matches_oracle():
@@ -118,12 +120,16 @@ def test_sds_train_step_matches_oracle():
     loss, ld = guide.train_step(lat, text.cuda(), t_val=t, noise=noise.cuda())
     loss.backward()
     assert isinstance(ld["loss_sds"], float)
-    assert rel_err(lat, lat_ref)[1] < 1e-2
     with torch.no_grad():
         grad = lat.detach() - (lat.detach() - guide.sds_grad(lat.detach(), text.cuda(), t, noise.cuda()))
-    assert rel_err(grad, grad_ref)[1] < 3e-2
-    assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 5e-2
-    assert rel_err(img_g.grad, img_ref.grad)[1] < 5e-2
+    e_lat, e_grad, e_img = rel_err(lat, lat_ref)[1], rel_err(grad, grad_ref)[1], rel_err(img_g.grad, img_ref.grad)[1]
+    e_loss = abs(float(loss) - float(loss_ref)) / float(loss_ref)
+    print(f"[sds tiny] L2 rel: latents {e_lat:.3e}, SDS gradient {e_grad:.3e}, d loss / d image {e_img:.3e}; loss rel {e_loss:.3e}")
+    # measured (round 5, MI355X): latents 5.7e-4, SDS gradient 4.2e-3, d loss / d image 4.3e-3, loss 6.7e-5; bounds = 3 x measured
+    assert e_lat < 2e-3
+    assert e_grad < 1.3e-2
+    assert e_loss < 2e-4
+    assert e_img < 1.3e-2
     # timestep draws follow sd.py:120-131
     ts = [guide.draw_timestep(None, 1) for _ in range(200)]
     assert min(ts) >= 20 and max(ts) <= 980
@@ -148,7 +154,9 @@ def test_clip_text_encoder(cfg_name):
         out = te.CLIPTextEncoder(cfg, sd, "cuda")(ids.cuda())[0]
     assert out.shape == (2, 77, cfg["width"])
     emax, el2 = rel_err(out, ref)
-    assert emax < 3e-2 and el2 < 1e-2, (emax, el2)
+    print(f"[clip text {cfg_name}] max rel {emax:.3e}, L2 rel {el2:.3e}")
+    # measured (round 5, MI355X): tiny 9.7e-4 max / 7.6e-4 L2, SD-1.5 shapes 1.9e-3 / 1.0e-3; bounds = 3 x the larger
+    assert emax < 6e-3 and el2 < 3.5e-3, (emax, el2)
     # causality: changing a late token must not change earlier positions
     ids2 = ids.clone()
     ids2[:, 50] = (ids2[:, 50] + 1) % cfg["vocab_size"]
