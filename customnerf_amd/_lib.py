@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcustomnerf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
 
@@ -99,6 +99,14 @@ SIGNATURES = {
     "cnerf_sd_timestep_embedding": [vp, u32, u32, vp, vp],
     "cnerf_sd_add_noise": [vp, vp, f32, u32, vp, vp],
     "cnerf_sd_sds_grad": [vp, u32, vp, f32, f32, f32, u32, vp, vp],
+    "cnerf_edit_ray_images": [vp, u32, u32, vp, vp, vp, vp],
+    "cnerf_edit_ray_images_backward": [vp, vp, vp, u32, u32, vp, vp],
+    "cnerf_edit_l1_loss": [vp, vp, u32, f32, vp, vp, vp],
+    "cnerf_edit_sds_loss": [vp, vp, u32, vp, vp, vp],
+    "cnerf_edit_scale_by_scalar": [vp, vp, f32, u32, vp, vp],
+    "cnerf_sd_sample_latents": [vp, vp, u32, u32, f32, vp, vp],
+    "cnerf_sd_sample_latents_backward": [vp, vp, vp, u32, u32, f32, vp, vp],
+    "cnerf_set_floats": [vp, vp, u32, vp],
     "cnerf_sd_add": [vp, vp, u64, vp, vp],
     "cnerf_sd_silu": [vp, u64, vp, vp],
     "cnerf_sd_concat": [vp, vp, u64, u32, u32, vp, vp],

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from ..optim import DynamicLossScaler, FusedAdam
+from .edit_fn import RayImages, ScaledL1
 from ..trainer import (CheckpointMixin, EvalMixin, allreduce_grads_flat, apply_optimizer_step, enable_grad_in_place, flat_grad_buffer, register_half_shadow,
                        setup_sharded_dp)
 
@@ -114,9 +115,14 @@ class EditTrainer(CheckpointMixin, EvalMixin):
         else:
             text_emb, img_rgb, t_ratio = text_z_fg, pred_rgb_fg, opt.local_t_ratio
         r = self.sds_resolution
-        latents = self.guidance.encode_imgs(img_rgb.float(), sample_noise=rp.get('sample_noise'), resize=(r, r))    # F.interpolate(..., (512, 512)) folded into the VAE front-end
+        sample_noise, noise = rp.get('sample_noise'), rp.get('noise')
+        if sample_noise is None and noise is None:
+            # the posterior-sample noise (sd.py:102) and the diffusion noise (sd.py:135) of the step: one generator launch for both
+            lc = self.guidance.vae_cfg["latent_channels"]
+            sample_noise, noise = torch.randn(2, img_rgb.shape[0], lc, r // 8, r // 8, device=img_rgb.device).unbind(0)
+        latents = self.guidance.encode_imgs(img_rgb.float(), sample_noise=sample_noise, resize=(r, r))              # F.interpolate(..., (512, 512)) folded into the VAE front-end
         t_val = int(rp['t'] * t_ratio) if 't' in rp else None                                                     # sd.py:132
-        return self.guidance.train_step(latents, text_emb, system=self, t_ratio=t_ratio, t_val=t_val, noise=rp.get('noise'))
+        return self.guidance.train_step(latents, text_emb, system=self, t_ratio=t_ratio, t_val=t_val, noise=noise)
 
     def train_step_editing(self, data):
         """utils_init_nerf.py:353-394.  data = (rgbs, mask, rays_o, rays_d, H, W, img_path)"""
@@ -126,8 +132,7 @@ class EditTrainer(CheckpointMixin, EvalMixin):
         bg_color = self._bg_color(rays_o, B, N)
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **self._render_kw)
-        img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
-        pred_rgb, pred_rgb_fg, pred_rgb_bg = img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
+        pred_rgb, pred_rgb_fg, pred_rgb_bg = self._pred_images(outputs, B, H, W)
         pred_ws = outputs['weights_sum'].reshape(B, H, W)
         pt_rgb_fg, pt_rgb_bg, pt_mask, pt_depth_fg, match_probs = self.get_pt(rays_o, rays_d, img_path, bg_color, B, H, W)
         if getattr(opt, 'ori_bg', False):
@@ -138,10 +143,20 @@ class EditTrainer(CheckpointMixin, EvalMixin):
         if opt.lambda_sd:
             loss, loss_dict = self.train_step_sd(pred_rgb, pred_rgb_fg, match_probs)
         if opt.keep_bg:
-            loss_bg = opt.keep_bg * F.l1_loss(pt_rgb_bg, pred_rgb_bg.float())
+            loss_bg = ScaledL1.apply(pt_rgb_bg, pred_rgb_bg, float(opt.keep_bg))            # opt.keep_bg * F.l1_loss(pt_rgb_bg, pred_rgb_bg): :389-391
             loss = loss + loss_bg
             loss_dict['loss_bg'] = loss_bg.detach()
         return pred_rgb, pred_ws, loss, loss_dict
+
+    @staticmethod
+    def _pred_images(outputs, B, H, W):
+        """the whole / fg / bg renders as [B, 3, H, W] float32 images (utils_init_nerf.py:361-366).  The fused run() path hands over its raw
+        composite buffer: one launch builds the three, one launch scatters their gradients back; other render paths go through torch views."""
+        out_ray = outputs.get('_out_ray') if hasattr(outputs, 'get') else None
+        if out_ray is not None and out_ray.is_cuda and out_ray.shape == (3, B * H * W, 6):
+            return RayImages.apply(out_ray, B, H, W)
+        img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous().float()
+        return img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
 
     def train_step_editing_multi(self, views):
         """V camera views in one step (BASELINE.json north_star: the per-iteration batch shards "rays (and optionally SDS camera views)"): every
@@ -158,8 +173,7 @@ class EditTrainer(CheckpointMixin, EvalMixin):
             bg_color = self._bg_color(rays_o, B, N)
             with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
                 outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, bg_color=bg_color, **self._render_kw)
-            img = lambda t: t.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
-            pred_rgb, pred_rgb_fg, pred_rgb_bg = img(outputs['image']), img(outputs['fg']['image']), img(outputs['bg']['image'])
+            pred_rgb, pred_rgb_fg, pred_rgb_bg = self._pred_images(outputs, B, H, W)
             pred_ws = outputs['weights_sum'].reshape(B, H, W)
             pt_rgb_fg, pt_rgb_bg, pt_mask, pt_depth_fg, match = self.get_pt(rays_o, rays_d, img_path, bg_color, B, H, W)
             if getattr(opt, 'ori_bg', False):
@@ -168,7 +182,7 @@ class EditTrainer(CheckpointMixin, EvalMixin):
             preds.append(pred_rgb)
             preds_fg.append(pred_rgb_fg)
             if opt.keep_bg:
-                losses_bg.append(opt.keep_bg * F.l1_loss(pt_rgb_bg, pred_rgb_bg.float()))
+                losses_bg.append(ScaledL1.apply(pt_rgb_bg, pred_rgb_bg, float(opt.keep_bg)))
         loss, loss_dict = 0.0, {}
         if opt.lambda_sd:
             loss, loss_dict = self.train_step_sd(torch.cat(preds, 0), torch.cat(preds_fg, 0), None if self.clip_view is False else match)

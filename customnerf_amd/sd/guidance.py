@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import arch, ops
+from .edit_fn import SDSLoss
 from .unet import UNet
 from .vae import VAEEncoder
 
@@ -111,14 +112,28 @@ class StableDiffusion(nn.Module):
         return ent[1]
 
     def eps_pred(self, unet_in, t, text_embeddings):
-        """unet_in [2V, h, w, 8]; t: one timestep, or V of them (one per (uncond, text) pair); text_embeddings [2, 77, D] is shared by the pairs"""
+        """unet_in [2V, h, w, 8]; t: one timestep, or V of them (one per (uncond, text) pair); text_embeddings [2, 77, D] is shared by the pairs.
+        With the graph, the timesteps reach its static input by kernel argument (cnerf_set_floats) and `unet_in` is copied only when it is not
+        that graph's own input buffer (unet_input_buffer): the single-view SDS step replays with no staging tensor and no copy."""
         B = unet_in.shape[0]
-        if isinstance(t, (list, tuple)):
-            tt = torch.tensor([float(x) for x in t for _ in (0, 1)], dtype=torch.float32).to(self.device, non_blocking=True)
-        else:
-            tt = torch.full((B,), float(t), dtype=torch.float32, device=self.device)
+        ts = [float(x) for x in t for _ in (0, 1)] if isinstance(t, (list, tuple)) else [float(t)] * B
         ctx = self._ctx_half(text_embeddings, B // 2)
+        if self.use_graph and B <= 16:
+            shape = tuple(unet_in.shape)
+            sx, st = self.unet.graph_inputs(shape, ctx)
+            if sx.data_ptr() != unet_in.data_ptr():
+                sx.copy_(unet_in)
+            ops.set_floats(st, ts)
+            return self.unet.graphed(None, None, ctx, shape=shape)
+        tt = torch.tensor(ts, dtype=torch.float32).to(self.device, non_blocking=True)
         return self.unet.graphed(unet_in, tt, ctx) if self.use_graph else self.unet(unet_in, tt, ctx)
+
+    def unet_input_buffer(self, text_embeddings, shape):
+        """the captured graph's own input tensor for this prompt and shape, once it exists (else None): cnerf_sd_add_noise writes into it directly"""
+        if not self.use_graph or self.unet is None:
+            return None
+        ent = self.unet.graph_inputs(tuple(shape), self._ctx_half(text_embeddings, shape[0] // 2), create=False)
+        return None if ent is None else ent[0]
 
     def sds_grad(self, latents, text_embeddings, t, noise):
         """sd.py:133-148 on device: add_noise, UNet on the CFG pair, `text + g (text - uncond)`, (1 - abar_t) weighting, nan_to_num.
@@ -127,7 +142,8 @@ class StableDiffusion(nn.Module):
         V = latents.shape[0]
         if V == 1 and not isinstance(t, (list, tuple)):
             ab = float(self.alphas_host[t])
-            unet_in = ops.add_noise(latents.contiguous(), noise, ab)
+            _, _, h, w = latents.shape
+            unet_in = ops.add_noise(latents.contiguous(), noise, ab, out=self.unet_input_buffer(text_embeddings, (2, h, w, 8)))
             eps = self.eps_pred(unet_in, t, text_embeddings)
             return ops.sds_grad(eps, noise, ab, float(self.opt.cfg), float(self.opt.lambda_sd))
         ts = list(t) if isinstance(t, (list, tuple)) else [int(t)] * V
@@ -157,8 +173,7 @@ class StableDiffusion(nn.Module):
                 noise = torch.randn(lat.shape, device=lat.device, dtype=torch.float32)
             noise = noise.contiguous()
             grad = self.sds_grad(lat, text_embeddings, t, noise)
-        target = (latents - grad).detach()
-        loss = 0.5 * F.mse_loss(latents, target, reduction="sum")                     # d loss / d latents = grad (sd.py:150-152)
+        loss = SDSLoss.apply(latents if latents.dtype == torch.float32 else latents.float(), grad)                                          # 0.5 * mse(latents, (latents - grad).detach(), 'sum'): sd.py:150-152
         if getattr(self.opt, 'log_loss_item', True):
             return loss, dict(loss_sds=loss.item())
         return loss, dict(loss_sds=loss.detach())

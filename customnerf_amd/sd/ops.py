@@ -379,3 +379,87 @@ def sds_grad(eps, noise, alpha_bar, guidance, lambda_sd, out=None):
     assert grad.is_contiguous() and grad.dtype == torch.float32 and grad.numel() == noise.numel()
     check(lib.cnerf_sd_sds_grad(ptr(eps), ld, ptr(noise), float(alpha_bar), float(guidance), float(lambda_sd), h * w, ptr(grad), stream()), "sd_sds_grad")
     return grad
+
+
+# ---- the small tensors of one editing step, one launch each (csrc/edit_ops.hip)
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def ray_images(out_ray, B, H, W):
+    """out_ray [3, B*H*W, 6] float32 (renderer results['_out_ray']) -> the all / fg / bg images [B, 3, H, W] float32 (utils_init_nerf.py:361-366)"""
+    require_cuda(out_ray)
+    out_ray = _f32c(out_ray)
+    assert out_ray.shape == (3, B * H * W, 6)
+    imgs = [torch.empty(B, 3, H, W, dtype=torch.float32, device=out_ray.device) for _ in range(3)]
+    check(lib.cnerf_edit_ray_images(ptr(out_ray), B, H * W, ptr(imgs[0]), ptr(imgs[1]), ptr(imgs[2]), stream()), "edit_ray_images")
+    return imgs
+
+
+def ray_images_backward(d_imgs, B, H, W, device):
+    """three image gradients [B, 3, H, W] (None = zeros) -> d(out_ray) [3, B*H*W, 6]"""
+    d = [None if g is None else _f32c(g) for g in d_imgs]
+    out = torch.empty(3, B * H * W, 6, dtype=torch.float32, device=device)
+    check(lib.cnerf_edit_ray_images_backward(ptr(d[0]), ptr(d[1]), ptr(d[2]), B, H * W, ptr(out), stream()), "edit_ray_images_backward")
+    return out
+
+
+def l1_loss_scaled(a, b, scale):
+    """-> (loss [1] = scale * mean|a - b|, dsign = d loss / d a, same shape as a)"""
+    require_cuda(a)
+    a, b = _f32c(a), _f32c(b)
+    assert a.shape == b.shape
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    dsign = torch.empty_like(a)
+    check(lib.cnerf_edit_l1_loss(ptr(a), ptr(b), a.numel(), float(scale), ptr(loss), ptr(dsign), stream()), "edit_l1_loss")
+    return loss, dsign
+
+
+def sds_loss(latents, grad):
+    """-> (loss [1] = 0.5 sum d^2, 2 d) with d = latents - (latents - grad); d loss / d latents = (2 d) * 0.5   (sd.py:150-152)"""
+    require_cuda(latents)
+    latents, grad = _f32c(latents), _f32c(grad)
+    assert latents.shape == grad.shape
+    loss = torch.empty(1, dtype=torch.float32, device=latents.device)
+    diff = torch.empty_like(latents)
+    check(lib.cnerf_edit_sds_loss(ptr(latents), ptr(grad), latents.numel(), ptr(loss), ptr(diff), stream()), "edit_sds_loss")
+    return loss, diff
+
+
+def scale_by_scalar(src, scalar, mult=1.0):
+    """src * (scalar * mult) with `scalar` a one-element device tensor (no host read)"""
+    src = _f32c(src)
+    scalar = _f32c(scalar.reshape(1)).to(src.device)
+    out = torch.empty_like(src)
+    check(lib.cnerf_edit_scale_by_scalar(ptr(src), ptr(scalar), float(mult), src.numel(), ptr(out), stream()), "edit_scale_by_scalar")
+    return out
+
+
+def sample_latents(moments, noise, scaling_factor):
+    """moments [B, h, w, 8] half (mean | logvar), noise [B, 4, h, w] float32 -> latents [B, 4, h, w] float32 (sd.py:102-104)"""
+    require_cuda(moments)
+    B, h, w, c = moments.shape
+    assert c == 8 and moments.dtype == torch.float16 and moments.is_contiguous()
+    noise = _f32c(noise)
+    assert noise.shape == (B, 4, h, w)
+    lat = torch.empty(B, 4, h, w, dtype=torch.float32, device=moments.device)
+    check(lib.cnerf_sd_sample_latents(ptr(moments), ptr(noise), B, h * w, float(scaling_factor), ptr(lat), stream()), "sd_sample_latents")
+    return lat
+
+
+def sample_latents_backward(moments, noise, d_lat, scaling_factor):
+    B, h, w, _ = moments.shape
+    d_lat, noise = _f32c(d_lat), _f32c(noise)
+    d_m = torch.empty_like(moments)
+    check(lib.cnerf_sd_sample_latents_backward(ptr(moments), ptr(noise), ptr(d_lat), B, h * w, float(scaling_factor), ptr(d_m), stream()),
+          "sd_sample_latents_backward")
+    return d_m
+
+
+def set_floats(dst, values):
+    """a handful of host floats into a float32 device tensor without a staging tensor (one launch, graph-capturable)"""
+    vals = [float(v) for v in values]
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == len(vals) <= 16
+    arr = (ctypes.c_float * len(vals))(*vals)
+    check(lib.cnerf_set_floats(ptr(dst), ctypes.cast(arr, ctypes.c_void_p), len(vals), stream()), "set_floats")
+    return dst

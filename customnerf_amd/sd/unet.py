@@ -231,19 +231,16 @@ class UNet:
 
     __call__ = forward
 
-    def graphed(self, x, t, ctx):
-        """Same as forward() but replayed from a HIP graph captured on first use (static shapes; x and t are copied into the graph's
-        buffers; the returned tensor is the graph's static output buffer, overwritten by the next call).  One graph per text embedding
-        (keyed by the tensor's storage and version; the editing loop alternates between two prompts): its cross-attention K / V^T are
-        computed once, outside the graph.  ~550 launches per forward would otherwise be host-bound."""
+    def _graph_entry(self, shape, ctx, x=None, t=None):
         if self._graph is None:
             self._graph = {}
-        key = (tuple(x.shape), ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        key = (tuple(shape), ctx.data_ptr(), ctx._version, tuple(ctx.shape))
         ent = self._graph.get(key)
         if ent is None:
             if len(self._graph) >= 4:                                                  # small LRU: drop the oldest context
                 self._graph.pop(next(iter(self._graph)))
-            sx, st = x.clone(), t.clone()
+            sx = x.clone() if x is not None else torch.zeros(shape, dtype=torch.float16, device=ctx.device)
+            st = t.clone() if t is not None else torch.full((shape[0],), 500.0, dtype=torch.float32, device=ctx.device)
             with torch.no_grad():
                 kv = self.context_kv(ctx)
             s = torch.cuda.Stream()
@@ -256,7 +253,25 @@ class UNet:
                 out = self.forward(sx, st, None, ctx_kv=kv)
             ent = (graph, sx, st, (kv, ctx), out)                                   # holding ctx keeps its storage (the cache key) from being recycled
             self._graph[key] = ent
-        graph, sx, st, _, out = ent
-        sx.copy_(x); st.copy_(t)
+        return ent
+
+    def graph_inputs(self, shape, ctx, create=True):
+        """the static input buffers (x [2V, h, w, 8] half, t [2V] float32) of the graph for `ctx`: a caller that writes them itself (the SDS
+        step: cnerf_sd_add_noise / cnerf_set_floats straight into them) replays with graphed(None, None, ctx, shape=shape).
+        create=False: None when that graph has not been captured yet."""
+        if not create and (self._graph is None or (tuple(shape), ctx.data_ptr(), ctx._version, tuple(ctx.shape)) not in self._graph):
+            return None
+        ent = self._graph_entry(shape, ctx)
+        return ent[1], ent[2]
+
+    def graphed(self, x, t, ctx, shape=None):
+        """Same as forward() but replayed from a HIP graph captured on first use (static shapes; x and t are copied into the graph's
+        buffers — unless both are None: the caller filled graph_inputs() — and the returned tensor is the graph's static output buffer,
+        overwritten by the next call).  One graph per text embedding (keyed by the tensor's storage and version; the editing loop alternates
+        between two prompts): its cross-attention K / V^T are computed once, outside the graph.  ~550 launches per forward would otherwise
+        be host-bound."""
+        graph, sx, st, _, out = self._graph_entry(shape if x is None else x.shape, ctx, x, t)
+        if x is not None:
+            sx.copy_(x); st.copy_(t)
         graph.replay()
         return out

@@ -12,6 +12,7 @@ from torch.autograd import Function
 
 from . import ops, pack
 from .arch import VAE_ATTN_ALIASES
+from .edit_fn import SampleLatents
 
 
 class _Conv(Function):
@@ -20,6 +21,7 @@ class _Conv(Function):
 
     @staticmethod
     def forward(ctx, x, w, wd, bias, k, stride, pad, out_hw, residual, gn_sums, groups):
+        ctx.set_materialize_grads(False)                     # the flag output has no gradient: no zeros are made for it in the backward
         ctx.wd, ctx.k, ctx.stride, ctx.pad, ctx.in_hw = wd, k, stride, pad, (x.shape[1], x.shape[2])
         ctx.has_res = residual is not None
         if gn_sums is None:
@@ -154,6 +156,7 @@ class _ResnetFn(Function):
 
     @staticmethod
     def forward(ctx, x, blk, groups, eps, pool, x_sums, x_ready, out_gn):
+        ctx.set_materialize_grads(False)                     # (statistics and flag outputs: no zero tensors for them in the backward)
         B, H, W, _ = x.shape
         if x_sums is not None:
             h, s1 = ops.groupnorm(x, *blk.n1, groups, eps, True, sums=x_sums, sums_ready=x_ready)
@@ -261,7 +264,4 @@ class VAEEncoder:
         imgs [B, 3, H, W] float32 in [0, 1] -> latents [B, latent, h, w] float32 = (mean + std * sample_noise) * 0.18215.
         Differentiable w.r.t. imgs."""
         x = _ImageInput.apply(imgs, resize[0], resize[1])
-        m = self.moments(x).float().permute(0, 3, 1, 2)                                # tiny [B, 8, 64, 64]: torch glue
-        mean, logvar = m.chunk(2, dim=1)
-        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
-        return (mean + std * sample_noise) * self.cfg["scaling_factor"]
+        return SampleLatents.apply(self.moments(x).contiguous(), sample_noise, self.cfg["scaling_factor"])     # clamp / exp / sample / scale: one launch

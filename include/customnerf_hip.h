@@ -32,7 +32,7 @@ extern "C" {
 
 /* ABI version of this header; cnerf_abi_version() of the loaded library must match.
  * 2: the GroupNorm / GEMM-epilogue statistics buffers of customnerf_sd.h are int64[B][G][2] fixed point (were float[B][G][2]). */
-#define CNERF_ABI_VERSION 2
+#define CNERF_ABI_VERSION 3
 int cnerf_abi_version(void);
 /* name of the code object's target ("gfx950") */
 const char *cnerf_target_arch(void);

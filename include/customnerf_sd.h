@@ -161,6 +161,33 @@ int cnerf_sd_silu(const void *x, uint64_t n, void *y, void *stream);
 /* channel concat of NHWC half tensors: y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r] */
 int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Glue of one editing step as single launches (round 5; each replaces a chain of framework element-wise ops).
+ *
+ * cnerf_edit_ray_images: out_ray [3][B*HW][6] float32 (cnerf_composite_run's all / fg / bg outputs; channels rgb, depth, weights_sum,
+ *   mask) -> the three NCHW images [B][3][HW] that train_step_editing builds with reshape/permute/contiguous (utils_init_nerf.py:361-366).
+ *   _backward: d(out_ray), written in full, from the three image gradients (any of them NULL = zeros; channels 3..5 get zeros).
+ * cnerf_edit_l1_loss: loss[0] = scale * mean |a - b| (keep_bg * F.l1_loss, utils_init_nerf.py:389-391), dsign[i] = (scale / n) sgn(a_i - b_i)
+ *   (= d loss / d a; d loss / d b = -dsign).  One workgroup, fixed order of additions.
+ * cnerf_edit_sds_loss: sd.py:150-152 — d = latents - (latents - grad), loss[0] = 0.5 sum d^2, diff2 = 2 d (d loss / d latents = diff2 * 0.5,
+ *   formed in that order like torch's mse backward: overflow to infinity included).
+ * cnerf_edit_scale_by_scalar: dst = src * (scalar[0] * mult), scalar a DEVICE float (the upstream gradient of a loss).
+ * cnerf_sd_sample_latents: encode_imgs' posterior sample (sd.py:102-104, diffusers DiagonalGaussianDistribution): moments [B][hw][8] half
+ *   NHWC (mean | logvar) -> latents [B][4][hw] float32 = (mean + exp(0.5 clamp(logvar, -30, 20)) noise) * scaling_factor;
+ *   _backward: d(moments) [B][hw][8] half from d(latents).
+ * cnerf_set_floats: n <= 16 floats from HOST memory into a device buffer by kernel argument (the UNet graph's timestep input). */
+int cnerf_edit_ray_images(const float *out_ray, uint32_t B, uint32_t HW, float *img_all, float *img_fg, float *img_bg, void *stream);
+int cnerf_edit_ray_images_backward(const float *d_all, const float *d_fg, const float *d_bg, uint32_t B, uint32_t HW, float *d_out_ray,
+                                   void *stream);
+int cnerf_edit_l1_loss(const float *a, const float *b, uint32_t n, float scale, float *loss, float *dsign, void *stream);
+int cnerf_edit_sds_loss(const float *latents, const float *grad, uint32_t n, float *loss, float *diff2, void *stream);
+int cnerf_edit_scale_by_scalar(const float *src, const float *scalar, float mult, uint32_t n, float *dst, void *stream);
+int cnerf_sd_sample_latents(const void *moments, const float *noise, uint32_t B, uint32_t hw, float scaling_factor, float *latents,
+                            void *stream);
+int cnerf_sd_sample_latents_backward(const void *moments, const float *noise, const float *d_latents, uint32_t B, uint32_t hw,
+                                     float scaling_factor, void *d_moments, void *stream);
+int cnerf_set_floats(float *dst, const float *host_values, uint32_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

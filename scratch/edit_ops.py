@@ -40,6 +40,9 @@ class Log(TorchDispatchMode):
                     where = f"{fr.filename.split('customnerf_amd/')[-1]}:{fr.lineno} {fr.name}"
                     break
             sh = [f"{tuple(a.shape)}{str(a.dtype).replace('torch.', ':')}{'' if a.is_contiguous() else ':nc'}{':cpu' if not a.is_cuda else ''}" for a in args if isinstance(a, torch.Tensor)]
+            if name in ('aten::zeros', 'aten::full', 'aten::zeros_like', 'aten::cat'):
+                sh.append(str([a if not isinstance(a, torch.Tensor) else tuple(a.shape) for a in args][:2])[:60])
+                if name == 'aten::cat': sh.append(str([tuple(t.shape) for t in args[0]])[:60])
             log.append((name, ' '.join(sh), where))
         return func(*args, **(kwargs or {}))
 N = 2
@@ -47,6 +50,13 @@ with Log():
     for i in range(N):
         tr.train_step(view(i))
 torch.cuda.synchronize()
+n_step = len(log)
+if len(sys.argv) > 2:                                           # the UNet's own ops (inside the hipGraph on the timed path): one eager call, counted per N
+    with torch.no_grad(), Log():
+        for i in range(N):
+            guidance.unet(torch.zeros(2, 64, 64, 8, device=dev, dtype=torch.float16), torch.full((2,), 500.0, device=dev), guidance._ctx_half(tr.text_z, 1))
+    torch.cuda.synchronize()
+    log = [(a, b, c if i < n_step else 'UNET ' + c) for i, (a, b, c) in enumerate(log)]
 acc = collections.Counter(log)
 out = open(sys.argv[1], 'w') if len(sys.argv) > 1 else sys.stdout
 out.write(f"{len(log) / N:.1f} aten ops per edit step (views / metadata ops not counted)\n")

@@ -441,3 +441,66 @@ def test_splitk_workspace_outgrown_after_graph_capture():
     finally:
         if saved is not None:
             ops._WS[dev] = saved
+
+
+def test_edit_step_glue_functions_match_the_torch_expressions():
+    """csrc/edit_ops.hip through sd/edit_fn.py, each against the chain of torch ops it replaced in the editing step (round 5): the ray buffer ->
+    NCHW images and back (exact: pure data movement), keep_bg * l1_loss and its gradient, the VAE posterior sample (clamp / exp / sample / scale)
+    and its gradient into the half moments, the SDS loss (value and gradient), and the host-float writer."""
+    import torch.nn.functional as F
+    from customnerf_amd.sd import ops
+    from customnerf_amd.sd.edit_fn import RayImages, ScaledL1, SDSLoss, SampleLatents
+    g = torch.Generator(device='cuda').manual_seed(3)
+    B, H, W = 2, 12, 20
+    # ---- ray buffer <-> images
+    out_ray = torch.randn(3, B * H * W, 6, device='cuda', generator=g).requires_grad_(True)
+    ref_ray = out_ray.detach().clone().requires_grad_(True)
+    imgs = RayImages.apply(out_ray, B, H, W)
+    refs = [ref_ray[v][:, 0:3].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous() for v in range(3)]
+    for a, b in zip(imgs, refs):
+        assert torch.equal(a, b)
+    d_all, d_bg = torch.randn(B, 3, H, W, device='cuda', generator=g), torch.randn(B, 3, H, W, device='cuda', generator=g)
+    torch.autograd.backward([imgs[0], imgs[2]], [d_all, d_bg])                       # the fg image is unused: its gradient arrives as None
+    torch.autograd.backward([refs[0], refs[2]], [d_all, d_bg])
+    assert torch.equal(out_ray.grad, ref_ray.grad)
+    # ---- scaled L1 (an exact tie a == b has gradient 0, like torch's sgn)
+    a = torch.rand(B, 3, H, W, device='cuda', generator=g)
+    b = torch.rand(B, 3, H, W, device='cuda', generator=g)
+    b[0, 0, 0, :5] = a[0, 0, 0, :5]
+    b1, b2 = b.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    l1 = ScaledL1.apply(a, b1, 1000.0)
+    l2 = 1000.0 * F.l1_loss(a, b2)
+    up = torch.tensor(32768.0, device='cuda')
+    l1.backward(up); l2.backward(up)
+    assert l1.shape == () and abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2))
+    assert torch.allclose(b1.grad, b2.grad, rtol=1e-6, atol=0) and float(b1.grad[0, 0, 0, 0]) == 0.0
+    # ---- posterior sample
+    h = w = 16
+    mom = (torch.randn(B, h, w, 8, device='cuda', generator=g) * 3).half()
+    mom[0, 0, 0, 4] = 25.0; mom[0, 0, 1, 5] = -31.0                                  # outside the clamp: no gradient into logvar there
+    noise = torch.randn(B, 4, h, w, device='cuda', generator=g)
+    m1, m2 = mom.clone().requires_grad_(True), mom.clone().requires_grad_(True)
+    lat = SampleLatents.apply(m1, noise, 0.18215)
+    mm = m2.float().permute(0, 3, 1, 2)
+    mean, logvar = mm.chunk(2, dim=1)
+    lat_ref = (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise) * 0.18215
+    assert lat.shape == (B, 4, h, w) and lat.is_contiguous()
+    assert torch.allclose(lat, lat_ref, rtol=2e-6, atol=1e-7)
+    d_lat = torch.randn(B, 4, h, w, device='cuda', generator=g)
+    lat.backward(d_lat); lat_ref.backward(d_lat)
+    assert m1.grad.dtype == torch.float16 and float(m1.grad[0, 0, 0, 4]) == 0.0 and float(m1.grad[0, 0, 1, 5]) == 0.0
+    fin = torch.isfinite(m2.grad.float())
+    assert torch.allclose(m1.grad.float()[fin], m2.grad.float()[fin], rtol=2e-3, atol=1e-6)       # one half rounding each, of float32 values 1 ulp apart
+    # ---- SDS loss
+    x = torch.randn(1, 4, 64, 64, device='cuda', generator=g)
+    gr = torch.randn(1, 4, 64, 64, device='cuda', generator=g) * 30
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    s1 = SDSLoss.apply(x1, gr)
+    s2 = 0.5 * F.mse_loss(x2, (x2 - gr).detach(), reduction='sum')
+    s1.backward(up); s2.backward(up)
+    assert abs(float(s1) - float(s2)) < 1e-5 * float(s2)
+    assert torch.equal(x1.grad, x2.grad)
+    # ---- host floats
+    dst = torch.zeros(2, device='cuda')
+    ops.set_floats(dst, (437.0, 437.0))
+    assert dst.tolist() == [437.0, 437.0]
