@@ -792,7 +792,12 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 //                     overflowed hashed bin, for the spill) walks the runs of the point blocks through a tile list in LDS
 //   k_bin3_reduce_split
 // Same 8-byte pair records, same exact 64-bit fixed-point sums, same split-bin reduction: the gradient is bit-identical to the second form's.
+#ifndef B3_PTS
 #define B3_PTS 2048
+#endif
+#ifndef B3_THREADS
+#define B3_THREADS 1024                          // workgroup of k_bin3_emit (B3_PTS / B3_THREADS samples per thread)
+#endif
 // staging capacity in records: a hashed level emits 4.125 records per sample on average (one x-pair in 32 leaves as two singles: 8448 +- 31 per
 // block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
 #define B3_CAP (B3_PTS * 4 + 640)
@@ -824,13 +829,13 @@ __device__ __forceinline__ bool b3_paired_h(uint32_t i0, uint32_t i1) {
     return m != 0 && m < (1u << B3_K) && (m & (m + 1)) == 0;
 }
 
-__global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+__global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                           const Bin3Plan plan, uint32_t *__restrict__ runs, uint32_t *__restrict__ cursor,
                                                           uint2 *__restrict__ hslab, uint2 *__restrict__ dslab, uint32_t B,
                                                           uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
                                                           uint32_t abl_arg) {
 #ifdef CNERF_TUNING
-    const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores
+    const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
 #else
     constexpr uint32_t abl = 0;
     (void)abl_arg;
@@ -856,14 +861,14 @@ __global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__res
     auto paired = [&](uint32_t a, uint32_t b) { return dense_lvl ? b2_paired(a, b) : b3_paired_h(a, b); };
     if (threadIdx.x < B2S_MAX_CHUNKS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    constexpr int PPT = B3_PTS / B2_THREADS;
+    constexpr int PPT = B3_PTS / B3_THREADS;
     bool ok[PPT];
     uint32_t i0[PPT][4], i1[PPT][4], tk[PPT][4];
     float wyz[PPT][4], fx[PPT], g0[PPT], g1[PPT];
     // ---- phase 1: corner pairs, gradients, one LDS ticket per record (ticket = rank of the record inside the block's run for its bin)
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
-        const uint32_t b = pb * B3_PTS + i * B2_THREADS + threadIdx.x;
+        const uint32_t b = pb * B3_PTS + i * B3_THREADS + threadIdx.x;
         float in[3];
         ok[i] = bn_load_point(inputs, b, B, in);
         g0[i] = g1[i] = fx[i] = 0.0f;
@@ -873,10 +878,17 @@ __global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__res
             ok[i] = g0[i] != 0.0f || g1[i] != 0.0f;                              // a zero gradient adds zero to every sum: no records,
         }                                                                        // and no corner arithmetic either (a NaN is not zero)
         if (ok[i]) {
-            b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
+            if (abl & 32) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { i0[i][q] = (b * 4 + q) * 2654435761u % lv.size[level]; i1[i][q] = i0[i][q] ^ 1u; wyz[i][q] = 0.25f; }
+                fx[i] = in[0] - floorf(in[0]);
+            } else {
+                b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
+            }
             b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if (abl & 16) { tk[i][q] = 0; continue; }
                 const uint32_t c0 = bin_of(i0[i][q]);
                 if (paired(i0[i][q], i1[i][q])) {
                     tk[i][q] = dense_lvl ? b2_ticket(cnt, c0) : atomicAdd(&cnt[c0], 1u);
@@ -965,10 +977,10 @@ __global__ void __launch_bounds__(B2_THREADS, 8) k_bin3_emit(const __half *__res
     __syncthreads();
     const uint32_t total = (abl & 2) ? 0u : min(*s_total, (uint32_t)B3_CAP);
     if (dense_lvl) {
-        for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) region[sl] = s_rec[sl];
+        for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) region[sl] = s_rec[sl];
     } else {
         const uint32_t capb = plan.capb;
-        for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) {
+        for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) {
             const uint32_t c = s_bin[sl];
             const uint32_t pos = gdst[c] + sl;                                      // (wrapping 32-bit arithmetic: gdst = reservation - run start)
             if (sl - start[c] < cnt[c]) hslab[(size_t)(bin0 + c) * capb + pos] = s_rec[sl];
@@ -1508,7 +1520,7 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     const Bin2Plan &p2 = plan.p;
     const uint32_t seg = b2_seg(B, b2_max_chunks(p2, nl));
     hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
-    hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B2_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
+    hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B3_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
                        interp, gemb, nl, (uint32_t)b2_env("CNERF_B3_EMIT_ABL", 0));
     hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
                        plan, nl);
