@@ -504,3 +504,39 @@ def test_edit_step_glue_functions_match_the_torch_expressions():
     dst = torch.zeros(2, device='cuda')
     ops.set_floats(dst, (437.0, 437.0))
     assert dst.tolist() == [437.0, 437.0]
+
+
+def test_split_k_gemms_are_exact_under_repetition():
+    """Shapes the cost model splits along K (small M, long K: the 8 x 8 / 16 x 16 UNet levels; fp32 partial tiles in the shared workspace, summed in
+    split order by the tail pass) — dense with bias + residual, GEGLU pairs, fp32 output, a 3 x 3 convolution, ragged M / N — each against the CPU
+    reference, and 60 back-to-back launches on rotating inputs bit-equal to a second pass over the same inputs (the workspace is reused by every
+    launch: a tail that read a partial tile of the previous launch shows up as a mismatch)."""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(91)
+    M, N, K = 128, 1280, 11520
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g)
+    wc, bc = w.half().cuda(), b.cuda()
+    xs = [h(torch.randn(M, K, generator=g)) for _ in range(6)]
+    r = h(torch.randn(M, N, generator=g))
+    y = ops.linear(xs[0].half().cuda(), wc, bias=bc, residual=r.half().cuda())
+    close(y, xs[0] @ w.t() + b + r, 2e-3, 4e-3)
+    y32 = ops.linear(xs[1].half().cuda(), wc, act=ops.ACT_GELU, out32=True)
+    close(y32, F.gelu(xs[1] @ w.t()), 1e-3, 1e-3)
+    yg = ops.linear(xs[2].half().cuda(), wc, bias=bc, act=ops.ACT_GEGLU)
+    full = xs[2] @ w.t() + b
+    close(yg, full[:, 0::2] * F.gelu(full[:, 1::2]), 2e-3, 4e-3)
+    Mr, Nr = 100, 1284                                                             # ragged: the last tiles lie partly outside
+    wr = h(torch.randn(Nr, K, generator=g) / math.sqrt(K))
+    xr = h(torch.randn(Mr, K, generator=g))
+    close(ops.linear(xr.half().cuda(), wr.half().cuda()), xr @ wr.t(), 2e-3, 4e-3)
+    x4 = torch.randn(2, 8, 8, 640, generator=g).half()
+    w4 = torch.randn(1280, 640, 3, 3, generator=g) / math.sqrt(9 * 640)
+    y4 = ops.conv2d(x4.cuda(), pack.pack_conv(w4).cuda(), None, 3)
+    close(y4.permute(0, 3, 1, 2), F.conv2d(x4.float().permute(0, 3, 1, 2), w4.half().float(), padding=1), 2e-3, 4e-3)
+    xg = [x.half().cuda() for x in xs]
+    first = [ops.linear(xg[i % 6], wc, bias=bc).clone() for i in range(60)]
+    torch.cuda.synchronize()
+    again = [ops.linear(xg[i % 6], wc, bias=bc).clone() for i in range(60)]
+    for i in range(60):
+        assert torch.equal(first[i], again[i]) and torch.equal(first[i], first[i % 6]), i
