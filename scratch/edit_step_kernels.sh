@@ -4,10 +4,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=gpurun_out/${1:-r05r}
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/prof_edit -o bench -- python3 bench.py --task edit --steps 12 --warmup 3 --no-cpu-baseline --no-roofline > $out/prof_edit.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/prof_esk -o bench -- python3 bench.py --task edit --steps 12 --warmup 3 --no-cpu-baseline --no-roofline > $out/prof_esk.log 2>&1
 python3 - <<E
 import csv, glob, collections
-f = glob.glob('$out/prof_edit/**/bench_kernel_trace.csv', recursive=True)[0]
+f = glob.glob('$out/prof_esk/**/bench_kernel_trace.csv', recursive=True)[0]
 rows = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))))
 emit = [s for s, e, n in rows if n.startswith('k_bin3_emit')]
 t0, t1 = emit[-6], emit[-1]
@@ -25,4 +25,4 @@ with open('$out/edit_step_kernels.txt', 'w') as fh:
         fh.write(line + "\n")
         if k in glue: print(line)
 E
-rm -rf $out/prof_edit
+rm -rf $out/prof_esk
