@@ -1510,7 +1510,8 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     if (!b3_plan(lv, nl, B, plan, n_dense)) return CNERF_EINVAL;
     Bin3Ws ws;
     b3_layout(plan, n_dense, B, nl, &ws, workspace);
-    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 32 + B3_MAXT * 8;
+    static const int emit_pad = cn_tune_env("CNERF_B3_EMIT_LDS_PAD", 0);        // tuning builds: extra LDS bytes per emit workgroup (occupancy experiments)
+    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16 + (uint32_t)emit_pad, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 32 + B3_MAXT * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_emit), hipFuncAttributeMaxDynamicSharedMemorySize, emit_lds);
