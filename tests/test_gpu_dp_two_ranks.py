@@ -86,3 +86,20 @@ def test_bench_two_ranks_on_one_device_runs_every_leg():
     assert rec["strong"]["value"] > 0                                   # one view's rays split over the two ranks
     sec = rec["secondary"]
     assert sec["value"] > 0 and sec["n_gpus"] == 2 and sec["multi_view"]["views_per_s"] > 0
+
+
+def test_bench_two_ranks_under_torchrun_on_one_device():
+    """the driver's own launch form (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`): the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment instead of being spawned by bench.py's launcher;
+    recon leg only (the other legs are covered above), rank 0 prints the one JSON line."""
+    env = dict(os.environ, CNERF_DP_BACKEND="gloo", CNERF_SINGLE_DEVICE="1", CNERF_BENCH_WATCHDOG="300")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--task", "recon",
+                          "--no-variants"], env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                        # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
