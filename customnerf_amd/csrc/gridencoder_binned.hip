@@ -1099,13 +1099,53 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     *dst = g;
 }
 
+#ifndef B3_WALK
+#define B3_WALK 8                                  // consecutive records of a run per thread in the run walk (combined in registers when they share entries);
+                                                  // measured: 4 -> 372 / 195 us (random init / fitted field), 8 -> 368 / 180, 16 -> 461 / 223 (over the 64-VGPR budget of two
+                                                  // resident workgroups; capped to it, 16 on the two coarsest tables only: 375 / 179 — no better than 8 everywhere)
+#endif
+struct B3Pending { uint32_t key; unsigned long long a0, b0, a1, b1; };   // key = (local entry | pair shift << 12): both entries of the record; sums per entry and channel
+__device__ __forceinline__ void b3_flush_pending(long long *acc, const B3Pending &c) {
+    if (c.key == 0xFFFFFFFFu) return;
+    const uint32_t e = c.key & (BN_CHUNK - 1), t = (c.key >> 12) & 15u;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), c.a0);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), c.b0);
+    if (t != B2_SINGLE) {
+        const uint32_t e1 = e ^ ((2u << t) - 1u);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e1]), c.a1);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e1]), c.b1);
+    }
+}
+__device__ __forceinline__ void b3_push_record(long long *acc, B3Pending &c, const uint2 r) {
+    union { uint32_t u; __half2 h; } v;
+    v.u = r.y;
+    const float2 f = __half22float2(v.h);
+    const uint32_t key = r.x & 0xFFFFu, t = (r.x >> 12) & 15u;
+    unsigned long long a0, b0, a1 = 0, b1 = 0;
+    if (t == B2_SINGLE) {
+        a0 = b2_fix(f.x * 16777216.0f); b0 = b2_fix(f.y * 16777216.0f);
+    } else {                                                                        // (the arithmetic of b2_add_record, value for value)
+        const float w1 = (float)(r.x >> 16) * (1.0f / 65536.0f), w0 = 1.0f - w1;
+        const float w1s = w1 * 16777216.0f, w0s = w0 * 16777216.0f;
+        a0 = b2_fix(w0s * f.x); b0 = b2_fix(w0s * f.y);
+        a1 = b2_fix(w1s * f.x); b1 = b2_fix(w1s * f.y);
+    }
+    if (key == c.key) {
+        c.a0 += a0; c.b0 += b0; c.a1 += a1; c.b1 += b1;
+    } else {
+        b3_flush_pending(acc, c);
+        c.key = key; c.a0 = a0; c.b0 = b0; c.a1 = a1; c.b1 = b1;
+    }
+}
+
 // The records of a bin segment that live in RUNS of the point blocks' private regions (a dense level's bins; the spill of a hashed bin): the
 // part [begin, end) of the bin's run index space, starting at block pb_first.  Runs are anything from a handful of records (a block that grazes
 // the chunk's slab of a level-4 table) to thousands, so the runs of 64 blocks at a time are flattened: the first wave clips each run to the
-// segment and leaves its source position and the exclusive prefix of the clipped lengths in LDS; thread t then takes records 4 t .. 4 t + 3 of
-// every 4096 of the flat index space (a 6-step search in the 64 prefix words for the first, a short walk for the next three) — four loads in
+// segment and leaves its source position and the exclusive prefix of the clipped lengths in LDS; thread t then takes records B3_WALK t .. B3_WALK (t + 1) - 1 of
+// every 1024 B3_WALK of the flat index space (a 6-step search in the 64 prefix words for the first, a short walk for the rest) — that many loads in
 // flight per thread, full lanes whatever the run lengths, and runs of same-entry records (neighbouring samples of a ray on a coarse level)
 // become successive atomics of one lane instead of same-address lanes of one instruction.
+template <int W>
 __device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint32_t *tiles, const uint32_t *__restrict__ rt, const uint32_t *__restrict__ pt,
                                              const uint2 *__restrict__ lvl_slab, uint32_t nb, uint32_t pb_first, uint32_t begin, uint32_t end) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1130,33 +1170,40 @@ __device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint
         }
         __syncthreads();
         const uint32_t total = s_pre[64], last = s_c[1];
-        for (uint32_t f0 = threadIdx.x * 4; f0 < total; f0 += 4096) {
+        for (uint32_t f0 = threadIdx.x * W; f0 < total; f0 += 1024 * W) {
             uint32_t j = 0;                                                         // largest j with s_pre[j] <= f0
 #pragma unroll
             for (uint32_t step = 32; step; step >>= 1)
                 if (s_pre[j + step] <= f0) j += step;
-            uint32_t idx[4];
-            bool ok4[4];
+            uint32_t idx[W];
+            bool ok4[W];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < W; u++) {
                 const uint32_t f = f0 + u;
                 ok4[u] = f < total;
                 while (ok4[u] && f >= s_pre[j + 1]) j++;                            // (empty runs are stepped over; j stays < 64 while f < total)
                 idx[u] = ok4[u] ? s_base[j] + (f - s_pre[j]) : s_base[0];
             }
-            uint2 v[4];
+            uint2 v[W];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = lvl_slab[idx[u]];                    // (unconditional on a valid index: masked at use)
+            for (int u = 0; u < W; u++) v[u] = lvl_slab[idx[u]];              // (unconditional on a valid index: masked at use)
+            // Consecutive records of a run come from consecutive samples of a ray (wave-aggregated tickets), and on a coarse level a ray
+            // spends a dozen samples in one cell: records with the same entry pair are summed in registers — integer sums, so the result is
+            // the one of separate atomics, bit for bit — and go to LDS as one update.  Neighbouring lanes still meet on such an entry
+            // (same-address atomics serialise); a longer in-lane stretch is fewer of them.
+            B3Pending c;
+            c.key = 0xFFFFFFFFu;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (ok4[u]) b2_add_record(acc, v[u]);
+            for (int u = 0; u < W; u++)
+                if (ok4[u]) b3_push_record(acc, c, v[u]);
+            b3_flush_pending(acc, c);
         }
         __syncthreads();
         if (last) break;
     }
 }
 
-__global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ hslab, const uint2 *__restrict__ dslab, const uint32_t *__restrict__ runs,
+__global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict__ hslab, const uint2 *__restrict__ dslab, const uint32_t *__restrict__ runs,
                                                      const uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin3Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin,
@@ -1237,10 +1284,10 @@ __global__ void __launch_bounds__(1024) k_bin3_accum(const uint2 *__restrict__ h
         // block's staging area was: the bin's record index space continues behind the region with the spilled runs, where the point blocks left them
         if (end > treg) {                                                            // (block-uniform)
             __syncthreads();
-            b3_walk_runs(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, max(begin, treg) - treg, end - treg);
+            b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, max(begin, treg) - treg, end - treg);
         }
     } else {
-        b3_walk_runs(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end);
+        b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end);
     }
     __syncthreads();
     b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot]);

@@ -1,0 +1,23 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+out=gpurun_out/r05ad
+mkdir -p $out
+prof() {
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $out/prof_$1 -o bench -- python3 bench.py --task recon --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-roofline $2 > $out/prof_$1.log 2>&1
+  python3 - <<E
+import csv, glob, collections
+f = glob.glob('$out/prof_$1/**/bench_kernel_trace.csv', recursive=True)[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    d[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+print('--- $1: ' + ', '.join(f"{k[:12]} {sum(v[-10:]) / len(v[-10:]) / 1e3:.0f}" for k, v in d.items() if 'k_bin3_accum' in k or 'k_bin3_emit' in k))
+E
+  rm -rf $out/prof_$1
+}
+timeout 600 python -m pytest tests/test_gpu_gridencoder.py tests/test_gpu_fullsize.py -q -x 2>&1 | grep -E "passed|failed"
+prof walk8_init ""; prof walk8_fit "--prefit 300"
+for w in 4 16; do
+  make -s -C customnerf_amd/csrc -B -j48 EXTRA="-DB3_WALK=$w" > $out/make_$w.log 2>&1
+  prof walk${w}_init ""; prof walk${w}_fit "--prefit 300"
+done
