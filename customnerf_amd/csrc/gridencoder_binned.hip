@@ -670,6 +670,48 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
     }
 }
 
+#ifndef B2_COMBINE
+#define B2_COMBINE 1
+#endif
+#ifndef B3_WALK
+#define B3_WALK 8                                  // consecutive records of a run per thread in the run walk (combined in registers when they share entries);
+                                                  // measured: 4 -> 372 / 195 us (random init / fitted field), 8 -> 368 / 180, 16 -> 461 / 223 (over the 64-VGPR budget of two
+                                                  // resident workgroups; capped to it, 16 on the two coarsest tables only: 375 / 179 — no better than 8 everywhere)
+#endif
+struct B3Pending { uint32_t key; unsigned long long a0, b0, a1, b1; };   // key = (local entry | pair shift << 12): both entries of the record; sums per entry and channel
+__device__ __forceinline__ void b3_flush_pending(long long *acc, const B3Pending &c) {
+    if (c.key == 0xFFFFFFFFu) return;
+    const uint32_t e = c.key & (BN_CHUNK - 1), t = (c.key >> 12) & 15u;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), c.a0);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), c.b0);
+    if (t != B2_SINGLE) {
+        const uint32_t e1 = e ^ ((2u << t) - 1u);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e1]), c.a1);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e1]), c.b1);
+    }
+}
+__device__ __forceinline__ void b3_push_record(long long *acc, B3Pending &c, const uint2 r) {
+    union { uint32_t u; __half2 h; } v;
+    v.u = r.y;
+    const float2 f = __half22float2(v.h);
+    const uint32_t key = r.x & 0xFFFFu, t = (r.x >> 12) & 15u;
+    unsigned long long a0, b0, a1 = 0, b1 = 0;
+    if (t == B2_SINGLE) {
+        a0 = b2_fix(f.x * 16777216.0f); b0 = b2_fix(f.y * 16777216.0f);
+    } else {                                                                        // (the arithmetic of b2_add_record, value for value)
+        const float w1 = (float)(r.x >> 16) * (1.0f / 65536.0f), w0 = 1.0f - w1;
+        const float w1s = w1 * 16777216.0f, w0s = w0 * 16777216.0f;
+        a0 = b2_fix(w0s * f.x); b0 = b2_fix(w0s * f.y);
+        a1 = b2_fix(w1s * f.x); b1 = b2_fix(w1s * f.y);
+    }
+    if (key == c.key) {
+        c.a0 += a0; c.b0 += b0; c.a1 += a1; c.b1 += b1;
+    } else {
+        b3_flush_pending(acc, c);
+        c.key = key; c.a0 = a0; c.b0 = b0; c.a1 = a1; c.b1 = b1;
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin, uint32_t slot0,
@@ -699,14 +741,27 @@ __global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ s
     // Crowded bins (the split ones: the small dense levels, where neighbouring samples of a ray update the same entry): a lane takes UNR
     // consecutive 16-byte units, so a run of same-entry records becomes successive atomics of one lane instead of same-address lanes of one
     // instruction (dense levels 171 -> 160 us).  Elsewhere consecutive units go to consecutive lanes (one line per four lanes on the load side).
-    // Measured and dropped: summing such a run in the lane's registers and issuing the atomics only when the destination changes — the
-    // divergent flush (four exec-masked atomics behind a branch, eight times per iteration) took the dense levels from 160 to 507 us.
+    // Round 3 measured and dropped summing such a run in the lane's registers (a flush of four exec-masked atomics behind a branch after every
+    // record: dense levels 160 -> 507 us); round 5's form — one pending record pair, compared by its 16-bit key, flushed when the key changes
+    // (b3_push_record) — does pay: 388 -> 371 us on the reference's bear table at random init, 413 -> 382 us fitted (B2_COMBINE).
     const bool crowded = nseg > 1;
     uint32_t ib = b2 >> 1;
     for (; ib + UNR * 1024 <= pend; ib += UNR * 1024) {
         uint4 r[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; u++) r[u] = slab2[crowded ? ib + threadIdx.x * UNR + u : ib + u * 1024 + threadIdx.x];
+        if (crowded && B2_COMBINE) {
+            // (round 5) the lane's eight consecutive records, summed in registers while they share their entries: see b3_push_record
+            B3Pending c;
+            c.key = 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                b3_push_record(acc, c, make_uint2(r[u].x, r[u].y));
+                b3_push_record(acc, c, make_uint2(r[u].z, r[u].w));
+            }
+            b3_flush_pending(acc, c);
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             b2_add_record(acc, make_uint2(r[u].x, r[u].y));
@@ -1097,45 +1152,6 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
     g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
     *dst = g;
-}
-
-#ifndef B3_WALK
-#define B3_WALK 8                                  // consecutive records of a run per thread in the run walk (combined in registers when they share entries);
-                                                  // measured: 4 -> 372 / 195 us (random init / fitted field), 8 -> 368 / 180, 16 -> 461 / 223 (over the 64-VGPR budget of two
-                                                  // resident workgroups; capped to it, 16 on the two coarsest tables only: 375 / 179 — no better than 8 everywhere)
-#endif
-struct B3Pending { uint32_t key; unsigned long long a0, b0, a1, b1; };   // key = (local entry | pair shift << 12): both entries of the record; sums per entry and channel
-__device__ __forceinline__ void b3_flush_pending(long long *acc, const B3Pending &c) {
-    if (c.key == 0xFFFFFFFFu) return;
-    const uint32_t e = c.key & (BN_CHUNK - 1), t = (c.key >> 12) & 15u;
-    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e]), c.a0);
-    atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e]), c.b0);
-    if (t != B2_SINGLE) {
-        const uint32_t e1 = e ^ ((2u << t) - 1u);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[e1]), c.a1);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BN_CHUNK + e1]), c.b1);
-    }
-}
-__device__ __forceinline__ void b3_push_record(long long *acc, B3Pending &c, const uint2 r) {
-    union { uint32_t u; __half2 h; } v;
-    v.u = r.y;
-    const float2 f = __half22float2(v.h);
-    const uint32_t key = r.x & 0xFFFFu, t = (r.x >> 12) & 15u;
-    unsigned long long a0, b0, a1 = 0, b1 = 0;
-    if (t == B2_SINGLE) {
-        a0 = b2_fix(f.x * 16777216.0f); b0 = b2_fix(f.y * 16777216.0f);
-    } else {                                                                        // (the arithmetic of b2_add_record, value for value)
-        const float w1 = (float)(r.x >> 16) * (1.0f / 65536.0f), w0 = 1.0f - w1;
-        const float w1s = w1 * 16777216.0f, w0s = w0 * 16777216.0f;
-        a0 = b2_fix(w0s * f.x); b0 = b2_fix(w0s * f.y);
-        a1 = b2_fix(w1s * f.x); b1 = b2_fix(w1s * f.y);
-    }
-    if (key == c.key) {
-        c.a0 += a0; c.b0 += b0; c.a1 += a1; c.b1 += b1;
-    } else {
-        b3_flush_pending(acc, c);
-        c.key = key; c.a0 = a0; c.b0 = b0; c.a1 = a1; c.b1 = b1;
-    }
 }
 
 // The records of a bin segment that live in RUNS of the point blocks' private regions (a dense level's bins; the spill of a hashed bin): the
