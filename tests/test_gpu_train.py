@@ -296,6 +296,46 @@ def test_training_is_bit_reproducible():
         assert torch.equal(pa, pb)
 
 
+def test_training_trajectory_is_bit_identical_with_and_without_early_termination():
+    """Early termination (the compositing backward flushes gradients the half-precision consumers would round to zero; field backward and scatter skip the
+    dead tiles / rows) is claimed to change no bit of any parameter gradient.  Compounded over a run: 400 optimiser steps on the analytic sphere scene from
+    one seed, with and without it — while the loss falls by two orders of magnitude, most rows die and the scatter's bins crowd — end in bit-identical
+    parameters (profiles/r05_early_termination_trajectory.log is the 1200-step version, scratch/soak_early_term.py)."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    H = W = 128
+    V = 8
+
+    def train(early):
+        torch.manual_seed(0)
+        opt = sc.make_opt(cuda_ray=False, fp16=True)
+        opt.early_termination = early
+        model = NeRFNetwork(opt).cuda()
+        c2w = torch.from_numpy(sc.poses(V)).cuda()
+        o, d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+        o, d = o.view(V, 1, H * W, 3), d.view(V, 1, H * W, 3)
+        rgb, mask = sc.sphere_targets(o.reshape(V, -1, 3), d.reshape(V, -1, 3))
+        tr = ReconTrainer(model, opt, fp16=True)
+        first = last = None
+        for i in range(400):
+            loss, _ = tr.train_step(o[i % V], d[i % V], rgb[i % V], mask[i % V], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+            if i == 0:
+                first = float(loss)
+            last = float(loss)
+        return [p.detach().clone() for p in model.parameters()], first, last
+
+    try:
+        (a, f0, l0), (b, f1, l1) = train(True), train(False)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+    assert f0 == f1 and l0 == l1 and l0 < 0.02 * f0, (f0, l0, f1, l1)       # it did train (and identically)
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+
+
 def test_half_batches_sum_to_the_full_batch():
     """SURVEY.md §4's data-parallel contract on the real field, on one GPU: the gradient of a ray batch equals the sum of the gradients of its
     two halves (each weighted by its share of the rays) — what two ranks of a ray-chunk split produce before the exchange.  Full-size view
