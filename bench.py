@@ -168,31 +168,16 @@ def run_edit(args, world, rank, dev):
     torch.manual_seed(0)
     opt = sc.make_opt(cuda_ray=False, fp16=True, keep_bg=1000.0, lambda_sd=0.01, cfg=100.0, log_loss_item=False)
     model = NeRFNetwork(opt).to(dev)
+    pretrained = copy.deepcopy(model).eval()
+    for p in pretrained.parameters():
+        p.requires_grad_(False)
+    guidance = StableDiffusion(dev, '1.5', opt, seed=0)                 # SD-1.5 shapes, seeded random weights (no checkpoint offline)
     H = W = args.res
     V = 8
     nv = max(1, int(getattr(args, 'sds_views', 1)))
     c2w = torch.from_numpy(sc.poses(V)).to(dev)
     rays_o, rays_d = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
     rays_o, rays_d = rays_o.view(V, 1, H * W, 3), rays_d.view(V, 1, H * W, 3)
-    edit_prefit = int(getattr(args, 'edit_prefit', 0) or 0)
-    if edit_prefit > 0:
-        # `fitted_field`: the reference's editing stage always starts from a RECONSTRUCTED field (main.py loads the stage-1 checkpoint into both the
-        # edited and the frozen model); fit a twin of the model to the analytic sphere scene for `edit_prefit` untimed steps and start from its weights.
-        # A fitted field has opaque surfaces: most samples of a ray get no gradient, which the backward's early termination skips.
-        from customnerf_amd.trainer import ReconTrainer
-        twin = NeRFNetwork(opt).to(dev)
-        twin.load_state_dict(model.state_dict())
-        fit = ReconTrainer(twin, opt, fp16=True)
-        f_rgb, f_mask = sc.sphere_targets(rays_o.reshape(V, -1, 3), rays_d.reshape(V, -1, 3))
-        for i in range(edit_prefit):
-            fit.train_step(rays_o[i % V], rays_d[i % V], f_rgb[i % V], f_mask[i % V], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=0,
-                           max_steps=opt.max_steps)
-        model.load_state_dict(twin.state_dict())
-        del fit, twin, f_rgb, f_mask
-    pretrained = copy.deepcopy(model).eval()
-    for p in pretrained.parameters():
-        p.requires_grad_(False)
-    guidance = StableDiffusion(dev, '1.5', opt, seed=0)                 # SD-1.5 shapes, seeded random weights (no checkpoint offline)
     rgb, mask = sc.targets(V, H, W)
     rgb, mask = rgb.to(dev), mask.to(dev)
     # the loss scale starts where the GradScaler policy settles on this workload (it backs off 65536 -> 32768 on the first high-noise timestep and
@@ -229,9 +214,6 @@ def run_edit(args, world, rank, dev):
                          "sds_views_per_step": nv, "views_per_s": world * nv * args.steps / dt,
                          "parallelism": f"dp{world} (view-parallel SDS, RCCL {trainer.dp_describe()})" if world > 1 else "single GPU", "final_loss": float(loss),
                          "loss_scale": f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}", "steps_skipped_on_overflow": skipped}}
-    if edit_prefit > 0:
-        result["config"]["prefit_steps"] = edit_prefit
-        result["config"]["workload"] += f", edited and frozen field start from a field fitted for {edit_prefit} steps to the analytic sphere scene (the reference edits a reconstructed field)"
     if not args.no_roofline:
         prof = []
         use_graph = guidance.use_graph
@@ -530,7 +512,6 @@ def main():
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded",
                     help="N>1 gradient exchange: sharded = fp16 (fp32 without a loss scaler) all-to-all + sharded Adam + all-gather of the shadow; allreduce = one fp32 all-reduce")
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
-    ap.add_argument("--edit-prefit", type=int, default=0, help="edit leg: start from a field fitted for N steps to the analytic sphere scene (secondary.fitted_field uses 300)")
     ap.add_argument("--prefit", type=int, default=0,
                     help="recon leg: fit the field to the analytic sphere scene for this many untimed steps first, so that the importance samples cluster around a surface")
     ap.add_argument("--dp-selftest", action="store_true", help="one GPU: force the sharded gradient exchange on over a one-rank RCCL group (no link time)")
@@ -653,12 +634,6 @@ def main():
                 edit["multi_view"] = mv if (mv is None or "error" in mv) else {
                     "sds_views_per_step": 4, "edit_steps_per_s": mv["value"], "views_per_s": mv["config"]["views_per_s"],
                     "ms_per_step": mv["ms_per_step"], "roofline": mv.get("roofline")}
-        if args.task == "both" and args.sds_views == 1 and not args.no_variants and world == 1 and not edit.get("error"):
-            # the edit step on a FITTED field — the state the reference's editing stage starts from; same step, same SDS half
-            ff = variant(run_edit, edit_prefit=300, no_roofline=True)
-            edit["fitted_field"] = ff if (ff is None or "error" in ff) else {
-                "edit_steps_per_s": ff["value"], "ms_per_step": ff["ms_per_step"], "prefit_steps": 300, "workload": ff["config"]["workload"],
-                "steps_skipped_on_overflow": ff["config"].get("steps_skipped_on_overflow")}
         if args.task == "edit":
             result = edit
         elif rank == 0:
