@@ -92,6 +92,19 @@ def test_argument_validation_without_launch():
     assert lib.cnerf_march_rays_train_count(one, one, one, 2.0, 0.0, 1024, 4, 0, 128, one, one, one, one, one, None) == -1   # C = 0
     assert lib.cnerf_adam_step(one, one, one, one, None, 8, 1e-3, 0.9, 0.99, 1e-15, 0, 1.0, 1, None) == -1                   # step 0
     assert lib.cnerf_generate_rays(one, 1, 4, 4, 0.0, 1.0, 2.0, 2.0, 1.0, 0, one, one, None) == -1                             # fx = 0
+    # round 5 entry points: the edit step's single-launch glue and the plan query
+    assert lib.cnerf_edit_ray_images(None, 1, 16, one, one, one, None) == -2 and lib.cnerf_edit_ray_images(one, 0, 16, one, one, one, None) == -1
+    assert lib.cnerf_edit_ray_images_backward(None, None, None, 1, 16, None, None) == -2           # the three gradients may be NULL, the output may not
+    assert lib.cnerf_edit_l1_loss(one, one, 0, 1.0, one, one, None) == -1 and lib.cnerf_edit_l1_loss(one, None, 8, 1.0, one, one, None) == -2
+    assert lib.cnerf_edit_sds_loss(one, one, 0, one, one, None) == -1 and lib.cnerf_edit_sds_loss(None, one, 8, one, one, None) == -2
+    assert lib.cnerf_edit_scale_by_scalar(one, one, 1.0, 0, one, None) == 0 and lib.cnerf_edit_scale_by_scalar(one, None, 1.0, 8, one, None) == -2
+    assert lib.cnerf_sd_sample_latents(one, one, 0, 64, 0.18215, one, None) == -1 and lib.cnerf_sd_sample_latents(None, one, 1, 64, 0.18215, one, None) == -2
+    assert lib.cnerf_sd_sample_latents_backward(one, one, None, 1, 64, 0.18215, one, None) == -2
+    vals = (ctypes.c_float * 2)(1.0, 2.0)
+    assert lib.cnerf_set_floats(one, ctypes.cast(vals, ctypes.c_void_p), 17, None) == -1 and lib.cnerf_set_floats(None, ctypes.cast(vals, ctypes.c_void_p), 2, None) == -2
+    needs = ctypes.c_int(7)
+    assert lib.cnerf_grid_encode_backward_needs_plan(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 0, 1, ctypes.addressof(needs)) == 0 and needs.value == 0   # third form: no plan
+    assert lib.cnerf_grid_encode_backward_needs_plan(big.ctypes.data, 2097152, 3, 2, 16, 16, S, 16, 0, 0, ctypes.addressof(needs)) == 0 and needs.value == 1   # float32 records: second form
 
 
 def test_host_side_modules_on_cpu():
