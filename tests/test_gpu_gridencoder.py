@@ -256,6 +256,37 @@ def test_scatter_skips_zero_rows_and_recomputes_overflowing_bins():
     assert scale > 100.0 and float((r1 - ra).abs().max()) < 2e-3 * scale
 
 
+@pytest.mark.parametrize("max_level", [1, 6, 9])
+def test_binned_scatter_with_fewer_active_levels(max_level):
+    """coarse-to-fine training hands `max_level < L` to the backward (grid.py: only the first max_level levels receive gradient): the histogram-free
+    scatter plans its slots for those levels only — same table gradient as the atomic kernel, the inactive levels' rows untouched, bit-reproducible"""
+    from customnerf_amd._lib import lib, ptr, stream, check
+    import ctypes
+    enc = build(CONFIGS[0][1])
+    L, C = enc.num_levels, enc.level_dim
+    S = float(np.log2(enc.per_level_scale))
+    B = 90001
+    x = cuda(make_inputs(B, 3, seed=31))
+    g = torch.from_numpy(np.random.default_rng(32).standard_normal((L, B, C)).astype(np.float32)).cuda().half().contiguous()
+    need = ctypes.c_uint64(0)
+    lib.cnerf_grid_encode_backward_workspace_bytes(enc._offsets_host.ctypes.data, B, 3, C, L, max_level, S, enc.base_resolution, 1, ctypes.addressof(need))
+
+    def scatter(ws):
+        out = torch.full(enc.embeddings.shape, 0.25, device='cuda')
+        check(lib.cnerf_grid_encode_backward(ptr(g), ptr(x), enc._offsets_host.ctypes.data, ptr(out), B, 3, C, L, max_level, S, enc.base_resolution, None, None,
+                                             enc.gridtype_id, int(enc.align_corners), enc.interp_id, 1, ptr(ws), ws.numel() if ws is not None else 0, stream()))
+        return out
+    atomic = scatter(None)
+    if need.value == 0:                                    # too little work for the binned path at this level count: nothing more to compare
+        return
+    ws = torch.empty(int(need.value) + 256, dtype=torch.uint8, device='cuda')
+    a, b = scatter(ws), scatter(ws)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), atomic.cpu().numpy(), rtol=2e-3, atol=2e-2)
+    first_inactive = int(enc._offsets_host[max_level])
+    assert torch.all(a[first_inactive:] == 0.25) and not torch.all(a[:first_inactive] == 0.25)
+
+
 def test_grad_total_variation():
     kw = CONFIGS[0][1]
     enc = build(kw, scale=0.5, seed=7)
