@@ -56,6 +56,26 @@ def test_code_object_is_gfx950_only():
     assert targets == {b"gfx950"}, targets
 
 
+def test_no_binaries_tracked_in_git():
+    """History stays source-only: nothing under customnerf_amd/ that git tracks is an ELF / code-object / offload bundle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, ".git")):
+        pytest.skip("not a git checkout (GPU-box snapshot)")
+    files = subprocess.run(["git", "ls-files", "customnerf_amd", "oracle", "include"], cwd=root, capture_output=True, text=True, check=True).stdout.split()
+    assert files
+    bad = []
+    for f in files:
+        p = os.path.join(root, f)
+        if not os.path.isfile(p):
+            continue                      # deleted in the work tree, not yet committed
+        head = open(p, "rb").read(24)
+        if head.startswith(b"\x7fELF") or head.startswith(b"__CLANG_OFFLOAD_BUNDLE__") or os.path.getsize(p) == 0 and ".so." in f:
+            bad.append(f)
+    assert not bad, bad
+
+
 def test_argument_validation_without_launch():
     """Rejected arguments return before anything touches the device (safe on a CPU-only box)."""
     from customnerf_amd._lib import lib
