@@ -130,6 +130,34 @@ def _dp_selftest(args, trainer, model, fp16):
         trainer._dp = setup_sharded_dp(trainer, model, fp16, rank=0)
 
 
+class _StageEvents:
+    """cnerf_profile_stage_events: the library records these events between the kernels of the grid scatter and of the field backward of the LAST
+    step issued (the handles are re-recorded every step); -> milliseconds per stage after a synchronize."""
+    NAMES = {(0, 1): "scatter_emit", (1, 2): "scatter_accumulate", (2, 3): "scatter_split_reduce", (4, 5): "field_backward", (5, 6): "field_reduce_partials"}
+
+    def __init__(self):
+        import ctypes
+        from customnerf_amd import _lib
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        for e in self.ev:
+            e.record()                                            # (creates the handle)
+        torch.cuda.synchronize()
+        arr = (ctypes.c_void_p * len(self.ev))(*[e.cuda_event for e in self.ev])
+        _lib.check(_lib.lib.cnerf_profile_stage_events(arr, len(self.ev)), "profile_stage_events")
+
+    def finish(self):
+        from customnerf_amd import _lib
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.cnerf_profile_stage_events(None, 0), "profile_stage_events")
+        out = {}
+        for (a, b), name in self.NAMES.items():
+            try:
+                out[name] = self.ev[a].elapsed_time(self.ev[b])
+            except Exception:
+                out[name] = None
+        return out
+
+
 def _timed(step, args, world, dist):
     """EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, last step's return value)"""
     if world > 1:
@@ -277,6 +305,8 @@ def run_recon(args, world, rank, dev):
     torch.manual_seed(0)
     grid_kw = dict(grid_type='tiledgrid', log2_hashmap_size=21, desired_resolution=8192) if args.grid == "bear" else {}
     opt = sc.make_opt(cuda_ray=(args.path == "march"), fp16=fp16, **grid_kw)
+    if getattr(args, "no_tune_traversal", False):
+        opt.tune_gather_traversal = False
     model = NeRFNetwork(opt).to(dev)
     H = W = args.res
     V = 8
@@ -290,6 +320,14 @@ def run_recon(args, world, rank, dev):
         grid = torch.from_numpy(sc.sphere_density_grid(model.cascade, 128, opt.bound, 1.0, 100.0)).to(dev)
         model.density_grid.copy_(grid)
         model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
+    if getattr(args, "rays", 0) and not (args.scaling == "strong" and world > 1):
+        # --rays N: the rays of all views regrouped into steps of N rays (2048 = what one of 8 ranks executes when ONE 128x128 view is split
+        # over the node; 32768 = two views per step) — the batch-size axis of profiles/r06_batch_sweep.json
+        if (V * H * W) % args.rays:
+            raise SystemExit(f"--rays {args.rays} does not divide {V * H * W}")
+        V = V * H * W // args.rays
+        rays_o, rays_d = rays_o.reshape(V, 1, args.rays, 3).contiguous(), rays_d.reshape(V, 1, args.rays, 3).contiguous()
+        rgb, mask = rgb.reshape(V, args.rays, 3).contiguous(), mask.reshape(V, args.rays, 1).contiguous()
     trainer = ReconTrainer(model, opt, fp16=fp16, world_size=world, dp_mode=args.dp)
     _dp_selftest(args, trainer, model, fp16)
     render_kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps, dt_gamma=0, max_steps=opt.max_steps)
@@ -301,7 +339,7 @@ def run_recon(args, world, rank, dev):
         rgb, mask = rgb[:, lo:hi].contiguous(), mask[:, lo:hi].contiguous()
         rays_per_step = H * W
     else:
-        n_rays = H * W
+        n_rays = rays_o.shape[2]
         rays_per_step = n_rays * world
 
     # --graph (one GPU, run() path): render + loss + backward of each view replayed as one hipGraph, eager optimiser step (ReconTrainer.train_step_graphed)
@@ -326,9 +364,11 @@ def run_recon(args, world, rank, dev):
     xev = [] if trainer._dp is not None else None
     trainer._exchange_events = xev
     good0 = trainer.scaler.good_steps() if trainer.scaler is not None else 0          # host read, outside the timed region
+    stage = _StageEvents() if getattr(args, "stage_events", False) else None       # events between the kernels of the scatter / the field backward
     dt, (loss, out) = _timed(step, args, world, dist)
     ge.set_profile(None)
     trainer._exchange_events = None
+    stage_ms = stage.finish() if stage is not None else None
 
     result = None
     if rank == 0:
@@ -342,6 +382,9 @@ def run_recon(args, world, rank, dev):
                                       if args.grid == "bear" else "hash grid L16 T2^19 (6.12M entries), ")
                                    + ("run() path 64+64 samples/ray" if args.path == "run" else "run_cuda() occupancy-march path, unit-sphere occupancy")
                                    + ", fwd+bwd+Adam", "rays_per_step_per_gpu": n_rays,
+                       # all ranks' rays behind ONE optimiser step: weak scaling multiplies it by N (N views per step where the reference takes one,
+                       # utils_init_nerf.py:599-629), strong scaling keeps it at one view — so a weak-scaling speed-up is not read as a faster one-view step
+                       "rays_per_optimizer_step": rays_per_step,
                        "parallelism": (f"dp{world} ({'ray-chunk' if strong else 'view-parallel'}, RCCL {trainer.dp_describe()})" if world > 1 else "single GPU"),
                        "path": args.path, "final_loss": float(loss),
                        "loss_scale": (f"dynamic (GradScaler policy on device), now {trainer.scaler.get_scale():g}" if trainer.scaler is not None else "none (fp32)"),
@@ -354,6 +397,10 @@ def run_recon(args, world, rank, dev):
         if args.prefit > 0:
             result["config"]["prefit_steps"] = args.prefit
             result["config"]["workload"] += f", field pre-fitted for {args.prefit} steps to the analytic sphere scene (targets of the timed steps too)"
+        if getattr(args, "rays", 0):
+            result["config"]["workload"] = result["config"]["workload"].replace(f"{H}x{W} view", f"{H}x{W} views regrouped into {n_rays}-ray steps")
+        if stage_ms:
+            result["config"]["stage_ms"] = stage_ms
         if xev:
             # gradient exchange (pack + all-to-all + fp32 sum + sharded Adam + shadow all-gather + MLP all-reduce), event pairs on the compute stream
             result["config"]["exchange_ms"] = sum(a.elapsed_time(b) for a, b in xev) / len(xev)
@@ -374,6 +421,10 @@ def run_recon(args, world, rank, dev):
                 for nm, sel in (("coarse", ms[0::2]), ("fine", ms[1::2])):
                     a_ = sum(pts[0::2]) * bpp / (sum(sel) * 1e-3) / 1e9
                     result["roofline"][nm] = {"avg_launch_ms": sum(sel) / len(sel), "achieved": a_, "frac": a_ / HBM_PEAK_GBS}
+            tuner = model.__dict__.get('_fine_tuner')
+            if tuner is not None:                                     # which traversal the importance-sample gather settled on, and the trial that decided it
+                result["roofline"]["fine_traversal"] = {"choice": "sample-major" if tuner.choice else "level-major", "trials": len(tuner.history),
+                                                        "last_trial_ms": ({"level_major": tuner.history[-1][1], "sample_major": tuner.history[-1][2]} if tuner.history else None)}
             if args.grid == "synthetic" and args.prefit == 0:         # the PMC pass was taken on this table in this (random-initialised) state
                 result["roofline"]["l2_fabric"] = l2_fabric(args.dtype, sum(pts) / len(pts), tot_ms / len(ms))
         if not args.no_cpu_baseline and world == 1:
@@ -479,6 +530,32 @@ def launch_ranks(args, argv, child_cmd=None, check_devices=True):
     return 0
 
 
+def device_identity(dev):
+    """what distinguishes one physical GPU from another on this node: the driver's UUID when torch exposes it, else the PCI address"""
+    pr = torch.cuda.get_device_properties(dev)
+    for attr in ("uuid",):
+        v = getattr(pr, attr, None)
+        if v is not None and str(v) not in ("", "00000000-0000-0000-0000-000000000000"):
+            return f"uuid:{v}"
+    pci = tuple(getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if any(x is not None for x in pci):
+        return f"pci:{pci}"
+    return f"index:{os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', ''))}:{dev.index}"
+
+
+def check_one_gpu_per_rank(dist, dev, world, rank, identities=None):
+    """Two ranks on one GPU (a mis-set HIP_VISIBLE_DEVICES, a launcher that hands every rank LOCAL_RANK 0) show up in RCCL only as a hang or a
+    'duplicate GPU' abort deep inside communicator creation.  Gather every rank's device identity and refuse to run unless they are all
+    different.  `identities` (tests): the gathered list, instead of a collective."""
+    if identities is None:
+        identities = [None] * world
+        dist.all_gather_object(identities, device_identity(dev))
+    if len(set(identities)) != world:
+        raise SystemExit(f"rank {rank}: {world} ranks but {len(set(identities))} distinct GPUs ({identities}) — one process per GPU is required "
+                         "(check HIP_VISIBLE_DEVICES / LOCAL_RANK)")
+    return identities
+
+
 def l2_fabric(dtype, points_per_launch, avg_launch_ms):
     """L1 -> L2 request traffic of the gather (what actually binds it: VERDICT r3) from the committed PMC pass: TCP_TCC_READ_REQ x 128-byte
     lines per launch / this run's live launch time, against the guide's L2 ceiling (MI355X_MICROARCH.md §L2: ~34.5 TB/s)."""
@@ -512,6 +589,10 @@ def main():
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded",
                     help="N>1 gradient exchange: sharded = fp16 (fp32 without a loss scaler) all-to-all + sharded Adam + all-gather of the shadow; allreduce = one fp32 all-reduce")
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
+    ap.add_argument("--rays", type=int, default=0,
+                    help="recon leg: regroup the views' rays into steps of this many rays (default 0 = one whole view per step); must divide 8 * res * res")
+    ap.add_argument("--no-tune-traversal", action="store_true", help="recon leg: keep the importance-sample gather level-major (no in-place TraversalTuner trials)")
+    ap.add_argument("--stage-events", action="store_true", help="recon leg: per-kernel event times of the last step's scatter and field backward (config.stage_ms)")
     ap.add_argument("--prefit", type=int, default=0,
                     help="recon leg: fit the field to the analytic sphere scene for this many untimed steps first, so that the importance samples cluster around a surface")
     ap.add_argument("--dp-selftest", action="store_true", help="one GPU: force the sharded gradient exchange on over a one-rank RCCL group (no link time)")
@@ -559,6 +640,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != world:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+        if world > 1 and os.environ.get("CNERF_SINGLE_DEVICE") != "1":
+            check_one_gpu_per_rank(dist, dev, world, rank)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     import copy as _copy
@@ -581,17 +664,17 @@ def main():
         if r is None or "error" in r:
             return r
         out = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"]}
-        for k in ("samples_per_ray", "prefit_steps", "exchange_ms", "graph"):
+        for k in ("samples_per_ray", "prefit_steps", "exchange_ms", "graph", "stage_ms", "rays_per_step_per_gpu"):
             if k in r["config"]:
                 out[k] = r["config"][k]
         if "roofline" in r:
-            out["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "points_per_launch", "coarse", "fine") if k in r["roofline"]}
+            out["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms", "points_per_launch", "coarse", "fine", "fine_traversal") if k in r["roofline"]}
         return out
 
     result = None
     if args.task in ("both", "recon"):
         result = run_recon(args, world, rank, dev)
-        plain = args.path == "run" and args.grid == "synthetic" and args.prefit == 0 and not args.no_variants and not args.graph   # rank-independent conditions only
+        plain = args.path == "run" and args.grid == "synthetic" and args.prefit == 0 and not args.no_variants and not args.graph and not args.rays  # rank-independent conditions only
         if plain and world == 1 and not args.dp_selftest:
             # the claims that used to live in builder-run profiles/, under the driver's clock: the reference field's own table
             # (network_grid.py:89-96), the occupancy-march path (renderer.py:597-718) and the gather on a FITTED field
@@ -607,8 +690,17 @@ def main():
                 os.environ["MASTER_PORT"] = str(_free_port())
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
                 v["dp_selftest"] = brief(variant(run_recon, dp_selftest=True, no_roofline=True))
+                # what ONE of 8 ranks executes per step when one 128x128 view is split over the node (north_star's own partition, SURVEY.md 8e:
+                # 2048 rays per GPU), exchange on: the strong-scaling bound of this design, measured instead of estimated
+                sb = brief(variant(run_recon, dp_selftest=True, no_roofline=True, rays=2048, stage_events=True))
+                if sb and "error" not in sb and rank == 0:
+                    sb["implied_strong_scaling_bound_8gpu"] = result["ms_per_step"] / sb["ms_per_step"]
+                    sb["note"] = ("one rank's share of a 16384-ray step under --scaling strong at 8 GPUs, gradient exchange on over a one-rank RCCL group "
+                                  "(no link time); bound = 16384-ray step time / this step time")
+                v["small_batch"] = sb
             except Exception as e:
-                v["dp_selftest"] = {"error": repr(e)}
+                v.setdefault("dp_selftest", {"error": repr(e)})
+                v.setdefault("small_batch", {"error": repr(e)})
             finally:
                 if dist.is_initialized():
                     dist.destroy_process_group()

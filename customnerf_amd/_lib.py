@@ -18,6 +18,7 @@ vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
 # name -> argtypes (must list every symbol include/customnerf_hip.h declares; tests/test_abi.py cross-checks)
 SIGNATURES = {
     "cnerf_abi_version": [],
+    "cnerf_profile_stage_events": [vp, u32],
     "cnerf_near_far_from_aabb": [vp, vp, vp, u32, f32, vp, vp, vp],
     "cnerf_sph_from_ray": [vp, vp, f32, u32, vp, vp],
     "cnerf_morton3D": [vp, u32, vp, vp],
@@ -35,6 +36,7 @@ SIGNATURES = {
     "cnerf_compact_rays_alive": [vp, u32, vp, vp, vp],
     "cnerf_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
     "cnerf_grid_encode_forward_strided": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, u32, vp],
+    "cnerf_grid_encode_forward_ordered": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, u32, u32, vp],
     "cnerf_grid_encode_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp, u64, vp],
     "cnerf_grid_encode_backward_prepare": [vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp, vp],
     "cnerf_grid_encode_backward_prepared": [vp, vp, vp, vp, u32, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, vp, u64, vp],

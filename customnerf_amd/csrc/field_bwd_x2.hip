@@ -715,13 +715,16 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
                            grad_enc, partials, (uint32_t)ablate, tile_live);                                                               \
     }
+    cn_stage(4, st);
     if (tile_live) {
         if (dm.n_hidden_geo == 2) X2_LAUNCH((k_field_bwd_x2<2, true>)) else X2_LAUNCH((k_field_bwd_x2<1, true>))
     } else {
         if (dm.n_hidden_geo == 2) X2_LAUNCH((k_field_bwd_x2<2, false>)) else X2_LAUNCH((k_field_bwd_x2<1, false>))
     }
+    cn_stage(5, st);
     int rc = cn_launch_status();
     if (rc) return rc;
     ff_reduce_partials(partials, blocks * 2, po.total, po.d0, po.r0 - po.d0, g_net, g_den, g_rgb, st);
+    cn_stage(6, st);
     return cn_launch_status();
 }

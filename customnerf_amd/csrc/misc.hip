@@ -290,10 +290,17 @@ __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, 
     }
 }
 
+void *g_cn_stage_events[CNERF_STAGE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
 extern "C" {
 
 int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
 const char *cnerf_target_arch(void) { return "gfx950"; }
+int cnerf_profile_stage_events(void *const *events, uint32_t n) {
+    if (n > CNERF_STAGE_EVENTS || (n && !events)) return CNERF_EINVAL;
+    for (uint32_t i = 0; i < CNERF_STAGE_EVENTS; i++) g_cn_stage_events[i] = i < n ? events[i] : nullptr;
+    return CNERF_OK;
+}
 
 int cnerf_generate_rays(const float *c2w, uint32_t V, uint32_t H, uint32_t W, float fx, float fy, float cx, float cy, float level,
                         int convention, float *origins, float *directions, void *stream) {

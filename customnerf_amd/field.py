@@ -76,9 +76,16 @@ class FieldFunction(Function):
         # early termination: the compositing backward (render_ops._CompositeRunIndexed with flush_half_zero) hands over, on the gradient tensor itself,
         # one byte per 32-row tile of the sample list — 0 = every output gradient of the tile is exactly zero (autograd passes the very tensor
         # object on; a gradient that was accumulated or copied on the way simply arrives without the attribute and nothing is skipped)
-        tile_live = getattr(g_sigma, '_cnerf_tile_live', None)
-        if tile_live is not None and not (g_sigma.is_contiguous() and g_sigma.dtype == torch.float32 and tile_live.numel() * 32 == P and tile_live.is_cuda):
-            tile_live = None
+        # Sound only while both gradients are EXACTLY what the compositing backward wrote: a second consumer of sigma / rgbc makes autograd
+        # accumulate — in place into the first arrival (same object, attribute and all: the version counter moves) or into a new tensor — and
+        # the dead-tile flags would then drop real gradient.  The hand-over therefore carries address + version of both tensors.
+        tile_live = None
+        flags = getattr(g_sigma, '_cnerf_tile_live', None)
+        if flags is not None:
+            tl, ps, vs, pc, vc = flags
+            if (g_sigma.data_ptr() == ps and g_sigma._version == vs and g_rgbc.data_ptr() == pc and g_rgbc._version == vc and g_sigma.is_contiguous()
+                    and g_rgbc.is_contiguous() and g_sigma.dtype == torch.float32 and g_rgbc.dtype == torch.float32 and tl.numel() * 32 == P and tl.is_cuda):
+                tile_live = tl
         g_sigma = g_sigma.contiguous().float()
         g_rgbc = g_rgbc.contiguous().float()
         g_enc = torch.empty_like(enc)

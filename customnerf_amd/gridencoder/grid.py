@@ -35,6 +35,56 @@ def forward_kernel_name(half):
     return "k_grid_fwd_fast" if half else "k_grid_fwd"
 
 
+LEVEL_MAJOR, SAMPLE_MAJOR = 0, 1          # include/customnerf_hip.h CNERF_GRID_LEVEL_MAJOR / CNERF_GRID_SAMPLE_MAJOR
+
+
+class TraversalTuner:
+    """Which traversal of the forward gather (cnerf_grid_encode_forward_ordered) a call site should use, MEASURED in place: the two forms are
+    bit-identical, and which one is faster depends on the scene's state — importance samples of a random-initialised field are spread over the
+    volume (level-major wins), those of a fitted field hug a surface (sample-major wins: profiles/r05_fused_fwd_lab.log).  On a trial call the
+    caller runs BOTH forms back to back on the same samples (the second overwrites the first's identical output) between event pairs; the
+    events are read without blocking on a later call, and the faster form is used until the next trial.  Two trial calls (order swapped) at
+    calls `first` / `first + 1`, then every `period` calls: 2 extra gathers per `period` steps."""
+
+    def __init__(self, first=2, period=256, margin=0.02):
+        self.choice = LEVEL_MAJOR
+        self.calls = 0
+        self.first, self.period, self.margin = first, period, margin
+        self.pending = []                 # [(traversal, e0, e1)]
+        self.history = []                 # [(call index, ms level-major, ms sample-major)]: diagnostics (bench.py prints the last entry)
+        self.enabled = True
+
+    def plan(self):
+        """-> list of traversals to launch for this call (one entry normally, both on a trial call: the LAST one's output stays)"""
+        i = self.calls
+        self.calls += 1
+        if not self.enabled or torch.cuda.is_current_stream_capturing():      # (no event may be recorded or queried while a hipGraph is captured)
+            return [self.choice]
+        self._harvest()
+        k = (i - self.first) % self.period if i >= self.first else -1
+        if k == 0:
+            return [LEVEL_MAJOR, SAMPLE_MAJOR]
+        if k == 1:
+            return [SAMPLE_MAJOR, LEVEL_MAJOR]
+        return [self.choice]
+
+    def record(self, traversal, e0, e1):
+        self.pending.append((traversal, e0, e1))
+
+    def _harvest(self):
+        if len(self.pending) < 4 or not all(e1.query() for _, _, e1 in self.pending):
+            return
+        ms = [0.0, 0.0]
+        for t, e0, e1 in self.pending:
+            ms[t] += e0.elapsed_time(e1)
+        self.pending = []
+        self.history.append((self.calls, ms[0] / 2, ms[1] / 2))
+        if ms[SAMPLE_MAJOR] < ms[LEVEL_MAJOR] * (1 - self.margin):
+            self.choice = SAMPLE_MAJOR
+        elif ms[LEVEL_MAJOR] < ms[SAMPLE_MAJOR] * (1 - self.margin):
+            self.choice = LEVEL_MAJOR
+
+
 _gridtype_to_id = {'hash': 0, 'tiled': 1}
 _interp_to_id = {'linear': 0, 'smoothstep': 1}
 
@@ -233,7 +283,6 @@ def _plan_rows(state, inputs, offsets_host, B, D, C, L, S, H, gridtype, align_co
         if side['ws'] is None or side['ws'].numel() < need.value:
             side['ws'] = torch.empty(int(need.value * 1.25) + 256, dtype=torch.uint8, device=device)
             scratch_reallocated()
-        scratch_reallocated()
         state = {'ws': side['ws'], 'token': _Plan(side['ws'], None)}
         state['token'].inputs_ptr, state['token'].rows = inputs.data_ptr(), B
         side['owner'] = weakref.ref(state['token'])                  # the side stream's workspace is taken from the first piece on
@@ -417,9 +466,10 @@ class GridEncoder(nn.Module):
                                   inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
 
     @torch.no_grad()
-    def encode_into(self, inputs_unit, out, row0, half=None):
+    def encode_into(self, inputs_unit, out, row0, half=None, traversal=LEVEL_MAJOR):
         """Gather the features of `inputs_unit` [B, D] (already mapped to [0,1]) into rows row0 .. row0+B of the kernel-layout buffer
-        `out` [L, P, C] (P >= row0 + B).  No autograd: pair with attach_backward once the buffer is complete."""
+        `out` [L, P, C] (P >= row0 + B).  No autograd: pair with attach_backward once the buffer is complete.
+        traversal: LEVEL_MAJOR (default), SAMPLE_MAJOR, or a TraversalTuner (the call site's; it measures both forms now and then)."""
         if half is None:
             half = torch.is_autocast_enabled() and self.level_dim % 2 == 0
         table = self.half_table() if half else self.embeddings.detach()
@@ -429,16 +479,23 @@ class GridEncoder(nn.Module):
         L, P, C = out.shape
         assert out.is_contiguous() and out.dtype == table.dtype and C == table.shape[1] and row0 + B <= P and L == self._offsets_host.shape[0] - 1
         prof = _PROFILE
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         dst = out.data_ptr() + row0 * C * out.element_size()
-        check(lib.cnerf_grid_encode_forward_strided(ptr(inputs_unit), ptr(table), self._offsets_host.ctypes.data, dst, B, D, C, L, L,
-                                                    float(np.log2(self.per_level_scale)), int(self.base_resolution), None, self.gridtype_id,
-                                                    int(self.align_corners), self.interp_id, dtype_id(table), P, stream()), "grid_encode_forward_strided")
-        if prof is not None:
-            e1.record()
-            prof.append((e0, e1, B, L, table.element_size()))
+        tuner = traversal if isinstance(traversal, TraversalTuner) else None
+        todo = tuner.plan() if tuner is not None else [int(traversal)]
+        for k, trav in enumerate(todo):
+            timed = prof is not None or len(todo) > 1
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.cnerf_grid_encode_forward_ordered(ptr(inputs_unit), ptr(table), self._offsets_host.ctypes.data, dst, B, D, C, L, L,
+                                                        float(np.log2(self.per_level_scale)), int(self.base_resolution), None, self.gridtype_id,
+                                                        int(self.align_corners), self.interp_id, dtype_id(table), P, trav, stream()), "grid_encode_forward_ordered")
+            if timed:
+                e1.record()
+                if len(todo) > 1:
+                    tuner.record(trav, e0, e1)
+                if prof is not None and k == len(todo) - 1:
+                    prof.append((e0, e1, B, L, table.element_size()))
 
     def prepare_backward(self, inputs_unit, half):
         """Issue the coordinate-only half of the backward scatter for inputs_unit [P, D] (float32, contiguous, [0, 1] grid coordinates) NOW, on

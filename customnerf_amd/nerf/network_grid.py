@@ -151,15 +151,22 @@ class NeRFNetwork(NeRFRenderer):
         return torch.empty(L, P, 2, dtype=dt, device=device), torch.empty(P, 3, dtype=torch.float32, device=device)
 
     @torch.no_grad()
-    def split_encode(self, enc, unit, x, row0, unit_ready=False):
+    def split_encode(self, enc, unit, x, row0, unit_ready=False, importance=False):
         """gather the features of x [B, 3] into rows row0.. of enc (and their [0,1] grid coordinates into unit; unit_ready: the sampling
-        kernel already wrote them)"""
+        kernel already wrote them).  importance: x are importance samples (renderer.py:340-352) — whether they are spread or hug a surface
+        depends on the field's state, so the gather's traversal is measured in place (gridencoder.grid.TraversalTuner)"""
         B = x.shape[0]
         u = unit[row0:row0 + B]
         if not unit_ready:
             torch.add(x, self.opt.bound, out=u)                                     # grid.py:156: (x + bound) / (2 bound)
             u.div_(2 * self.opt.bound)
-        self.pos_en.encode_into(u, enc, row0, half=self._half())
+        trav = 0
+        if importance and getattr(self.opt, 'tune_gather_traversal', True):
+            trav = self.__dict__.get('_fine_tuner')
+            if trav is None:
+                from ..gridencoder.grid import TraversalTuner
+                trav = self.__dict__['_fine_tuner'] = TraversalTuner()
+        self.pos_en.encode_into(u, enc, row0, half=self._half(), traversal=trav)
 
     @torch.no_grad()
     def split_density(self, enc, x):

@@ -110,7 +110,9 @@ class _CompositeRunIndexed(Function):
                                                                  thr, dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), 1, ptr(tile_live), stream()),
                   "composite_run_backward_indexed_flush")
             if tile_live is not None:
-                g_sigma._cnerf_tile_live = tile_live
+                # the flags describe THESE two tensors as written here: identity (address) and version counter of both travel with them, so the
+                # field backward can tell a gradient that autograd accumulated into (in place: same object, version bumped) or replaced
+                g_sigma._cnerf_tile_live = (tile_live, g_sigma.data_ptr(), g_sigma._version, g_rgbc.data_ptr(), g_rgbc._version)
         else:
             check(lib.cnerf_composite_run_backward_indexed(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr,
                                                            dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward_indexed")

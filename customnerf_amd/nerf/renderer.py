@@ -221,7 +221,7 @@ class NeRFRenderer(nn.Module):
                     plan, _ = self.split_prepare_rows(pstate, unit, grad_on, Pc, P - Pc, True)
                 elif not piecewise:
                     plan = self.split_prepare(unit, grad_on)                 # all coordinates exist: the scatter's histogram runs beside the gather below
-                self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True)
+                self.split_encode(enc, unit, xyz_list[Pc:], Pc, unit_ready=True, importance=True)
                 if blockwise:
                     self.split_forward_rows(enc, Pc, xyz_list[Pc:], rays_d, upsample_steps, sig_all, rgbc_all)
             else:

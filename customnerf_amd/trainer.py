@@ -334,13 +334,14 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         tensors = (rays_o, rays_d, rgbs, mask)
         key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors) + (tuple(sorted(render_kw.items())),)
         cache = self.__dict__.setdefault('_graphs', {})
-        if cache and self.__dict__.get('_graphs_generation') != scratch_generation():
-            # a grow-on-demand workspace (scatter plan, partial-gradient rows) was reallocated since these graphs were captured — e.g. by an
-            # eval_step on a larger view: they hold the freed buffer's address.  Drop them all (and their pool); every view recaptures.
+        if cache and any(e[3] != scratch_generation() for e in cache.values()):
+            # a grow-on-demand workspace (scatter plan, partial-gradient rows) was reallocated since a cached graph was captured — e.g. by an
+            # eval_step on a larger view: it holds the freed buffer's address.  Drop them all (and their pool); every view recaptures.
             cache.clear()
             self.__dict__.pop('_graph_pool', None)
         ent = cache.get(key)
         if ent is None:
+            gen0 = scratch_generation()
             for _ in range(2):
                 self.train_step(rays_o, rays_d, rgbs, mask, **render_kw)
             torch.cuda.synchronize()
@@ -352,9 +353,17 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
                     loss = self.loss(outputs, rgbs, mask)
                 self.scaler.backward(loss)
                 loss = loss.detach()
+            gen1 = scratch_generation()
+            if gen1 != gen0 and cache:
+                # The workspaces are keyed by (device, stream): the ones a graph references belong to the CAPTURE stream and are allocated
+                # (graph pool) or re-grown during a capture.  This view grew one — in its warm-up or in its capture — so every graph captured
+                # before holds the address of a block that went back to the shared pool and may alias this view's allocations: drop them
+                # (they recapture on their next visit); the new graph, captured against the buffers as they are now, stays.
+                cache.clear()
             self._graph_pool = graph.pool()
-            ent = cache[key] = (graph, loss, tensors)                # (the tensors keep the captured addresses alive)
-            self._graphs_generation = scratch_generation()           # (the two eager steps above did every allocation: capture moves nothing)
+            ent = cache[key] = (graph, loss, tensors, gen1)          # (the tensors keep the captured addresses alive; gen1: the scratch generation this graph is valid for)
+            for k_ in list(cache):                                   # (entries that survived are valid for the current generation too)
+                cache[k_] = cache[k_][:3] + (gen1,)
         self.model.train()
         ent[0].replay()
         apply_optimizer_step(self)

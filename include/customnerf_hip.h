@@ -36,6 +36,13 @@ extern "C" {
 int cnerf_abi_version(void);
 /* name of the code object's target ("gfx950") */
 const char *cnerf_target_arch(void);
+/* Measurement aid (bench.py `variants.small_batch`; no reference counterpart): hipEvent_t handles that the multi-kernel entry points record on
+ * their launch stream between their kernels, or NULL entries / n = 0 to switch it off (the default).  Slots:
+ *   0 / 1 before / after the scatter's emit kernel, 2 after its accumulate kernel, 3 after its split-bin reduction (cnerf_grid_encode_backward*);
+ *   4 / 5 before / after the field backward's main kernel, 6 after its partial-gradient reduction (cnerf_field_backward*).
+ * The handles are borrowed: the caller keeps them alive until it clears the slots. */
+#define CNERF_STAGE_EVENTS 8
+int cnerf_profile_stage_events(void *const *events, uint32_t n);
 
 /* ------------------------------------------------------------------------------------------------
  * _raymarching  (reference: raymarching/src/raymarching.h:7-21, bindings.cpp:5-20)
@@ -150,6 +157,18 @@ int cnerf_grid_encode_forward_strided(const float *inputs, const void *embedding
                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                       void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
                                       uint32_t out_level_stride, void *stream);
+/* Same with the traversal of the sample list chosen by the caller (results are bit-identical either way; only the specialised
+ * fp16 / D = 3 / C = 2 / linear kernel has two forms, every other configuration ignores it):
+ *   CNERF_GRID_LEVEL_MAJOR  0  one level at a time per XCD (its table stays in that XCD's L2): right for samples spread over the volume
+ *                              — the stratified samples of NeRFRenderer.run (renderer.py:317-325) — and the default of the entry points above;
+ *   CNERF_GRID_SAMPLE_MAJOR 1  all levels of a tile of consecutive samples per workgroup: right when neighbours of the list are neighbours
+ *                              in space — the importance samples (renderer.py:340-352) of a field that has a surface. */
+#define CNERF_GRID_LEVEL_MAJOR 0
+#define CNERF_GRID_SAMPLE_MAJOR 1
+int cnerf_grid_encode_forward_ordered(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
+                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                      void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                      uint32_t out_level_stride, uint32_t traversal, void *stream);
 
 /* grid_encode_backward — gridencoder.h:13, kernels gridencoder.cu:247-339 (+ :342-368 when dy_dx != NULL).
  * grad [L,B,C] (dtype).  grad_embeddings is ALWAYS float32 [offsets[L], C], pre-zeroed by the caller

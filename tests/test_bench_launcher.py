@@ -75,3 +75,39 @@ def test_launcher_fails_fast_when_a_rank_dies(tmp_path):
     t0 = time.time()
     rc = _launch(tmp_path, "if rank == 1:\n    sys.exit(7)\ntime.sleep(600)\n")
     assert rc == 1 and time.time() - t0 < 60
+
+
+def test_one_gpu_per_rank_guard():
+    """`world` ranks must sit on `world` DIFFERENT GPUs — two ranks that landed on one device (mis-set HIP_VISIBLE_DEVICES)
+    would surface in RCCL only as a hang or a 'duplicate GPU' abort.  The guard compares the gathered device identities (here: handed in)."""
+    import pytest
+    import bench
+    assert bench.check_one_gpu_per_rank(None, None, 4, 0, identities=["uuid:a", "uuid:b", "uuid:c", "uuid:d"]) == ["uuid:a", "uuid:b", "uuid:c", "uuid:d"]
+    with pytest.raises(SystemExit) as e:
+        bench.check_one_gpu_per_rank(None, None, 4, 2, identities=["uuid:a", "uuid:b", "uuid:a", "uuid:d"])
+    assert "3 distinct GPUs" in str(e.value) and "rank 2" in str(e.value)
+
+
+def test_one_gpu_per_rank_guard_over_gloo_world2(tmp_path):
+    """the same guard through its collective (all_gather_object) on two host processes: both ranks report the same made-up identity -> both exit non-zero"""
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch.distributed as dist\n"
+        "import bench\n"
+        "rank, same = int(os.environ['RANK']), sys.argv[1] == 'same'\n"
+        "dist.init_process_group('gloo', rank=rank, world_size=2)\n"
+        "bench.device_identity = lambda dev: 'uuid:x' if same else f'uuid:{rank}'\n"
+        "ids = bench.check_one_gpu_per_rank(dist, None, 2, rank)\n"
+        "print('ok', ids)\n"
+        "dist.destroy_process_group()\n")
+    import socket
+    for mode, want in (("same", 1), ("different", 0)):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        procs = [subprocess.Popen([sys.executable, str(child), mode], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all((p.returncode != 0) == bool(want) for p in procs), outs
+        if want:
+            assert all("1 distinct GPUs" in o for o in outs), outs

@@ -84,6 +84,8 @@ def test_bench_two_ranks_on_one_device_runs_every_leg():
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and "gloo" in rec["collective_backend"]
     assert rec["value"] > 0 and rec["config"]["exchange_ms"] > 0 and "dp2" in rec["config"]["parallelism"]
     assert rec["strong"]["value"] > 0                                   # one view's rays split over the two ranks
+    # weak scaling: two views behind one optimiser step (the reference takes one) — said in the record, so a weak-scaling speed-up is not read as a faster one-view step
+    assert rec["config"]["rays_per_optimizer_step"] == 2 * rec["config"]["rays_per_step_per_gpu"] == 2 * 128 * 128
     sec = rec["secondary"]
     assert sec["value"] > 0 and sec["n_gpus"] == 2 and sec["multi_view"]["views_per_s"] > 0
 
@@ -103,3 +105,17 @@ def test_bench_two_ranks_under_torchrun_on_one_device():
     assert len(lines) == 1, lines                                        # rank 0 only
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_bench_two_ranks_allreduce_mode_edit_and_recon_legs():
+    """`--dp allreduce` (the plain fp32 all-reduce `north_star` names) through both legs with two ranks on one device —
+    the default test above runs the sharded exchange only."""
+    env = dict(os.environ, CNERF_DP_BACKEND="gloo", CNERF_SINGLE_DEVICE="1", CNERF_BENCH_WATCHDOG="420")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants",
+                          "--dp", "allreduce"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["value"] > 0 and "all-reduce" in rec["config"]["parallelism"]
+    sec = rec["secondary"]
+    assert sec["value"] > 0 and sec["n_gpus"] == 2 and "all-reduce" in sec["config"]["parallelism"], sec["config"]

@@ -653,6 +653,22 @@ def test_graphed_step_owns_its_buffers():
     assert len(trg._graphs) == 1 and trg.global_step == step0 + 3 and np.isfinite(float(loss))
     loss, _ = trg.train_step_graphed(*views[0], **kw)                    # and the recaptured graph replays
     assert len(trg._graphs) == 1 and trg.global_step == step0 + 4 and np.isfinite(float(loss))
+    # (3) ADVICE r5: the workspaces a graph references are keyed by the CAPTURE stream and grown inside a capture.  A larger view captured
+    # after a smaller one re-grows them in its own capture (the eager stream's are big enough since (2), so its warm-up moves nothing): the
+    # smaller view's graph — which holds the old block, now back in the shared graph pool — must be dropped, not replayed
+    mid = make_views(1, 64, 64)[0]
+    gen = _lib.scratch_generation()
+    loss, _ = trg.train_step_graphed(*mid, **kw)
+    assert _lib.scratch_generation() > gen                               # grown during the capture
+    assert len(trg._graphs) == 1 and np.isfinite(float(loss))            # views[0]'s graph is gone, the new one stays
+    step0 = trg.global_step
+    loss, _ = trg.train_step_graphed(*views[0], **kw)                    # recaptures (two eager steps + the captured one) against the grown buffers
+    assert len(trg._graphs) == 2 and trg.global_step == step0 + 3 and np.isfinite(float(loss))
+    for _ in range(2):                                                   # both replay side by side from now on
+        la, _ = trg.train_step_graphed(*mid, **kw)
+        lb, _ = trg.train_step_graphed(*views[0], **kw)
+        assert len(trg._graphs) == 2 and np.isfinite(float(la)) and np.isfinite(float(lb))
+    assert trg.global_step == step0 + 7
 
 
 @pytest.mark.gpu
@@ -689,6 +705,7 @@ def test_early_termination_leaves_every_gradient_bit_identical(fitted):
 
     def spy(ctx, g_sigma, g_rgbc):
         tl = getattr(g_sigma, '_cnerf_tile_live', None)
+        tl = None if tl is None else tl[0]
         seen.append((None if tl is None else float(tl.float().mean()), float((g_sigma == 0).float().mean())))
         return orig(ctx, g_sigma, g_rgbc)
     fld.FieldFunction.backward = staticmethod(spy)
@@ -722,3 +739,75 @@ def test_early_termination_leaves_every_gradient_bit_identical(fitted):
         assert torch.equal(a, b)
     assert all(bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0 for a in grads[True])
 
+
+
+@pytest.mark.gpu
+def test_early_termination_flags_are_dropped_when_sigma_has_a_second_consumer():
+    """the dead-tile flags ride on the gradient tensor the compositing backward hands to the field backward.  With a second
+    differentiable consumer of sigma (a sparsity term) autograd ACCUMULATES into that tensor — in place, attribute and all — and stale flags
+    would drop the second consumer's gradient for every 'dead' tile.  The hand-over carries address + version of both gradient tensors, so
+    the flags are ignored here: the gradients must agree with the run without early termination (loosely: the flush itself rounds rows whose
+    composite gradient is below half resolution to zero before the sum, which is below the tolerance; dropped tiles would not be)."""
+    from customnerf_amd import scene as sc, tcnn, field as fld
+    from customnerf_amd.nerf import render_ops
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.nerf.provider_utils import generate_rays
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    H = W = 64
+    V = 4
+    torch.manual_seed(0)
+    opt = sc.make_opt(fp16=True, num_steps=32, upsample_steps=32, iters=1000)
+    model = NeRFNetwork(opt).cuda()
+    c2w = torch.from_numpy(sc.poses(V)).cuda()
+    ro, rd = generate_rays(c2w, *sc.intrinsics(H, W), H, W, 1.0, 'nerfstudio')
+    ro, rd = ro.view(V, 1, H * W, 3), rd.view(V, 1, H * W, 3)
+    rgb, mask = sc.sphere_targets(ro.reshape(V, -1, 3), rd.reshape(V, -1, 3))
+    kw = dict(num_steps=32, upsample_steps=32, dt_gamma=0, max_steps=1024)
+    tr = ReconTrainer(model, opt, fp16=True)
+    for i in range(200):                                     # a fitted field: most tiles are dead
+        tr.train_step(ro[i % V], rd[i % V], rgb[i % V], mask[i % V], **kw)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    draws = dict(z=torch.rand(H * W, 32, device="cuda", generator=g), u=torch.rand(H * W, 32, device="cuda", generator=g))
+    captured, used = {}, []
+    orig_c, orig_b = render_ops.composite_run_indexed, fld.FieldFunction.backward
+
+    def tap(sig, rgbc, *a, **k):
+        captured['sigma'], captured['rgbc'] = sig, rgbc
+        return orig_c(sig, rgbc, *a, **k)
+
+    def spy(ctx, g_sigma, g_rgbc):
+        flags = getattr(g_sigma, '_cnerf_tile_live', None)
+        ok = flags is not None and g_sigma.data_ptr() == flags[1] and g_sigma._version == flags[2] and g_rgbc.data_ptr() == flags[3] and g_rgbc._version == flags[4]
+        used.append((flags is not None, ok, None if flags is None else float(flags[0].float().mean())))
+        return orig_b(ctx, g_sigma, g_rgbc)
+    render_ops.composite_run_indexed = tap
+    fld.FieldFunction.backward = staticmethod(spy)
+    try:
+        grads = {}
+        for second, et in ((True, True), (True, False), (False, True)):
+            model.opt.early_termination = et
+            for p in model.parameters():
+                p.grad.zero_()
+            model.train()
+            with torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(ro[1], rd[1], staged=False, perturb=True, force_all_rays=True, _draws=draws, **kw)
+                loss = tr.loss(out, rgb[1], mask[1])
+            if second:                                       # second consumers of sigma AND of rgbc: every row gets gradient, dead tiles included
+                loss = loss + 1e-3 * captured['sigma'].float().mean() + 1e-3 * captured['rgbc'].float().mean()
+            tr.scaler.backward(loss)
+            grads[(second, et)] = [p.grad.detach().clone() for p in model.parameters()]
+    finally:
+        render_ops.composite_run_indexed = orig_c
+        fld.FieldFunction.backward = orig_b
+        model.opt.early_termination = True
+    (had1, ok1, live1), (had2, _, _), (had3, ok3, live3) = used
+    assert not had2                                          # early termination off: no flags at all
+    assert had3 and ok3 and live3 < 0.9                      # single consumer: flags arrive intact and most tiles are dead
+    assert not ok1                                           # second consumer: whatever arrived no longer describes the tensors -> ignored
+    for a, b in zip(grads[(True, True)], grads[(True, False)]):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale, (float((a - b).abs().max()), scale)
+    # and the control: with stale flags the sparsity gradient of the dead tiles would be missing — it is a large part of these gradients
+    diff = max(float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(grads[(True, True)], grads[(False, True)]))
+    assert diff > 1e-2, diff
