@@ -112,6 +112,7 @@ SIGNATURES = {
     "cnerf_sd_add": [vp, vp, u64, vp, vp],
     "cnerf_sd_silu": [vp, u64, vp, vp],
     "cnerf_sd_concat": [vp, vp, u64, u32, u32, vp, vp],
+    "cnerf_sd_concat_gn": [vp, vp, u64, u32, u32, vp, vp, u32, u32, vp],
 }
 
 

@@ -210,41 +210,6 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd_fast(const float *__restr
     *out = gf_eval_level(in, table, lv.size[level], lv.resolution[level], lv.scale[level], gridtype);
 }
 
-// K samples per thread, same level-major XCD-sliced work list: a workgroup takes 256 K consecutive samples of one level, thread t the samples
-// t, t + 256, ... of the tile (every load instruction stays coalesced over the lanes), all K evaluations issued back to back so that 4 K row
-// loads are in flight per lane instead of 4.  Out-of-range samples are evaluated at a valid stand-in coordinate and masked at the store
-// (no divergent early exit between the K evaluations).  Bit-identical to k_grid_fwd_fast.
-template <int K>
-__global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd_fast_k(const float *__restrict__ inputs, const __half *__restrict__ grid, const GridLevels lv,
-                                                              __half *__restrict__ outputs, uint32_t B, uint32_t n_levels, uint32_t nb, uint32_t gridtype,
-                                                              int swizzle, uint32_t ostride) {
-    uint32_t level, pb;
-    if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
-    const uint32_t t0 = pb * (GE_BLOCK * K) + threadIdx.x;
-    if (t0 >= B) return;
-    float in[K][3];
-    bool ok[K];
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        ge_load_coords<3>(inputs, min(t0 + s * GE_BLOCK, B - 1), in[s]);
-        ok[s] = !(in[s][0] < 0 || in[s][0] > 1 || in[s][1] < 0 || in[s][1] > 1 || in[s][2] < 0 || in[s][2] > 1);
-#pragma unroll
-        for (int d = 0; d < 3; d++) in[s][d] = ok[s] ? in[s][d] : 0.5f;
-    }
-    const unsigned char *__restrict__ table = reinterpret_cast<const unsigned char *>(grid) + (size_t)lv.offset[level] * 4;
-    const uint32_t size = lv.size[level], res = lv.resolution[level];
-    const float scale = lv.scale[level];
-    uint32_t r[K];
-#pragma unroll
-    for (int s = 0; s < K; s++) r[s] = gf_eval_level(in[s], table, size, res, scale, gridtype);
-    uint32_t *out = reinterpret_cast<uint32_t *>(outputs) + (size_t)level * ostride;
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        const uint32_t b = t0 + s * GE_BLOCK;
-        if (b < B) out[b] = ok[s] ? r[s] : 0u;
-    }
-}
-
 // Sample-major traversal: a workgroup evaluates ALL levels of a tile of 256 SPT consecutive samples (level loop outside, the tile's samples
 // inside).  Every XCD touches every table, so this loses to the level-major list when the samples are spread over the volume (the 16 tables
 // do not fit an L2) and wins when neighbours of the list are neighbours in space — the importance samples of a fitted field, whose rows are
@@ -444,11 +409,8 @@ static bool ge_fast_eligible(const GridLevels &lv, uint32_t nl, uint32_t gridtyp
 // (cnerf_grid_encode_forward_ordered: the caller knows that neighbours of its list are neighbours in space)
 #define GE_TRAV_LEVEL 0u
 #define GE_TRAV_SAMPLE 1u
-#ifndef GE_FAST_K
-#define GE_FAST_K 1                                 // samples per thread of the level-major kernel (tuning builds: CNERF_GRID_K)
-#endif
 #ifndef GE_FAST_SPT
-#define GE_FAST_SPT 8                               // samples per thread of the sample-major kernel (tuning builds: CNERF_GRID_SPT)
+#define GE_FAST_SPT 16                              // samples per thread of the sample-major kernel (tuning builds: CNERF_GRID_SPT)
 #endif
 
 template <typename T, int D>
@@ -465,18 +427,8 @@ static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *
             if (traversal == GE_TRAV_SAMPLE) {
                 static const int spt = cn_tune_env("CNERF_GRID_SPT", GE_FAST_SPT);
 #define GE_SM(SPT_) case SPT_: hipLaunchKernelGGL(k_grid_fwd_fast_sm<SPT_>, dim3(cn_div_up(B, GE_BLOCK * SPT_)), block, 0, st, inputs, emb, lvb, out, B, nl, gridtype, ostride); break;
-                switch (spt) { GE_SM(4) GE_SM(16) default: GE_SM(8) }
+                switch (spt) { GE_SM(4) GE_SM(8) GE_SM(32) default: GE_SM(16) }
 #undef GE_SM
-                return cn_launch_status();
-            }
-            static const int kk = cn_tune_env("CNERF_GRID_K", GE_FAST_K);
-            if (kk > 1 && sw == 2) {
-                const uint32_t k = kk >= 8 ? 8 : (kk >= 4 ? 4 : 2);
-                nb = cn_div_up(B, GE_BLOCK * k);
-                const dim3 gk(CN_NXCD * ge_balance(lvb, nl, nb, D, gridtype, ac != 0, ge_dense_weight()));
-                if (k == 8) hipLaunchKernelGGL(k_grid_fwd_fast_k<8>, gk, block, 0, st, inputs, emb, lvb, out, B, nl, nb, gridtype, sw, ostride);
-                else if (k == 4) hipLaunchKernelGGL(k_grid_fwd_fast_k<4>, gk, block, 0, st, inputs, emb, lvb, out, B, nl, nb, gridtype, sw, ostride);
-                else hipLaunchKernelGGL(k_grid_fwd_fast_k<2>, gk, block, 0, st, inputs, emb, lvb, out, B, nl, nb, gridtype, sw, ostride);
                 return cn_launch_status();
             }
         }

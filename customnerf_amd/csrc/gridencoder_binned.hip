@@ -678,9 +678,6 @@ __device__ __forceinline__ void b2_add_record(long long *acc, const uint2 r) {
                                                   // measured: 4 -> 372 / 195 us (random init / fitted field), 8 -> 368 / 180, 16 -> 461 / 223 (over the 64-VGPR budget of two
                                                   // resident workgroups; capped to it, 16 on the two coarsest tables only: 375 / 179 — no better than 8 everywhere)
 #endif
-#ifndef B3_WALK_MODE
-#define B3_WALK_MODE 0                             // 1: strided run walk on the dense levels (see b3_walk_runs)
-#endif
 struct B3Pending { uint32_t key; unsigned long long a0, b0, a1, b1; };   // key = (local entry | pair shift << 12): both entries of the record; sums per entry and channel
 __device__ __forceinline__ void b3_flush_pending(long long *acc, const B3Pending &c) {
     if (c.key == 0xFFFFFFFFu) return;
@@ -1173,8 +1170,7 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
 // become successive atomics of one lane instead of same-address lanes of one instruction.
 template <int W>
 __device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint32_t *tiles, const uint32_t *__restrict__ rt, const uint32_t *__restrict__ pt,
-                                             const uint2 *__restrict__ lvl_slab, uint32_t nb, uint32_t pb_first, uint32_t begin, uint32_t end,
-                                             uint32_t walk_mode = 0) {
+                                             const uint2 *__restrict__ lvl_slab, uint32_t nb, uint32_t pb_first, uint32_t begin, uint32_t end) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *s_pre = tiles, *s_base = tiles + 65;                                  // [65] exclusive prefix of the clipped run lengths (+ total), [64] first record of each
     for (uint32_t pb0 = pb_first; pb0 < nb; pb0 += 64) {
@@ -1197,28 +1193,19 @@ __device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint
         }
         __syncthreads();
         const uint32_t total = s_pre[64], last = s_c[1];
-        // walk_mode 1 (strided): a dense level's run is a sequence of 64-record stretches — the 64 samples of one ray for one (y, z) row, then the
-        // next row, four rows per ray (wave-aggregated tickets).  With W CONSECUTIVE records per lane, neighbouring lanes hold neighbouring
-        // samples of a ray: the same cell on a coarse level, i.e. same-address LDS atomics inside one instruction.  Strided, lane l of wave
-        // (g, q) takes sample l of row q of the W rays g W .. g W + W - 1: the lanes of an instruction are 64 different depths of one ray
-        // (different cells), and a lane's W records are the same depth of W neighbouring rays (the same cell on a coarse level: combined
-        // in registers).  Any assignment is correct — the sums are integers — only the conflict pattern changes.
-        const uint32_t tq = walk_mode ? ((threadIdx.x >> 8) * (256u * W) + ((threadIdx.x >> 6) & 3u) * 64u + (threadIdx.x & 63u)) : threadIdx.x * W;
-        const uint32_t ustep = walk_mode ? 256u : 1u;
-        for (uint32_t c0 = 0; c0 < total; c0 += 1024 * W) {
-            const uint32_t f0 = c0 + tq;
-            if (!walk_mode && f0 >= total) break;
+        // (Round 6, measured and dropped: a STRIDED assignment — lane l of a wave takes sample l of one (y, z) row of W neighbouring rays, so that
+        // the lanes of an instruction are 64 different depths and a lane's W records share a cell across rays — 369 -> 389 us at random init and
+        // 194 -> 383 us on a fitted field: profiles/r06_gather_scatter_ab.txt.  Consecutive records per lane it stays.)
+        for (uint32_t f0 = threadIdx.x * W; f0 < total; f0 += 1024 * W) {
             uint32_t j = 0;                                                         // largest j with s_pre[j] <= f0
-            if (f0 < total) {
 #pragma unroll
-                for (uint32_t step = 32; step; step >>= 1)
-                    if (s_pre[j + step] <= f0) j += step;
-            }
+            for (uint32_t step = 32; step; step >>= 1)
+                if (s_pre[j + step] <= f0) j += step;
             uint32_t idx[W];
             bool ok4[W];
 #pragma unroll
             for (int u = 0; u < W; u++) {
-                const uint32_t f = f0 + u * ustep;
+                const uint32_t f = f0 + u;
                 ok4[u] = f < total;
                 while (ok4[u] && f >= s_pre[j + 1]) j++;                            // (empty runs are stepped over; j stays < 64 while f < total)
                 idx[u] = ok4[u] ? s_base[j] + (f - s_pre[j]) : s_base[0];
@@ -1246,7 +1233,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
                                                      const uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin3Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin,
-                                                     uint32_t n_slots, uint32_t seg_records, uint32_t only, uint32_t walk_mode) {
+                                                     uint32_t n_slots, uint32_t seg_records, uint32_t only) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [2][BN_CHUNK] accumulators, scratch words, the tile list (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t *s_w = reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
@@ -1326,7 +1313,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
             b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, max(begin, treg) - treg, end - treg);
         }
     } else {
-        b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end, walk_mode);
+        b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end);
     }
     __syncthreads();
     b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot]);
@@ -1620,7 +1607,7 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
                        (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
-                       (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0), (uint32_t)b2_env("CNERF_B3_WALK_MODE", B3_WALK_MODE));
+                       (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0));
     cn_stage(2, st);
     hipLaunchKernelGGL(k_bin3_reduce_split, dim3(p2.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
                        gemb, nl);

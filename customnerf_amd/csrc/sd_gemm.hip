@@ -763,9 +763,27 @@ __global__ void __launch_bounds__(SGB_THREADS) k_sd_gemm_big(const CnerfSdGemm g
 }
 #endif  // CNERF_TUNING
 
-// split-K tail: sum the partials, apply the epilogue
+// split-K tail: sum the partials, apply the epilogue.
+// Round 6: a GroupNorm-statistics request (g.gn_sums) is served here too — rounds 2-5 left it to a separate k_gn_stats launch whenever the
+// producing GEMM ran split-K, i.e. for almost every norm of the 8^2 / 16^2 / 32^2 UNet levels (59 launches of ~8 us per edit step).  A thread
+// owns 4 consecutive columns of a row: at most two groups (N / groups >= 4); its two (sum, sum of squares) pairs of the ROUNDED outputs — what the
+// consumer reads — go to a per-workgroup LDS table [images][groups][2] in 64-bit fixed point (sd_gn_fix.h), the table to the global sums by one
+// atomic per touched entry.  SG_EPI_GN_MAX entries (images x groups): the host keeps larger requests off the split-K path.
+#define SG_EPI_GN_MAX 512
 __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGemm g, const float *__restrict__ partial, uint32_t splits) {
     const size_t total = (size_t)g.M * g.N;
+    __shared__ long long gn_tab[SG_EPI_GN_MAX][2];
+    const bool do_gn = g.gn_sums != nullptr;
+    const uint32_t gn_cg = do_gn ? g.N / g.gn_groups : 1u, gn_entries = do_gn ? (g.M / g.gn_rows) * g.gn_groups : 0u;
+    if (do_gn) {
+        for (uint32_t i = threadIdx.x; i < gn_entries * 2; i += 256) (&gn_tab[0][0])[i] = 0;
+        __syncthreads();
+    }
+    auto gn_flush = [&]() {
+        __syncthreads();
+        long long *dst = reinterpret_cast<long long *>(g.gn_sums);
+        for (uint32_t i = threadIdx.x; i < gn_entries * 2; i += 256) gn_add_fixed(dst + i, (&gn_tab[0][0])[i]);
+    };
     if (g.act == 4) {                                       // GEGLU pairs: one thread per output element
         const size_t half = total / 2;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
@@ -811,6 +829,18 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
                     for (int e = 0; e < 4; e++) v[e] += (float)rp[e];
                 }
             }
+            if (do_gn) {
+                const uint32_t img = m / g.gn_rows, g_lo = n / gn_cg, split_c = (g_lo + 1) * gn_cg - n;     // columns [0, split_c) of the four belong to g_lo
+                float s0 = 0.0f, q0 = 0.0f, s1 = 0.0f, q1 = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float xf = (float)(_Float16)v[e];                         // what the consumer will read
+                    if ((uint32_t)e < split_c) { s0 += xf; q0 += xf * xf; } else { s1 += xf; q1 += xf * xf; }
+                }
+                long long *t0 = gn_tab[img * g.gn_groups + g_lo];
+                gn_add(t0, s0); gn_add(t0 + 1, q0);
+                if (split_c < 4) { gn_add(t0 + 2, s1); gn_add(t0 + 3, q1); }        // (the next group of the same image: n + 3 < N)
+            }
             if (g.C) {
                 typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));
                 sd_h4 o;
@@ -828,6 +858,7 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
                 for (int e = 0; e < 4; e++) g.C32[(size_t)m * g.ldc + n + e] = v[e];
             }
         }
+        if (do_gn) gn_flush();
         return;
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -838,9 +869,15 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
         if (g.bias_rows) v += g.bias_rows[(size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) + n];
         v = sg_act(v, g.act);
         if (g.residual) v += (float)reinterpret_cast<const _Float16 *>(g.residual)[(size_t)m * g.ldr + n];
+        if (do_gn) {
+            const float xf = (float)(_Float16)v;
+            long long *t0 = gn_tab[(m / g.gn_rows) * g.gn_groups + n / gn_cg];
+            gn_add(t0, xf); gn_add(t0 + 1, xf * xf);
+        }
         if (g.C) reinterpret_cast<_Float16 *>(g.C)[(size_t)m * g.ldc + n] = (_Float16)v;
         if (g.C32) g.C32[(size_t)m * g.ldc + n] = v;
     }
+    if (do_gn) gn_flush();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1019,6 +1056,10 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
     uint32_t kps = plan.kps;
     uint32_t splits = plan.splits;
     if (splits > 1 && (!workspace || workspace_bytes < (uint64_t)splits * g->M * g->N * sizeof(float))) {
+        splits = 1;
+        kps = cn_div_up(g->K, SG_BK);
+    }
+    if (splits > 1 && g->gn_sums && (uint64_t)(g->M / g->gn_rows) * g->gn_groups > SG_EPI_GN_MAX) {      // the split-K tail's statistics table (images x groups)
         splits = 1;
         kps = cn_div_up(g->K, SG_BK);
     }

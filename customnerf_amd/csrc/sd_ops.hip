@@ -326,15 +326,42 @@ __global__ void __launch_bounds__(256) k_ew(const _Float16 *__restrict__ a, cons
         }
 }
 
+// gn_sums != NULL: also the GroupNorm statistics of the OUTPUT (the UNet's up blocks normalise a channel concat first thing: round 6 — their
+// twelve k_gn_stats launches per forward ride on this copy).  A thread owns 8 consecutive output channels = at most two groups (host: >= 8
+// channels per group); per-workgroup LDS table [images x groups][2] in 64-bit fixed point (sd_gn_fix.h), one global atomic per touched entry.
+#define SO_CONCAT_GN_MAX 512
 __global__ void __launch_bounds__(256) k_concat(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b, uint64_t rows, uint32_t C1, uint32_t C2,
-                                                _Float16 *__restrict__ y) {
+                                                _Float16 *__restrict__ y, long long *__restrict__ gn_sums, uint32_t gn_groups, uint32_t gn_rows) {
+    __shared__ long long gn_tab[SO_CONCAT_GN_MAX][2];
+    const bool do_gn = gn_sums != nullptr;
     const uint32_t n1 = C1 / 8, nc = (C1 + C2) / 8;
     const uint32_t total = (uint32_t)(rows * nc);
+    const uint32_t cg = do_gn ? (C1 + C2) / gn_groups : 1u, entries = do_gn ? (uint32_t)(rows / gn_rows) * gn_groups : 0u;
+    if (do_gn) {
+        for (uint32_t i = threadIdx.x; i < entries * 2; i += 256) (&gn_tab[0][0])[i] = 0;
+        __syncthreads();
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t row = i / nc;
         const uint32_t col = i - row * nc;
         const so_h8 v = col < n1 ? so_ld8(a + (size_t)row * C1 + col * 8) : so_ld8(b + (size_t)row * C2 + (col - n1) * 8);
         so_st8(y + (size_t)i * 8, v);
+        if (do_gn) {
+            const uint32_t n = col * 8, g_lo = n / cg, split_c = (g_lo + 1) * cg - n;      // channels [0, split_c) of the eight belong to g_lo
+            float s0 = 0.0f, q0 = 0.0f, s1 = 0.0f, q1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xf = (float)v[e];
+                if ((uint32_t)e < split_c) { s0 += xf; q0 += xf * xf; } else { s1 += xf; q1 += xf * xf; }
+            }
+            long long *t0 = gn_tab[(row / gn_rows) * gn_groups + g_lo];
+            gn_add(t0, s0); gn_add(t0 + 1, q0);
+            if (split_c < 8) { gn_add(t0 + 2, s1); gn_add(t0 + 3, q1); }
+        }
+    }
+    if (do_gn) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < entries * 2; i += 256) gn_add_fixed(gn_sums + i, (&gn_tab[0][0])[i]);
     }
 }
 
@@ -739,13 +766,23 @@ int cnerf_sd_silu(const void *x, uint64_t n, void *y, void *stream) {
     hipLaunchKernelGGL((k_ew<1>), dim3(so_blocks(n / 8, 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)x, (const _Float16 *)nullptr, n / 8, n, (_Float16 *)y);
     return cn_launch_status();
 }
-int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream) {
+int cnerf_sd_concat_gn(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, int64_t *gn_sums, uint32_t gn_groups,
+                       uint32_t gn_rows, void *stream) {
     if ((C1 & 7) || (C2 & 7) || C1 + C2 == 0 || rows * ((C1 + C2) / 8) >= (1ull << 32)) return CNERF_EINVAL;
+    if (gn_sums && (gn_groups == 0 || (C1 + C2) % gn_groups || (C1 + C2) / gn_groups < 8 || gn_rows == 0 || rows % gn_rows ||
+                    (rows / gn_rows) * gn_groups > SO_CONCAT_GN_MAX))
+        return CNERF_EINVAL;
     if (rows == 0) return CNERF_OK;
     if (!a || !b || !y) return CNERF_ENULL;
-    hipLaunchKernelGGL(k_concat, dim3(so_blocks((size_t)rows * ((C1 + C2) / 8), 256, 8192)), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b,
-                       rows, C1, C2, (_Float16 *)y);
+    // (statistics: fewer, fatter workgroups — every workgroup flushes its table with one global atomic per touched entry)
+    const uint32_t blocks = so_blocks((size_t)rows * ((C1 + C2) / 8), 256, gn_sums ? 512 : 8192);
+    hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b, rows, C1, C2, (_Float16 *)y,
+                       reinterpret_cast<long long *>(gn_sums), gn_groups, gn_rows);
     return cn_launch_status();
+}
+
+int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream) {
+    return cnerf_sd_concat_gn(a, b, rows, C1, C2, y, nullptr, 0, 0, stream);
 }
 
 }  // extern "C"

@@ -37,7 +37,7 @@ def _workspace(nbytes, device):
 
 
 def _launch(d, device):
-    """-> True when the library ran the problem split-K (then desc.gn_sums was NOT filled)"""
+    """-> True when the library ran the problem split-K (round 6: its tail kernel fills desc.gn_sums like the one-launch epilogue does)"""
     need = ctypes.c_uint64(0)
     check(lib.cnerf_sd_gemm_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "sd_gemm_workspace_bytes")
     ws = _workspace(need.value, device) if need.value else None
@@ -89,9 +89,9 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
     d = _desc(x2, w, None if out32 else out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=r2,
               ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
     want = _attach_gn(d, gn, M, N)
-    split = _launch(d, x.device)
+    _launch(d, x.device)
     y = out.reshape(*x.shape[:-1], No)
-    return (y, want and not split) if gn is not None else y
+    return (y, want) if gn is not None else y
 
 
 def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bias_rows=None, residual=None, act=ACT_NONE, gn=None):
@@ -116,8 +116,8 @@ def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bi
         d.ld_bias_rows = bias_rows.stride(0)
     d.stride, d.pad_t, d.pad_l, d.ups, d.tstride = stride, pad, pad, ups, tstride
     want = _attach_gn(d, gn, M, Cout)
-    split = _launch(d, x.device)
-    return (y, want and not split) if gn is not None else y
+    _launch(d, x.device)
+    return (y, want) if gn is not None else y
 
 
 GN_FRAC_BITS = 20        # include/customnerf_sd.h CNERF_SD_GN_FRAC_BITS: GroupNorm statistics are int64 fixed point (exact, order-independent sums)
@@ -209,11 +209,19 @@ def silu(x):
     return y
 
 
-def concat_channels(a, b):
+def concat_channels(a, b, gn=None):
+    """channel concat of NHWC half tensors.  gn = (sums [B, G, 2] int64 pre-zeroed, groups, rows_per_image): also accumulate the GroupNorm
+    statistics of the result (returns (y, ok) then; ok False = request not admissible, nothing written to sums)."""
     assert a.shape[:-1] == b.shape[:-1] and a.is_contiguous() and b.is_contiguous()
     C1, C2 = a.shape[-1], b.shape[-1]
     y = torch.empty(*a.shape[:-1], C1 + C2, dtype=torch.float16, device=a.device)
-    check(lib.cnerf_sd_concat(ptr(a), ptr(b), a.numel() // C1, C1, C2, ptr(y), stream()), "sd_concat")
+    rows = a.numel() // C1
+    if gn is not None:
+        sums, groups, rpi = gn
+        ok = (C1 + C2) % groups == 0 and (C1 + C2) // groups >= 8 and rows % rpi == 0 and (rows // rpi) * groups <= 512
+        check(lib.cnerf_sd_concat_gn(ptr(a), ptr(b), rows, C1, C2, ptr(y), ptr(sums) if ok else None, groups if ok else 0, rpi if ok else 0, stream()), "sd_concat_gn")
+        return y, ok
+    check(lib.cnerf_sd_concat(ptr(a), ptr(b), rows, C1, C2, ptr(y), stream()), "sd_concat")
     return y
 
 

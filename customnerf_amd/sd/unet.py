@@ -193,7 +193,7 @@ class UNet:
         temb = ops.linear(ops.linear(temb, self.t1w, bias=self.t1b, act=ops.ACT_SILU), self.t2w, bias=self.t2b)
         temb_act = ops.silu(temb)                                                      # every resnet applies SiLU before time_emb_proj
         tp = ops.linear(temb_act, self.tpw, bias=self.tpb, out32=True)                 # [B, sum Cout] float32
-        pool = ops.SumsPool(3 * len(self._resnets) + 34, x.shape[0], G, x.device)        # one zero-fill for every GroupNorm of the pass (a few slices go unused)
+        pool = ops.SumsPool(4 * len(self._resnets) + 34, x.shape[0], G, x.device)        # one zero-fill for every GroupNorm of the pass (a few slices go unused)
         tbs = {id(r): tp[:, r.t_off:r.t_off + r.t_n] for r in self._resnets}          # per-block [B, Cout] strided views (bias_rows operand)
         hs0 = pool.take()
         h, ok = ops.conv2d(x, self.ciw, self.cib, 3, gn=(hs0, G, x.shape[1] * x.shape[2]))
@@ -216,8 +216,11 @@ class UNet:
         n_up = len(self.up)
         for bi, (res, att, us) in enumerate(self.up):
             for j, r in enumerate(res):
-                # the block input is a channel concat: its norm computes its own statistics; the output feeds a norm only through attention
-                h, hs = r(ops.concat_channels(h, skips.pop()), tbs[id(r)], G, eps, pool, out_gn=att is not None)
+                # the block input is a channel concat: the concat kernel accumulates its norm's statistics (round 6; a k_gn_stats launch before);
+                # the output feeds a norm only through attention
+                sc_ = pool.take()
+                hc, okc = ops.concat_channels(h, skips.pop(), gn=(sc_, G, h.shape[1] * h.shape[2]))
+                h, hs = r(hc, tbs[id(r)], G, eps, pool, x_sums=(sc_, okc), out_gn=att is not None)
                 if att is not None:
                     last = bi == n_up - 1 and j == len(res) - 1                     # -> conv_norm_out
                     h, hs = att[j](h, ctx, G, pool, x_sums=hs, out_gn=last, kv=kvs.get(id(att[j])))

@@ -61,7 +61,8 @@ typedef struct CnerfSdGemm {
     /* optional GroupNorm statistics of the OUTPUT (the norm that consumes C next): gn_sums [M / gn_rows][gn_groups][2] int64 fixed point
      * (CNERF_SD_GN_FRAC_BITS fractional bits), pre-zeroed, receives sum and sum of squares of the half-rounded outputs per (image,
      * channel group); N % gn_groups == 0, gn_rows >= 64.
-     * Ignored (left untouched) when the library runs this problem split-K: cnerf_sd_gemm_workspace_bytes() != 0 tells. */
+     * Served on every schedule (round 6: the split-K tail kernel accumulates them; a request of more than 512 (image, group) pairs keeps
+     * the problem off the split-K path). */
     int64_t *gn_sums;
     uint32_t gn_groups, gn_rows;
 } CnerfSdGemm;
@@ -160,6 +161,11 @@ int cnerf_sd_add(const void *a, const void *b, uint64_t n, void *y, void *stream
 int cnerf_sd_silu(const void *x, uint64_t n, void *y, void *stream);
 /* channel concat of NHWC half tensors: y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r] */
 int cnerf_sd_concat(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, void *stream);
+/* Same, also accumulating the GroupNorm statistics of y into gn_sums [rows / gn_rows][gn_groups][2] (int64 fixed point, pre-zeroed: the
+ * gn_sums contract of CnerfSdGemm) — the UNet's up blocks normalise the concat first thing.  gn_sums NULL: plain concat.
+ * (C1 + C2) / gn_groups >= 8, rows % gn_rows == 0, (rows / gn_rows) * gn_groups <= 512 — else CNERF_EINVAL. */
+int cnerf_sd_concat_gn(const void *a, const void *b, uint64_t rows, uint32_t C1, uint32_t C2, void *y, int64_t *gn_sums, uint32_t gn_groups,
+                       uint32_t gn_rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Glue of one editing step as single launches (round 5; each replaces a chain of framework element-wise ops).

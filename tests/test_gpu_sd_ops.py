@@ -315,9 +315,11 @@ def test_image_front_end_and_sds_tail():
 
 
 @pytest.mark.parametrize("B,C,H,Co", [(2, 320, 64, 320), (1, 128, 96, 128), (2, 64, 8, 128), (2, 320, 16, 640),
-                                      (1, 128, 256, 128), (2, 256, 128, 256)])                       # the VAE's large-M shapes
+                                      (1, 128, 256, 128), (2, 256, 128, 256),                        # the VAE's large-M shapes
+                                      (2, 640, 8, 1280), (2, 1280, 16, 1280), (2, 640, 32, 640), (8, 1280, 8, 1280), (2, 2560, 8, 1280)])   # split-K schedules (UNet 8^2 / 16^2 / 32^2)
 def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
-    """the producing conv accumulates the next GroupNorm's statistics in its epilogue (gn=): same normalised output as the two-pass norm"""
+    """the producing conv accumulates the next GroupNorm's statistics in its epilogue (gn=): same normalised output as the two-pass norm.
+    Round 6: also when the library runs the problem split-K (the tail kernel accumulates them) — the request is always served."""
     from customnerf_amd.sd import ops, pack
     g = torch.Generator().manual_seed(C + H)
     x = torch.randn(B, H, H, C, generator=g).half().cuda()
@@ -329,9 +331,7 @@ def test_gemm_fused_groupnorm_statistics(B, C, H, Co):
     y_ref = ops.conv2d(x, w, b, 3)
     assert torch.equal(y, y_ref)
     n_ref, s_ref = ops.groupnorm(y_ref, gamma, beta, 32, 1e-5, True)
-    if not ok:                                           # split-K schedule: the library leaves the statistics to the norm
-        assert torch.all(sums == 0)
-        return
+    assert ok
     close(ops.gn_sums_to_float(sums).float(), ops.gn_sums_to_float(s_ref).float(), 2e-4, 1e-2)
     n_fused, _ = ops.groupnorm(y, gamma, beta, 32, 1e-5, True, sums=sums)
     close(n_fused, n_ref, 2e-3, 2e-3)
@@ -540,3 +540,31 @@ def test_split_k_gemms_are_exact_under_repetition():
     again = [ops.linear(xg[i % 6], wc, bias=bc).clone() for i in range(60)]
     for i in range(60):
         assert torch.equal(first[i], again[i]) and torch.equal(first[i], first[i % 6]), i
+
+
+@pytest.mark.parametrize("B,H,C1,C2", [(2, 8, 1280, 1280), (2, 16, 1280, 640), (2, 32, 640, 320), (2, 64, 320, 320), (8, 8, 1280, 1280), (1, 8, 64, 64)])
+def test_concat_accumulates_groupnorm_statistics(B, H, C1, C2):
+    """round 6: the UNet's up blocks normalise a channel concat first thing — cnerf_sd_concat_gn accumulates that norm's statistics while it copies
+    (a k_gn_stats launch per up block before): same copy, same fixed-point statistics as the stand-alone pass up to the rounding of the partial sums,
+    bit-identical from run to run."""
+    from customnerf_amd.sd import ops
+    g = torch.Generator().manual_seed(C1 + H)
+    a = (torch.randn(B, H, H, C1, generator=g) * 1.5 + 0.3).half().cuda()
+    b = (torch.randn(B, H, H, C2, generator=g) * 0.7 - 0.2).half().cuda()
+    y_ref = ops.concat_channels(a, b)
+    assert torch.equal(y_ref, torch.cat([a, b], -1))
+    sums = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+    y, ok = ops.concat_channels(a, b, gn=(sums, 32, H * H))
+    assert torch.equal(y, y_ref)
+    if (C1 + C2) // 32 < 8:                               # fewer than 8 channels per group: not admissible, nothing accumulated
+        assert not ok and torch.all(sums == 0)
+        return
+    assert ok
+    gamma, beta = (torch.rand(C1 + C2, generator=g) + 0.5).cuda(), torch.randn(C1 + C2, generator=g).cuda()
+    n_ref, s_ref = ops.groupnorm(y_ref, gamma, beta, 32, 1e-5, True)
+    close(ops.gn_sums_to_float(sums).float(), ops.gn_sums_to_float(s_ref).float(), 2e-4, 1e-2)
+    n_fused, _ = ops.groupnorm(y, gamma, beta, 32, 1e-5, True, sums=sums)
+    close(n_fused, n_ref, 2e-3, 2e-3)
+    sums2 = torch.zeros_like(sums)
+    ops.concat_channels(a, b, gn=(sums2, 32, H * H))
+    assert torch.equal(sums, sums2)
