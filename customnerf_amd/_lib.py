@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcustomnerf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     # ---- include/customnerf_sd.h (score-distillation primitives)
     "cnerf_sd_gemm": [vp, vp, u64, vp],
     "cnerf_sd_gemm_workspace_bytes": [vp, vp],
+    "cnerf_sd_gemm_serves_ln": [vp, vp],
     "cnerf_sd_groupnorm_forward": [vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, i32, vp, vp],
     "cnerf_sd_groupnorm_backward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, vp, vp],
     "cnerf_sd_groupnorm_backward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, i32, vp, vp, i32, vp, vp, vp],
@@ -124,7 +125,8 @@ class SdGemmDesc(C.Structure):
                 ("sa_o", u64), ("sa_i", u64), ("sb_o", u64), ("sb_i", u64), ("sc_o", u64), ("sc_i", u64),
                 ("mode", C.c_int32), ("Cin", u32), ("H_in", u32), ("W_in", u32), ("H_out", u32), ("W_out", u32),
                 ("KH", u32), ("KW", u32), ("stride", u32), ("pad_t", u32), ("pad_l", u32), ("ups", u32), ("tstride", u32),
-                ("gn_sums", vp), ("gn_groups", u32), ("gn_rows", u32)]
+                ("gn_sums", vp), ("gn_groups", u32), ("gn_rows", u32),
+                ("ln_out", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32)]
 
 ADAM_MAX_JOBS = 8
 

@@ -880,7 +880,81 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
     if (do_gn) gn_flush();
 }
 
+// split-K tail with the LayerNorm of the output rows (round 6): one wave per row — the transformer blocks normalise the result of proj_in /
+// attn1.to_out / attn2.to_out right away, a k_layernorm launch of ~5 us each (48 per UNet forward) that reads back what this kernel just wrote.
+// Lane l owns the 8-column chunks l, l + 64, ...; the element arithmetic is the 4-column path's above (same partial order, alpha, bias, per-image
+// bias, activation, residual), the LayerNorm is k_layernorm's (sd_ops.hip) on the half-rounded values: both outputs are bit-identical to the two launches.
+template <int CPL>
+__global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue_ln(const CnerfSdGemm g, const float *__restrict__ partial, uint32_t splits) {
+    const uint32_t lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= g.M) return;
+    const uint32_t nchunks = g.N / 8;
+    const size_t total = (size_t)g.M * g.N;
+    float v[CPL][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const uint32_t col = lane + 64 * c, n = col * 8;
+        if (col < nchunks) {
+            sd_f4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float *pp = partial + (size_t)m * g.N + n;
+            for (uint32_t s = 0; s < splits; s++) {
+                a0 += *reinterpret_cast<const sd_f4 *>(pp + (size_t)s * total);
+                a1 += *reinterpret_cast<const sd_f4 *>(pp + (size_t)s * total + 4);
+            }
+            float x[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = x[e] * g.alpha + (g.bias ? g.bias[n + e] : 0.0f);
+            if (g.bias_rows) {
+                const float *br = g.bias_rows + (size_t)(m / g.rows_per_bias_row) * (g.ld_bias_rows ? g.ld_bias_rows : g.N) + n;
+#pragma unroll
+                for (int e = 0; e < 8; e++) x[e] += br[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = sg_act(x[e], g.act);
+            if (g.residual) {
+                const _Float16 *rp = reinterpret_cast<const _Float16 *>(g.residual) + (size_t)m * g.ldr + n;
+#pragma unroll
+                for (int e = 0; e < 8; e++) x[e] += (float)rp[e];
+            }
+            sd_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { o[e] = (_Float16)x[e]; v[c][e] = (float)o[e]; sum += v[c][e]; }
+            *reinterpret_cast<sd_h8 *>(reinterpret_cast<_Float16 *>(g.C) + (size_t)m * g.ldc + n) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[c][e] = 0.0f;
+        }
+    }
+    const float mean = cn_wave_sum(sum) / (float)g.N;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        if (lane + 64 * c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = v[c][e] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(cn_wave_sum(sq) / (float)g.N + g.ln_eps);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const uint32_t col = lane + 64 * c;
+        if (col < nchunks) {
+            sd_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (_Float16)((v[c][e] - mean) * rstd * g.ln_gamma[col * 8 + e] + g.ln_beta[col * 8 + e]);
+            *reinterpret_cast<sd_h8 *>(reinterpret_cast<_Float16 *>(g.ln_out) + (size_t)m * g.N + col * 8) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
+// the LayerNorm request is served by the split-K tail only: dense half output rows of at most 2048 columns, 16-byte aligned chunks
+static bool sg_ln_admissible(const CnerfSdGemm *g) {
+    return g->ln_out && g->ln_gamma && g->ln_beta && g->C && !g->C32 && !g->gn_sums && g->act != 4 && (g->N & 7) == 0 && g->N <= 2048 && (g->ldc & 7) == 0 &&
+           (!g->residual || (g->ldr & 7) == 0) && g->batch_outer * g->batch_inner == 1 &&
+           ((((uintptr_t)g->C) | ((uintptr_t)g->ln_out) | ((uintptr_t)g->residual)) & 15) == 0;
+}
+
 static int sg_check(const CnerfSdGemm *g) {
     if (!g) return CNERF_ENULL;
     if (!g->A || !g->B || (!g->C && !g->C32)) return CNERF_ENULL;
@@ -1076,12 +1150,30 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
     if (amode == 0) sg_launch_nt<0>(g, nt, split, grid, st, partial, kps);
     else if (amode == 1) sg_launch_nt<1>(g, nt, split, grid, st, partial, kps);
     else sg_launch_nt<2>(g, nt, split, grid, st, partial, kps);
-    if (split) {
+    if (split && sg_ln_admissible(g)) {
+        const dim3 eg(cn_div_up(g->M, 4));
+        const float *pw = reinterpret_cast<const float *>(workspace);
+        const uint32_t cpl = cn_div_up(g->N / 8, 64);
+        if (cpl == 1) hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue_ln<1>, eg, dim3(256), 0, st, *g, pw, splits);
+        else if (cpl == 2) hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue_ln<2>, eg, dim3(256), 0, st, *g, pw, splits);
+        else hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue_ln<4>, eg, dim3(256), 0, st, *g, pw, splits);
+    } else if (split) {
         const size_t total = (size_t)g->M * g->N;
         const uint32_t eb = (uint32_t)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue, dim3(eb), dim3(256), 0, st, *g, reinterpret_cast<const float *>(workspace), splits);
     }
     return cn_launch_status();
+}
+
+int cnerf_sd_gemm_serves_ln(const CnerfSdGemm *g, int *yes) {
+    if (!yes) return CNERF_ENULL;
+    *yes = 0;
+    int rc = sg_check(g);
+    if (rc) return rc;
+    uint32_t splits = sg_plan(g).splits;
+    if (splits > 1 && g->gn_sums && (uint64_t)(g->M / g->gn_rows) * g->gn_groups > SG_EPI_GN_MAX) splits = 1;
+    *yes = (splits > 1 && sg_ln_admissible(g)) ? 1 : 0;
+    return CNERF_OK;
 }
 
 }  // extern "C"

@@ -73,9 +73,11 @@ def _desc(A, B, C, M, N, K, lda, ldb, ldc, bias=None, bias_rows=None, rows_per_b
     return d
 
 
-def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, out32=False, gn=None):
+def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, out32=False, gn=None, ln=None):
     """x [..., K] half, w [N, K] half -> [..., N] half (float32 when out32).
-    gn = (sums, groups, rows_per_image): also accumulate the GroupNorm statistics of the output into `sums`; returns (y, ok) then."""
+    gn = (sums, groups, rows_per_image): also accumulate the GroupNorm statistics of the output into `sums`; returns (y, ok) then.
+    ln = (gamma, beta[, eps]): also return LayerNorm(y) over the last dimension -> (y, n).  When the library runs the problem split-K its tail
+    kernel writes n while it finishes y (one wave per row); otherwise n comes from a layernorm() launch — the same values either way."""
     require_cuda(x, w)
     K = x.shape[-1]
     N = w.shape[0]
@@ -89,8 +91,21 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
     d = _desc(x2, w, None if out32 else out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=r2,
               ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
     want = _attach_gn(d, gn, M, N)
+    n_out = None
+    if ln is not None and gn is None and not out32 and act != ACT_GEGLU:
+        gamma, beta = ln[0], ln[1]
+        n_out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+        d.ln_out, d.ln_gamma, d.ln_beta, d.ln_eps = ptr(n_out), ptr(gamma), ptr(beta), float(ln[2]) if len(ln) > 2 else 1e-5
+        yes = ctypes.c_int(0)
+        check(lib.cnerf_sd_gemm_serves_ln(ctypes.byref(d), ctypes.byref(yes)), "sd_gemm_serves_ln")
+        if not yes.value:
+            d.ln_out = None
+            n_out = None
     _launch(d, x.device)
     y = out.reshape(*x.shape[:-1], No)
+    if ln is not None:
+        n = n_out.reshape(y.shape) if n_out is not None else layernorm(y.contiguous(), ln[0], ln[1], float(ln[2]) if len(ln) > 2 else 1e-5)
+        return y, n
     return (y, want) if gn is not None else y
 
 

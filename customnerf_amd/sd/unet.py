@@ -94,18 +94,17 @@ class _Transformer:
             h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, sums=x_sums[0], sums_ready=x_sums[1])
         else:
             h, _ = ops.groupnorm(x, self.nw, self.nb, groups, 1e-6, False, pool)
-        h = ops.linear(h.view(B, H * W, C), self.piw, bias=self.pib)                     # 1x1 conv on NHWC = linear over channels
-        n = ops.layernorm(h, *self.ln[0])
+        # (each LayerNorm rides on the tail kernel of the GEMM that produces its input when that GEMM runs split-K — the 8^2 / 16^2 / 32^2 levels —
+        # and is its own launch otherwise: ops.linear(ln=))
+        h, n = ops.linear(h.view(B, H * W, C), self.piw, bias=self.pib, ln=self.ln[0])   # 1x1 conv on NHWC = linear over channels
         qkv = ops.linear(n, self.qkv1)                                                   # [B, T, 3C]
         a = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads)
-        h = ops.linear(a, self.o1w, bias=self.o1b, residual=h)
-        n = ops.layernorm(h, *self.ln[1])
+        h, n = ops.linear(a, self.o1w, bias=self.o1b, residual=h, ln=self.ln[1])
         q = ops.linear(n, self.q2)
         if kv is None:
             kv = self.context_kv(ctx)
         a = ops.attention(q, kv[0], kv[1], self.heads)
-        h = ops.linear(a, self.o2w, bias=self.o2b, residual=h)
-        n = ops.layernorm(h, *self.ln[2])
+        h, n = ops.linear(a, self.o2w, bias=self.o2b, residual=h, ln=self.ln[2])
         f = ops.linear(n, self.f1w, bias=self.f1b, act=ops.ACT_GEGLU)                     # [B, T, 4C]
         h = ops.linear(f, self.f2w, bias=self.f2b, residual=h)
         if not out_gn:

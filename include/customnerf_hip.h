@@ -31,8 +31,10 @@ extern "C" {
 #define CNERF_F16 1
 
 /* ABI version of this header; cnerf_abi_version() of the loaded library must match.
- * 2: the GroupNorm / GEMM-epilogue statistics buffers of customnerf_sd.h are int64[B][G][2] fixed point (were float[B][G][2]). */
-#define CNERF_ABI_VERSION 3
+ * 2: the GroupNorm / GEMM-epilogue statistics buffers of customnerf_sd.h are int64[B][G][2] fixed point (were float[B][G][2]).
+ * 4: struct CnerfSdGemm grew the ln_* fields (LayerNorm of the output rows in the split-K tail); new entry points
+ *    cnerf_grid_encode_forward_ordered, cnerf_sd_concat_gn, cnerf_sd_gemm_serves_ln, cnerf_profile_stage_events. */
+#define CNERF_ABI_VERSION 4
 int cnerf_abi_version(void);
 /* name of the code object's target ("gfx950") */
 const char *cnerf_target_arch(void);

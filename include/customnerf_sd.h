@@ -65,10 +65,20 @@ typedef struct CnerfSdGemm {
      * the problem off the split-K path). */
     int64_t *gn_sums;
     uint32_t gn_groups, gn_rows;
+    /* optional LayerNorm of the OUTPUT rows (ABI 4; the transformer blocks normalise the result of proj_in / attn.to_out right away):
+     * ln_out [M, N] half (row pitch N) receives (row - mean) * rstd * ln_gamma + ln_beta of the half-rounded row of C, biased variance, ln_eps —
+     * exactly cnerf_sd_layernorm_forward on C.  Served only by the split-K tail kernel (cnerf_sd_gemm_serves_ln tells): a one-launch GEMM
+     * leaves ln_out untouched and the caller runs cnerf_sd_layernorm_forward. */
+    void *ln_out;
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
 } CnerfSdGemm;
 
 int cnerf_sd_gemm(const CnerfSdGemm *desc, void *workspace, uint64_t workspace_bytes, void *stream);
 int cnerf_sd_gemm_workspace_bytes(const CnerfSdGemm *desc, uint64_t *bytes);
+/* *yes = 1 when cnerf_sd_gemm (given the workspace cnerf_sd_gemm_workspace_bytes asks for) will write desc->ln_out: split-K schedule, dense half
+ * output with ldc == N, N % 8 == 0, N <= 2048, no GEGLU, no GroupNorm-statistics request. */
+int cnerf_sd_gemm_serves_ln(const CnerfSdGemm *desc, int *yes);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC half activations x [B, HW, C] (torch.nn.GroupNorm(G, C, eps) semantics, biased variance, statistics in

@@ -568,3 +568,24 @@ def test_concat_accumulates_groupnorm_statistics(B, H, C1, C2):
     sums2 = torch.zeros_like(sums)
     ops.concat_channels(a, b, gn=(sums2, 32, H * H))
     assert torch.equal(sums, sums2)
+
+
+@pytest.mark.parametrize("M,N,K,res", [(128, 1280, 1280, True), (512, 1280, 1280, True), (2048, 640, 640, True), (2048, 640, 640, False), (512, 1280, 5120, True),
+                                       (8192, 320, 320, True), (77, 768, 768, False), (130, 320, 1280, True)])
+def test_linear_fused_layernorm(M, N, K, res):
+    """round 6: LayerNorm of a projection's output rows written by the split-K tail kernel (ops.linear(ln=)) — y and LayerNorm(y) must be
+    bit-identical to the projection followed by the stand-alone layernorm launch, whichever schedule the library picks (the one-launch GEMM
+    falls back to that launch inside ops.linear)."""
+    from customnerf_amd.sd import ops, pack
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(1, M, K, generator=g).half().cuda()
+    w = pack.pack_linear(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(1, M, N, generator=g).half().cuda() if res else None
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    y_ref = ops.linear(x, w, bias=b, residual=r)
+    n_ref = ops.layernorm(y_ref, gamma, beta)
+    y, n = ops.linear(x, w, bias=b, residual=r, ln=(gamma, beta))
+    assert torch.equal(y, y_ref) and torch.equal(n, n_ref)
+    want = torch.nn.functional.layer_norm(y_ref.float().cpu(), (N,), gamma.cpu(), beta.cpu(), 1e-5)
+    close(n, want, 2e-3, 2e-3)
