@@ -341,7 +341,12 @@ __global__ void __launch_bounds__(256) k_concat(const _Float16 *__restrict__ a, 
         for (uint32_t i = threadIdx.x; i < entries * 2; i += 256) (&gn_tab[0][0])[i] = 0;
         __syncthreads();
     }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    // (statistics: a workgroup owns a contiguous range of chunks — a few rows of one or two images — so that its table flush touches few entries)
+    const uint32_t per = do_gn ? (total + gridDim.x - 1) / gridDim.x : total;
+    const uint32_t i_lo = do_gn ? blockIdx.x * per + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i_hi = do_gn ? min(total, (blockIdx.x + 1) * per) : total;
+    const uint32_t i_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
+    for (uint32_t i = i_lo; i < i_hi; i += i_step) {
         const uint32_t row = i / nc;
         const uint32_t col = i - row * nc;
         const so_h8 v = col < n1 ? so_ld8(a + (size_t)row * C1 + col * 8) : so_ld8(b + (size_t)row * C2 + (col - n1) * 8);
@@ -775,7 +780,7 @@ int cnerf_sd_concat_gn(const void *a, const void *b, uint64_t rows, uint32_t C1,
     if (rows == 0) return CNERF_OK;
     if (!a || !b || !y) return CNERF_ENULL;
     // (statistics: fewer, fatter workgroups — every workgroup flushes its table with one global atomic per touched entry)
-    const uint32_t blocks = so_blocks((size_t)rows * ((C1 + C2) / 8), 256, gn_sums ? 512 : 8192);
+    const uint32_t blocks = so_blocks((size_t)rows * ((C1 + C2) / 8), 256, gn_sums ? 256 : 8192);
     hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b, rows, C1, C2, (_Float16 *)y,
                        reinterpret_cast<long long *>(gn_sums), gn_groups, gn_rows);
     return cn_launch_status();

@@ -770,8 +770,6 @@ def test_early_termination_flags_are_dropped_when_sigma_has_a_second_consumer():
     rgb, mask = sc.sphere_targets(ro.reshape(V, -1, 3), rd.reshape(V, -1, 3))
     kw = dict(num_steps=32, upsample_steps=32, dt_gamma=0, max_steps=1024)
     tr = ReconTrainer(model, opt, fp16=True)
-    for i in range(200):                                     # a fitted field: most tiles are dead
-        tr.train_step(ro[i % V], rd[i % V], rgb[i % V], mask[i % V], **kw)
     g = torch.Generator(device="cuda").manual_seed(9)
     draws = dict(z=torch.rand(H * W, 32, device="cuda", generator=g), u=torch.rand(H * W, 32, device="cuda", generator=g))
     captured, used = {}, []
@@ -797,9 +795,10 @@ def test_early_termination_flags_are_dropped_when_sigma_has_a_second_consumer():
             model.train()
             with torch.autocast('cuda', dtype=torch.float16):
                 out = model.render(ro[1], rd[1], staged=False, perturb=True, force_all_rays=True, _draws=draws, **kw)
-                loss = tr.loss(out, rgb[1], mask[1])
+                # a loss that ignores the lower half of the image: those rays' composite gradients are exact zeros, their tiles dead
+                loss = (out['image'][:, :H * W // 2] ** 2).mean() + out['fg']['weights_sum'][:H * W // 2].mean()
             if second:                                       # second consumers of sigma AND of rgbc: every row gets gradient, dead tiles included
-                loss = loss + 1e-3 * captured['sigma'].float().mean() + 1e-3 * captured['rgbc'].float().mean()
+                loss = loss + 0.5 * captured['sigma'].float().mean() + 0.5 * captured['rgbc'].float().mean()
             tr.scaler.backward(loss)
             grads[(second, et)] = [p.grad.detach().clone() for p in model.parameters()]
     finally:
@@ -808,7 +807,7 @@ def test_early_termination_flags_are_dropped_when_sigma_has_a_second_consumer():
         model.opt.early_termination = True
     (had1, ok1, live1), (had2, _, _), (had3, ok3, live3) = used
     assert not had2                                          # early termination off: no flags at all
-    assert had3 and ok3 and live3 < 0.9                      # single consumer: flags arrive intact and most tiles are dead
+    assert had3 and ok3 and 0.45 < live3 < 0.55              # single consumer: flags arrive intact, the tiles of the rays without loss are dead
     assert not ok1                                           # second consumer: whatever arrived no longer describes the tensors -> ignored
     for a, b in zip(grads[(True, True)], grads[(True, False)]):
         scale = float(b.abs().max())
