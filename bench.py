@@ -343,7 +343,7 @@ def run_recon(args, world, rank, dev):
         rays_per_step = n_rays * world
 
     # --graph (one GPU, run() path): render + loss + backward of each view replayed as one hipGraph, eager optimiser step (ReconTrainer.train_step_graphed)
-    use_graph = bool(getattr(args, "graph", False)) and world == 1 and args.path == "run" and fp16
+    use_graph = bool(getattr(args, "graph", False)) and args.path == "run" and fp16
 
     def step(i):
         v = (i % V) if strong else (i * world + rank) % V      # weak: each rank renders its own view (view-parallel data parallelism)
@@ -693,10 +693,18 @@ def main():
                 # what ONE of 8 ranks executes per step when one 128x128 view is split over the node (north_star's own partition, SURVEY.md 8e:
                 # 2048 rays per GPU), exchange on: the strong-scaling bound of this design, measured instead of estimated
                 sb = brief(variant(run_recon, dp_selftest=True, no_roofline=True, rays=2048, stage_events=True))
+                # ... and the same with render + loss + backward replayed as one hipGraph per ray chunk (exchange + optimiser eager): at 2048 rays the
+                # eager step is bound by the host's enqueue (~1 ms), not by its 0.5 ms of kernels
+                sg = brief(variant(run_recon, dp_selftest=True, no_roofline=True, rays=2048, graph=True))
                 if sb and "error" not in sb and rank == 0:
                     sb["implied_strong_scaling_bound_8gpu"] = result["ms_per_step"] / sb["ms_per_step"]
                     sb["note"] = ("one rank's share of a 16384-ray step under --scaling strong at 8 GPUs, gradient exchange on over a one-rank RCCL group "
                                   "(no link time); bound = 16384-ray step time / this step time")
+                    if sg and "error" not in sg:
+                        sb["graphed"] = {"ms_per_step": sg["ms_per_step"], "value": sg["value"], "exchange_ms": sg.get("exchange_ms"),
+                                         "implied_strong_scaling_bound_8gpu": result["ms_per_step"] / sg["ms_per_step"]}
+                    else:
+                        sb["graphed"] = sg
                 v["small_batch"] = sb
             except Exception as e:
                 v.setdefault("dp_selftest", {"error": repr(e)})
@@ -708,8 +716,10 @@ def main():
                 result["variants"] = v
         if plain and world > 1 and args.scaling == "weak":
             st = brief(variant(run_recon, scaling="strong", no_roofline=True))
+            sg = brief(variant(run_recon, scaling="strong", no_roofline=True, graph=True))     # the same with each rank's chunk replayed as a hipGraph
             if rank == 0:
                 result["strong"] = st
+                result["strong_graphed"] = sg
     if args.task in ("both", "edit"):
         if world > 1 or args.task == "edit":
             edit = run_edit(args, world, rank, dev)

@@ -418,7 +418,16 @@ static int ge_fwd_C(const float *inputs, const T *emb, const GridLevels &lv, T *
                     uint32_t gridtype, int ac, uint32_t interp, hipStream_t st, uint32_t ostride, uint32_t traversal = GE_TRAV_LEVEL) {
     uint32_t nb = cn_div_up(B, GE_BLOCK);
     const dim3 block(GE_BLOCK);
-    const int sw = ge_swizzle_default();
+    int sw = ge_swizzle_default();
+    // The XCD slices (swizzle 2) pay when the one or two levels an XCD works on FIT its 4 MiB L2 (T = 2^19: 2 MiB per level in fp16).  The
+    // reference field's own table (T = 2^21: 8 MiB per level) does not: there the plain order — consecutive workgroups, i.e. all eight XCDs, on
+    // the same level at the same time, each L2 holding what its neighbours also fetch through the Infinity Cache — is faster: coarse pass
+    // 364 -> 283 us, importance pass 229 -> 215 us (profiles/r06_bear_gather_ab.txt).
+    if (sw == 2 && cn_tune_env("CNERF_GRID_SWIZZLE", -1) < 0) {
+        uint64_t biggest = 0;
+        for (uint32_t l = 0; l < nl; l++) biggest = biggest > lv.size[l] ? biggest : lv.size[l];
+        if (biggest * C * sizeof(T) > (4ull << 20)) sw = 0;
+    }
     GridLevels lvb = lv;
     if constexpr (std::is_same<T, __half>::value && D == 3) {
         if (C == 2 && !dy_dx && interp == 0 && !ac && ge_fast_eligible(lvb, nl, gridtype)) {

@@ -803,14 +803,23 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
     // the element-wise loop below is the general form
     if ((g.N & 3u) == 0 && (g.ldc & 3u) == 0 && (!g.residual || (g.ldr & 3u) == 0) && total < 0xFFFFFFFFull) {
         const uint32_t total4 = (uint32_t)(total / 4), n4 = g.N / 4;
-        // with a statistics request every workgroup owns a CONTIGUOUS range of items (a few rows of one or two images): its table then holds a
-        // few dozen non-zero entries to flush.  (Grid-stride, every workgroup touched every (image, group) pair: 2048 workgroups x 128 atomics on
-        // the same 128 addresses made this kernel 15 us instead of 6.5 — profiles/r06_edit_step_kernels_gnstats_first.txt.)
-        const uint32_t per = do_gn ? (total4 + gridDim.x - 1) / gridDim.x : total4;
-        const uint32_t i_lo = do_gn ? blockIdx.x * per + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
-        const uint32_t i_hi = do_gn ? min(total4, (blockIdx.x + 1) * per) : total4;
-        const uint32_t i_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
-        for (uint32_t i = i_lo; i < i_hi; i += i_step) {
+        // With a statistics request a workgroup owns a TILE of the output — a slab of four whole groups x a range of rows (gridDim = slabs x row
+        // chunks) — so that its table flush is four or five entries per image instead of every (image, group) pair.  (Grid-stride, 2048 workgroups x
+        // 128 atomics on the same 128 addresses made this kernel 15 us instead of 6.5; contiguous row ranges under a 256-workgroup cap still 11:
+        // profiles/r06_edit_step_kernels_gnstats_first.txt, r06_edit_step_kernels_gnstats_rows.txt.)
+        const bool tiled = do_gn && (g.gn_groups & 3u) == 0;
+        const uint32_t n_slabs = tiled ? g.gn_groups / 4 : 1u, slab_items = tiled ? gn_cg : n4;          // items (4 columns) per row of a slab
+        const uint32_t row_chunks = do_gn ? gridDim.x / n_slabs : 1u, rpb = do_gn ? (g.M + row_chunks - 1) / row_chunks : g.M;
+        const uint32_t slab = do_gn ? blockIdx.x % n_slabs : 0u, row0 = do_gn ? (blockIdx.x / n_slabs) * rpb : 0u;
+        const uint32_t rows_in = do_gn ? (row0 < g.M ? min(rpb, g.M - row0) : 0u) : g.M;
+        const uint32_t my_items = do_gn ? rows_in * slab_items : total4;
+        const uint32_t j_lo = do_gn ? threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x, j_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
+        for (uint32_t j = j_lo; j < my_items; j += j_step) {
+            uint32_t i = j;
+            if (do_gn) {
+                const uint32_t r = j / slab_items, c4 = j - r * slab_items;
+                i = (row0 + r) * n4 + slab * slab_items + c4;
+            }
             const uint32_t m = i / n4, n = (i - m * n4) * 4;
             sd_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
             for (uint32_t s = 0; s < splits; s++) a += *reinterpret_cast<const sd_f4 *>(partial + (size_t)s * total + (size_t)i * 4);
@@ -1166,8 +1175,13 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
         else hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue_ln<4>, eg, dim3(256), 0, st, *g, pw, splits);
     } else if (split) {
         const size_t total = (size_t)g->M * g->N;
-        const uint32_t cap = g->gn_sums ? 256u : 2048u;                   // (statistics: one table flush per workgroup — fewer, fatter workgroups)
-        const uint32_t eb = (uint32_t)((total + 255) / 256 > cap ? cap : (total + 255) / 256);
+        uint32_t eb = (uint32_t)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        if (g->gn_sums) {                                                   // statistics: the grid is (slabs of four groups) x (row chunks), see the kernel
+            const uint32_t n_slabs = (g->gn_groups & 3u) == 0 ? g->gn_groups / 4 : 1u;
+            uint32_t row_chunks = cn_div_up(eb, n_slabs);
+            if (row_chunks > g->M) row_chunks = g->M;
+            eb = n_slabs * (row_chunks ? row_chunks : 1u);
+        }
         hipLaunchKernelGGL(k_sd_gemm_splitk_epilogue, dim3(eb), dim3(256), 0, st, *g, reinterpret_cast<const float *>(workspace), splits);
     }
     return cn_launch_status();

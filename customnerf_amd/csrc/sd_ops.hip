@@ -341,12 +341,21 @@ __global__ void __launch_bounds__(256) k_concat(const _Float16 *__restrict__ a, 
         for (uint32_t i = threadIdx.x; i < entries * 2; i += 256) (&gn_tab[0][0])[i] = 0;
         __syncthreads();
     }
-    // (statistics: a workgroup owns a contiguous range of chunks — a few rows of one or two images — so that its table flush touches few entries)
-    const uint32_t per = do_gn ? (total + gridDim.x - 1) / gridDim.x : total;
-    const uint32_t i_lo = do_gn ? blockIdx.x * per + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i_hi = do_gn ? min(total, (blockIdx.x + 1) * per) : total;
-    const uint32_t i_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
-    for (uint32_t i = i_lo; i < i_hi; i += i_step) {
+    // statistics: a workgroup owns a TILE of the output — a slab of four whole groups x a range of rows (gridDim = slabs x row chunks) — so that
+    // its table flush is a handful of entries (k_sd_gemm_splitk_epilogue, sd_gemm.hip, has the measurements behind this)
+    const bool tiled = do_gn && (gn_groups & 3u) == 0 && (cg & 1u) == 0;
+    const uint32_t n_slabs = tiled ? gn_groups / 4 : 1u, slab_chunks = tiled ? cg / 2 : nc;
+    const uint32_t row_chunks = do_gn ? gridDim.x / n_slabs : 1u, rpb = do_gn ? (uint32_t)((rows + row_chunks - 1) / row_chunks) : (uint32_t)rows;
+    const uint32_t slab = do_gn ? blockIdx.x % n_slabs : 0u, row0 = do_gn ? (blockIdx.x / n_slabs) * rpb : 0u;
+    const uint32_t rows_in = do_gn ? (row0 < rows ? min(rpb, (uint32_t)rows - row0) : 0u) : (uint32_t)rows;
+    const uint32_t my = do_gn ? rows_in * slab_chunks : total;
+    const uint32_t j_lo = do_gn ? threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x, j_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
+    for (uint32_t j = j_lo; j < my; j += j_step) {
+        uint32_t i = j;
+        if (do_gn) {
+            const uint32_t r = j / slab_chunks, c8 = j - r * slab_chunks;
+            i = (row0 + r) * nc + slab * slab_chunks + c8;
+        }
         const uint32_t row = i / nc;
         const uint32_t col = i - row * nc;
         const so_h8 v = col < n1 ? so_ld8(a + (size_t)row * C1 + col * 8) : so_ld8(b + (size_t)row * C2 + (col - n1) * 8);
@@ -780,7 +789,14 @@ int cnerf_sd_concat_gn(const void *a, const void *b, uint64_t rows, uint32_t C1,
     if (rows == 0) return CNERF_OK;
     if (!a || !b || !y) return CNERF_ENULL;
     // (statistics: fewer, fatter workgroups — every workgroup flushes its table with one global atomic per touched entry)
-    const uint32_t blocks = so_blocks((size_t)rows * ((C1 + C2) / 8), 256, gn_sums ? 256 : 8192);
+    uint32_t blocks = so_blocks((size_t)rows * ((C1 + C2) / 8), 256, gn_sums ? 2048 : 8192);
+    if (gn_sums) {                                                          // (slabs of four groups) x (row chunks), see the kernel
+        const uint32_t cg = (C1 + C2) / gn_groups;
+        const uint32_t n_slabs = ((gn_groups & 3u) == 0 && (cg & 1u) == 0) ? gn_groups / 4 : 1u;
+        uint32_t row_chunks = cn_div_up(blocks, n_slabs);
+        if (row_chunks > rows) row_chunks = (uint32_t)rows;
+        blocks = n_slabs * (row_chunks ? row_chunks : 1u);
+    }
     hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, CN_STREAM(stream), (const _Float16 *)a, (const _Float16 *)b, rows, C1, C2, (_Float16 *)y,
                        reinterpret_cast<long long *>(gn_sums), gn_groups, gn_rows);
     return cn_launch_status();

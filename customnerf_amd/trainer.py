@@ -326,10 +326,12 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         (allocations, workspaces) and captures the third, later visits replay it.  The optimiser step stays eager: its learning rate is a host-side
         scalar that changes every step.  The GPU time is the eager step's (the step is GPU-bound: DESIGN.md section 6); what the graph buys is the
         host — 0.18 instead of 0.79 ms of enqueue per step (scratch/graph_probe.py) — i.e. immunity against a slow or shared host.
-        One GPU, fused Adam with the on-device loss scaler, no --batch_rays subsampling.  -> (loss, None): the loss is a static tensor that the
+        Fused Adam with the on-device loss scaler, no --batch_rays subsampling; data-parallel trainers too (round 6): the gradient exchange and
+        the optimiser step run eagerly after the replay — what matters under `--scaling strong`, where a rank's 2048-ray share of a view is 0.5 ms
+        of kernels behind 1 ms of eager enqueue (profiles/r06_batch_sweep.json).  -> (loss, None): the loss is a static tensor that the
         next replay of the same view overwrites; the per-ray outputs stay inside the graph's memory pool."""
-        if not (self.fused_adam and self.scaler is not None and self.world_size == 1) or int(getattr(self.opt, 'batch_rays', -1) or -1) > 0:
-            raise ValueError("train_step_graphed: one GPU, fused Adam with the dynamic loss scaler, no batch_rays")
+        if not (self.fused_adam and self.scaler is not None) or int(getattr(self.opt, 'batch_rays', -1) or -1) > 0:
+            raise ValueError("train_step_graphed: fused Adam with the dynamic loss scaler, no batch_rays")
         from ._lib import scratch_generation
         tensors = (rays_o, rays_d, rgbs, mask)
         key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors) + (tuple(sorted(render_kw.items())),)

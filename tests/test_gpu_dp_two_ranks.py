@@ -84,6 +84,7 @@ def test_bench_two_ranks_on_one_device_runs_every_leg():
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and "gloo" in rec["collective_backend"]
     assert rec["value"] > 0 and rec["config"]["exchange_ms"] > 0 and "dp2" in rec["config"]["parallelism"]
     assert rec["strong"]["value"] > 0                                   # one view's rays split over the two ranks
+    assert rec["strong_graphed"]["value"] > 0 and "hipGraph" in rec["strong_graphed"]["graph"]   # ... and with each rank's chunk replayed as a hipGraph
     # weak scaling: two views behind one optimiser step (the reference takes one) — said in the record, so a weak-scaling speed-up is not read as a faster one-view step
     assert rec["config"]["rays_per_optimizer_step"] == 2 * rec["config"]["rays_per_step_per_gpu"] == 2 * 128 * 128
     sec = rec["secondary"]
