@@ -348,3 +348,33 @@ def test_backward_propagates_non_finite_gradients(bad):
         out = enc(x * 2 - 1, bound=1.0)
     out.backward(torch.randn(out.shape, device='cuda').half() * 1e-3)
     assert bool(torch.isfinite(enc.embeddings.grad).all())
+
+
+@pytest.mark.parametrize("name,kw", [c for c in CONFIGS if c[1].get('input_dim', 3) == 3 and c[1]['level_dim'] == 2], ids=[c[0] for c in CONFIGS if c[1].get('input_dim', 3) == 3 and c[1]['level_dim'] == 2])
+@pytest.mark.parametrize("B,row0", [(4099, 0), (1 << 16, 256), (40961, 7), (1, 0), (255, 3)])
+def test_sample_major_traversal_is_bit_identical(name, kw, B, row0):
+    """the sample-major gather (cnerf_grid_encode_forward_ordered, traversal 1 — what the TraversalTuner may pick for the
+    importance pass) must write exactly what the level-major kernel writes: ragged sizes, a row offset into a larger feature buffer,
+    out-of-range and boundary samples, every fp16 D = 3 / C = 2 table of the suite (the kernel is specialised; other tables ignore the switch)."""
+    from customnerf_amd.gridencoder.grid import LEVEL_MAJOR, SAMPLE_MAJOR, TraversalTuner
+    enc = build(kw)
+    x = cuda(make_inputs(B, 3, seed=B))
+    L = enc.num_levels
+    P = row0 + B + 5
+    outs = []
+    for trav in (LEVEL_MAJOR, SAMPLE_MAJOR):
+        out = torch.full((L, P, 2), 7.0, dtype=torch.float16, device="cuda")
+        enc.encode_into(x, out, row0, half=True, traversal=trav)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.all(outs[1][:, :row0] == 7.0) and torch.all(outs[1][:, row0 + B:] == 7.0)          # nothing outside the rows asked for
+    assert not torch.isnan(outs[1].float()).any()
+    # a tuner's trial call runs both forms back to back into the same rows: the result is the same buffer again
+    tuner = TraversalTuner(first=0, period=4)
+    for _ in range(6):
+        out = torch.full((L, P, 2), 7.0, dtype=torch.float16, device="cuda")
+        enc.encode_into(x, out, row0, half=True, traversal=tuner)
+        assert torch.equal(out, outs[0])
+    torch.cuda.synchronize()
+    tuner.plan()
+    assert len(tuner.history) >= 1 and tuner.choice in (LEVEL_MAJOR, SAMPLE_MAJOR)
