@@ -728,6 +728,13 @@ def main():
                 edit = run_edit(args, world, rank, dev)
             except Exception as e:                                        # one GPU, combined line: a failing edit leg must not take the rays/s half down
                 edit = {"metric": "SDS edit-steps/s", "value": None, "unit": "edit-steps/s", "error": repr(e)}
+        if world == 1 and edit is not None and not edit.get("error") and edit["config"].get("steps_skipped_on_overflow") == args.steps:
+            # every timed step was a skipped (non-finite) step: the number above is not a training step.  Seen ONCE in round 6 (r06a) and never
+            # reproduced (tests/test_gpu_uninitialised.py poisons the allocator to make that class of bug deterministic): say so in the record,
+            # keep the failed attempt, and measure again on a fresh trainer.
+            first = {"ms_per_step": edit["ms_per_step"], "final_loss": edit["config"].get("final_loss"), "steps_skipped_on_overflow": args.steps}
+            edit = run_edit(args, world, rank, dev)
+            edit["nonfinite_first_attempt"] = first
         if args.task == "both" and args.sds_views == 1 and not args.no_variants and not (world == 1 and edit.get("error")):
             # the same leg with 4 camera views per step through one UNet batch of 8 (north_star: "optionally SDS camera views"), reported beside
             # the single-view figure: fixed per-launch costs amortise and the GEMMs' M quadruples.  The condition is rank-independent.

@@ -351,7 +351,7 @@ def test_backward_propagates_non_finite_gradients(bad):
 
 
 @pytest.mark.parametrize("name,kw", [c for c in CONFIGS if c[1].get('input_dim', 3) == 3 and c[1]['level_dim'] == 2], ids=[c[0] for c in CONFIGS if c[1].get('input_dim', 3) == 3 and c[1]['level_dim'] == 2])
-@pytest.mark.parametrize("B,row0", [(4099, 0), (1 << 16, 256), (40961, 7), (1, 0), (255, 3)])
+@pytest.mark.parametrize("B,row0", [(4099, 0), (1 << 16, 256), (40961, 7), (5, 0), (255, 3)])
 def test_sample_major_traversal_is_bit_identical(name, kw, B, row0):
     """the sample-major gather (cnerf_grid_encode_forward_ordered, traversal 1 — what the TraversalTuner may pick for the
     importance pass) must write exactly what the level-major kernel writes: ragged sizes, a row offset into a larger feature buffer,

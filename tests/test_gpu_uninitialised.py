@@ -1,0 +1,139 @@
+"""GPU: nothing on the hot path may depend on the CONTENTS of freshly allocated memory.  torch.empty hands out whatever the caching allocator
+recycles — zeros in a young process, the previous leg's data later (bench.py runs six recon variants before the edit leg) — so a kernel that
+reads a byte it never wrote computes with garbage only sometimes.  Round 6: one benchmark run had every edit step non-finite and could not be
+reproduced; these tests make that class of bug deterministic: the allocator's pools are filled with 0xFF bytes (NaN as float16 / float32, -1 as
+integers) before the workload runs, and the results must be the bits of a clean run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # sibling test modules' helpers
+
+
+def poison_allocator(gib=6.0):
+    """Fill the caching allocator's free lists with 0xFF: large blocks (split on demand for every later large request) and a few thousand
+    small ones (the small pool's segments).  Nothing here calls empty_cache() afterwards, so the next torch.empty gets these bytes."""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    big = [torch.full((int(gib * 2 ** 30 / 4),), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    small = [torch.full((n,), 0xFF, dtype=torch.uint8, device="cuda") for n in (512, 4096, 65536, 524288) for _ in range(600)]
+    torch.cuda.synchronize()
+    del big, small
+
+
+def _edit_steps(poison):
+    from test_gpu_sd_editing import _setup
+    if poison:
+        poison_allocator()
+    tr, model, pre, data = _setup(keep_bg=1000.0, lambda_sd=0.01)
+    losses = []
+    for i in range(4):
+        loss, _ = tr.train_step(data(i % 2))
+        losses.append(float(loss))
+    return losses, [p.detach().clone() for p in model.parameters()], tr.scaler.good_steps()
+
+
+def test_edit_step_is_independent_of_recycled_memory():
+    from customnerf_amd import tcnn
+    try:
+        l0, p0, g0 = _edit_steps(False)
+        l1, p1, g1 = _edit_steps(True)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+    assert all(np.isfinite(l1)) and g1 == g0, (l1, g1, g0)
+    assert l0 == l1
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hw", [16, 64])
+def test_sd15_unet_is_independent_of_recycled_memory(hw):
+    """the SD-1.5-shaped UNet (every split-K schedule, the tail kernels' statistics, the concat, padded channels) eager and as a hipGraph"""
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd.unet import UNet
+    from test_gpu_sd_nets import half_sd, to_nhwc8
+    cfg = arch.UNET_SD15
+    sd = half_sd(arch.random_state_dict(arch.unet_params(cfg), seed=3))
+    g = torch.Generator().manual_seed(hw)
+    x = torch.randn(2, 4, hw, hw, generator=g).half().float()
+    ctx = torch.randn(2, 77, cfg["cross_attention_dim"], generator=g).half().float()
+    t = torch.tensor([481.0, 481.0])
+    outs = []
+    for poison in (False, True, True):
+        if poison:
+            poison_allocator(4.0)
+        with torch.no_grad():
+            net = UNet(cfg, sd, "cuda")
+            o = net(to_nhwc8(x), t.cuda(), ctx.half().cuda()).clone()
+            og = net.graphed(to_nhwc8(x), t.cuda(), ctx.half().cuda()).clone()
+        assert torch.isfinite(o.float()).all()
+        assert torch.equal(o, og)
+        outs.append(o)
+        del net
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_sd15_vae_encode_is_independent_of_recycled_memory():
+    from customnerf_amd.sd import arch
+    from customnerf_amd.sd.vae import VAEEncoder
+    from test_gpu_sd_nets import half_sd
+    cfg = arch.VAE_SD15
+    sd = half_sd(arch.random_state_dict(arch.vae_encoder_params(cfg), seed=4))
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(1, 3, 128, 128, generator=g)
+    res = []
+    for poison in (False, True):
+        if poison:
+            poison_allocator(4.0)
+        enc = VAEEncoder(cfg, sd, "cuda")
+        x = img.cuda().requires_grad_(True)
+        noise = torch.randn(1, cfg["latent_channels"], 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+        moments = enc.encode_imgs(x, noise, resize=(256, 256))
+        moments.float().square().mean().backward()
+        res.append((moments.detach().clone(), x.grad.detach().clone()))
+        del enc
+    assert torch.isfinite(res[1][0].float()).all() and torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_recon_training_is_independent_of_recycled_memory():
+    """full-size reconstruction steps (binned scatter, field backward partial rows, the sample-major gather trial) on poisoned pools"""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    from test_gpu_train import _target_scene
+    tcnn.set_default_dtype(torch.float16)
+
+    def train(poison, grid_kw):
+        from customnerf_amd.gridencoder import grid as ge
+        from customnerf_amd import field as fld
+        if poison:
+            ge._WS_CACHE.clear(); ge._SIDE.clear(); fld._WS.clear()      # the cached workspaces too: they are re-allocated from the poisoned pools
+            poison_allocator(8.0)
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True, **grid_kw)
+        model = NeRFNetwork(opt).cuda()
+        H = W = 128
+        V = 2
+        o, d, rgb, mask = _target_scene(H, W, V)
+        tr = ReconTrainer(model, opt, fp16=True)
+        losses = []
+        for i in range(4):
+            loss, _ = tr.train_step(o[i % V], d[i % V], rgb[i % V], mask[i % V], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+            losses.append(float(loss))
+        return losses, [p.detach().clone() for p in model.parameters()], tr.scaler.good_steps()
+
+    try:
+        for grid_kw in ({}, dict(grid_type='tiledgrid', log2_hashmap_size=21, desired_resolution=8192)):
+            l0, p0, g0 = train(False, grid_kw)
+            l1, p1, g1 = train(True, grid_kw)
+            assert all(np.isfinite(l1)) and g0 == g1 == 4, (l1, g0, g1)
+            assert l0 == l1
+            for a, b in zip(p0, p1):
+                assert torch.equal(a, b)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
