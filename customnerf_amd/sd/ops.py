@@ -9,6 +9,9 @@ import torch
 from .._lib import lib, check, ptr, stream, require_cuda, SdGemmDesc
 
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
+# round 6: GroupNorm statistics / LayerNorm riding on the split-K tail kernel and on the channel concat.  False restores the round-5 launches
+# (stand-alone k_gn_stats / k_layernorm) — the A side of scratch/edit_ab.py's same-box comparison; nothing else reads it.
+TAIL_FUSION = True
 _WS = {}
 _PROFILE = None
 
@@ -41,6 +44,8 @@ def _launch(d, device):
     need = ctypes.c_uint64(0)
     check(lib.cnerf_sd_gemm_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "sd_gemm_workspace_bytes")
     ws = _workspace(need.value, device) if need.value else None
+    if not TAIL_FUSION and need.value:
+        d.gn_sums = None
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -92,7 +97,7 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
               ldr=r2.stride(0) if r2 is not None else 0, act=act, alpha=alpha, C32=out if out32 else None)
     want = _attach_gn(d, gn, M, N)
     n_out = None
-    if ln is not None and gn is None and not out32 and act != ACT_GEGLU:
+    if ln is not None and gn is None and not out32 and act != ACT_GEGLU and TAIL_FUSION:
         gamma, beta = ln[0], ln[1]
         n_out = torch.empty(M, N, dtype=torch.float16, device=x.device)
         d.ln_out, d.ln_gamma, d.ln_beta, d.ln_eps = ptr(n_out), ptr(gamma), ptr(beta), float(ln[2]) if len(ln) > 2 else 1e-5
@@ -101,7 +106,8 @@ def linear(x, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ou
         if not yes.value:
             d.ln_out = None
             n_out = None
-    _launch(d, x.device)
+    split = _launch(d, x.device)
+    want = want and (TAIL_FUSION or not split)
     y = out.reshape(*x.shape[:-1], No)
     if ln is not None:
         n = n_out.reshape(y.shape) if n_out is not None else layernorm(y.contiguous(), ln[0], ln[1], float(ln[2]) if len(ln) > 2 else 1e-5)
@@ -131,8 +137,8 @@ def conv2d(x, w, bias, ksize, stride=1, pad=1, ups=1, tstride=1, out_hw=None, bi
         d.ld_bias_rows = bias_rows.stride(0)
     d.stride, d.pad_t, d.pad_l, d.ups, d.tstride = stride, pad, pad, ups, tstride
     want = _attach_gn(d, gn, M, Cout)
-    _launch(d, x.device)
-    return (y, want) if gn is not None else y
+    split = _launch(d, x.device)
+    return (y, want and (TAIL_FUSION or not split)) if gn is not None else y
 
 
 GN_FRAC_BITS = 20        # include/customnerf_sd.h CNERF_SD_GN_FRAC_BITS: GroupNorm statistics are int64 fixed point (exact, order-independent sums)
@@ -233,7 +239,7 @@ def concat_channels(a, b, gn=None):
     rows = a.numel() // C1
     if gn is not None:
         sums, groups, rpi = gn
-        ok = (C1 + C2) % groups == 0 and (C1 + C2) // groups >= 8 and rows % rpi == 0 and (rows // rpi) * groups <= 512
+        ok = TAIL_FUSION and (C1 + C2) % groups == 0 and (C1 + C2) // groups >= 8 and rows % rpi == 0 and (rows // rpi) * groups <= 512
         check(lib.cnerf_sd_concat_gn(ptr(a), ptr(b), rows, C1, C2, ptr(y), ptr(sums) if ok else None, groups if ok else 0, rpi if ok else 0, stream()), "sd_concat_gn")
         return y, ok
     check(lib.cnerf_sd_concat(ptr(a), ptr(b), rows, C1, C2, ptr(y), stream()), "sd_concat")
