@@ -229,16 +229,20 @@ __global__ void __launch_bounds__(256) k_adam_scaled(float *__restrict__ p, floa
     }
 }
 
-// The small parameter tensors of a step (the three MLPs: 22.5 k floats) in ONE single-workgroup launch — three launches of ~6 us each
-// before — which, being the last Adam launch of the step, also applies GradScaler.update() once every thread is past its state reads
-// (one more launch saved).  Same arithmetic as k_adam_scaled, element by element.
+// The small parameter tensors of a step (the three MLPs: 22.5 k floats) in ONE launch — three launches of ~6 us each before round 4 — which,
+// being the last Adam launch of the step, also applies GradScaler.update() (one more launch saved).  Round 6: several workgroups (one element
+// per thread and job; a single workgroup walked 22 trips of dependent loads: 21 us for 90 KB), the scaler update by whichever workgroup
+// finishes LAST (a device-global ticket: every workgroup has read the state — scale, found_inf, step count — before it takes its ticket).
+// Same arithmetic as k_adam_scaled, element by element.
+__device__ unsigned int g_adam_multi_ticket = 0;
 __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, float beta1, float beta2, float eps, float *__restrict__ state,
                                                             float extra_inv, int zero_grad, int update_scaler, float growth, float backoff, float interval) {
     __shared__ double s_bc1;
     __shared__ float s_r2;
+    __shared__ unsigned int s_last;
     const bool skip = state[2] != 0.0f;
     const float gscale = extra_inv / state[0];
-    if (threadIdx.x == 0) {                                               // the double-precision pow()s once, not once per thread
+    if (threadIdx.x == 0) {                                               // the double-precision pow()s once per workgroup, not once per thread
         const double step = (double)state[3] + 1.0;
         s_bc1 = 1.0 - pow((double)beta1, step);
         s_r2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
@@ -251,34 +255,27 @@ __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, 
         __half *__restrict__ ph = reinterpret_cast<__half *>(jobs.p_half[j]);
         const float step_size = (float)((double)jobs.lr[j] / bc1);             // (the same expression as k_adam_scaled: bit-identical updates)
         const uint64_t n = jobs.n[j];
-        // a single workgroup is latency-bound: eight elements per thread and trip, all their loads issued before the first is used
-        for (uint64_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
-            float gk[8], mk[8], vk[8], pk[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint64_t i = i0 + (uint64_t)u * 1024;
-                const bool in = i < n;
-                gk[u] = in ? g[i] : 0.0f; mk[u] = in ? m[i] : 0.0f; vk[u] = in ? v[i] : 0.0f; pk[u] = in ? p[i] : 0.0f;
+        for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024) {
+            if (!skip) {
+                const float gs = g[i] * gscale;
+                const float mn = beta1 * m[i] + (1.0f - beta1) * gs;
+                const float vn = beta2 * v[i] + (1.0f - beta2) * gs * gs;
+                const float pn = p[i] - step_size * mn / (sqrtf(vn) * rsqrt_bc2 + eps);
+                m[i] = mn; v[i] = vn; p[i] = pn;
+                if (ph) ph[i] = __float2half_rn(pn);
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint64_t i = i0 + (uint64_t)u * 1024;
-                if (i >= n) continue;
-                if (!skip) {
-                    const float gs = gk[u] * gscale;
-                    const float mn = beta1 * mk[u] + (1.0f - beta1) * gs;
-                    const float vn = beta2 * vk[u] + (1.0f - beta2) * gs * gs;
-                    const float pn = pk[u] - step_size * mn / (sqrtf(vn) * rsqrt_bc2 + eps);
-                    m[i] = mn; v[i] = vn; p[i] = pn;
-                    if (ph) ph[i] = __float2half_rn(pn);
-                }
-                if (zero_grad) g[i] = 0;
-            }
+            if (zero_grad) g[i] = 0;
         }
     }
     if (update_scaler) {
-        __syncthreads();                                                      // every thread has read the state
+        __syncthreads();                                                      // every thread of this workgroup has read the state
         if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = atomicAdd(&g_adam_multi_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x == 0) {                                     // ... and so has every other workgroup: they took their tickets before
+            g_adam_multi_ticket = 0;
             if (skip) { state[0] *= backoff; state[1] = 0.0f; }
             else {
                 state[3] += 1.0f;
@@ -289,8 +286,6 @@ __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, 
         }
     }
 }
-
-void *g_cn_stage_events[CNERF_STAGE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 extern "C" {
 
@@ -379,7 +374,10 @@ int cnerf_adam_step_scaled_multi(const CnerfAdamJobs *jobs, float beta1, float b
     for (uint32_t j = 0; j < jobs->n_jobs; j++)
         if (!jobs->p[j] || !jobs->g[j] || !jobs->m[j] || !jobs->v[j]) return CNERF_ENULL;
     if (jobs->n_jobs == 0 && !update_scaler) return CNERF_OK;
-    hipLaunchKernelGGL(k_adam_scaled_multi, dim3(1), dim3(1024), 0, CN_STREAM(stream), *jobs, beta1, beta2, eps, state, extra_inv, zero_grad, update_scaler,
+    uint64_t max_n = 1;
+    for (uint32_t j = 0; j < jobs->n_jobs; j++) max_n = max_n > jobs->n[j] ? max_n : jobs->n[j];
+    const uint32_t blocks = (uint32_t)(cn_div_up64(max_n, 1024) < 64 ? cn_div_up64(max_n, 1024) : 64);
+    hipLaunchKernelGGL(k_adam_scaled_multi, dim3(blocks), dim3(1024), 0, CN_STREAM(stream), *jobs, beta1, beta2, eps, state, extra_inv, zero_grad, update_scaler,
                        growth_factor, backoff_factor, (float)growth_interval);
     return cn_launch_status();
 }

@@ -806,36 +806,19 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
         // With a statistics request a workgroup owns a TILE of the output — a slab of four whole groups x a range of rows (gridDim = slabs x row
         // chunks) — so that its table flush is four or five entries per image instead of every (image, group) pair.  (Grid-stride, 2048 workgroups x
         // 128 atomics on the same 128 addresses made this kernel 15 us instead of 6.5; contiguous row ranges under a 256-workgroup cap still 11:
-        // profiles/r06_edit_step_kernels_gnstats_first.txt, r06_edit_step_kernels_gnstats_rows.txt.)
-        // A thread of such a tile keeps ONE column chunk (c4) and walks the tile's rows (row lane rl, stride = row lanes): its one or two groups
-        // are fixed, so the sums stay in registers and reach the LDS table once per image instead of once per item (9.2 -> ~7 us per launch).
+        // profiles/r06_edit_step_kernels_gnstats_first.txt, r06_edit_step_kernels_gnstats_rows.txt.  Tiles: 9.2 us.  Also measured and dropped: a
+        // fixed column chunk per thread walking four rows with its sums in registers — fewer LDS atomics, but a quarter of the workgroups and a
+        // serial chain of split loads per thread: 12.9 us, profiles/r06_edit_step_kernels_gnstats_regs.txt.)
         const bool tiled = do_gn && (g.gn_groups & 3u) == 0;
         const uint32_t n_slabs = tiled ? g.gn_groups / 4 : 1u, slab_items = tiled ? gn_cg : n4;          // items (4 columns) per row of a slab
         const uint32_t row_chunks = do_gn ? gridDim.x / n_slabs : 1u, rpb = do_gn ? (g.M + row_chunks - 1) / row_chunks : g.M;
         const uint32_t slab = do_gn ? blockIdx.x % n_slabs : 0u, row0 = do_gn ? (blockIdx.x / n_slabs) * rpb : 0u;
         const uint32_t rows_in = do_gn ? (row0 < g.M ? min(rpb, g.M - row0) : 0u) : g.M;
-        const bool regs = tiled && slab_items <= 256;                                    // register-resident sums: a row of the slab fits the workgroup
-        const uint32_t row_lanes = regs ? 256u / slab_items : 1u;
-        const uint32_t my_c4 = regs ? threadIdx.x % slab_items : 0u, my_rl = regs ? threadIdx.x / slab_items : 0u;
-        const uint32_t my_items = regs ? ((my_rl < row_lanes && my_rl < rows_in) ? (rows_in - my_rl + row_lanes - 1) / row_lanes : 0u)
-                                       : (do_gn ? rows_in * slab_items : total4);
-        const uint32_t j_lo = regs ? 0u : (do_gn ? threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x);
-        const uint32_t j_step = regs ? 1u : (do_gn ? blockDim.x : gridDim.x * blockDim.x);
-        float rs0 = 0.0f, rq0 = 0.0f, rs1 = 0.0f, rq1 = 0.0f;                            // (regs) sums of the thread's two groups over its rows of one image
-        uint32_t r_img = 0xFFFFFFFFu;
-        const uint32_t r_n = (slab * slab_items + my_c4) * 4, r_glo = r_n / gn_cg, r_split = (r_glo + 1) * gn_cg - r_n;
-        auto regs_flush = [&]() {
-            if (r_img == 0xFFFFFFFFu) return;
-            long long *t0 = gn_tab[r_img * g.gn_groups + r_glo];
-            gn_add(t0, rs0); gn_add(t0 + 1, rq0);
-            if (r_split < 4) { gn_add(t0 + 2, rs1); gn_add(t0 + 3, rq1); }
-            rs0 = rq0 = rs1 = rq1 = 0.0f;
-        };
+        const uint32_t my_items = do_gn ? rows_in * slab_items : total4;
+        const uint32_t j_lo = do_gn ? threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x, j_step = do_gn ? blockDim.x : gridDim.x * blockDim.x;
         for (uint32_t j = j_lo; j < my_items; j += j_step) {
             uint32_t i = j;
-            if (regs) {
-                i = (row0 + my_rl + j * row_lanes) * n4 + slab * slab_items + my_c4;
-            } else if (do_gn) {
+            if (do_gn) {
                 const uint32_t r = j / slab_items, c4 = j - r * slab_items;
                 i = (row0 + r) * n4 + slab * slab_items + c4;
             }
@@ -872,14 +855,9 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
                     const float xf = (float)(_Float16)v[e];                         // what the consumer will read
                     if ((uint32_t)e < split_c) { s0 += xf; q0 += xf * xf; } else { s1 += xf; q1 += xf * xf; }
                 }
-                if (regs) {
-                    if (img != r_img) { regs_flush(); r_img = img; }
-                    rs0 += s0; rq0 += q0; rs1 += s1; rq1 += q1;
-                } else {
-                    long long *t0 = gn_tab[img * g.gn_groups + g_lo];
-                    gn_add(t0, s0); gn_add(t0 + 1, q0);
-                    if (split_c < 4) { gn_add(t0 + 2, s1); gn_add(t0 + 3, q1); }    // (the next group of the same image: n + 3 < N)
-                }
+                long long *t0 = gn_tab[img * g.gn_groups + g_lo];
+                gn_add(t0, s0); gn_add(t0 + 1, q0);
+                if (split_c < 4) { gn_add(t0 + 2, s1); gn_add(t0 + 3, q1); }        // (the next group of the same image: n + 3 < N)
             }
             if (g.C) {
                 typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));
@@ -898,7 +876,6 @@ __global__ void __launch_bounds__(256) k_sd_gemm_splitk_epilogue(const CnerfSdGe
                 for (int e = 0; e < 4; e++) g.C32[(size_t)m * g.ldc + n + e] = v[e];
             }
         }
-        if (regs) regs_flush();
         if (do_gn) gn_flush();
         return;
     }
@@ -1203,8 +1180,6 @@ int cnerf_sd_gemm(const CnerfSdGemm *g, void *workspace, uint64_t workspace_byte
         uint32_t eb = (uint32_t)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         if (g->gn_sums) {                                                   // statistics: the grid is (slabs of four groups) x (row chunks), see the kernel
             const uint32_t n_slabs = (g->gn_groups & 3u) == 0 ? g->gn_groups / 4 : 1u;
-            const uint32_t eb4 = (uint32_t)((total / 4 + 1023) / 1024);     // four items (rows) per thread: the sums stay in registers that long
-            eb = eb4 > 1024 ? 1024 : (eb4 < n_slabs * 8 ? (eb < n_slabs * 8 ? eb : n_slabs * 8) : eb4);
             uint32_t row_chunks = cn_div_up(eb, n_slabs);
             if (row_chunks > g->M) row_chunks = g->M;
             eb = n_slabs * (row_chunks ? row_chunks : 1u);
