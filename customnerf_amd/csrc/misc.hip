@@ -287,6 +287,8 @@ __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, 
     }
 }
 
+void *g_cn_stage_events[CNERF_STAGE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
 extern "C" {
 
 int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
