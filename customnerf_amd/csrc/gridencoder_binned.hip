@@ -856,6 +856,7 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 // staging capacity in records: a hashed level emits 4.125 records per sample on average (one x-pair in 32 leaves as two singles: 8448 +- 31 per
 // block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
 #define B3_CAP (B3_PTS * 4 + 640)
+#define B3_WIDE_CHUNKS BN_MAX_CHUNKS               // bins per level of a wide level (T = 2^21: 512 chunks of 4096 entries)
 #define B3_MAXT 72                               // LDS words pairs of the run walk: 65 prefix words + 64 run positions
 #define B3_REGION (B3_PTS * 8)                    // records a block may emit on one level (8 single records per sample): its region on a dense level
 
@@ -898,10 +899,6 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];        // one LDS object: staged records, bin ids, counters, run starts, run destinations
     uint2 *s_rec = reinterpret_cast<uint2 *>(b3_lds);
     uint8_t *s_bin = b3_lds + (size_t)B3_CAP * 8;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(b3_lds + (size_t)B3_CAP * 9);
-    uint32_t *start = cnt + B2S_MAX_CHUNKS;
-    uint32_t *gdst = start + B2S_MAX_CHUNKS;                                        // hashed: first record of the block's run inside the bin's region
-    uint32_t *s_total = gdst + B2S_MAX_CHUNKS;
     const uint32_t nb = plan.p.nb;
     // level fastest: the workgroups resident at one time cover all levels of a few point blocks — their reservations spread over every bin
     // cursor of the table instead of hammering the 128 of one level (same-address atomics serialise at the memory side), and the blocks that
@@ -911,10 +908,19 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     const uint32_t bin0 = plan.p.bin_first[slot], nch = plan.p.bin_first[slot + 1] - bin0;
     const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu;
     const uint32_t hb = plan.hbits[slot];
+    // WIDE levels (round 6: more than 128 bins — T = 2^20 / 2^21 tables, the reference field's own): B3_WIDE_CHUNKS-entry counter tables in place of
+    // the one-byte bin ids of the staged records (the copy-out then goes bin by bin instead of slot by slot), so that the workgroup's LDS
+    // stays below half a CU's.  Block-uniform.
+    const bool wide = nch > B2S_MAX_CHUNKS;
+    const uint32_t NBN = wide ? B3_WIDE_CHUNKS : B2S_MAX_CHUNKS;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(b3_lds + (size_t)B3_CAP * (wide ? 8 : 9));
+    uint32_t *start = cnt + NBN;
+    uint32_t *gdst = start + NBN;                                                   // hashed: first record of the block's run inside the bin's region
+    uint32_t *s_total = gdst + NBN;
     auto bin_of = [&](uint32_t e) { return dense_lvl ? e >> BN_CHUNK_LOG2 : b3_bin_of(e, hb); };
     auto local_of = [&](uint32_t e) { return dense_lvl ? e & (BN_CHUNK - 1) : b3_local_of(e, hb); };
     auto paired = [&](uint32_t a, uint32_t b) { return dense_lvl ? b2_paired(a, b) : b3_paired_h(a, b); };
-    if (threadIdx.x < B2S_MAX_CHUNKS) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < NBN) cnt[threadIdx.x] = 0;
     __syncthreads();
     constexpr int PPT = B3_PTS / B3_THREADS;
     bool ok[PPT];
@@ -965,7 +971,35 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     __syncthreads();
     // ---- the block's histogram is complete: run starts (two bins per lane of the first wave); dense: the run table; hashed: the reservations
     uint32_t res_a = 0, res_b = 0;
-    if (threadIdx.x < 64) {
+    if (wide) {
+        // 512 counters: the first wave takes eight consecutive bins per lane (run starts in bin order, as below); the reservations are then
+        // issued by 512 threads, one bin each (one register per thread: they come back during phase 2)
+        if (threadIdx.x < 64) {
+            const uint32_t lane = threadIdx.x;
+            constexpr uint32_t KPL = B3_WIDE_CHUNKS / 64;
+            uint32_t c8[KPL], loc = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < KPL; k++) { c8[k] = cnt[lane * KPL + k]; loc += c8[k]; }
+            const uint32_t incl = cn_wave_incl_scan(loc);
+            uint32_t run = incl - loc;
+#pragma unroll
+            for (uint32_t k = 0; k < KPL; k++) {
+                const uint32_t c = lane * KPL + k;
+                start[c] = run;
+                if (dense_lvl && c < nch && !(abl & 8)) runs[(size_t)(bin0 + c) * nb + pb] = c8[k] | (run << 16);
+                run += c8[k];
+            }
+            if (lane == 63) *s_total = incl;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!dense_lvl && !(abl & 1) && threadIdx.x < nch) {
+            const uint32_t c = threadIdx.x, n = cnt[c], st0 = start[c];
+            const uint32_t sa = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
+            if (sa) res_a = atomicAdd(&cursor[bin0 + c], sa) & 0x7FFFFFFFu;
+        }
+    } else if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         const uint32_t ca = cnt[lane], cb = cnt[lane + 64];
         const uint32_t ia = cn_wave_incl_scan(ca);
@@ -998,7 +1032,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t ticket, uint32_t word, uint32_t val) {
             const uint32_t sl = start[c] + ticket;
-            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
+            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); if (!wide) s_bin[sl] = (uint8_t)c; }
             else region[sl] = make_uint2(word, val);                                // beyond the staging capacity: straight into the block's region
         };
 #pragma unroll
@@ -1018,7 +1052,19 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
             }
         }
     }
-    if (!dense_lvl && threadIdx.x < 64) {                                           // the reservations have had phase 2 to come back
+    if (!dense_lvl && wide) {
+        if (threadIdx.x < NBN) {                                                    // (one bin per thread; the arithmetic of the narrow form below)
+            const uint32_t capb = plan.capb, c = threadIdx.x;
+            const uint32_t n = cnt[c], st0 = start[c], res = res_a;
+            const uint32_t staged = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
+            const uint32_t room = res >= capb ? 0u : capb - res;
+            const uint32_t fit = min(min(n, room), staged);
+            gdst[c] = res - st0;
+            cnt[c] = fit;
+            if (c < nch && !(abl & 8)) runs[(size_t)(bin0 + c) * nb + pb] = (n - fit) | ((st0 + fit) << 16);
+            if (c < nch && n > fit) atomicOr(&cursor[bin0 + c], 0x80000000u);
+        }
+    } else if (!dense_lvl && threadIdx.x < 64) {                                    // the reservations have had phase 2 to come back
         // what of the run fits the bin's region goes there; the rest SPILLS: it stays in the block's region (where the staging order puts it anyway)
         // and the run table says so — the accumulate workgroup of an overflowed bin walks those runs after its region.  Records beyond the staging
         // capacity (already in the block's region) count as spilled whatever the cursor says.
@@ -1040,6 +1086,16 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     const uint32_t total = (abl & 2) ? 0u : min(*s_total, (uint32_t)B3_CAP);
     if (dense_lvl) {
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) region[sl] = s_rec[sl];
+    } else if (wide) {
+        // bin by bin: wave w takes the bins w, w + 16, ...; a bin's staged records are the slots [start, next start) below `total`
+        const uint32_t capb = plan.capb, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (uint32_t c = wave; c < nch; c += B3_THREADS / 64) {
+            const uint32_t st0 = start[c], en = min(c + 1 < NBN ? start[c + 1] : *s_total, total), fit = cnt[c], gd = gdst[c];
+            for (uint32_t sl = st0 + lane; sl < en; sl += 64) {
+                if (sl - st0 < fit) hslab[(size_t)(bin0 + c) * capb + (gd + sl)] = s_rec[sl];
+                else region[sl] = s_rec[sl];
+            }
+        }
     } else {
         const uint32_t capb = plan.capb;
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) {
@@ -1534,11 +1590,16 @@ static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &pla
 // (gridtype 1 = tiled: its wrapping levels are x-contiguous, the interleave does not balance them — second form)
 static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype, uint32_t gridtype) {
     static const int on = b2_env("CNERF_B3", 1);
-    if (!on || !b2_enabled(dtype) || gridtype != 0) return false;
+    static const int wide_on = b2_env("CNERF_B3_WIDE", 1);                     // tuning builds: 0 = tables of more than 128 bins per level keep the second form
+    (void)gridtype;                                                            // (round 6: tiled levels that wrap take the interleaved bins like hashed ones)
+    if (!on || !b2_enabled(dtype)) return false;
     Bin3Plan plan;
     uint32_t nd;
     if (!b3_plan(lv, nl, B, plan, nd)) return false;
-    return b2_max_chunks(plan.p, nl) <= B2S_MAX_CHUNKS && (uint64_t)nl * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
+    const uint32_t mc = b2_max_chunks(plan.p, nl);
+    if (mc > (wide_on ? (uint32_t)B3_WIDE_CHUNKS : (uint32_t)B2S_MAX_CHUNKS)) return false;
+    if ((uint64_t)plan.p.total_bins * plan.capb >= 0xF0000000ull) return false;           // record positions inside the bin-major slab stay 32-bit in the accumulate
+    return (uint64_t)nl * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
 }
 
 static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, uint32_t nl, Bin3Ws *ws, void *base) {
@@ -1588,7 +1649,8 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     Bin3Ws ws;
     b3_layout(plan, n_dense, B, nl, &ws, workspace);
     static const int emit_pad = cn_tune_env("CNERF_B3_EMIT_LDS_PAD", 0);        // tuning builds: extra LDS bytes per emit workgroup (occupancy experiments)
-    const uint32_t emit_lds = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16 + (uint32_t)emit_pad, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 32 + B3_MAXT * 8;
+    const uint32_t lds_n = B3_CAP * 9 + B2S_MAX_CHUNKS * 12 + 16, lds_w = B3_CAP * 8 + B3_WIDE_CHUNKS * 12 + 16;
+    const uint32_t emit_lds = (lds_n > lds_w ? lds_n : lds_w) + (uint32_t)emit_pad, acc_lds = BN_CHUNK * 2 * sizeof(long long) + 32 + B3_MAXT * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin3_emit), hipFuncAttributeMaxDynamicSharedMemorySize, emit_lds);
