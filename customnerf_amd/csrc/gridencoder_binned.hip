@@ -994,10 +994,26 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (!dense_lvl && !(abl & 1) && threadIdx.x < nch) {
-            const uint32_t c = threadIdx.x, n = cnt[c], st0 = start[c];
-            const uint32_t sa = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
-            if (sa) res_a = atomicAdd(&cursor[bin0 + c], sa) & 0x7FFFFFFFu;
+        // The reservations of TWO neighbouring bins in one 64-bit returning atomic (the cursors are consecutive 32-bit words; a cursor stays
+        // below 2^31 plus its flag bit, so the low word never carries): 512 bins x 1024 point blocks x 11 levels are 5.8 M reservations per step,
+        // 0.27 ms of the memory-side atomic unit (A.1 item 1) that phase 2 cannot hide — pairs halve them.  Pairs are aligned on the GLOBAL bin
+        // index; a pair that straddles the level's first / last bin adds zero to its neighbour.
+        if (!dense_lvl && !(abl & 1) && threadIdx.x <= NBN / 2) {
+            const uint32_t b_lo = ((bin0 >> 1) + threadIdx.x) * 2u;                 // global bin of the pair's low word
+            uint32_t sa[2] = {0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t c = b_lo + h - bin0;                                 // (wraps for a bin in front of the level: fails c < nch)
+                if (c < nch) {
+                    const uint32_t n = cnt[c], st0 = start[c];
+                    sa[h] = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
+                }
+            }
+            if (sa[0] | sa[1]) {
+                const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(cursor + b_lo), (unsigned long long)sa[0] | ((unsigned long long)sa[1] << 32));
+                res_a = (uint32_t)old & 0x7FFFFFFFu;
+                res_b = (uint32_t)(old >> 32) & 0x7FFFFFFFu;
+            }
         }
     } else if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
@@ -1053,16 +1069,21 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         }
     }
     if (!dense_lvl && wide) {
-        if (threadIdx.x < NBN) {                                                    // (one bin per thread; the arithmetic of the narrow form below)
-            const uint32_t capb = plan.capb, c = threadIdx.x;
-            const uint32_t n = cnt[c], st0 = start[c], res = res_a;
-            const uint32_t staged = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
-            const uint32_t room = res >= capb ? 0u : capb - res;
-            const uint32_t fit = min(min(n, room), staged);
-            gdst[c] = res - st0;
-            cnt[c] = fit;
-            if (c < nch && !(abl & 8)) runs[(size_t)(bin0 + c) * nb + pb] = (n - fit) | ((st0 + fit) << 16);
-            if (c < nch && n > fit) atomicOr(&cursor[bin0 + c], 0x80000000u);
+        if (threadIdx.x <= NBN / 2) {                                               // (the pair's two bins; the arithmetic of the narrow form below)
+            const uint32_t capb = plan.capb, b_lo = ((bin0 >> 1) + threadIdx.x) * 2u;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t c = b_lo + h - bin0;
+                if (c >= nch) continue;
+                const uint32_t n = cnt[c], st0 = start[c], res = h ? res_b : res_a;
+                const uint32_t staged = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
+                const uint32_t room = res >= capb ? 0u : capb - res;
+                const uint32_t fit = min(min(n, room), staged);
+                gdst[c] = res - st0;
+                cnt[c] = fit;
+                if (!(abl & 8)) runs[(size_t)(bin0 + c) * nb + pb] = (n - fit) | ((st0 + fit) << 16);
+                if (n > fit) atomicOr(&cursor[bin0 + c], 0x80000000u);
+            }
         }
     } else if (!dense_lvl && threadIdx.x < 64) {                                    // the reservations have had phase 2 to come back
         // what of the run fits the bin's region goes there; the rest SPILLS: it stays in the block's region (where the staging order puts it anyway)
@@ -1087,11 +1108,12 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     if (dense_lvl) {
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) region[sl] = s_rec[sl];
     } else if (wide) {
-        // bin by bin: wave w takes the bins w, w + 16, ...; a bin's staged records are the slots [start, next start) below `total`
-        const uint32_t capb = plan.capb, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (uint32_t c = wave; c < nch; c += B3_THREADS / 64) {
+        // bin by bin, four bins per wave at a time (a run is ~16 records: sixteen lanes each); a bin's staged records are the slots
+        // [start, next start) below `total`
+        const uint32_t capb = plan.capb, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+        for (uint32_t c = grp; c < nch; c += B3_THREADS / 16) {
             const uint32_t st0 = start[c], en = min(c + 1 < NBN ? start[c + 1] : *s_total, total), fit = cnt[c], gd = gdst[c];
-            for (uint32_t sl = st0 + lane; sl < en; sl += 64) {
+            for (uint32_t sl = st0 + l16; sl < en; sl += 16) {
                 if (sl - st0 < fit) hslab[(size_t)(bin0 + c) * capb + (gd + sl)] = s_rec[sl];
                 else region[sl] = s_rec[sl];
             }
@@ -1607,7 +1629,7 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
     uint64_t off = 0;
     const uint64_t o_runs = off; off = bn_align(off + (uint64_t)p2.total_bins * p2.nb * 4);
     const uint64_t o_pre = off; off = bn_align(off + (uint64_t)p2.total_bins * p2.nb * 4);
-    const uint64_t o_cur = off; off = bn_align(off + (uint64_t)p2.total_bins * 4);
+    const uint64_t o_cur = off; off = bn_align(off + ((uint64_t)p2.total_bins + 2) * 4);       // (+ the partner word of a 64-bit pair reservation past the last bin)
     const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
