@@ -76,6 +76,7 @@ SIGNATURES = {
     "cnerf_composite_run_backward_indexed_flush": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, i32, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
     "cnerf_scaler_check": [vp, u64, vp, vp],
+    "cnerf_scaler_watch": [vp],
     "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],
     "cnerf_dp_pack": [vp, vp, u64, f32, vp],
     "cnerf_dp_reduce": [vp, u32, u64, vp, vp, vp],

@@ -19,6 +19,7 @@ static inline uint64_t cn_div_up64(uint64_t a, uint64_t b) { return (a + b - 1) 
 #define CN_STREAM(s) ((hipStream_t)(s))
 
 // cnerf_profile_stage_events (misc.hip): event handles recorded between the kernels of a multi-kernel entry point; all NULL unless a benchmark set them
+extern float *g_cn_found_inf;            // cnerf_scaler_watch (misc.hip): &state[2] of the watched loss scaler, or NULL
 extern void *g_cn_stage_events[CNERF_STAGE_EVENTS];
 static inline void cn_stage(int slot, hipStream_t st) {
     if (g_cn_stage_events[slot]) (void)hipEventRecord((hipEvent_t)g_cn_stage_events[slot], st);

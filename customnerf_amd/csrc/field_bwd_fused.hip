@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_fused(const void *__r
 // 256 rows is one long dependent-latency chain: 100 us for 23 MB), combined through LDS.
 __global__ void __launch_bounds__(256) k_field_reduce_partials(const float *__restrict__ partials, uint32_t n_blocks, uint32_t total, uint32_t n_net,
                                                                uint32_t n_den, float *__restrict__ g_net, float *__restrict__ g_den,
-                                                               float *__restrict__ g_rgb) {
+                                                               float *__restrict__ g_rgb, float *__restrict__ found_inf) {
     __shared__ float red[4][64];
     const uint32_t col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * 64 + col;
@@ -370,9 +370,10 @@ __global__ void __launch_bounds__(256) k_field_reduce_partials(const float *__re
     __syncthreads();
     if (grp == 0 && i < total) {
         const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        if (i < n_net) g_net[i] += s;
-        else if (i < n_net + n_den) g_den[i - n_net] += s;
-        else g_rgb[i - n_net - n_den] += s;
+        float *dst = i < n_net ? g_net + i : (i < n_net + n_den ? g_den + (i - n_net) : g_rgb + (i - n_net - n_den));
+        const float gn = *dst + s;
+        *dst = gn;
+        if (!(fabsf(gn) <= 3.4e38f) && found_inf) *found_inf = 1.0f;                // cnerf_scaler_watch: a non-finite parameter gradient
     }
 }
 
@@ -388,7 +389,7 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
 
 void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
                         hipStream_t st) {
-    hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(total, 64)), dim3(256), 0, st, partials, n_partials, total, n_net, n_den, g_net, g_den, g_rgb);
+    hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(total, 64)), dim3(256), 0, st, partials, n_partials, total, n_net, n_den, g_net, g_den, g_rgb, g_cn_found_inf);
 }
 
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
@@ -438,6 +439,6 @@ int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
     if (rc) return rc;
     const uint32_t n_net = po.d0, n_den = po.r0 - po.d0;
     hipLaunchKernelGGL(k_field_reduce_partials, dim3(cn_div_up(po.total, 64)), dim3(256), 0, st, partials, blocks, po.total, n_net, n_den, g_net,
-                       g_den, g_rgb);
+                       g_den, g_rgb, g_cn_found_inf);
     return cn_launch_status();
 }

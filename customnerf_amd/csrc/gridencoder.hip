@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_fwd_fast_sm(const float *__re
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(GE_BLOCK) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                        float *__restrict__ grad_grid, uint32_t B, uint32_t n_levels, uint32_t nb,
-                                                       uint32_t gridtype, int align_corners, uint32_t interp, int swizzle) {
+                                                       uint32_t gridtype, int align_corners, uint32_t interp, int swizzle, float *__restrict__ found_inf) {
     uint32_t level, pb;
     if (!ge_work_item(nb, n_levels, swizzle, lv, level, pb)) return;
     const uint32_t b = pb * GE_BLOCK + threadIdx.x;
@@ -277,7 +277,10 @@ __global__ void __launch_bounds__(GE_BLOCK) k_grid_bwd(const T *__restrict__ gra
     }
     float gf[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) gf[c] = ge_to_float(g.v[c]);
+    for (int c = 0; c < C; c++) {
+        gf[c] = ge_to_float(g.v[c]);
+        if (!(fabsf(gf[c]) <= 3.4e38f) && found_inf) *found_inf = 1.0f;             // cnerf_scaler_watch (the atomics below carry the value into the table)
+    }
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float w = 1;
@@ -482,19 +485,19 @@ static int ge_bwd_C(const T *grad, const float *inputs, const GridLevels &lv, fl
     const dim3 gin(cn_div_up(B * D, GE_BLOCK));
     switch (C) {
         case 1:
-            hipLaunchKernelGGL((k_grid_bwd<T, D, 1>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 1>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw, g_cn_found_inf);
             if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 1>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
             break;
         case 2:
-            hipLaunchKernelGGL((k_grid_bwd<T, D, 2>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 2>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw, g_cn_found_inf);
             if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 2>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
             break;
         case 4:
-            hipLaunchKernelGGL((k_grid_bwd<T, D, 4>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 4>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw, g_cn_found_inf);
             if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 4>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
             break;
         case 8:
-            hipLaunchKernelGGL((k_grid_bwd<T, D, 8>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw);
+            hipLaunchKernelGGL((k_grid_bwd<T, D, 8>), grid, block, 0, st, grad, inputs, lv, gemb, B, nl, nb, gridtype, ac, interp, sw, g_cn_found_inf);
             if (dy_dx) hipLaunchKernelGGL((k_input_bwd<T, D, 8>), gin, block, 0, st, grad, dy_dx, grad_inputs, B, L);
             break;
         default: return CNERF_EINVAL;

@@ -200,7 +200,8 @@ template <typename T>
 __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                          const BinPlan plan, const uint32_t *__restrict__ hist,
                                                          const uint32_t *__restrict__ bin_base, BinRec<T> *__restrict__ records, uint32_t B,
-                                                         uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
+                                                         uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid,
+                                                         float *__restrict__ found_inf) {
     __shared__ uint32_t cursor[BN_MAX_CHUNKS];
     const uint32_t level = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t nch = plan.bin_first[level + 1] - plan.bin_first[level];
@@ -221,7 +222,12 @@ __global__ void __launch_bounds__(BN_THREADS) k_bin_emit(const T *__restrict__ g
         const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
         const float g0 = ge_to_float(g.v[0]), g1 = ge_to_float(g.v[1]);
         if constexpr (sizeof(T) == 2) {                      // fixed-point sums: see b2_poison below
-            if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) grad_grid[((size_t)lv.offset[level] + index[0]) * 2] = __builtin_nanf("");
+            if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) {
+                grad_grid[((size_t)lv.offset[level] + index[0]) * 2] = __builtin_nanf("");
+                if (found_inf) *found_inf = 1.0f;
+            }
+        } else {
+            if ((!(fabsf(g0) <= 3.4e38f) || !(fabsf(g1) <= 3.4e38f)) && found_inf) *found_inf = 1.0f;      // (float32 records carry the value itself)
         }
         // one cursor update and one double-width store per x-pair of corners (see k_bin_hist); record order inside a bin is
         // irrelevant: fp16 sums are exact fixed point, fp32 sums are order-dependent at rounding level only
@@ -482,15 +488,20 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restric
 // The fixed-point sums cannot carry an infinity or a NaN (llrint of one is an arbitrary finite pattern), but the loss scaler finds overflow by
 // looking for exactly those in the gradients (the reference's half2 atomics propagate them: gridencoder.cu:324-337).  A non-finite incoming
 // gradient therefore poisons one of its destination entries directly; the accumulate's read-modify-write keeps it non-finite.
-__device__ __forceinline__ void b2_poison(float g0, float g1, float *__restrict__ grad_grid, const GridLevels &lv, uint32_t level, uint32_t entry) {
-    if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) grad_grid[((size_t)lv.offset[level] + entry) * 2] = __builtin_nanf("");
+__device__ __forceinline__ void b2_poison(float g0, float g1, float *__restrict__ grad_grid, const GridLevels &lv, uint32_t level, uint32_t entry,
+                                          float *__restrict__ found_inf) {
+    if (!(fabsf(g0) <= 65504.0f) || !(fabsf(g1) <= 65504.0f)) {
+        grad_grid[((size_t)lv.offset[level] + entry) * 2] = __builtin_nanf("");
+        if (found_inf) *found_inf = 1.0f;                                          // cnerf_scaler_watch (benign race: every writer stores the same value)
+    }
 }
 
 template <int PTS>
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                           const Bin2Plan plan, const uint32_t *__restrict__ hist,
                                                           const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0, float *__restrict__ grad_grid) {
+                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0, float *__restrict__ grad_grid,
+                                                          float *__restrict__ found_inf) {
     __shared__ uint32_t cursor[BN_MAX_CHUNKS];
     const uint32_t slot = slot0 + blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
     const uint32_t level = lv.order[slot];
@@ -510,7 +521,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
         b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
         const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
         const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
-        b2_poison(g0, g1, grad_grid, lv, level, i0[0]);
+        b2_poison(g0, g1, grad_grid, lv, level, i0[0], found_inf);
         const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
         union { __half2 h; uint32_t u; } v;
 #pragma unroll
@@ -548,7 +559,8 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restri
 __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                                  const Bin2Plan plan, const uint32_t *__restrict__ hist,
                                                                  const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                                 uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid) {
+                                                                 uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid,
+                                                                 float *__restrict__ found_inf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char b2s_lds[];       // one LDS object: records, bin ids, cursors, displacements
     uint2 *s_rec = reinterpret_cast<uint2 *>(b2s_lds);
     uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
@@ -598,7 +610,7 @@ __global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *_
             b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
             const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
             g0[i] = __half2float(g.v[0]); g1[i] = __half2float(g.v[1]);
-            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
+            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0], found_inf);
         }
     }
     __syncthreads();
@@ -889,7 +901,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
                                                           const Bin3Plan plan, uint32_t *__restrict__ runs, uint32_t *__restrict__ cursor,
                                                           uint2 *__restrict__ hslab, uint2 *__restrict__ dslab, uint32_t B,
                                                           uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
-                                                          uint32_t abl_arg) {
+                                                          uint32_t abl_arg, float *__restrict__ found_inf) {
 #ifdef CNERF_TUNING
     const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
 #else
@@ -953,7 +965,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
             } else {
                 b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
             }
-            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0]);
+            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0], found_inf);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (abl & 16) { tk[i][q] = 0; continue; }
@@ -1553,9 +1565,9 @@ static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &
     cn_stage(0, st);
     if (staged && b2_pts() == B2S_PTS && max_chunks <= B2S_MAX_CHUNKS)          // larger tables (T = 2^20, 2^21): direct emit below
         hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 8 + 16, st, grad, inputs, lv, plan, ws.hist,
-                           ws.bin_base, ws.slab, B, gridtype, ac, interp, gemb);
+                           ws.bin_base, ws.slab, B, gridtype, ac, interp, gemb, g_cn_found_inf);
     else switch (b2_pts()) {
-#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u, gemb); break;
+#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u, gemb, g_cn_found_inf); break;
         B2_EMIT(1024) B2_EMIT(2048) B2_EMIT(4096) B2_EMIT(8192)
 #undef B2_EMIT
     }
@@ -1684,7 +1696,7 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
     cn_stage(0, st);
     hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B3_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
-                       interp, gemb, nl, (uint32_t)b2_env("CNERF_B3_EMIT_ABL", 0));
+                       interp, gemb, nl, (uint32_t)b2_env("CNERF_B3_EMIT_ABL", 0), g_cn_found_inf);
     cn_stage(1, st);
     hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
                        plan, nl);
@@ -1755,7 +1767,7 @@ static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, f
     bn_layout(plan, B, nl, dtype, &ws, workspace);
     const dim3 grid1(plan.nb * nl);
     hipLaunchKernelGGL((k_bin_emit<T>), grid1, dim3(BN_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, (BinRec<T> *)ws.records, B,
-                       gridtype, ac, interp, gemb);
+                       gridtype, ac, interp, gemb, g_cn_found_inf);
     // upper bound of accumulate workgroups: every bin may add one partial segment
     const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64((uint64_t)B * nl * 8, BN_SEG);
     const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(typename BinAcc<T>::type) + 16;

@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(1024) k_adam_scaled_multi(CnerfAdamJobs jobs, 
 }
 
 void *g_cn_stage_events[CNERF_STAGE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+float *g_cn_found_inf = nullptr;
 
 extern "C" {
 
@@ -346,6 +347,11 @@ int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream) {
     const uint32_t blocks = (uint32_t)(want < 2048 ? (want ? want : 1) : 2048);
     hipLaunchKernelGGL(k_scaler_check, dim3(blocks), dim3(256), 0, CN_STREAM(stream), g, n, state);
     return cn_launch_status();
+}
+
+int cnerf_scaler_watch(float *state) {
+    g_cn_found_inf = state ? state + 2 : nullptr;
+    return CNERF_OK;
 }
 
 int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream) {

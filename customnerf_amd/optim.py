@@ -39,6 +39,12 @@ class DynamicLossScaler:
         require_cuda(flat_grads)
         check(lib.cnerf_scaler_check(ptr(flat_grads), flat_grads.numel(), ptr(self.state), stream()), "scaler_check")
 
+    def watch(self, on=True):
+        """cnerf_scaler_watch: while watched, the field backward and the grid scatter raise found_inf themselves when they produce a non-finite
+        gradient — a trainer whose gradients all come from those two (trainer.inf_check_is_folded) then skips check().  One watched scaler
+        per process: the trainers call this at the start of every step."""
+        check(lib.cnerf_scaler_watch(ptr(self.state) if on else None), "scaler_watch")
+
     def update(self):
         """GradScaler.update().  A no-op for the step whose FusedAdam.step() already applied it in the tail of its multi-tensor launch, so the
         standard idiom `opt.step(); scaler.update()` (the reference's Trainer, the drop-in flows) counts every step exactly once."""

@@ -80,6 +80,26 @@ def refresh_half_shadow(optimizer, model):
         enc.set_half_table(optimizer.half_shadows[enc.embeddings])   # the step just rewrote it: mark it current
 
 
+def inf_check_is_folded(trainer):
+    """Round 6: GradScaler's inf check is a pass over every gradient (9 us for the benchmark table, 30 us for the reference
+    field's).  With the scaler WATCHED (DynamicLossScaler.watch) the two kernels that produce the gradients raise found_inf themselves — the field
+    backward's partial reduction for the three MLPs, the scatter's emit for the table (a non-finite incoming gradient is the only way its exact
+    fixed-point sums can go non-finite) — so the pass is skipped when EVERY trainable parameter is one of those four tensors of a fused
+    half-precision NeRFNetwork and no gradient exchange runs in between (the exchange checks its own reduced shards)."""
+    m = trainer.model
+    if trainer.world_size != 1 or getattr(trainer, '_dp', None) is not None or trainer.scaler is None or not getattr(trainer, 'fused_adam', True):
+        return False
+    if not (hasattr(m, '_fused_cfg') and hasattr(m, '_half') and hasattr(m, 'pos_en') and getattr(m, 'grad_in_place', False)):
+        return False
+    try:
+        if not (m._fused_cfg() and m._half()):
+            return False
+        known = {id(m.pos_en.embeddings), id(m.network.params), id(m.density_network.params), id(m.rgb_network.params)}
+    except Exception:
+        return False
+    return all(id(p) in known for p in m.parameters() if p.requires_grad) and bool(getattr(trainer.opt, 'fold_inf_check', True))
+
+
 def check_grads_finite(scaler, parameters, flat):
     """GradScaler's inf check on the (all-reduced) gradients: one pass over the flat buffer when the gradients alias it."""
     grads = [p.grad for p in parameters if p.grad is not None]
@@ -139,7 +159,8 @@ def apply_optimizer_step(trainer):
     else:
         trainer.allreduce_grads()
         if trainer.scaler is not None:
-            check_grads_finite(trainer.scaler, list(trainer.model.parameters()), trainer._flat)      # on the all-reduced gradients: every rank takes the same skip decision
+            if not getattr(trainer, '_inf_folded', False):
+                check_grads_finite(trainer.scaler, list(trainer.model.parameters()), trainer._flat)  # on the all-reduced gradients: every rank takes the same skip decision
             trainer.optimizer.step()
             trainer.scaler.update()                                  # (a no-op when FusedAdam's multi-tensor launch of the small tensors already did it)
         else:
@@ -291,7 +312,21 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
         pick = lambda t, c: t.reshape(1, N, c).index_select(1, idx) if t is not None else None
         return pick(rays_o, 3), pick(rays_d, 3), pick(rgbs, 3), pick(mask, 1)
 
+    def _watch_scaler(self):
+        """at the start of every step: is the inf check folded into the gradient producers (inf_check_is_folded), and if so point them at this scaler"""
+        self._inf_folded = inf_check_is_folded(self)
+        if self.scaler is not None:
+            self.scaler.watch(self._inf_folded)
+
     def train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
+        self._watch_scaler()
+        try:
+            return self._train_step(rays_o, rays_d, rgbs, mask, select_inds, **render_kw)
+        finally:
+            if self.scaler is not None:
+                self.scaler.watch(False)                 # (the library holds a raw pointer into the scaler's state only for the duration of a step)
+
+    def _train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
         self.model.train()
         rays_o, rays_d, rgbs, mask = self.select_rays(rays_o, rays_d, rgbs, mask, select_inds)
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
@@ -349,12 +384,16 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             torch.cuda.synchronize()
             self.model.train()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')):
-                with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
-                    outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
-                    loss = self.loss(outputs, rgbs, mask)
-                self.scaler.backward(loss)
-                loss = loss.detach()
+            self._watch_scaler()
+            try:
+                with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')):
+                    with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
+                        outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
+                        loss = self.loss(outputs, rgbs, mask)
+                    self.scaler.backward(loss)
+                    loss = loss.detach()
+            finally:
+                self.scaler.watch(False)
             gen1 = scratch_generation()
             if gen1 != gen0 and cache:
                 # The workspaces are keyed by (device, stream): the ones a graph references belong to the CAPTURE stream and are allocated
@@ -367,6 +406,7 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             for k_ in list(cache):                                   # (entries that survived are valid for the current generation too)
                 cache[k_] = cache[k_][:3] + (gen1,)
         self.model.train()
+        self._inf_folded = inf_check_is_folded(self)                 # (the captured kernels carry the pointer they were captured with: this scaler's)
         ent[0].replay()
         apply_optimizer_step(self)
         self.global_step += 1

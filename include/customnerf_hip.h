@@ -419,6 +419,12 @@ int cnerf_adam_step(float *p, float *g, float *m, float *v, void *p_half, uint64
  *                          {scale *= growth, tracker = 0}}; found_inf = 0.  Call once per step after every adam_step_scaled.
  * ---------------------------------------------------------------------------------------------- */
 int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream);
+/* Round 6: while a scaler state is WATCHED (state != NULL; NULL switches it off — the default), the two gradient-producing entry points of the
+ * field raise its found_inf themselves on their launch stream: cnerf_field_backward* when a parameter gradient it writes is not finite,
+ * cnerf_grid_encode_backward* when an incoming feature gradient is not finite (the value it then also poisons the table gradient with).  A caller
+ * whose gradients ALL come from these entry points may skip cnerf_scaler_check (a pass over every gradient: 9 us for the benchmark table, 30 us
+ * for the reference field's).  One watched state per process; host-side switch, no launch. */
+int cnerf_scaler_watch(float *state);
 int cnerf_adam_step_scaled(float *p, float *g, float *m, float *v, void *p_half, uint64_t n, float lr, float beta1, float beta2,
                            float eps, const float *state, float extra_inv, int zero_grad, void *stream);
 int cnerf_scaler_update(float *state, float growth_factor, float backoff_factor, uint32_t growth_interval, void *stream);

@@ -815,3 +815,66 @@ def test_early_termination_flags_are_dropped_when_sigma_has_a_second_consumer():
     # and the control: with stale flags the sparsity gradient of the dead tiles would be missing — it is a large part of these gradients
     diff = max(float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(grads[(True, True)], grads[(False, True)]))
     assert diff > 1e-2, diff
+
+
+@pytest.mark.gpu
+def test_inf_check_is_folded_into_the_gradient_producers():
+    """with the scaler watched (cnerf_scaler_watch) the field backward and the grid scatter raise found_inf themselves, and the
+    trainer skips the pass over every gradient.  (1) the two producers raise the flag for a non-finite gradient — binned and atomic scatter sizes —
+    and leave it alone otherwise; (2) a training step whose targets contain an infinity is skipped exactly as with the explicit check: parameters
+    untouched, loss scale halved, gradients zeroed, the next clean step counts."""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.gridencoder import GridEncoder
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.optim import DynamicLossScaler
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+    try:
+        # (1) the scatter
+        sclr = DynamicLossScaler(torch.device("cuda"))
+        enc = GridEncoder(num_levels=16, log2_hashmap_size=19, desired_resolution=2048, gridtype='hash').cuda()
+        for B in (70001, 3000):                                  # binned (>= 2^20 pairs) and atomic scatter
+            x = torch.rand(B, 3, device="cuda") * 2 - 1
+            for bad in (False, True):
+                sclr.state[2] = 0.0
+                enc.embeddings.grad = None
+                out = enc.encode(x, bound=1.0, half=True)
+                g = torch.randn_like(out) * 0.01
+                if bad:
+                    g[7, B // 2, 1] = float("inf")
+                sclr.watch(True)
+                try:
+                    out.backward(g)
+                finally:
+                    sclr.watch(False)
+                assert float(sclr.state[2]) == (1.0 if bad else 0.0), (B, bad)
+                assert bool(torch.isfinite(enc.embeddings.grad).all()) == (not bad)
+        # (2) the trainer
+        H = W = 128
+        o, d, rgb, mask = _target_scene(H, W, 2)
+        results = {}
+        for fold in (True, False):
+            torch.manual_seed(0)
+            opt = sc.make_opt(fp16=True, fold_inf_check=fold)
+            model = NeRFNetwork(opt).cuda()
+            tr = ReconTrainer(model, opt, fp16=True)
+            kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+            tr.train_step(o[0], d[0], rgb[0], mask[0], **kw)
+            assert tr._inf_folded == fold
+            before = [p.detach().clone() for p in model.parameters()]
+            bad_rgb = rgb[1].clone()
+            bad_rgb[1234, 1] = float("inf")
+            loss, _ = tr.train_step(o[1], d[1], bad_rgb, mask[1], **kw)
+            st = tr.scaler.state.detach().cpu().tolist()
+            assert not np.isfinite(float(loss))
+            assert st[0] == 32768.0 and st[2] == 0.0 and st[3] == 1.0, st           # backed off, flag cleared, still one good step
+            for a, p in zip(before, model.parameters()):
+                assert torch.equal(a, p.detach())                                      # the optimiser step was skipped
+                assert bool((p.grad == 0).all())                                       # ... and the gradients were zeroed all the same
+            loss, _ = tr.train_step(o[0], d[0], rgb[0], mask[0], **kw)
+            assert np.isfinite(float(loss)) and tr.scaler.good_steps() == 2
+            results[fold] = [p.detach().clone() for p in model.parameters()]
+        for a, b in zip(results[True], results[False]):
+            assert torch.equal(a, b)                                                   # the folded check changes no bit of the training
+    finally:
+        tcnn.set_default_dtype(torch.float32)
