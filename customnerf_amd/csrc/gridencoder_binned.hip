@@ -1028,22 +1028,32 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
             }
         }
     } else if (threadIdx.x < 64) {
+        // 128 counters: lane l takes the bins 2 l and 2 l + 1 (run starts in bin order); their two reservations are ONE 64-bit returning atomic
+        // when the pair is aligned (round 6: the memory-side atomic unit is the resource, A.1 item 1 — 1.4 M reservations per step become 0.7 M)
         const uint32_t lane = threadIdx.x;
-        const uint32_t ca = cnt[lane], cb = cnt[lane + 64];
-        const uint32_t ia = cn_wave_incl_scan(ca);
-        const uint32_t tot_a = __shfl(ia, 63, 64);
-        const uint32_t ib = cn_wave_incl_scan(cb);
-        const uint32_t oa = ia - ca, ob = tot_a + ib - cb;
-        start[lane] = oa; start[lane + 64] = ob;
-        if (lane == 63) *s_total = tot_a + ib;
+        const uint32_t ca = cnt[2 * lane], cb = cnt[2 * lane + 1];
+        const uint32_t incl = cn_wave_incl_scan(ca + cb);
+        const uint32_t oa = incl - (ca + cb), ob = oa + ca;
+        start[2 * lane] = oa; start[2 * lane + 1] = ob;
+        if (lane == 63) *s_total = incl;
         if (dense_lvl) {
-            if (lane < nch && !(abl & 8)) runs[(size_t)(bin0 + lane) * nb + pb] = ca | (oa << 16);
-            if (lane + 64 < nch && !(abl & 8)) runs[(size_t)(bin0 + lane + 64) * nb + pb] = cb | (ob << 16);
+            if (2 * lane < nch && !(abl & 8)) runs[(size_t)(bin0 + 2 * lane) * nb + pb] = ca | (oa << 16);
+            if (2 * lane + 1 < nch && !(abl & 8)) runs[(size_t)(bin0 + 2 * lane + 1) * nb + pb] = cb | (ob << 16);
         } else if (!(abl & 1)) {
             // reserve room in the bin's region for what the staging area holds of the run (the rest, if any, is already in the block's region)
-            const uint32_t sa = oa >= B3_CAP ? 0u : min(ca, (uint32_t)B3_CAP - oa), sb = ob >= B3_CAP ? 0u : min(cb, (uint32_t)B3_CAP - ob);
-            if (lane < nch && sa) res_a = atomicAdd(&cursor[bin0 + lane], sa) & 0x7FFFFFFFu;
-            if (lane + 64 < nch && sb) res_b = atomicAdd(&cursor[bin0 + lane + 64], sb) & 0x7FFFFFFFu;
+            const uint32_t sa = (2 * lane < nch && oa < B3_CAP) ? min(ca, (uint32_t)B3_CAP - oa) : 0u;
+            const uint32_t sb = (2 * lane + 1 < nch && ob < B3_CAP) ? min(cb, (uint32_t)B3_CAP - ob) : 0u;
+            if ((bin0 & 1u) == 0) {
+                if (sa | sb) {
+                    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(cursor + bin0 + 2 * lane),
+                                                             (unsigned long long)sa | ((unsigned long long)sb << 32));
+                    res_a = (uint32_t)old & 0x7FFFFFFFu;
+                    res_b = (uint32_t)(old >> 32) & 0x7FFFFFFFu;
+                }
+            } else {
+                if (sa) res_a = atomicAdd(&cursor[bin0 + 2 * lane], sa) & 0x7FFFFFFFu;
+                if (sb) res_b = atomicAdd(&cursor[bin0 + 2 * lane + 1], sb) & 0x7FFFFFFFu;
+            }
         }
     }
     // bare barrier: only the LDS writes above (start[], *s_total) must have landed; __syncthreads() would also wait for the returning atomics
@@ -1104,7 +1114,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         const uint32_t capb = plan.capb;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t c = threadIdx.x + 64 * h;
+            const uint32_t c = 2 * threadIdx.x + h;
             const uint32_t n = cnt[c], st0 = start[c], res = h ? res_b : res_a;
             const uint32_t staged = st0 >= B3_CAP ? 0u : min(n, (uint32_t)B3_CAP - st0);
             const uint32_t room = res >= capb ? 0u : capb - res;
