@@ -531,25 +531,30 @@ def launch_ranks(args, argv, child_cmd=None, check_devices=True):
 
 
 def device_identity(dev):
-    """what distinguishes one physical GPU from another on this node: the driver's UUID when torch exposes it, else the PCI address"""
+    """what distinguishes one physical GPU from another on this node: the driver's UUID AND the PCI address (MI355X / torch 2.10: both are
+    exposed — uuid=65373131-..., pci_bus_id=220); None when neither is available (the guard below then cannot decide and says so)"""
     pr = torch.cuda.get_device_properties(dev)
-    for attr in ("uuid",):
-        v = getattr(pr, attr, None)
-        if v is not None and str(v) not in ("", "00000000-0000-0000-0000-000000000000"):
-            return f"uuid:{v}"
+    u = getattr(pr, "uuid", None)
+    u = str(u) if u is not None else ""
+    if u in ("", "00000000-0000-0000-0000-000000000000") or "object at" in u:
+        u = ""
     pci = tuple(getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    if any(x is not None for x in pci):
-        return f"pci:{pci}"
-    return f"index:{os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', ''))}:{dev.index}"
+    pci = ":".join(str(x) for x in pci) if all(x is not None for x in pci) else ""
+    return f"uuid={u}/pci={pci}" if (u or pci) else None
 
 
 def check_one_gpu_per_rank(dist, dev, world, rank, identities=None):
     """Two ranks on one GPU (a mis-set HIP_VISIBLE_DEVICES, a launcher that hands every rank LOCAL_RANK 0) show up in RCCL only as a hang or a
     'duplicate GPU' abort deep inside communicator creation.  Gather every rank's device identity and refuse to run unless they are all
-    different.  `identities` (tests): the gathered list, instead of a collective."""
+    different.  A rank whose identity is unknown (no UUID, no PCI address) cannot be judged: warn and go on.  `identities` (tests): the gathered
+    list, instead of a collective."""
     if identities is None:
         identities = [None] * world
         dist.all_gather_object(identities, device_identity(dev))
+    if any(i is None for i in identities):
+        if rank == 0:
+            print(f"bench.py: device identities unavailable on some ranks ({identities}): one-GPU-per-rank not verified", file=sys.stderr)
+        return identities
     if len(set(identities)) != world:
         raise SystemExit(f"rank {rank}: {world} ranks but {len(set(identities))} distinct GPUs ({identities}) — one process per GPU is required "
                          "(check HIP_VISIBLE_DEVICES / LOCAL_RANK)")

@@ -86,6 +86,8 @@ def test_one_gpu_per_rank_guard():
     with pytest.raises(SystemExit) as e:
         bench.check_one_gpu_per_rank(None, None, 4, 2, identities=["uuid:a", "uuid:b", "uuid:a", "uuid:d"])
     assert "3 distinct GPUs" in str(e.value) and "rank 2" in str(e.value)
+    # an identity that cannot be established (no UUID, no PCI address) is not a collision: warn, do not abort
+    assert bench.check_one_gpu_per_rank(None, None, 2, 0, identities=[None, "uuid=a/pci=0:1:0"]) == [None, "uuid=a/pci=0:1:0"]
 
 
 def test_one_gpu_per_rank_guard_over_gloo_world2(tmp_path):
