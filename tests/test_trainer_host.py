@@ -22,3 +22,98 @@ def test_batch_rays_draw_is_the_references_numpy_draw():
     assert len(set(want.tolist())) == 100                                  # without replacement
     shim.opt.batch_rays = 0                                                # default: the whole view, untouched
     assert ReconTrainer.select_rays(shim, rays_o, rays_d, rgbs, mask)[0] is rays_o
+
+
+class _FakeEvent:
+    def __init__(self, t, done=True):
+        self.t, self.done = t, done
+
+    def query(self):
+        return self.done
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def test_traversal_tuner_schedule_and_decision(monkeypatch):
+    """gridencoder.grid.TraversalTuner (round 6): both traversals on calls `first` and `first + 1` (order swapped), then every `period` calls; the
+    decision is taken from the four event pairs once ALL of them have completed (no blocking), with a 2 % margin; nothing is recorded or queried
+    while a hipGraph is being captured."""
+    from customnerf_amd.gridencoder import grid as G
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    t = G.TraversalTuner(first=2, period=8)
+    plans = [t.plan() for _ in range(12)]
+    assert plans[0] == plans[1] == [G.LEVEL_MAJOR]
+    assert plans[2] == [G.LEVEL_MAJOR, G.SAMPLE_MAJOR] and plans[3] == [G.SAMPLE_MAJOR, G.LEVEL_MAJOR]
+    assert plans[4:10] == [[G.LEVEL_MAJOR]] * 6 and plans[10] == [G.LEVEL_MAJOR, G.SAMPLE_MAJOR] and plans[11] == [G.SAMPLE_MAJOR, G.LEVEL_MAJOR]
+    # a finished trial: sample-major 10 % faster -> chosen; the decision needs all four pairs complete
+    t = G.TraversalTuner(first=0, period=100)
+    t.plan(); t.plan()
+    pend = _FakeEvent(3.0, done=False)
+    t.record(G.LEVEL_MAJOR, _FakeEvent(0.0), _FakeEvent(1.0)); t.record(G.SAMPLE_MAJOR, _FakeEvent(1.0), _FakeEvent(1.9))
+    t.record(G.SAMPLE_MAJOR, _FakeEvent(2.0), _FakeEvent(2.9)); t.record(G.LEVEL_MAJOR, _FakeEvent(3.0), pend)
+    assert t.plan() == [G.LEVEL_MAJOR] and not t.history                   # one pair still running: nothing decided, nothing blocked
+    pend.t, pend.done = 4.0, True
+    assert t.plan() == [G.SAMPLE_MAJOR] and t.choice == G.SAMPLE_MAJOR and len(t.history) == 1
+    assert abs(t.history[0][1] - 1.0) < 1e-9 and abs(t.history[0][2] - 0.9) < 1e-9
+    # inside the margin: the choice stays
+    t.pending = [(G.LEVEL_MAJOR, _FakeEvent(0.0), _FakeEvent(1.0)), (G.SAMPLE_MAJOR, _FakeEvent(0.0), _FakeEvent(0.995)),
+                 (G.LEVEL_MAJOR, _FakeEvent(0.0), _FakeEvent(1.0)), (G.SAMPLE_MAJOR, _FakeEvent(0.0), _FakeEvent(0.995))]
+    t.choice = G.LEVEL_MAJOR
+    t.plan()
+    assert t.choice == G.LEVEL_MAJOR
+    # under capture: the current choice, no event traffic
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    t2 = G.TraversalTuner(first=0, period=4)
+    t2.pending = [(G.LEVEL_MAJOR, None, None)] * 4                          # would raise if harvested
+    assert [t2.plan() for _ in range(6)] == [[G.LEVEL_MAJOR]] * 6
+
+
+def test_inf_check_fold_conditions():
+    """trainer.inf_check_is_folded: only a single-GPU fused half-precision field whose trainable parameters are exactly the four tensors the two
+    watched producers write may skip the explicit GradScaler check"""
+    from customnerf_amd.trainer import inf_check_is_folded
+
+    class P:
+        def __init__(self, t):
+            self.embeddings = t
+
+    class Net:
+        def __init__(self, t):
+            self.params = t
+
+    class Model:
+        grad_in_place = True
+
+        def __init__(self, extra=None, fused=True, half=True):
+            mk = lambda: torch.nn.Parameter(torch.zeros(4))
+            self.pos_en, self.network, self.density_network, self.rgb_network = P(mk()), Net(mk()), Net(mk()), Net(mk())
+            self.extra, self._f, self._h = extra, fused, half
+
+        def _fused_cfg(self):
+            return (32, 2, 4) if self._f else None
+
+        def _half(self):
+            return self._h
+
+        def parameters(self):
+            ps = [self.pos_en.embeddings, self.network.params, self.density_network.params, self.rgb_network.params]
+            return ps + ([self.extra] if self.extra is not None else [])
+
+    def trainer(model, **kw):
+        d = dict(model=model, world_size=1, _dp=None, scaler=object(), fused_adam=True, opt=argparse.Namespace())
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    assert inf_check_is_folded(trainer(Model()))
+    assert not inf_check_is_folded(trainer(Model(), world_size=2))
+    assert not inf_check_is_folded(trainer(Model(), _dp=object()))
+    assert not inf_check_is_folded(trainer(Model(), scaler=None))
+    assert not inf_check_is_folded(trainer(Model(fused=False)))
+    assert not inf_check_is_folded(trainer(Model(half=False)))
+    assert not inf_check_is_folded(trainer(Model(extra=torch.nn.Parameter(torch.zeros(2)))))      # a parameter nobody watches
+    frozen = torch.nn.Parameter(torch.zeros(2), requires_grad=False)
+    assert inf_check_is_folded(trainer(Model(extra=frozen)))                                       # ... unless it is not trained
+    assert not inf_check_is_folded(trainer(Model(), opt=argparse.Namespace(fold_inf_check=False)))
+    m = Model(); m.grad_in_place = False
+    assert not inf_check_is_folded(trainer(m))
