@@ -869,7 +869,10 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 // block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
 #define B3_CAP (B3_PTS * 4 + 640)
 #define B3_WIDE_CHUNKS BN_MAX_CHUNKS               // bins per level of a wide level (T = 2^21: 512 chunks of 4096 entries)
-#define B3_MAXT 72                               // LDS words pairs of the run walk: 65 prefix words + 64 run positions
+#ifndef B3_WALK_BLOCKS
+#define B3_WALK_BLOCKS 256                       // point blocks whose runs the run walk flattens at a time (a multiple of 64; round 6: 64 -> 256, see b3_walk_runs)
+#endif
+#define B3_MAXT (B3_WALK_BLOCKS + 8)             // LDS word pairs of the run walk: B3_WALK_BLOCKS + 1 prefix words + B3_WALK_BLOCKS run positions
 #define B3_REGION (B3_PTS * 8)                    // records a block may emit on one level (8 single records per sample): its region on a dense level
 
 struct Bin3Plan {
@@ -903,7 +906,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
                                                           uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
                                                           uint32_t abl_arg, float *__restrict__ found_inf) {
 #ifdef CNERF_TUNING
-    const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
+    const uint32_t abl = abl_arg & 0xFFu;          // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
 #else
     constexpr uint32_t abl = 0;
     (void)abl_arg;
@@ -924,6 +927,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     // the one-byte bin ids of the staged records (the copy-out then goes bin by bin instead of slot by slot), so that the workgroup's LDS
     // stays below half a CU's.  Block-uniform.
     const bool wide = nch > B2S_MAX_CHUNKS;
+    const bool bybin = wide || (abl_arg & 0x100u);                                   // (tuning builds, CNERF_B3_EMIT_ABL bit 8: the bin-by-bin copy-out on narrow levels too)
     const uint32_t NBN = wide ? B3_WIDE_CHUNKS : B2S_MAX_CHUNKS;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(b3_lds + (size_t)B3_CAP * (wide ? 8 : 9));
     uint32_t *start = cnt + NBN;
@@ -1070,7 +1074,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t ticket, uint32_t word, uint32_t val) {
             const uint32_t sl = start[c] + ticket;
-            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); if (!wide) s_bin[sl] = (uint8_t)c; }
+            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); if (!bybin) s_bin[sl] = (uint8_t)c; }
             else region[sl] = make_uint2(word, val);                                // beyond the staging capacity: straight into the block's region
         };
 #pragma unroll
@@ -1129,13 +1133,13 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     const uint32_t total = (abl & 2) ? 0u : min(*s_total, (uint32_t)B3_CAP);
     if (dense_lvl) {
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) region[sl] = s_rec[sl];
-    } else if (wide) {
-        // bin by bin, four bins per wave at a time (a run is ~16 records: sixteen lanes each); a bin's staged records are the slots
-        // [start, next start) below `total`
-        const uint32_t capb = plan.capb, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-        for (uint32_t c = grp; c < nch; c += B3_THREADS / 16) {
+    } else if (bybin) {
+        // bin by bin; a bin's staged records are the slots [start, next start) below `total`.  Wide levels: four bins per wave at a time (a run
+        // is ~16 records: sixteen lanes each); narrow levels (tuning switch): one bin per wave (~66 records)
+        const uint32_t capb = plan.capb, G = wide ? 16u : 64u, lg = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+        for (uint32_t c = grp; c < nch; c += B3_THREADS / G) {
             const uint32_t st0 = start[c], en = min(c + 1 < NBN ? start[c + 1] : *s_total, total), fit = cnt[c], gd = gdst[c];
-            for (uint32_t sl = st0 + l16; sl < en; sl += 16) {
+            for (uint32_t sl = st0 + lg; sl < en; sl += G) {
                 if (sl - st0 < fit) hslab[(size_t)(bin0 + c) * capb + (gd + sl)] = s_rec[sl];
                 else region[sl] = s_rec[sl];
             }
@@ -1272,34 +1276,49 @@ template <int W>
 __device__ __forceinline__ void b3_walk_runs(long long *acc, uint32_t *s_c, uint32_t *tiles, const uint32_t *__restrict__ rt, const uint32_t *__restrict__ pt,
                                              const uint2 *__restrict__ lvl_slab, uint32_t nb, uint32_t pb_first, uint32_t begin, uint32_t end) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t *s_pre = tiles, *s_base = tiles + 65;                                  // [65] exclusive prefix of the clipped run lengths (+ total), [64] first record of each
-    for (uint32_t pb0 = pb_first; pb0 < nb; pb0 += 64) {
+    // B3_WALK_BLOCKS runs at a time (round 6: 256 — with 64, a level whose (block, bin) runs are short gave the 8192 record slots of an iteration
+    // a few thousand records and paid two barriers per 64 blocks: the reference field's level 4 has 156 bins, ~53 records per run)
+    constexpr uint32_t CB = B3_WALK_BLOCKS, KPL = CB / 64;
+    uint32_t *s_pre = tiles, *s_base = tiles + CB + 1;                              // [CB + 1] exclusive prefix of the clipped run lengths (+ total), [CB] first record of each
+    for (uint32_t pb0 = pb_first; pb0 < nb; pb0 += CB) {
         if (threadIdx.x < 64) {
-            const uint32_t pbl = pb0 + lane;
-            uint32_t p_j = 0xFFFFFFFFu, r_j = 0;
-            if (pbl < nb) { p_j = pt[pbl]; r_j = rt[pbl]; }
-            uint32_t lo = 0, hi = 0;
-            if (p_j < end) {
-                const uint32_t c_j = r_j & 0xFFFFu;
-                lo = max(p_j, begin) - p_j;
-                hi = max(min(p_j + c_j, end), p_j) - p_j;
-                if (hi < lo) hi = lo;
+            uint32_t len[KPL], base[KPL], loc = 0, p_last = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < KPL; k++) {
+                const uint32_t pbl = pb0 + lane * KPL + k;
+                uint32_t p_j = 0xFFFFFFFFu, r_j = 0;
+                if (pbl < nb) { p_j = pt[pbl]; r_j = rt[pbl]; }
+                uint32_t lo = 0, hi = 0;
+                if (p_j < end) {
+                    const uint32_t c_j = r_j & 0xFFFFu;
+                    lo = max(p_j, begin) - p_j;
+                    hi = max(min(p_j + c_j, end), p_j) - p_j;
+                    if (hi < lo) hi = lo;
+                }
+                len[k] = hi - lo;
+                base[k] = pbl * B3_REGION + (r_j >> 16) + lo;
+                loc += len[k];
+                p_last = p_j;
             }
-            const uint32_t len = hi - lo;
-            const uint32_t incl = cn_wave_incl_scan(len);
-            s_pre[lane] = incl - len;
-            s_base[lane] = pbl * B3_REGION + (r_j >> 16) + lo;
-            if (lane == 63) { s_pre[64] = incl; s_c[1] = p_j >= end ? 1u : 0u; }    // 1 = the segment ends inside this chunk
+            const uint32_t incl = cn_wave_incl_scan(loc);
+            uint32_t run = incl - loc;
+#pragma unroll
+            for (uint32_t k = 0; k < KPL; k++) {
+                s_pre[lane * KPL + k] = run;
+                s_base[lane * KPL + k] = base[k];
+                run += len[k];
+            }
+            if (lane == 63) { s_pre[CB] = incl; s_c[1] = p_last >= end ? 1u : 0u; } // 1 = the segment ends inside this chunk
         }
         __syncthreads();
-        const uint32_t total = s_pre[64], last = s_c[1];
+        const uint32_t total = s_pre[CB], last = s_c[1];
         // (Round 6, measured and dropped: a STRIDED assignment — lane l of a wave takes sample l of one (y, z) row of W neighbouring rays, so that
         // the lanes of an instruction are 64 different depths and a lane's W records share a cell across rays — 369 -> 389 us at random init and
         // 194 -> 383 us on a fitted field: profiles/r06_gather_scatter_ab.txt.  Consecutive records per lane it stays.)
         for (uint32_t f0 = threadIdx.x * W; f0 < total; f0 += 1024 * W) {
             uint32_t j = 0;                                                         // largest j with s_pre[j] <= f0
 #pragma unroll
-            for (uint32_t step = 32; step; step >>= 1)
+            for (uint32_t step = CB / 2; step; step >>= 1)
                 if (s_pre[j + step] <= f0) j += step;
             uint32_t idx[W];
             bool ok4[W];
