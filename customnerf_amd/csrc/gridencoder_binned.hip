@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
                                                           uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
                                                           uint32_t abl_arg, float *__restrict__ found_inf) {
 #ifdef CNERF_TUNING
-    const uint32_t abl = abl_arg & 0xFFu;          // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
+    const uint32_t abl = abl_arg;                  // timing aid (results wrong): 1 no reservations, 2 no copy-out, 4 no phase 2, 8 no run-table stores, 16 no tickets, 32 no corner arithmetic, 64 no loads
 #else
     constexpr uint32_t abl = 0;
     (void)abl_arg;
@@ -927,7 +927,6 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     // the one-byte bin ids of the staged records (the copy-out then goes bin by bin instead of slot by slot), so that the workgroup's LDS
     // stays below half a CU's.  Block-uniform.
     const bool wide = nch > B2S_MAX_CHUNKS;
-    const bool bybin = wide || (abl_arg & 0x100u);                                   // (tuning builds, CNERF_B3_EMIT_ABL bit 8: the bin-by-bin copy-out on narrow levels too)
     const uint32_t NBN = wide ? B3_WIDE_CHUNKS : B2S_MAX_CHUNKS;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(b3_lds + (size_t)B3_CAP * (wide ? 8 : 9));
     uint32_t *start = cnt + NBN;
@@ -1074,7 +1073,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         union { __half2 h; uint32_t u; } v;
         auto put = [&](uint32_t c, uint32_t ticket, uint32_t word, uint32_t val) {
             const uint32_t sl = start[c] + ticket;
-            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); if (!bybin) s_bin[sl] = (uint8_t)c; }
+            if (sl < B3_CAP) { s_rec[sl] = make_uint2(word, val); if (!wide) s_bin[sl] = (uint8_t)c; }
             else region[sl] = make_uint2(word, val);                                // beyond the staging capacity: straight into the block's region
         };
 #pragma unroll
@@ -1133,13 +1132,14 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     const uint32_t total = (abl & 2) ? 0u : min(*s_total, (uint32_t)B3_CAP);
     if (dense_lvl) {
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) region[sl] = s_rec[sl];
-    } else if (bybin) {
-        // bin by bin; a bin's staged records are the slots [start, next start) below `total`.  Wide levels: four bins per wave at a time (a run
-        // is ~16 records: sixteen lanes each); narrow levels (tuning switch): one bin per wave (~66 records)
-        const uint32_t capb = plan.capb, G = wide ? 16u : 64u, lg = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-        for (uint32_t c = grp; c < nch; c += B3_THREADS / G) {
+    } else if (wide) {
+        // bin by bin, four bins per wave at a time (a run is ~16 records: sixteen lanes each); a bin's staged records are the slots
+        // [start, next start) below `total`.  (Measured on the narrow levels too — one bin per wave, no bin-id bytes in the staging area: emit
+        // 469 -> 485 us, fitted 266 -> 304: the flat slot-by-slot copy below stays for them, profiles/r06_scatter_walk_bybin_ab.txt.)
+        const uint32_t capb = plan.capb, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+        for (uint32_t c = grp; c < nch; c += B3_THREADS / 16) {
             const uint32_t st0 = start[c], en = min(c + 1 < NBN ? start[c + 1] : *s_total, total), fit = cnt[c], gd = gdst[c];
-            for (uint32_t sl = st0 + lg; sl < en; sl += G) {
+            for (uint32_t sl = st0 + l16; sl < en; sl += 16) {
                 if (sl - st0 < fit) hslab[(size_t)(bin0 + c) * capb + (gd + sl)] = s_rec[sl];
                 else region[sl] = s_rec[sl];
             }
