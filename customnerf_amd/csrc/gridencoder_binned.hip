@@ -868,7 +868,6 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 // staging capacity in records: a hashed level emits 4.125 records per sample on average (one x-pair in 32 leaves as two singles: 8448 +- 31 per
 // block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
 #define B3_CAP (B3_PTS * 4 + 640)
-#define B3_REGION_MIN_BINS 32                      // dense levels of at least this many bins take regions (contiguous bins) instead of block-major runs
 #define B3_WIDE_CHUNKS BN_MAX_CHUNKS               // bins per level of a wide level (T = 2^21: 512 chunks of 4096 entries)
 #ifndef B3_WALK_BLOCKS
 #define B3_WALK_BLOCKS 256                       // point blocks whose runs the run walk flattens at a time (a multiple of 64; round 6: 64 -> 256, see b3_walk_runs)
@@ -878,8 +877,7 @@ __global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__re
 
 struct Bin3Plan {
     Bin2Plan p;
-    uint32_t capb_s[GE_MAX_LEVELS];                // slot -> record capacity of a bin's region on that level (0: block-major dense level, no regions)
-    uint32_t reg0[GE_MAX_LEVELS];                  // slot -> first record of the level's regions inside the bin-major slab
+    uint32_t capb;                                 // record capacity of a hashed bin's region
     uint32_t dense_slot[GE_MAX_LEVELS];            // slot -> index among the dense slots (block-major regions), or 0xFFFFFFFF for a hashed level
     uint8_t hbits[GE_MAX_LEVELS];                  // hashed slot: log2(bins of the level)
 };
@@ -934,15 +932,9 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     uint32_t *start = cnt + NBN;
     uint32_t *gdst = start + NBN;                                                   // hashed: first record of the block's run inside the bin's region
     uint32_t *s_total = gdst + NBN;
-    // three kinds of level: block-major dense (dense_lvl: a few heavy bins, runs in the block's own region), REGION levels with interleaved bins
-    // (hashed / wrapped tiled) and — round 6 — region levels with CONTIGUOUS bins (hb == 0xFF: dense levels of B3_REGION_MIN_BINS bins and more,
-    // whose short block-major runs made the accumulate's run walk slow)
-    const bool contig = dense_lvl || hb == 0xFFu;
-    const uint32_t capb = plan.capb_s[slot];
-    uint2 *__restrict__ hreg = hslab + plan.reg0[slot];                              // the level's regions: bin c at hreg + c * capb
-    auto bin_of = [&](uint32_t e) { return contig ? e >> BN_CHUNK_LOG2 : b3_bin_of(e, hb); };
-    auto local_of = [&](uint32_t e) { return contig ? e & (BN_CHUNK - 1) : b3_local_of(e, hb); };
-    auto paired = [&](uint32_t a, uint32_t b) { return contig ? b2_paired(a, b) : b3_paired_h(a, b); };
+    auto bin_of = [&](uint32_t e) { return dense_lvl ? e >> BN_CHUNK_LOG2 : b3_bin_of(e, hb); };
+    auto local_of = [&](uint32_t e) { return dense_lvl ? e & (BN_CHUNK - 1) : b3_local_of(e, hb); };
+    auto paired = [&](uint32_t a, uint32_t b) { return dense_lvl ? b2_paired(a, b) : b3_paired_h(a, b); };
     if (threadIdx.x < NBN) cnt[threadIdx.x] = 0;
     __syncthreads();
     constexpr int PPT = B3_PTS / B3_THREADS;
@@ -982,7 +974,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
                 if (abl & 16) { tk[i][q] = 0; continue; }
                 const uint32_t c0 = bin_of(i0[i][q]);
                 if (paired(i0[i][q], i1[i][q])) {
-                    tk[i][q] = contig ? b2_ticket(cnt, c0) : atomicAdd(&cnt[c0], 1u);
+                    tk[i][q] = dense_lvl ? b2_ticket(cnt, c0) : atomicAdd(&cnt[c0], 1u);
                 } else {
                     const uint32_t t0 = atomicAdd(&cnt[c0], 1u);
                     const uint32_t t1 = atomicAdd(&cnt[bin_of(i1[i][q])], 1u);
@@ -1103,7 +1095,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
     }
     if (!dense_lvl && wide) {
         if (threadIdx.x <= NBN / 2) {                                               // (the pair's two bins; the arithmetic of the narrow form below)
-            const uint32_t b_lo = ((bin0 >> 1) + threadIdx.x) * 2u;
+            const uint32_t capb = plan.capb, b_lo = ((bin0 >> 1) + threadIdx.x) * 2u;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t c = b_lo + h - bin0;
@@ -1122,6 +1114,7 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         // what of the run fits the bin's region goes there; the rest SPILLS: it stays in the block's region (where the staging order puts it anyway)
         // and the run table says so — the accumulate workgroup of an overflowed bin walks those runs after its region.  Records beyond the staging
         // capacity (already in the block's region) count as spilled whatever the cursor says.
+        const uint32_t capb = plan.capb;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t c = 2 * threadIdx.x + h;
@@ -1143,19 +1136,20 @@ __global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__res
         // bin by bin, four bins per wave at a time (a run is ~16 records: sixteen lanes each); a bin's staged records are the slots
         // [start, next start) below `total`.  (Measured on the narrow levels too — one bin per wave, no bin-id bytes in the staging area: emit
         // 469 -> 485 us, fitted 266 -> 304: the flat slot-by-slot copy below stays for them, profiles/r06_scatter_walk_bybin_ab.txt.)
-        const uint32_t l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+        const uint32_t capb = plan.capb, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
         for (uint32_t c = grp; c < nch; c += B3_THREADS / 16) {
             const uint32_t st0 = start[c], en = min(c + 1 < NBN ? start[c + 1] : *s_total, total), fit = cnt[c], gd = gdst[c];
             for (uint32_t sl = st0 + l16; sl < en; sl += 16) {
-                if (sl - st0 < fit) hreg[(size_t)c * capb + (gd + sl)] = s_rec[sl];
+                if (sl - st0 < fit) hslab[(size_t)(bin0 + c) * capb + (gd + sl)] = s_rec[sl];
                 else region[sl] = s_rec[sl];
             }
         }
     } else {
+        const uint32_t capb = plan.capb;
         for (uint32_t sl = threadIdx.x; sl < total; sl += B3_THREADS) {
             const uint32_t c = s_bin[sl];
             const uint32_t pos = gdst[c] + sl;                                      // (wrapping 32-bit arithmetic: gdst = reservation - run start)
-            if (sl - start[c] < cnt[c]) hreg[(size_t)c * capb + pos] = s_rec[sl];
+            if (sl - start[c] < cnt[c]) hslab[(size_t)(bin0 + c) * capb + pos] = s_rec[sl];
             else region[sl] = s_rec[sl];
         }
     }
@@ -1176,7 +1170,7 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t 
     if (hashed) {
         const uint32_t cw = cursor[bin], c = cw & 0x7FFFFFFFu;                      // bit 31: some block spilled a run of this bin
         if (!(cw >> 31)) {
-            if (threadIdx.x == 0) bin_total[bin] = min(c, plan.capb_s[slot]);
+            if (threadIdx.x == 0) bin_total[bin] = min(c, plan.capb);
             return;
         }
     }
@@ -1213,7 +1207,7 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t 
         __syncthreads();
     }
     // (a hashed bin's record index space: what its region holds, then its spilled runs)
-    if (tid == 0) bin_total[bin] = hashed ? min(cursor[bin] & 0x7FFFFFFFu, plan.capb_s[slot]) + carry : carry;
+    if (tid == 0) bin_total[bin] = hashed ? min(cursor[bin] & 0x7FFFFFFFu, plan.capb) + carry : carry;
 }
 
 // flush of a finished LDS image: sole owner -> read-modify-write of the gradient table; a split bin parks its fixed-point image.
@@ -1249,8 +1243,8 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     uint32_t slot = 0;
     while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
     const uint32_t level = lv.order[slot];
+    const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu;
     const uint32_t hb = plan.hbits[slot], cb = bin - plan.p.bin_first[slot];
-    const bool dense_lvl = plan.dense_slot[slot] != 0xFFFFFFFFu || hb == 0xFFu;          // contiguous 4096-entry chunk (block-major dense level, or a dense region level)
     const uint32_t e0 = dense_lvl ? cb << BN_CHUNK_LOG2 : 0u;
     const uint32_t n_entries = dense_lvl ? min(BN_CHUNK, lv.size[level] - e0) : min(BN_CHUNK, lv.size[level] >> hb);
     const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // group of four values (two local entries x two channels)
@@ -1382,7 +1376,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
         uint32_t lo = 0;
         const bool hashed = plan.dense_slot[slot] == 0xFFFFFFFFu;
         const uint32_t cw = hashed ? cursor[bin] : 0u;
-        const uint32_t treg = hashed ? min(cw & 0x7FFFFFFFu, plan.capb_s[slot]) : 0u;   // records in the bin's region (region levels); the run space starts behind them
+        const uint32_t treg = hashed ? min(cw & 0x7FFFFFFFu, plan.capb) : 0u;      // records in the bin's region (hashed); the run space starts behind them
         uint32_t begin = (gseg - seg_first[bin]) * seg_records;
         if (!hashed || ((cw >> 31) && begin > treg)) {
             // first run that reaches into [begin, ...): the last block whose prefix is <= begin
@@ -1407,7 +1401,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
     const uint2 *__restrict__ lvl_slab = dslab + (size_t)slot * nb * B3_REGION;
     if (plan.dense_slot[slot] == 0xFFFFFFFFu) {
         // ---- hashed level: the bin's records are one contiguous range of its region (the second form's stream: 16-byte loads, two records per lane)
-        const uint2 *__restrict__ slab = hslab + plan.reg0[slot] + (size_t)(bin - plan.p.bin_first[slot]) * plan.capb_s[slot];   // (capacities and offsets are even: 16-byte aligned)
+        const uint2 *__restrict__ slab = hslab + (size_t)bin * plan.capb;           // (capb is even: the region starts 16-byte aligned)
         uint32_t b2 = min(begin, treg), e2 = min(end, treg);                          // the segment's part of the region
         if ((b2 & 1u) && b2 < e2) { if (threadIdx.x == 0) b2_add_record(acc, slab[b2]); b2++; }
         if ((e2 & 1u) && b2 < e2) { e2--; if (threadIdx.x == 0) b2_add_record(acc, slab[e2]); }
@@ -1631,40 +1625,26 @@ static bool b3_is_dense(const GridLevels &lv, uint32_t level) {                 
 
 // -> false when a level is neither dense nor a power-of-two hashed level of at least 2^(12 + B3_K) ... entries (tiled levels that wrap, odd sizes):
 // such tables keep the second form
-static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense, uint64_t *h_records = nullptr) {
+static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense) {
     b2_plan(lv, nl, B, plan.p);
     plan.p.nb = cn_div_up(B, B3_PTS);
     n_dense = 0;
+    uint64_t cap = 0;
     bool ok = true;
-    static const uint32_t region_min = (uint32_t)b2_env("CNERF_B3_REGION_MIN_BINS", B3_REGION_MIN_BINS);
-    uint64_t reg = 0;
-    for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) { plan.dense_slot[s] = 0xFFFFFFFFu; plan.hbits[s] = 0; plan.capb_s[s] = 0; plan.reg0[s] = 0; }
+    for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) { plan.dense_slot[s] = 0xFFFFFFFFu; plan.hbits[s] = 0; }
     for (uint32_t s = 0; s < nl; s++) {
         const uint32_t level = lv.order[s], size = lv.size[level];
+        if (b3_is_dense(lv, level)) { plan.dense_slot[s] = n_dense++; continue; }
         const uint32_t nch = plan.p.bin_first[s + 1] - plan.p.bin_first[s];
-        uint64_t c;
-        if (b3_is_dense(lv, level)) {
-            if (nch < region_min) { plan.dense_slot[s] = n_dense++; continue; }       // a few heavy, uneven bins: block-major runs
-            // a dense level of many bins: contiguous bins with regions (hbits 0xFF).  Its bins are spatial slabs — loads follow the scene — so
-            // the capacity is twice the mean (what still does not fit spills, as everywhere)
-            plan.hbits[s] = 0xFFu;
-            const uint64_t mean = (uint64_t)B * 4 / nch;
-            c = 2 * mean + 16384;
-        } else {
-            if ((size & (size - 1)) != 0 || (nch & (nch - 1)) != 0 || size != nch * BN_CHUNK) ok = false;  // interleaved bins need 2^k bins of exactly 4096 entries
-            uint32_t hb = 0;
-            while ((1u << hb) < nch) hb++;
-            plan.hbits[s] = (uint8_t)hb;
-            const uint64_t mean = (uint64_t)B * 17 / 4 / nch;                      // four pair records per sample (one in 16 travels as two singles), spread evenly by the interleave
-            c = mean + mean / 2 + 8192;
-        }
-        c = (c + 1) & ~(uint64_t)1;
-        if (c > 0x7FFFFFF0ull || reg + c * nch >= 0xF0000000ull) { ok = false; c = 2; }
-        plan.capb_s[s] = (uint32_t)c;
-        plan.reg0[s] = (uint32_t)reg;
-        reg += c * nch;
+        if ((size & (size - 1)) != 0 || (nch & (nch - 1)) != 0 || size != nch * BN_CHUNK) ok = false;      // interleaved bins need 2^k bins of exactly 4096 entries
+        uint32_t hb = 0;
+        while ((1u << hb) < nch) hb++;
+        plan.hbits[s] = (uint8_t)hb;
+        const uint64_t mean = (uint64_t)B * 17 / 4 / nch;                          // four pair records per sample (one in 16 travels as two singles), spread evenly by the interleave
+        const uint64_t c = mean + mean / 2 + 8192;
+        cap = cap > c ? cap : c;
     }
-    if (h_records) *h_records = reg;
+    plan.capb = (uint32_t)((cap + 1) & ~(uint64_t)1);
     return ok;
 }
 
@@ -1681,6 +1661,7 @@ static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype,
     if (!b3_plan(lv, nl, B, plan, nd)) return false;
     const uint32_t mc = b2_max_chunks(plan.p, nl);
     if (mc > (wide_on ? (uint32_t)B3_WIDE_CHUNKS : (uint32_t)B2S_MAX_CHUNKS)) return false;
+    if ((uint64_t)plan.p.total_bins * plan.capb >= 0xF0000000ull) return false;           // record positions inside the bin-major slab stay 32-bit in the accumulate
     return (uint64_t)nl * plan.p.nb * B3_REGION < 0xF0000000ull && (uint64_t)B * 8 < 0x7FFFFFFFull;
 }
 
@@ -1692,8 +1673,7 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
     const uint64_t o_cur = off; off = bn_align(off + ((uint64_t)p2.total_bins + 2) * 4);       // (+ the partner word of a 64-bit pair reservation past the last bin)
     const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
-    uint64_t h_records = 0;                                                        // bin-major regions of the region levels
-    for (uint32_t sl = 0; sl < nl; sl++) h_records += (uint64_t)plan.capb_s[sl] * (p2.bin_first[sl + 1] - p2.bin_first[sl]);
+    const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
     const uint64_t d_records = (uint64_t)nl * p2.nb * B3_REGION;                   // the point blocks' private regions: every record of a dense level, the spill of a hashed one
     (void)n_dense;
     const uint64_t o_h = off; off = bn_align(off + h_records * 8);
