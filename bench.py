@@ -16,6 +16,7 @@ either timed region.  Prints ONE JSON line from rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -437,6 +438,17 @@ def run_recon(args, world, rank, dev):
     return result
 
 
+def _json_safe(x):
+    """strict JSON has no NaN / Infinity: a non-finite float (a diverged loss) goes out as null, so that the one record line always parses"""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _json_safe(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_json_safe(v) for v in x]
+    return x
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -756,7 +768,7 @@ def main():
         result["rccl_ranks"] = rccl_ranks
         if backend != "nccl":
             result["collective_backend"] = backend + " (host-staged: test mode, no links)"
-        os.write(record_fd, (json.dumps(result) + "\n").encode())
+        os.write(record_fd, (json.dumps(_json_safe(result)) + "\n").encode())
     os.close(record_fd)
     if world > 1:
         dist.barrier()

@@ -113,3 +113,11 @@ def test_one_gpu_per_rank_guard_over_gloo_world2(tmp_path):
         assert all((p.returncode != 0) == bool(want) for p in procs), outs
         if want:
             assert all("1 distinct GPUs" in o for o in outs), outs
+
+
+def test_record_line_is_strict_json():
+    """a diverged loss must not put NaN / Infinity into the one record line (strict JSON parsers reject them)"""
+    import bench
+    rec = bench._json_safe({"value": 1.0, "config": {"final_loss": float("nan"), "xs": [float("inf"), 2.0, (3.0, float("-inf"))]}})
+    text = json.dumps(rec, allow_nan=False)
+    assert json.loads(text) == {"value": 1.0, "config": {"final_loss": None, "xs": [None, 2.0, [3.0, None]]}}
