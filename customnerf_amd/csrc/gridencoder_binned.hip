@@ -21,6 +21,11 @@
 // Traffic: 8 corners x 16 levels x 8 B = 1 KiB/sample written + read once — about the algorithmic RMW bytes of the
 // scatter itself (2048 B/sample fp32), all of it coalesced or L2-merged.
 // D = 3, C = 2 only (the configuration CustomNeRF uses); other shapes take the atomic kernel in gridencoder.hip.
+//
+// Forms in this file (round 6): the FIRST form described above (k_bin_*: histogram + scans + one record per corner) serves float32 records and the
+// fp16 shapes the third form does not take (hashed levels smaller than one bin, more than 512 bins per level); the THIRD form (k_bin3_*: no histogram,
+// 8-byte pair records, block-local counting, fixed-capacity bin regions with spill) serves everything CustomNeRF runs — the benchmark table and the
+// reference field's own 2^21-entry table.  The second form (histogram-driven pair records, rounds 2-4) is gone; its record format lives on.
 #include "grid_common.h"
 
 #define BN_CHUNK_LOG2 12
@@ -343,7 +348,8 @@ __global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict_
 }
 
 
-// ================================================================================================ fp16 records, second form
+// ================================================================================================ fp16 pair records (rounds 2-4: the "second form"; its
+// histogram-driven emit / accumulate kernels were removed in round 6 — what follows is the record format and the helpers the third form keeps)
 // What the first form above pays for (rocprofv3, 2.1 M samples x 16 levels): 2.1 GB of records written by 16-byte stores that land in
 // up to 128 bins per wave instruction, then read back — emit 1.0 ms + accumulate 0.55 ms, one after the other.  Measured on the side
 // (scratch/mall_bench.hip, scratch/lds_atomic_bench.hip): (i) the LDS integer atomics are NOT the accumulate's limit (>= 1.6 T
@@ -359,9 +365,6 @@ __global__ void __launch_bounds__(1024) k_bin_accum(const BinRec<T> *__restrict_
 // Sums stay 64-bit fixed point with 24 fractional bits (order-independent, so bit-deterministic wherever one workgroup owns a chunk);
 // the per-corner products are rounded to that grid instead of to binary16 (the reference rounds w*g to half, gridencoder.cu:328: the
 // difference is below one half ulp of each product).
-#ifndef B2_THREADS
-#define B2_THREADS 1024
-#endif
 #define B2_SEG_MIN ((1u << 16) + (1u << 13))       // records per accumulate workgroup, see b2_seg()
 #define B2_SINGLE 15u
 
@@ -371,13 +374,6 @@ struct Bin2Plan {
     uint32_t total_bins;
 };
 
-struct Bin2Ws {
-    uint32_t *hist, *bin_base, *seg_first;
-    uint2 *slab;
-    long long *partial;
-    uint32_t *seg_bin;
-    uint64_t max_seg;
-};
 
 // the four (y, z) corner pairs of a sample on one level: entries of the x and x+1 corner, the weight of the pair, the x fraction
 __device__ __forceinline__ void b2_pairs(const float (&in)[3], const GridLevels &lv, uint32_t level, uint32_t gridtype, bool align_corners,
@@ -453,38 +449,6 @@ __device__ __forceinline__ uint32_t b2_ticket(uint32_t *counters, uint32_t c) {
     return atomicAdd(&counters[c], 1u);
 }
 
-// (pb0, nbl): the launch covers point blocks pb0 .. pb0 + nbl - 1 of every level — the histogram of a sample list may be taken in several
-// launches, each as soon as its rows exist (cnerf_grid_encode_backward_prepare_rows)
-template <int PTS>
-__global__ void __launch_bounds__(B2_THREADS) k_bin2_hist(const float *__restrict__ inputs, const GridLevels lv, const Bin2Plan plan,
-                                                          uint32_t *__restrict__ hist, uint32_t B, uint32_t gridtype, int align_corners,
-                                                          uint32_t interp, uint32_t pb0, uint32_t nbl) {
-    __shared__ uint32_t cnt[BN_MAX_CHUNKS];
-    const uint32_t slot = blockIdx.x / nbl, pb = pb0 + blockIdx.x % nbl;
-    const uint32_t level = lv.order[slot];
-    const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
-    if (threadIdx.x < BN_MAX_CHUNKS) cnt[threadIdx.x] = 0;
-    const bool dense = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PTS / B2_THREADS; i++) {
-        const uint32_t b = pb * PTS + i * B2_THREADS + threadIdx.x;
-        float in[3];
-        if (!bn_load_point(inputs, b, B, in)) continue;
-        uint32_t i0[4], i1[4];
-        float wyz[4], fx;
-        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (dense) (void)b2_ticket(cnt, i0[q] >> BN_CHUNK_LOG2);              // a wave's samples share the chunk: one aggregated update
-            else atomicAdd(&cnt[i0[q] >> BN_CHUNK_LOG2], 1u);                      // hashed: the chunks are unrelated, skip the uniformity test
-            if (!b2_paired(i0[q], i1[q])) atomicAdd(&cnt[i1[q] >> BN_CHUNK_LOG2], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < nch) hist[(size_t)(plan.bin_first[slot] + threadIdx.x) * plan.nb + pb] = cnt[threadIdx.x];
-}
-
 // The fixed-point sums cannot carry an infinity or a NaN (llrint of one is an arbitrary finite pattern), but the loss scaler finds overflow by
 // looking for exactly those in the gradients (the reference's half2 atomics propagate them: gridencoder.cu:324-337).  A non-finite incoming
 // gradient therefore poisons one of its destination entries directly; the accumulate's read-modify-write keeps it non-finite.
@@ -496,159 +460,9 @@ __device__ __forceinline__ void b2_poison(float g0, float g1, float *__restrict_
     }
 }
 
-template <int PTS>
-__global__ void __launch_bounds__(B2_THREADS) k_bin2_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
-                                                          const Bin2Plan plan, const uint32_t *__restrict__ hist,
-                                                          const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                          uint32_t gridtype, int align_corners, uint32_t interp, uint32_t slot0, float *__restrict__ grad_grid,
-                                                          float *__restrict__ found_inf) {
-    __shared__ uint32_t cursor[BN_MAX_CHUNKS];
-    const uint32_t slot = slot0 + blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
-    const uint32_t level = lv.order[slot];
-    const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
-    if (threadIdx.x < nch) {
-        const uint32_t bin = plan.bin_first[slot] + threadIdx.x;
-        cursor[threadIdx.x] = bin_base[bin] + hist[(size_t)bin * plan.nb + pb] - bin_base[plan.bin_first[slot0]];     // slab-relative
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PTS / B2_THREADS; i++) {
-        const uint32_t b = pb * PTS + i * B2_THREADS + threadIdx.x;
-        float in[3];
-        if (!bn_load_point(inputs, b, B, in)) continue;
-        uint32_t i0[4], i1[4];
-        float wyz[4], fx;
-        b2_pairs(in, lv, level, gridtype, align_corners, interp, i0, i1, wyz, fx);
-        const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
-        const float g0 = __half2float(g.v[0]), g1 = __half2float(g.v[1]);
-        b2_poison(g0, g1, grad_grid, lv, level, i0[0], found_inf);
-        const uint32_t fxq = min((uint32_t)(fx * 65536.0f), 65535u);
-        union { __half2 h; uint32_t u; } v;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t c0 = i0[q] >> BN_CHUNK_LOG2;
-            if (b2_paired(i0[q], i1[q])) {
-                const uint32_t t = 31u - (uint32_t)__clz((int)(i0[q] ^ i1[q]));
-                v.h = __floats2half2_rn(wyz[q] * g0, wyz[q] * g1);
-                const uint32_t pos = b2_ticket(cursor, c0);
-                slab[pos] = make_uint2((i0[q] & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
-            } else {
-                const float w0 = (1 - fx) * wyz[q], w1 = fx * wyz[q];
-                v.h = __floats2half2_rn(w0 * g0, w0 * g1);
-                const uint32_t pos0 = atomicAdd(&cursor[c0], 1u);
-                slab[pos0] = make_uint2((i0[q] & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
-                v.h = __floats2half2_rn(w1 * g0, w1 * g1);
-                const uint32_t pos1 = atomicAdd(&cursor[i1[q] >> BN_CHUNK_LOG2], 1u);
-                slab[pos1] = make_uint2((i1[q] & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
-            }
-        }
-    }
-}
-
-// The same records, leaving the workgroup as contiguous runs.  The direct emit above issues one 8-byte store request per record and
-// sits at the L2 request rate (~220 G requests/s, the wall the forward gather hits too).  Here the block's record counts per bin are
-// already known (the scanned histogram), so the LDS cursors start at the bins' offsets inside an LDS staging area: a record's cursor
-// ticket IS its staging slot.  After one barrier the staging area is copied out slot by slot — consecutive lanes hold consecutive
-// records of one (block, bin) run, i.e. whole cache lines per store instruction.  Records beyond the staging capacity (blocks with
-// many chunk-straddling pairs) take the direct store; slot -> position is the same map either way.
-#ifndef B2S_PTS
-#define B2S_PTS 2048
-#endif
-#define B2S_MAX_CHUNKS 128                        // bins per level the staging area's tables (and its one-byte bin ids) cover
-#define B2S_CAP (B2S_PTS * 4 + 256)
-__global__ void __launch_bounds__(B2_THREADS) k_bin2_emit_staged(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
-                                                                 const Bin2Plan plan, const uint32_t *__restrict__ hist,
-                                                                 const uint32_t *__restrict__ bin_base, uint2 *__restrict__ slab, uint32_t B,
-                                                                 uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid,
-                                                                 float *__restrict__ found_inf) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char b2s_lds[];       // one LDS object: records, bin ids, cursors, displacements
-    uint2 *s_rec = reinterpret_cast<uint2 *>(b2s_lds);
-    uint8_t *s_bin = b2s_lds + (size_t)B2S_CAP * 8;
-    uint32_t *cursor = reinterpret_cast<uint32_t *>(b2s_lds + (size_t)B2S_CAP * 9);
-    uint32_t *gdelta = cursor + B2S_MAX_CHUNKS;                                     // staging slot -> slab position (wrapping uint32 arithmetic)
-    uint32_t *s_total = gdelta + B2S_MAX_CHUNKS;
-    const uint32_t slot = blockIdx.x / plan.nb, pb = blockIdx.x % plan.nb;
-    const uint32_t level = lv.order[slot];
-    const uint32_t nch = plan.bin_first[slot + 1] - plan.bin_first[slot];
-    const bool dense_lvl = ge_level_mode<3>(gridtype, align_corners, lv.size[level], lv.resolution[level]) == GE_MODE_DENSE;
-    if (threadIdx.x < 64) {
-        // counts of this block per bin (difference of the scanned histogram), two bins per lane -> staging offsets
-        const uint32_t lane = threadIdx.x;
-        uint32_t cnt[2], gpos[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t c = lane + 64 * h;
-            cnt[h] = 0; gpos[h] = 0;
-            if (c < nch) {
-                const uint32_t bin = plan.bin_first[slot] + c;
-                const uint32_t here = hist[(size_t)bin * plan.nb + pb];
-                const uint32_t next = pb + 1 < plan.nb ? hist[(size_t)bin * plan.nb + pb + 1] : bin_base[bin + 1] - bin_base[bin];
-                cnt[h] = next - here;
-                gpos[h] = bin_base[bin] + here;
-            }
-        }
-        const uint32_t ia = cn_wave_incl_scan(cnt[0]);
-        const uint32_t tot_a = __shfl(ia, 63, 64);
-        const uint32_t ib = cn_wave_incl_scan(cnt[1]);
-        const uint32_t oa = ia - cnt[0], ob = tot_a + ib - cnt[1];
-        cursor[lane] = oa; cursor[lane + 64] = ob;
-        gdelta[lane] = gpos[0] - oa; gdelta[lane + 64] = gpos[1] - ob;
-        if (lane == 63) *s_total = tot_a + ib;
-    }
-    // the corner arithmetic does not need the offsets: it runs while the first wave is still in the prologue above
-    constexpr int PPT = B2S_PTS / B2_THREADS;
-    bool ok[PPT];
-    uint32_t i0[PPT][4], i1[PPT][4];
-    float wyz[PPT][4], fx[PPT], g0[PPT], g1[PPT];
-#pragma unroll
-    for (int i = 0; i < PPT; i++) {
-        const uint32_t b = pb * B2S_PTS + i * B2_THREADS + threadIdx.x;
-        float in[3];
-        ok[i] = bn_load_point(inputs, b, B, in);
-        g0[i] = g1[i] = fx[i] = 0.0f;
-        if (ok[i]) {
-            b2_pairs(in, lv, level, gridtype, align_corners, interp, i0[i], i1[i], wyz[i], fx[i]);
-            const FeatVec<__half, 2> g = reinterpret_cast<const FeatVec<__half, 2> *>(grad)[(size_t)level * B + b];
-            g0[i] = __half2float(g.v[0]); g1[i] = __half2float(g.v[1]);
-            b2_poison(g0[i], g1[i], grad_grid, lv, level, i0[i][0], found_inf);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PPT; i++) {
-        if (!ok[i]) continue;
-        const uint32_t fxq = min((uint32_t)(fx[i] * 65536.0f), 65535u);
-        union { __half2 h; uint32_t u; } v;
-        auto put = [&](uint32_t c, uint32_t word, uint32_t val) {
-            // dense levels: a wave's samples share the chunk — one aggregated ticket; hashed levels: no wave-uniform chunks to aggregate.
-            // (Round 2 also scattered a dense bin's tickets over its run so that an accumulate wave would not hold runs of same-entry records;
-            // measured again in round 3 with the lane-chunked record order of the accumulate in place: 2.157 ms per step either way — removed.)
-            const uint32_t sl = dense_lvl ? b2_ticket(cursor, c) : atomicAdd(&cursor[c], 1u);
-            if (sl < B2S_CAP) { s_rec[sl] = make_uint2(word, val); s_bin[sl] = (uint8_t)c; }
-            else slab[gdelta[c] + sl] = make_uint2(word, val);
-        };
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t a0 = i0[i][q], a1 = i1[i][q];
-            const uint32_t c0 = a0 >> BN_CHUNK_LOG2;
-            if (b2_paired(a0, a1)) {
-                const uint32_t t = 31u - (uint32_t)__clz((int)(a0 ^ a1));
-                v.h = __floats2half2_rn(wyz[i][q] * g0[i], wyz[i][q] * g1[i]);
-                put(c0, (a0 & (BN_CHUNK - 1)) | (t << 12) | (fxq << 16), v.u);
-            } else {
-                const float w0 = (1 - fx[i]) * wyz[i][q], w1 = fx[i] * wyz[i][q];
-                v.h = __floats2half2_rn(w0 * g0[i], w0 * g1[i]);
-                put(c0, (a0 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
-                v.h = __floats2half2_rn(w1 * g0[i], w1 * g1[i]);
-                put(a1 >> BN_CHUNK_LOG2, (a1 & (BN_CHUNK - 1)) | (B2_SINGLE << 12), v.u);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t total = min(*s_total, (uint32_t)B2S_CAP);
-    for (uint32_t sl = threadIdx.x; sl < total; sl += B2_THREADS) slab[gdelta[s_bin[sl]] + sl] = s_rec[sl];
-}
-
+// (The second form's emit kernels — direct and LDS-staged, both driven by a histogram pre-pass — were removed in round 6: the histogram-free
+// third form below serves every table they served, up to 512 bins per level.)
+#define B2S_MAX_CHUNKS 128                        // bins per level of a NARROW level of the third form (one-byte bin ids in its staging area)
 // llrint(a) as a two's-complement 64-bit pattern, a = (value * 2^24) already in float32, |a| < 2^41.  The library's float -> int64
 // conversion is a dozen vector instructions (no such conversion in hardware) and there are four of them per record: they were most of this
 // kernel's instruction stream, and the kernel is issue-bound.  In double precision the classic "add 1.5 * 2^52" trick does it in one add:
@@ -722,118 +536,6 @@ __device__ __forceinline__ void b3_push_record(long long *acc, B3Pending &c, con
         b3_flush_pending(acc, c);
         c.key = key; c.a0 = a0; c.b0 = b0; c.a1 = a1; c.b1 = b1;
     }
-}
-
-__global__ void __launch_bounds__(1024) k_bin2_accum(const uint2 *__restrict__ slab, const uint32_t *__restrict__ bin_base,
-                                                     const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin2Plan plan,
-                                                     float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin, uint32_t slot0,
-                                                     uint32_t slot1, uint32_t seg_records) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [BN_CHUNK][2] accumulators, then one uint32 (one LDS object)
-    long long *acc = reinterpret_cast<long long *>(bn_lds);
-    uint32_t &s_bin = *reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
-    const uint32_t bin_lo = plan.bin_first[slot0], bin_hi = plan.bin_first[slot1];
-    const uint32_t gseg = blockIdx.x + seg_first[bin_lo];
-    if (gseg >= seg_first[bin_hi]) return;
-    if (threadIdx.x == 0) s_bin = seg_bin[gseg];                       // (a binary search over seg_first was ~11 dependent loads per workgroup)
-    for (uint32_t i = threadIdx.x; i < sizeof(long long) * BN_CHUNK * 2 / 16; i += 1024) reinterpret_cast<uint4 *>(bn_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t bin = s_bin;
-    const uint32_t seg = gseg - seg_first[bin], nseg = seg_first[bin + 1] - seg_first[bin];
-    const uint32_t rec_off = bin_base[bin_lo];
-    const uint32_t r0 = bin_base[bin] - rec_off, r1 = bin_base[bin + 1] - rec_off;
-    const uint32_t begin = r0 + seg * seg_records, end = min(begin + seg_records, r1);
-    // the kernel is bound by its record stream (stream alone 0.29 of 0.43 ms): 16-byte loads, two consecutive records per lane
-    // (consecutive records often hit the same entry: in one lane they are successive instructions, not same-address lanes of one)
-    uint32_t b2 = begin, e2 = end;
-    if ((b2 & 1u) && b2 < e2) { if (threadIdx.x == 0) b2_add_record(acc, slab[b2]); b2++; }
-    if ((e2 & 1u) && b2 < e2) { e2--; if (threadIdx.x == 0) b2_add_record(acc, slab[e2]); }
-    const uint4 *__restrict__ slab2 = reinterpret_cast<const uint4 *>(slab);
-    const uint32_t pend = e2 >> 1;
-    constexpr int UNR = 4;
-    // Crowded bins (the split ones: the small dense levels, where neighbouring samples of a ray update the same entry): a lane takes UNR
-    // consecutive 16-byte units, so a run of same-entry records becomes successive atomics of one lane instead of same-address lanes of one
-    // instruction (dense levels 171 -> 160 us).  Elsewhere consecutive units go to consecutive lanes (one line per four lanes on the load side).
-    // Round 3 measured and dropped summing such a run in the lane's registers (a flush of four exec-masked atomics behind a branch after every
-    // record: dense levels 160 -> 507 us); round 5's form — one pending record pair, compared by its 16-bit key, flushed when the key changes
-    // (b3_push_record) — does pay: 388 -> 371 us on the reference's bear table at random init, 413 -> 382 us fitted (B2_COMBINE).
-    const bool crowded = nseg > 1;
-    uint32_t ib = b2 >> 1;
-    for (; ib + UNR * 1024 <= pend; ib += UNR * 1024) {
-        uint4 r[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) r[u] = slab2[crowded ? ib + threadIdx.x * UNR + u : ib + u * 1024 + threadIdx.x];
-        if (crowded && B2_COMBINE) {
-            // (round 5) the lane's eight consecutive records, summed in registers while they share their entries: see b3_push_record
-            B3Pending c;
-            c.key = 0xFFFFFFFFu;
-#pragma unroll
-            for (int u = 0; u < UNR; u++) {
-                b3_push_record(acc, c, make_uint2(r[u].x, r[u].y));
-                b3_push_record(acc, c, make_uint2(r[u].z, r[u].w));
-            }
-            b3_flush_pending(acc, c);
-            continue;
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            b2_add_record(acc, make_uint2(r[u].x, r[u].y));
-            b2_add_record(acc, make_uint2(r[u].z, r[u].w));
-        }
-    }
-    for (uint32_t i = ib + threadIdx.x; i < pend; i += 1024) {
-        const uint4 r = slab2[i];
-        b2_add_record(acc, make_uint2(r.x, r.y));
-        b2_add_record(acc, make_uint2(r.z, r.w));
-    }
-    __syncthreads();
-    uint32_t slot = slot0;
-    while (plan.bin_first[slot + 1] <= bin) slot++;
-    const uint32_t level = lv.order[slot];
-    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
-    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
-    float *__restrict__ dst = grad_grid + ((size_t)lv.offset[level] + e0) * 2;
-    if (nseg == 1) {
-        for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024) {             // two entries x two channels per thread
-            float4 g = reinterpret_cast<float4 *>(dst)[j];
-            g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
-            g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
-            reinterpret_cast<float4 *>(dst)[j] = g;
-        }
-    } else {
-        // a split bin (the small dense levels): park the fixed-point partial image; k_bin2_reduce_split adds the segments exactly and rounds
-        // once.  (Flushing with float atomics cost 3.1 M memory-side atomics = 0.15 ms per scatter, and neither they nor float partial
-        // images are reproducible: which records fall into which segment depends on the ticket order.)
-        long long *__restrict__ img = partial + (size_t)gseg * (BN_CHUNK * 2);
-        for (uint32_t j = threadIdx.x; j < n_entries * 2; j += 1024) img[j] = acc[(j & 1) * BN_CHUNK + (j >> 1)];      // interleaved (entry, channel) order
-    }
-}
-
-// sum the fixed-point partial images of the split bins into the gradient table (grid: bins x 8 tiles; exact, so order-independent)
-__global__ void __launch_bounds__(256) k_bin2_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
-                                                           const GridLevels lv, const Bin2Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
-    const uint32_t bin = blockIdx.x;
-    const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
-    if (nseg <= 1) return;
-    uint32_t slot = 0;
-    while (slot + 1 < n_slots && plan.bin_first[slot + 1] <= bin) slot++;
-    const uint32_t level = lv.order[slot];
-    const uint32_t e0 = (bin - plan.bin_first[slot]) << BN_CHUNK_LOG2;
-    const uint32_t n_entries = min(BN_CHUNK, lv.size[level] - e0);
-    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // group of four values (two entries x two channels)
-    if (j >= n_entries / 2) return;
-    long long sum[4] = {0, 0, 0, 0};
-    const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
-#pragma unroll 4
-    for (uint32_t s = 0; s < nseg; s++) {
-        const longlong2 v0 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[0];
-        const longlong2 v1 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[1];
-        sum[0] += v0.x; sum[1] += v0.y; sum[2] += v1.x; sum[3] += v1.y;
-    }
-    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e0) * 2) + j;
-    float4 g = *dst;
-    g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
-    g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
-    *dst = g;
 }
 
 // ================================================================================================ fp16 records, third form (round 5)
@@ -1234,7 +936,7 @@ __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels 
     }
 }
 
-// sum the fixed-point partial images of the split bins into the gradient table (k_bin2_reduce_split with the interleaved bins of the hashed levels)
+// sum the fixed-point partial images of the split bins into the gradient table (contiguous chunks on dense levels, interleaved bins on hashed / wrapped ones)
 __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
                                                            const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
     const uint32_t bin = blockIdx.x;
@@ -1479,12 +1181,6 @@ static bool b2_enabled(int dtype) {
 }
 
 // points per block and level in the hist / emit sweeps
-static uint32_t b2_pts() {
-    static int p = -1;
-    if (p < 0) { p = b2_env("CNERF_B2_PTS", B2S_PTS); if (p != 1024 && p != 2048 && p != 4096 && p != 8192) p = 2048; }
-    return (uint32_t)p;
-}
-
 // Records per accumulate workgroup: 1/8 above the expected size of a hashed level's bin (4 pair records per sample over 128 bins), so
 // that those bins keep one owner each (plain read-modify-write flush) while the crowded bins of the small dense levels split into
 // workgroups of about the same length (uniform durations pack the last round of workgroups better: 0.40 -> 0.38 ms).
@@ -1503,7 +1199,7 @@ static uint32_t b2_max_chunks(const Bin2Plan &plan, uint32_t nl) {
 
 
 static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &plan) {
-    plan.nb = cn_div_up(B, b2_pts());
+    plan.nb = cn_div_up(B, B3_PTS);                 // (point blocks of the third form; the first form plans with BinPlan)
     uint32_t acc = 0;
     for (uint32_t s = 0; s < nl; s++) {
         plan.bin_first[s] = acc;
@@ -1511,103 +1207,6 @@ static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &pla
     }
     for (uint32_t s = nl; s <= GE_MAX_LEVELS; s++) plan.bin_first[s] = acc;
     plan.total_bins = acc;
-}
-
-static uint64_t b2_layout(const Bin2Plan &plan, uint32_t B, uint32_t nl, Bin2Ws *ws, void *base) {
-    uint64_t off = 0;
-    const uint64_t o_hist = off; off = bn_align(off + (uint64_t)plan.total_bins * plan.nb * 4);
-    const uint64_t o_base = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
-    const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(plan.total_bins + 1) * 4);
-    const uint64_t slab_records = (uint64_t)B * nl * 8;               // worst case: every pair straddles a chunk border
-    const uint64_t o_s0 = off; off = bn_align(off + slab_records * 8);
-    const uint64_t max_seg = (uint64_t)plan.total_bins + cn_div_up64(slab_records, b2_seg(B, b2_max_chunks(plan, nl)));    // every bin may add one partial segment
-    const uint64_t o_segbin = off; off = bn_align(off + max_seg * 4);
-    const uint64_t o_part = off; off = bn_align(off + max_seg * BN_CHUNK * 2 * 8);                 // fixed-point partial images of split bins (sparsely used)
-    if (ws) {
-        char *p = (char *)base;
-        ws->hist = (uint32_t *)(p + o_hist);
-        ws->bin_base = (uint32_t *)(p + o_base);
-        ws->seg_first = (uint32_t *)(p + o_seg);
-        ws->slab = (uint2 *)(p + o_s0);
-        ws->partial = (long long *)(p + o_part);
-        ws->seg_bin = (uint32_t *)(p + o_segbin);
-        ws->max_seg = max_seg;
-    }
-    return off;
-}
-
-// histogram of the point blocks that cover rows [row0, row0 + rows) (row0 a multiple of the block size; the range ends on a block border or at B)
-static int b2_hist_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
-                        hipStream_t st, uint32_t row0, uint32_t rows) {
-    if (nl == 0) return CNERF_OK;
-    Bin2Plan plan;
-    b2_plan(lv, nl, B, plan);
-    Bin2Ws ws;
-    b2_layout(plan, B, nl, &ws, workspace);
-    const uint32_t pts = b2_pts();
-    if (row0 % pts || row0 + rows > B || ((row0 + rows) % pts && row0 + rows != B) || rows == 0) return CNERF_EINVAL;
-    const uint32_t pb0 = row0 / pts, nbl = cn_div_up(rows, pts);
-    switch (pts) {
-#define B2_HIST(P) case P: hipLaunchKernelGGL(k_bin2_hist<P>, dim3(nbl * nl), dim3(B2_THREADS), 0, st, inputs, lv, plan, ws.hist, B, gridtype, ac, interp, pb0, nbl); break;
-        B2_HIST(1024) B2_HIST(2048) B2_HIST(4096) B2_HIST(8192)
-#undef B2_HIST
-    }
-    return cn_launch_status();
-}
-
-static int b2_scans(const GridLevels &lv, uint32_t B, uint32_t nl, void *workspace, hipStream_t st) {
-    if (nl == 0) return CNERF_OK;
-    Bin2Plan plan;
-    b2_plan(lv, nl, B, plan);
-    Bin2Ws ws;
-    b2_layout(plan, B, nl, &ws, workspace);
-    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(plan.total_bins), dim3(BN_SCAN_THREADS), 0, st, ws.hist, ws.bin_base, plan.nb);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, plan.total_bins, b2_seg(B, b2_max_chunks(plan, nl)), ws.seg_bin);
-    return cn_launch_status();
-}
-
-static int b2_phase1(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, void *workspace,
-                     hipStream_t st) {
-    const int rc = b2_hist_rows(inputs, lv, B, nl, gridtype, ac, interp, workspace, st, 0, B);
-    return rc ? rc : b2_scans(lv, B, nl, workspace, st);
-}
-
-static int b2_phase2(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
-                     uint32_t interp, void *workspace, hipStream_t st) {
-    if (nl == 0) return CNERF_OK;
-    Bin2Plan plan;
-    b2_plan(lv, nl, B, plan);
-    Bin2Ws ws;
-    b2_layout(plan, B, nl, &ws, workspace);
-    const uint32_t lds_bytes = BN_CHUNK * 2 * sizeof(long long) + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_accum), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
-    static int staged = -1;
-    if (staged < 0) {
-        staged = b2_env("CNERF_B2_STAGED", 1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin2_emit_staged), hipFuncAttributeMaxDynamicSharedMemorySize, B2S_CAP * 9 + B2S_MAX_CHUNKS * 8 + 16);
-    }
-    const uint32_t max_chunks = b2_max_chunks(plan, nl);
-    cn_stage(0, st);
-    if (staged && b2_pts() == B2S_PTS && max_chunks <= B2S_MAX_CHUNKS)          // larger tables (T = 2^20, 2^21): direct emit below
-        hipLaunchKernelGGL(k_bin2_emit_staged, dim3(plan.nb * nl), dim3(B2_THREADS), B2S_CAP * 9 + B2S_MAX_CHUNKS * 8 + 16, st, grad, inputs, lv, plan, ws.hist,
-                           ws.bin_base, ws.slab, B, gridtype, ac, interp, gemb, g_cn_found_inf);
-    else switch (b2_pts()) {
-#define B2_EMIT(P) case P: hipLaunchKernelGGL(k_bin2_emit<P>, dim3(plan.nb * nl), dim3(B2_THREADS), 0, st, grad, inputs, lv, plan, ws.hist, ws.bin_base, ws.slab, B, gridtype, ac, interp, 0u, gemb, g_cn_found_inf); break;
-        B2_EMIT(1024) B2_EMIT(2048) B2_EMIT(4096) B2_EMIT(8192)
-#undef B2_EMIT
-    }
-    cn_stage(1, st);
-    hipLaunchKernelGGL(k_bin2_accum, dim3((uint32_t)ws.max_seg), dim3(1024), lds_bytes, st, (const uint2 *)ws.slab, ws.bin_base, ws.seg_first, lv, plan,
-                       gemb, ws.partial, ws.seg_bin, 0u, nl, b2_seg(B, b2_max_chunks(plan, nl)));
-    cn_stage(2, st);
-    hipLaunchKernelGGL(k_bin2_reduce_split, dim3(plan.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
-                       gemb, nl);
-    cn_stage(3, st);
-    return cn_launch_status();
 }
 
 // ---- third form, host side
@@ -1761,15 +1360,10 @@ uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int d
         b3_plan(lv, nl, B, p3, nd);
         b3 = b3_layout(p3, nd, B, nl, nullptr, nullptr);
     }
-    if (b2_enabled(dtype)) {
-        Bin2Plan p2;
-        b2_plan(lv, nl, B, p2);
-        const uint64_t b2 = b2_layout(p2, B, nl, nullptr, nullptr);
-        return b2 > b3 ? b2 : b3;
-    }
     BinPlan plan;
     bn_plan(lv, nl, B, plan);
-    return bn_layout(plan, B, nl, dtype, nullptr, nullptr);
+    const uint64_t b1 = bn_layout(plan, B, nl, dtype, nullptr, nullptr);
+    return b1 > b3 ? b1 : b3;
 }
 
 // phase 1 (needs the sample coordinates only): histogram + scans.  phase 2 (needs the gradients): emit + accumulate.
@@ -1810,34 +1404,20 @@ static int bn_phase2(const T *grad, const float *inputs, const GridLevels &lv, f
     return cn_launch_status();
 }
 
-// the plan in pieces (float16 records only): histogram of a row range / the scans once every range is counted
-int bn_prepare_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
-                    void *workspace, hipStream_t st, uint32_t row0, uint32_t rows) {
-    if (!b2_enabled(dtype)) return CNERF_EINVAL;
-    return b2_hist_rows(inputs, lv, B, nl, gridtype, ac, interp, workspace, st, row0, rows);
-}
-int bn_prepare_finish(const GridLevels &lv, uint32_t B, uint32_t nl, int dtype, void *workspace, hipStream_t st) {
-    if (!b2_enabled(dtype)) return CNERF_EINVAL;
-    return b2_scans(lv, B, nl, workspace, st);
-}
-uint32_t bn_hist_block_points(int dtype) { return b2_enabled(dtype) ? b2_pts() : 0u; }
+// The plan in pieces (cnerf_grid_encode_backward_prepare_rows / _finish) was the second form's: with that form gone (round 6) no shape offers it —
+// bn_hist_block_points() = 0 makes the entry points report *prepared = 0 before they get here.
+int bn_prepare_rows(const float *, const GridLevels &, uint32_t, uint32_t, uint32_t, int, uint32_t, int, void *, hipStream_t, uint32_t, uint32_t) { return CNERF_EINVAL; }
+int bn_prepare_finish(const GridLevels &, uint32_t, uint32_t, int, void *, hipStream_t) { return CNERF_EINVAL; }
+uint32_t bn_hist_block_points(int) { return 0u; }
 
 int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t nl, uint32_t gridtype, int ac, uint32_t interp, int dtype,
                void *workspace, hipStream_t st) {
-    if (b2_enabled(dtype)) return b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);
     return bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
 }
 
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
     if (b3_enabled(lv, nl, B, dtype, gridtype)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
-    if (b2_enabled(dtype)) {
-        if (!prepared) {
-            const int rc = b2_phase1(inputs, lv, B, nl, gridtype, ac, interp, workspace, st);
-            if (rc) return rc;
-        }
-        return b2_phase2((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
-    }
     if (!prepared) {
         const int rc = bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
         if (rc) return rc;

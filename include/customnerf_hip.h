@@ -197,11 +197,14 @@ int cnerf_grid_encode_backward_prepare(const float *inputs, const int32_t *offse
  * exist — run()'s coarse block at the very beginning of the forward, its fine block after the importance sampling — so that all of it is done
  * before the field backward starts (a histogram that is still running then slows that kernel from 407 to 491 us: DESIGN.md §4 round 3).
  * row0 must be a multiple of *block_points (cnerf_grid_encode_backward_prepare_block) and the range must end on a block border or at B;
- * ..._finish runs the scans once every row has been counted.  *prepared = 0: nothing launched (the shape takes the atomic kernel / float32 records). */
+ * ..._finish runs the scans once every row has been counted.  *prepared = 0: nothing launched (the shape takes the atomic kernel / float32 records).
+ * Round 6: the histogram-driven float16 form these pieces belonged to is gone (the histogram-free form took over its shapes); the three entry points
+ * stay in the ABI and report *block_points = 0 / *prepared = 0 for every shape. */
 int cnerf_grid_encode_backward_prepare_block(int dtype, uint32_t *block_points);
 /* *needs_plan = 1 when cnerf_grid_encode_backward of this shape profits from a plan prepared ahead of time (the forms that need the exact record
- * counts before the emit: float16 records on tables of more than 128 chunks per level, e.g. T = 2^21; float32 records); 0 when there is nothing to
- * prepare — the atomic kernel, or (round 5) the scatter that counts inside its emit kernel: float16 records on a hash grid (gridtype 0) of <= 128 chunks of 4096 entries per level.
+ * counts before the emit: float32 records; float16 records on hashed levels smaller than one 4096-entry bin or of more than 512 bins); 0 when there
+ * is nothing to prepare — the atomic kernel, or the scatter that counts inside its emit kernel (round 5; round 6: up to 512 bins per level, hash and
+ * tiled grids — the benchmark table and the reference field's own T = 2^21 table).
  * The _prepare* entry points report *prepared = 0 for such shapes; this query lets a caller skip them (and their workspace) altogether. */
 int cnerf_grid_encode_backward_needs_plan(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
                                           uint32_t H, uint32_t gridtype, int dtype, int *needs_plan);

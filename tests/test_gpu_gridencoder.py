@@ -148,14 +148,18 @@ BINNED_CONFIGS = [CONFIGS[0], CONFIGS[1],
                                                      desired_resolution=2048, gridtype='hash', align_corners=True, interpolation='smoothstep')),
                   ("tiled_L12_T17_odd", dict(input_dim=3, num_levels=12, level_dim=2, base_resolution=12, log2_hashmap_size=17,
                                              per_level_scale=1.38, gridtype='tiled')),
-                  # the reference's bear table (tiled, T = 2^21, desired 8192): 512 chunks per level -> the direct (unstaged) record emit
+                  # the reference's bear table (tiled, T = 2^21, desired 8192): 512 bins per level -> the WIDE form of the histogram-free emit (round 6)
                   ("tiled_L16_T21_8192_bear", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=21,
                                                    desired_resolution=8192, gridtype='tiled')),
-                  # align_corners on a table wide enough for the direct record emit (256 chunks per level): points on the upper boundary have a
+                  # align_corners on a wide table (256 bins per level): points on the upper boundary have a
                   # corner one grid line past the level — the dense index must wrap into the level as the reference's `% hashmap_size` does
                   # (an unwrapped index used an uninitialised bin cursor there and overwrote some other record)
                   ("hash_L16_T20_align", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=20,
-                                              desired_resolution=1024, gridtype='hash', align_corners=True))]
+                                              desired_resolution=1024, gridtype='hash', align_corners=True)),
+                  # hashed levels smaller than one 4096-entry bin: not a shape of the third form — the FIRST form (histogram + per-corner records)
+                  # serves it in both precisions (the second form, which used to, was removed in round 6)
+                  ("hash_L16_T10_small", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=10,
+                                              desired_resolution=512, gridtype='hash'))]
 
 
 @pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
