@@ -1217,14 +1217,16 @@ struct Bin3Ws {
     uint64_t max_seg, cursor_bytes;
 };
 
-static bool b3_is_dense(const GridLevels &lv, uint32_t level) {                  // (every dimension's stride fits the table: see ge_level_mode; align_corners only shrinks the grid)
-    const uint64_t r1 = (uint64_t)lv.resolution[level] + 1;
+// does ge_index take the strided (un-hashed, un-wrapped) sum on this level?  (ge_level_mode's GE_MODE_DENSE: every dimension's stride fits the
+// table; with align_corners the grid has `resolution` lines per axis instead of `resolution + 1`, and its boundary corner wraps once)
+static bool b3_is_dense(const GridLevels &lv, uint32_t level, int ac) {
+    const uint64_t r1 = (uint64_t)lv.resolution[level] + (ac ? 0 : 1);
     return r1 * r1 * r1 <= lv.size[level];
 }
 
-// -> false when a level is neither dense nor a power-of-two hashed level of at least 2^(12 + B3_K) ... entries (tiled levels that wrap, odd sizes):
-// such tables keep the second form
-static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense) {
+// -> false when a level is neither dense nor a power-of-two hashed / wrapped level made of whole 4096-entry bins (or, round 6, of ONE bin of at
+// most 4096 entries: the small tables): such tables take the first form
+static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &plan, uint32_t &n_dense, int ac) {
     b2_plan(lv, nl, B, plan.p);
     plan.p.nb = cn_div_up(B, B3_PTS);
     n_dense = 0;
@@ -1233,9 +1235,10 @@ static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &pla
     for (uint32_t s = 0; s < GE_MAX_LEVELS; s++) { plan.dense_slot[s] = 0xFFFFFFFFu; plan.hbits[s] = 0; }
     for (uint32_t s = 0; s < nl; s++) {
         const uint32_t level = lv.order[s], size = lv.size[level];
-        if (b3_is_dense(lv, level)) { plan.dense_slot[s] = n_dense++; continue; }
+        if (b3_is_dense(lv, level, ac)) { plan.dense_slot[s] = n_dense++; continue; }
         const uint32_t nch = plan.p.bin_first[s + 1] - plan.p.bin_first[s];
-        if ((size & (size - 1)) != 0 || (nch & (nch - 1)) != 0 || size != nch * BN_CHUNK) ok = false;      // interleaved bins need 2^k bins of exactly 4096 entries
+        // interleaved bins need 2^k bins of exactly 4096 entries — or a single bin that IS the (power-of-two, >= 32-entry) level
+        if ((size & (size - 1)) != 0 || (nch & (nch - 1)) != 0 || !(size == nch * BN_CHUNK || (nch == 1 && size >= 32))) ok = false;
         uint32_t hb = 0;
         while ((1u << hb) < nch) hb++;
         plan.hbits[s] = (uint8_t)hb;
@@ -1250,14 +1253,14 @@ static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &pla
 // the third form serves float16 records on tables of at most B2S_MAX_CHUNKS bins per level (the staging area's counters); larger tables
 // (T = 2^20, 2^21: the reference's bear table) keep the second form with its histogram
 // (gridtype 1 = tiled: its wrapping levels are x-contiguous, the interleave does not balance them — second form)
-static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype, uint32_t gridtype) {
+static bool b3_enabled(const GridLevels &lv, uint32_t nl, uint32_t B, int dtype, uint32_t gridtype, int ac) {
     static const int on = b2_env("CNERF_B3", 1);
     static const int wide_on = b2_env("CNERF_B3_WIDE", 1);                     // tuning builds: 0 = tables of more than 128 bins per level keep the second form
     (void)gridtype;                                                            // (round 6: tiled levels that wrap take the interleaved bins like hashed ones)
     if (!on || !b2_enabled(dtype)) return false;
     Bin3Plan plan;
     uint32_t nd;
-    if (!b3_plan(lv, nl, B, plan, nd)) return false;
+    if (!b3_plan(lv, nl, B, plan, nd, ac)) return false;
     const uint32_t mc = b2_max_chunks(plan.p, nl);
     if (mc > (wide_on ? (uint32_t)B3_WIDE_CHUNKS : (uint32_t)B2S_MAX_CHUNKS)) return false;
     if ((uint64_t)plan.p.total_bins * plan.capb >= 0xF0000000ull) return false;           // record positions inside the bin-major slab stay 32-bit in the accumulate
@@ -1307,7 +1310,7 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     if (nl == 0) return CNERF_OK;
     Bin3Plan plan;
     uint32_t n_dense;
-    if (!b3_plan(lv, nl, B, plan, n_dense)) return CNERF_EINVAL;
+    if (!b3_plan(lv, nl, B, plan, n_dense, ac)) return CNERF_EINVAL;
     Bin3Ws ws;
     b3_layout(plan, n_dense, B, nl, &ws, workspace);
     static const int emit_pad = cn_tune_env("CNERF_B3_EMIT_LDS_PAD", 0);        // tuning builds: extra LDS bytes per emit workgroup (occupancy experiments)
@@ -1341,7 +1344,11 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
 
 // does the binned backward of this shape use a plan prepared ahead of time (histogram + scans on the sample coordinates)?  The third form
 // counts inside its emit kernel: nothing to prepare.
-bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype, uint32_t gridtype) { return !b3_enabled(lv, nl, B, dtype, gridtype); }
+// (the query has no align_corners argument: a plan is "needed" unless the third form takes the shape either way — a plan prepared for a launch
+// that then does not use it is wasted work, never wrong)
+bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype, uint32_t gridtype) {
+    return !(b3_enabled(lv, nl, B, dtype, gridtype, 0) && b3_enabled(lv, nl, B, dtype, gridtype, 1));
+}
 
 // used by gridencoder.hip
 bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLevels &lv) {
@@ -1354,11 +1361,13 @@ bool bn_eligible(uint32_t B, uint32_t D, uint32_t C, uint32_t nl, const GridLeve
 // (the size does not depend on the grid type — the entry point that asks has none — so it covers whichever form the launch will take)
 uint64_t bn_workspace_bytes(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype) {
     uint64_t b3 = 0;
-    if (b3_enabled(lv, nl, B, dtype, 0u)) {
+    for (int ac = 0; ac < 2; ac++) {                                             // (the query has no align_corners argument either: the larger of the two layouts)
+        if (!b3_enabled(lv, nl, B, dtype, 0u, ac)) continue;
         Bin3Plan p3;
         uint32_t nd;
-        b3_plan(lv, nl, B, p3, nd);
-        b3 = b3_layout(p3, nd, B, nl, nullptr, nullptr);
+        b3_plan(lv, nl, B, p3, nd, ac);
+        const uint64_t b = b3_layout(p3, nd, B, nl, nullptr, nullptr);
+        b3 = b > b3 ? b : b3;
     }
     BinPlan plan;
     bn_plan(lv, nl, B, plan);
@@ -1417,7 +1426,7 @@ int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t n
 
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
-    if (b3_enabled(lv, nl, B, dtype, gridtype)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
+    if (b3_enabled(lv, nl, B, dtype, gridtype, ac)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
     if (!prepared) {
         const int rc = bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
         if (rc) return rc;
