@@ -23,7 +23,7 @@
 // D = 3, C = 2 only (the configuration CustomNeRF uses); other shapes take the atomic kernel in gridencoder.hip.
 //
 // Forms in this file (round 6): the FIRST form described above (k_bin_*: histogram + scans + one record per corner) serves float32 records and the
-// fp16 shapes the third form does not take (hashed levels smaller than one bin, more than 512 bins per level); the THIRD form (k_bin3_*: no histogram,
+// fp16 shapes the third form does not take (more than 512 bins per level, hashed levels of odd size or fewer than 32 entries); the THIRD form (k_bin3_*: no histogram,
 // 8-byte pair records, block-local counting, fixed-capacity bin regions with spill) serves everything CustomNeRF runs — the benchmark table and the
 // reference field's own 2^21-entry table.  The second form (histogram-driven pair records, rounds 2-4) is gone; its record format lives on.
 #include "grid_common.h"

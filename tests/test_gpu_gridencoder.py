@@ -156,8 +156,8 @@ BINNED_CONFIGS = [CONFIGS[0], CONFIGS[1],
                   # (an unwrapped index used an uninitialised bin cursor there and overwrote some other record)
                   ("hash_L16_T20_align", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=20,
                                               desired_resolution=1024, gridtype='hash', align_corners=True)),
-                  # hashed levels smaller than one 4096-entry bin: not a shape of the third form — the FIRST form (histogram + per-corner records)
-                  # serves it in both precisions (the second form, which used to, was removed in round 6)
+                  # hashed levels smaller than one 4096-entry bin: single-bin levels of the third form (round 6; the second form, which used to serve
+                  # them — and the align_corners tables above, whose dense levels have odd sizes — was removed)
                   ("hash_L16_T10_small", dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=10,
                                               desired_resolution=512, gridtype='hash'))]
 
