@@ -46,21 +46,7 @@ E
   rm -rf $out/pmce_$c
 done
 
-python3 - <<E
-import csv, json, os
-out = '$out'
-def mean(counter):
-    try:
-        rows = [float(r['Counter_Value']) for r in csv.DictReader(open(f'{out}/pmc_{counter}_gather_rows.csv'))]
-        return sum(rows) / len(rows) if rows else None
-    except Exception:
-        return None
-d = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum / TA_BUSY_avr (separate passes, --kernel-trace only: scratch/final_r06.sh) on bench.py --task recon --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants, end of round 6, kernels k_grid_fwd_fast (coarse pass, level-major) and k_grid_fwd_fast_sm (importance pass, sample-major when the TraversalTuner picks it), mean over their launches (, 1,048,576 samples x 16 levels each); FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE is half the real fetched bytes for streaming reads on gfx950 (MI355X_MICROARCH.md) and is doubled by bench.py.  Algorithmic bytes of one launch: 588 B x 1,048,576 = 0.617 GB.  Rows: profiles/r06_pmc_*_gather_rows.csv.",
-     "f16": {"points": 1048576, "fetch_size_kb": mean('FETCH_SIZE'), "write_size_kb": mean('WRITE_SIZE'), "tcp_tcc_read_req": mean('TCP_TCC_READ_REQ_sum'),
-             "tcp_total_cache_accesses": mean('TCP_TOTAL_CACHE_ACCESSES_sum'), "ta_busy_avr_cycles": mean('TA_BUSY_avr')}}
-json.dump(d, open(f'{out}/gather_pmc.json', 'w'), indent=1)
-print(d['f16'])
-E
+python3 scratch/gather_pmc_summary.py $out
 bash scratch/edit_step_kernels.sh $tag > $out/edit_step_kernels.log 2>&1; head -3 $out/edit_step_kernels.log
 # bear table: kernel stats and the batch sweep (item 1a)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bear -o bench -- python3 bench.py --task recon --grid bear --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $out/prof_bear.log 2>&1
