@@ -308,6 +308,8 @@ def run_recon(args, world, rank, dev):
     opt = sc.make_opt(cuda_ray=(args.path == "march"), fp16=fp16, **grid_kw)
     if getattr(args, "no_tune_traversal", False):
         opt.tune_gather_traversal = False
+    if getattr(args, "no_packed_weights", False):
+        opt.packed_field_weights = False
     model = NeRFNetwork(opt).to(dev)
     H = W = args.res
     V = 8
@@ -608,6 +610,7 @@ def main():
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
     ap.add_argument("--rays", type=int, default=0,
                     help="recon leg: regroup the views' rays into steps of this many rays (default 0 = one whole view per step); must divide 8 * res * res")
+    ap.add_argument("--no-packed-weights", action="store_true", help="recon leg: the field kernels stage their weights from the float32 parameters in every launch (A/B of trainer.packed_weights_window)")
     ap.add_argument("--no-tune-traversal", action="store_true", help="recon leg: keep the importance-sample gather level-major (no in-place TraversalTuner trials)")
     ap.add_argument("--stage-events", action="store_true", help="recon leg: per-kernel event times of the last step's scatter and field backward (config.stage_ms)")
     ap.add_argument("--prefit", type=int, default=0,

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcustomnerf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
 
@@ -52,6 +52,11 @@ SIGNATURES = {
     "cnerf_field_backward": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp],
     "cnerf_field_backward_ex": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp, vp],
     "cnerf_field_backward_workspace_bytes": [u32, u32, u32, u32, i32, vp],
+    "cnerf_stream_capture_id": [vp, vp],
+    "cnerf_field_weight_image_bytes": [u32, u32, u32, vp],
+    "cnerf_field_pack_weights": [u32, u32, u32, vp, vp, vp, vp, u64, vp],
+    "cnerf_field_forward_img": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, i32, u32, vp, vp],
+    "cnerf_field_backward_img": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, vp, vp, vp],
     "cnerf_mlp_forward": [vp, u32, vp, u32, u32, u32, u32, u32, i32, vp, u32, i32, vp],
     "cnerf_mlp_backward": [vp, u32, vp, vp, u32, u32, u32, u32, u32, u32, i32, vp, u32, vp, vp, u64, i32, vp],
     "cnerf_mlp_backward_workspace_bytes": [u32, u32, u32, u32, u32, i32, vp],

@@ -10,10 +10,10 @@
 // KIND 2: rgb layer 0 = [C-ordered fea at column 27.., then natural dir features at column 0..26].
 template <bool H, int KIND>
 __device__ __forceinline__ void fld_stage_layer(typename Prec<H>::elem_t *dst, const float *__restrict__ W, uint32_t rows, uint32_t in_stride,
-                                                uint32_t T, uint32_t S, uint32_t n_valid_cols) {
+                                                uint32_t T, uint32_t S, uint32_t n_valid_cols, uint32_t i0 = threadIdx.x, uint32_t istride = FLD_THREADS) {
     using P = Prec<H>;
     const uint32_t total = T * S * 64 * P::J;
-    for (uint32_t i = threadIdx.x; i < total; i += FLD_THREADS) {
+    for (uint32_t i = i0; i < total; i += istride) {
         const uint32_t j = i % P::J, lane = (i / P::J) % 64, ts = i / (P::J * 64);
         const uint32_t s = ts % S, t = ts / S;
         const uint32_t row = 32 * t + (lane & 31), hi = lane >> 5;
@@ -36,21 +36,39 @@ __device__ __forceinline__ void fld_stage_layer(typename Prec<H>::elem_t *dst, c
 
 template <bool H>
 __device__ __forceinline__ void fld_stage_all(typename Prec<H>::elem_t *lds, const FieldDims &dm, const FieldLds &lo, const float *__restrict__ pnet,
-                                              const float *__restrict__ pden, const float *__restrict__ prgb, bool with_rgb) {
+                                              const float *__restrict__ pden, const float *__restrict__ prgb, bool with_rgb,
+                                              uint32_t i0 = threadIdx.x, uint32_t istride = FLD_THREADS) {
     using P = Prec<H>;
     const uint32_t S64 = FLD_HID / P::KS, Senc = dm.enc_pad / P::KS;
     const float *n0 = pnet, *n1 = pnet + FLD_HID * dm.enc_pad;
     const float *n2 = n1 + (dm.n_hidden_geo == 2 ? FLD_HID * FLD_HID : 0);
-    fld_stage_layer<H, 0>(lds + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, Senc, dm.enc_pad);
-    if (dm.n_hidden_geo == 2) fld_stage_layer<H, 1>(lds + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fld_stage_layer<H, 1>(lds + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fld_stage_layer<H, 1>(lds + lo.off[3], pden, FLD_HID, FLD_HID, 2, S64, FLD_HID);
-    fld_stage_layer<H, 1>(lds + lo.off[4], pden + FLD_HID * FLD_HID, 16, FLD_HID, 1, S64, FLD_HID);
+    fld_stage_layer<H, 0>(lds + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, Senc, dm.enc_pad, i0, istride);
+    if (dm.n_hidden_geo == 2) fld_stage_layer<H, 1>(lds + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID, i0, istride);
+    fld_stage_layer<H, 1>(lds + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID, i0, istride);
+    fld_stage_layer<H, 1>(lds + lo.off[3], pden, FLD_HID, FLD_HID, 2, S64, FLD_HID, i0, istride);
+    fld_stage_layer<H, 1>(lds + lo.off[4], pden + FLD_HID * FLD_HID, 16, FLD_HID, 1, S64, FLD_HID, i0, istride);
     if (with_rgb) {
         const uint32_t in_r0 = FLD_HID + FLD_DIR;       // 96 = pad16(27 + 64)
-        fld_stage_layer<H, 2>(lds + lo.off[5], prgb, FLD_HID, in_r0, 2, in_r0 / P::KS, in_r0);
-        fld_stage_layer<H, 1>(lds + lo.off[6], prgb + FLD_HID * in_r0, 16, FLD_HID, 1, S64, FLD_HID);
+        fld_stage_layer<H, 2>(lds + lo.off[5], prgb, FLD_HID, in_r0, 2, in_r0 / P::KS, in_r0, i0, istride);
+        fld_stage_layer<H, 1>(lds + lo.off[6], prgb + FLD_HID * in_r0, 16, FLD_HID, 1, S64, FLD_HID, i0, istride);
     }
+}
+
+// The staged image as a tensor in global memory (round 6): staging from the float32 parameters — a scattered 4-byte load, a division chain
+// and a 2-byte LDS store per weight, 96 of them per thread — costs 14 us per launch (measured by staging twice: k_field_fwd 62.4 -> 76.5 us at
+// 1 M samples and 24.3 -> 38.7 at 131 k; k_field_bwd_x2 449 -> 464 / 85 -> 97), three launches per step.  k_field_pack writes the fp16 image
+// ONCE per parameter version (cnerf_field_pack_weights: the host keys it on the parameters' versions), and the kernels that are handed an
+// image copy it into LDS in 16-byte chunks — same bits, same slots.
+__global__ void __launch_bounds__(FLD_THREADS) k_field_pack(_Float16 *__restrict__ img, FieldDims dm, const float *__restrict__ pnet,
+                                                            const float *__restrict__ pden, const float *__restrict__ prgb) {
+    const FieldLds lo = fld_lds_layout<true>(dm);
+    fld_stage_all<true>(img, dm, lo, pnet, pden, prgb, true, blockIdx.x * FLD_THREADS + threadIdx.x, gridDim.x * FLD_THREADS);
+}
+// image -> LDS, 16-byte chunks (n_halves is a multiple of 512: every layer is whole 64-lane fragments)
+__device__ __forceinline__ void fld_copy_image(_Float16 *lds, const void *__restrict__ img, uint32_t n_halves) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(img);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t c = threadIdx.x; c < n_halves / 8; c += FLD_THREADS) dst[c] = src[c];
 }
 
 // ------------------------------------------------------------------------------------------------ per-wave building blocks
@@ -168,14 +186,25 @@ template <bool H, int SENC, int NGEO>
 __global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void *__restrict__ enc, const float *__restrict__ xyz, const float *__restrict__ dirs,
                                                            uint32_t dir_group, uint32_t P_, FieldDims dm, const float *__restrict__ pnet,
                                                            const float *__restrict__ pden, const float *__restrict__ prgb,
-                                                           float *__restrict__ sigma, float *__restrict__ rgbc, uint32_t enc_stride) {
+                                                           float *__restrict__ sigma, float *__restrict__ rgbc, uint32_t enc_stride,
+                                                           const void *__restrict__ wimg) {
     using PR = Prec<H>;
     using frag_t = typename PR::frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char fld_lds[];
     typename PR::elem_t *wl = reinterpret_cast<typename PR::elem_t *>(fld_lds);
     const FieldLds lo = fld_lds_layout<H>(dm);
     const bool with_rgb = rgbc != nullptr;
-    fld_stage_all<H>(wl, dm, lo, pnet, pden, prgb, with_rgb);
+#ifdef CNERF_TUNING
+    const bool nostage = (dir_group >> 31) != 0;                 // timing aid (results wrong): CNERF_FLD_NOSTAGE
+    dir_group &= 0x7FFFFFFFu;
+    if (nostage) { fld_stage_all<H>(wl, dm, lo, pnet, pden, prgb, with_rgb); __syncthreads(); }      // (staged TWICE: the delta is the staging time)
+#endif
+    if constexpr (H) {
+        if (wimg) fld_copy_image(wl, wimg, with_rgb ? lo.off[7] : lo.off[5]);
+        else fld_stage_all<H>(wl, dm, lo, pnet, pden, prgb, with_rgb);
+    } else {
+        fld_stage_all<H>(wl, dm, lo, pnet, pden, prgb, with_rgb);
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -261,7 +290,8 @@ __global__ void __launch_bounds__(FLD_THREADS, H ? 2 : 1) k_field_fwd(const void
 // ------------------------------------------------------------------------------------------------ C-ABI
 template <bool H>
 static int fld_launch_fwd(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm,
-                          const float *pnet, const float *pden, const float *prgb, float *sigma, float *rgbc, hipStream_t st, uint32_t enc_stride) {
+                          const float *pnet, const float *pden, const float *prgb, float *sigma, float *rgbc, hipStream_t st, uint32_t enc_stride,
+                          const void *wimg = nullptr) {
     const FieldLds lo = fld_lds_layout<H>(dm);
     const uint32_t lds_bytes = lo.off[7] * sizeof(typename Prec<H>::elem_t) + FLD_WAVES * 64;       // weight fragments + per-wave direction scratch
     const uint32_t n_tiles = cn_div_up(P_, FLD_TILE);
@@ -269,11 +299,15 @@ static int fld_launch_fwd(const void *enc, const float *xyz, const float *dirs, 
     const uint32_t max_blocks = H ? 768 : 256;            // persistent: LDS allows 3 (fp16) / 1 (fp32) workgroups per CU
     if (blocks > max_blocks) blocks = max_blocks;
     const uint32_t senc = dm.enc_pad / Prec<H>::KS;
+#ifdef CNERF_TUNING
+    static const int nostage = cn_tune_env("CNERF_FLD_NOSTAGE", 0);
+    if (nostage) dir_group |= 0x80000000u;
+#endif
 #define FLD_FWD_CASE(SE, NG)                                                                                                           \
     {                                                                                                                                  \
         auto kern = k_field_fwd<H, SE, NG>;                                                                                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);        \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, sigma, rgbc, enc_stride); \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, sigma, rgbc, enc_stride, wimg); \
     }
     const uint32_t se16 = dm.enc_pad / 16;               // 1..4
     if (dm.n_hidden_geo == 1) {
@@ -310,6 +344,49 @@ static int fld_dims(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out,
 }
 
 extern "C" {
+
+int cnerf_field_weight_image_bytes(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, uint64_t *bytes) {
+    FieldDims dm;
+    int rc = fld_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
+    if (rc) return rc;
+    if (!bytes) return CNERF_ENULL;
+    *bytes = (uint64_t)fld_lds_layout<true>(dm).off[7] * sizeof(_Float16);
+    return CNERF_OK;
+}
+
+int cnerf_field_pack_weights(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                             const float *params_rgb, void *image, uint64_t image_bytes, void *stream) {
+    FieldDims dm;
+    int rc = fld_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
+    if (rc) return rc;
+    if (!params_net || !params_den || !params_rgb || !image) return CNERF_ENULL;
+    const uint32_t n = fld_lds_layout<true>(dm).off[7];
+    if ((((uintptr_t)image) & 15) || image_bytes < (uint64_t)n * sizeof(_Float16)) return CNERF_EINVAL;
+    // ~4 weights per thread: the packing is latency, not bandwidth (25 k scattered loads)
+    hipLaunchKernelGGL(k_field_pack, dim3(cn_div_up(n, 4 * FLD_THREADS)), dim3(FLD_THREADS), 0, CN_STREAM(stream), reinterpret_cast<_Float16 *>(image), dm,
+                       params_net, params_den, params_rgb);
+    return cn_launch_status();
+}
+
+int cnerf_field_forward_img(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
+                            uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
+                            float *sigma, float *rgbc, int dtype, uint32_t enc_level_stride, const void *weight_image, void *stream) {
+    FieldDims dm;
+    int rc = fld_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
+    if (rc) return rc;
+    if (!weight_image || dtype != CNERF_F16)
+        return cnerf_field_forward_strided(enc, xyz, dirs, dir_group, P_, enc_dim, n_hidden_geo, n_rgb_out, params_net, params_den, params_rgb, sigma, rgbc,
+                                           dtype, enc_level_stride, stream);
+    if (((uintptr_t)weight_image) & 15) return CNERF_EINVAL;
+    if (enc_level_stride == 0) enc_level_stride = P_;
+    if (enc_level_stride < P_) return CNERF_EINVAL;
+    if (P_ == 0) return CNERF_OK;
+    if (!enc || !xyz || !params_net || !params_den || !sigma) return CNERF_ENULL;
+    if (rgbc && (!dirs || !params_rgb || dir_group == 0)) return CNERF_ENULL;
+    if (rgbc && (((uintptr_t)rgbc) & 15)) return CNERF_EINVAL;
+    return fld_launch_fwd<true>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, sigma, rgbc, CN_STREAM(stream), enc_level_stride,
+                                weight_image);
+}
 
 int cnerf_field_forward_strided(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
                                 uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,

@@ -294,7 +294,7 @@ static int fb_launch(const void *enc, const float *xyz, const float *dirs, uint3
 uint64_t ff_workspace_bytes(const FieldDims &dm);
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
-              float *g_rgb, void *workspace, const uint8_t *tile_live, hipStream_t st);
+              float *g_rgb, void *workspace, const uint8_t *tile_live, hipStream_t st, const void *wimg);
 static bool fb_use_fused(const FieldDims &dm, int dtype) {
     static const int env = cn_tune_env("CNERF_FIELD_FUSED_BWD", 1);
     return env && dtype == CNERF_F16 && dm.enc_pad <= 32;           // 92 KiB weight fragments + 64 KiB staging must fit the 160 KiB LDS
@@ -326,6 +326,15 @@ int cnerf_field_backward_ex(const void *enc, const float *xyz, const float *dirs
                             uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
                             const float *grad_sigma, const float *grad_rgbc, void *grad_enc, float *grad_params_net, float *grad_params_den,
                             float *grad_params_rgb, void *workspace, uint64_t workspace_bytes, int dtype, const uint8_t *tile_live, void *stream) {
+    return cnerf_field_backward_img(enc, xyz, dirs, dir_group, P_, enc_dim, n_hidden_geo, n_rgb_out, params_net, params_den, params_rgb, grad_sigma, grad_rgbc,
+                                    grad_enc, grad_params_net, grad_params_den, grad_params_rgb, workspace, workspace_bytes, dtype, tile_live, nullptr, stream);
+}
+
+int cnerf_field_backward_img(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, uint32_t enc_dim,
+                             uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den, const float *params_rgb,
+                             const float *grad_sigma, const float *grad_rgbc, void *grad_enc, float *grad_params_net, float *grad_params_den,
+                             float *grad_params_rgb, void *workspace, uint64_t workspace_bytes, int dtype, const uint8_t *tile_live,
+                             const void *weight_image, void *stream) {
     FieldDims dm;
     int rc = fb_dims(enc_dim, n_hidden_geo, n_rgb_out, dm);
     if (rc) return rc;
@@ -334,13 +343,13 @@ int cnerf_field_backward_ex(const void *enc, const float *xyz, const float *dirs
     if (!enc || !xyz || !dirs || !params_net || !params_den || !params_rgb || !grad_sigma || !grad_rgbc || !grad_enc || !grad_params_net ||
         !grad_params_den || !grad_params_rgb || !workspace)
         return CNERF_ENULL;
-    if (dir_group == 0 || (((uintptr_t)grad_rgbc) & 15) || (((uintptr_t)workspace) & 15)) return CNERF_EINVAL;
+    if (dir_group == 0 || (((uintptr_t)grad_rgbc) & 15) || (((uintptr_t)workspace) & 15) || (((uintptr_t)weight_image) & 15)) return CNERF_EINVAL;
     uint64_t need = 0;
     cnerf_field_backward_workspace_bytes(P_, enc_dim, n_hidden_geo, n_rgb_out, dtype, &need);
     if (workspace_bytes < need) return CNERF_EINVAL;
     if (fb_use_fused(dm, dtype))
         return ff_launch(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, grad_sigma, grad_rgbc, grad_enc, grad_params_net,
-                         grad_params_den, grad_params_rgb, workspace, tile_live, CN_STREAM(stream));
+                         grad_params_den, grad_params_rgb, workspace, tile_live, CN_STREAM(stream), weight_image);
     if (dtype == CNERF_F16)
         return fb_launch<true>(enc, xyz, dirs, dir_group, P_, dm, params_net, params_den, params_rgb, grad_sigma, grad_rgbc, grad_enc,
                                grad_params_net, grad_params_den, grad_params_rgb, workspace, CN_STREAM(stream));

@@ -385,7 +385,7 @@ uint64_t ff_workspace_bytes(const FieldDims &dm) { return (uint64_t)FF_MAX_BLOCK
 bool x2_eligible(const FieldDims &dm);
 int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
-              uint32_t max_partials, const uint8_t *tile_live, hipStream_t st);
+              uint32_t max_partials, const uint8_t *tile_live, hipStream_t st, const void *wimg);
 
 void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t total, uint32_t n_net, uint32_t n_den, float *g_net, float *g_den, float *g_rgb,
                         hipStream_t st) {
@@ -394,10 +394,12 @@ void ff_reduce_partials(const float *partials, uint32_t n_partials, uint32_t tot
 
 int ff_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet,
               const float *pden, const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den,
-              float *g_rgb, void *workspace, const uint8_t *tile_live, hipStream_t st) {
+              float *g_rgb, void *workspace, const uint8_t *tile_live, hipStream_t st, const void *wimg) {
     if (x2_eligible(dm)) {
-        return x2_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, tile_live, st);
+        return x2_launch(enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, grad_enc, g_net, g_den, g_rgb, workspace, FF_MAX_BLOCKS, tile_live, st,
+                         wimg);
     }
+    (void)wimg;                                                 // (the four-wave kernel stages from the float32 parameters)
     // (the four-wave kernel below serves the narrow encodings: it evaluates every tile, which is always correct — dead rows carry zero gradients)
     const FieldLds lo = fld_lds_layout<true>(dm);
     const FieldLdsT lt = fb_ldsT_layout<true>(dm);

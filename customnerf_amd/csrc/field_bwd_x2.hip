@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
                                                               const float *__restrict__ pden, const float *__restrict__ prgb,
                                                               const float *__restrict__ g_sigma, const float *__restrict__ g_rgbc,
                                                               void *__restrict__ grad_enc, float *__restrict__ partials, uint32_t ablate_arg,
-                                                              const uint8_t *__restrict__ tile_live) {
+                                                              const uint8_t *__restrict__ tile_live, const void *__restrict__ wimg) {
 #ifdef CNERF_TUNING
     const uint32_t ablate = ablate_arg;                       // measurement aid, tuning builds only
 #else
@@ -295,6 +295,14 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     const float *d0 = pden, *dO = pden + FLD_HID * FLD_HID;
     const float *r0 = prgb, *rO = prgb + FLD_HID * in_r0;
 
+    if (wimg) {
+        // the packed fp16 image of the forward (field.hip: k_field_pack), 16-byte chunks into the bank-swizzled slots of fb_stage_layer<.., SWZ>:
+        // half index i -> i ^ (((i >> 8) & 3) << 5), i.e. chunk c -> c ^ (((c >> 5) & 3) << 2) (every layer starts at a multiple of 2048 halves)
+        const uint4 *src = reinterpret_cast<const uint4 *>(wimg);
+        uint4 *dst = reinterpret_cast<uint4 *>(wl);
+        for (uint32_t c = threadIdx.x; c < lo.off[7] / 8; c += FLD_THREADS) dst[c ^ (((c >> 5) & 3u) << 2)] = src[c];
+    } else
+    for (int rep = 0; rep < ((ablate & 64) ? 2 : 1); rep++) {                    // (bit 6: staged TWICE — the delta is the staging time)
     fb_stage_layer<H, 0, true>(wl + lo.off[0], n0, FLD_HID, dm.enc_pad, 2, SENC, dm.enc_pad);
     if (NGEO == 2) fb_stage_layer<H, 1, true>(wl + lo.off[1], n1, FLD_HID, FLD_HID, 2, S64, FLD_HID);
     fb_stage_layer<H, 1, true>(wl + lo.off[2], n2, FLD_HID, FLD_HID, 2, S64, FLD_HID);
@@ -302,6 +310,8 @@ __global__ void __launch_bounds__(FLD_THREADS) k_field_bwd_x2(const void *__rest
     fb_stage_layer<H, 1, true>(wl + lo.off[4], dO, 16, FLD_HID, 1, S64, FLD_HID);
     fb_stage_layer<H, 2, true>(wl + lo.off[5], r0, FLD_HID, in_r0, 2, SR0, in_r0);
     fb_stage_layer<H, 1, true>(wl + lo.off[6], rO, 16, FLD_HID, 1, S64, FLD_HID);
+    if (ablate & 64) __syncthreads();
+    }
     // the second K-step of the output-gradient images (features 16..31 of their padded 32-row tile) is never written: zero it once
     for (uint32_t i = threadIdx.x; i < 2 * 2 * (X4_K / 4); i += FLD_THREADS) {
         const uint32_t pr_ = i / (2 * (X4_K / 4)), w = i % (2 * (X4_K / 4));
@@ -693,7 +703,7 @@ bool x2_eligible(const FieldDims &dm) {
 
 int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P_, const FieldDims &dm, const float *pnet, const float *pden,
               const float *prgb, const float *g_sigma, const float *g_rgbc, void *grad_enc, float *g_net, float *g_den, float *g_rgb, void *workspace,
-              uint32_t max_partials, const uint8_t *tile_live, hipStream_t st) {
+              uint32_t max_partials, const uint8_t *tile_live, hipStream_t st, const void *wimg) {
     const FieldLds lo = fld_lds_layout<true>(dm);
     if (lo.off[7] > FLD_HID * (32 + 3 * FLD_HID + (FLD_HID + FLD_DIR)) + 2 * 32 * FLD_HID) return CNERF_EINVAL;
     const uint32_t lds_bytes = 2 * X2_PAIR_BYTES;                               // dynamic part; the weight fragments are a 48 KiB static array
@@ -713,7 +723,7 @@ int x2_launch(const void *enc, const float *xyz, const float *dirs, uint32_t dir
         auto kern = KERN;                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FLD_THREADS), lds_bytes, st, enc, xyz, dirs, dir_group, P_, dm, pnet, pden, prgb, g_sigma, g_rgbc, \
-                           grad_enc, partials, (uint32_t)ablate, tile_live);                                                               \
+                           grad_enc, partials, (uint32_t)ablate, tile_live, wimg);                                                             \
     }
     cn_stage(4, st);
     if (tile_live) {

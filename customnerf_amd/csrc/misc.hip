@@ -349,6 +349,16 @@ int cnerf_scaler_check(const float *g, uint64_t n, float *state, void *stream) {
     return cn_launch_status();
 }
 
+int cnerf_stream_capture_id(void *stream, uint64_t *id) {
+    if (!id) return CNERF_ENULL;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    const hipError_t e = hipStreamGetCaptureInfo(CN_STREAM(stream), &status, &cid);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    *id = status == hipStreamCaptureStatusActive ? (uint64_t)cid : 0;
+    return CNERF_OK;
+}
+
 int cnerf_scaler_watch(float *state) {
     g_cn_found_inf = state ? state + 2 : nullptr;
     return CNERF_OK;

@@ -6,34 +6,76 @@ from torch.autograd import Function
 from ._lib import lib, check, ptr, stream, F16, F32, require_cuda, scratch_key, grad_chain_wait, grad_chain_record, scratch_reallocated
 
 
-def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, with_rgb=True):
+def capture_id():
+    """capture sequence id of the current stream while it records a hipGraph, else 0"""
+    import ctypes
+    cid = ctypes.c_uint64(0)
+    check(lib.cnerf_stream_capture_id(stream(), ctypes.addressof(cid)), "stream_capture_id")
+    return cid.value
+
+
+def packed_weights(cache, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb):
+    """fp16 MFMA fragment image of the three MLPs (cnerf_field_pack_weights) for the current stream, repacked when a parameter moved.
+
+    Every field launch otherwise re-derives that image from the float32 parameters (14 us per launch, three launches per training step).
+    `cache`: a dict owned by the module whose parameters these are.  Freshness = (address, autograd version, fused-optimiser epoch) of the
+    three parameters — which a write through `.data` does NOT move: only callers that control every parameter write for as long as they
+    hold the image may use it (the trainers switch it on for the duration of a training step: NeRFNetwork.packed_field_weights); everyone
+    else leaves it off and the kernels stage from the float32 parameters, which is always right.
+    Under stream capture a pack is RECORDED, not executed: the first use inside a capture (and any use after a parameter moved inside it)
+    records one, so every replay starts from the parameters as they are then; the eager freshness is dropped, because the replays rewrite
+    the image at times this cache does not see."""
+    import ctypes
+    require_cuda(p_net, p_den, p_rgb)
+    key = tuple((p.data_ptr(), p._version, getattr(p, '_cnerf_epoch', 0)) for p in (p_net, p_den, p_rgb))
+    slot = (scratch_key(p_net.device), enc_dim, n_hidden_geo, n_rgb_out)
+    ent = cache.get(slot)
+    if ent is None:
+        need = ctypes.c_uint64(0)
+        check(lib.cnerf_field_weight_image_bytes(int(enc_dim), int(n_hidden_geo), int(n_rgb_out), ctypes.addressof(need)), "field_weight_image_bytes")
+        ent = cache[slot] = {'img': torch.empty(need.value, dtype=torch.uint8, device=p_net.device), 'key': None, 'cap': 0, 'cap_key': None}
+    cap = capture_id()
+    if cap:
+        fresh = ent['cap'] == cap and ent['cap_key'] == key
+        ent['cap'], ent['cap_key'], ent['key'] = cap, key, None
+    else:
+        fresh = ent['key'] == key
+        ent['key'] = key
+    if not fresh:
+        img = ent['img']
+        check(lib.cnerf_field_pack_weights(int(enc_dim), int(n_hidden_geo), int(n_rgb_out), ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(img), img.numel(),
+                                           stream()), "field_pack_weights")
+    return ent['img']
+
+
+def field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, with_rgb=True, wimg=None):
     """enc [L,P',2] (half or float) in kernel layout with P' >= P samples per level (the first P are read), xyz [P,3] f32,
-    dirs [ceil(P/dir_group),3] f32 -> sigma [P], rgbc [P,4] | None."""
-    require_cuda(enc, xyz, p_net, p_den)
+    dirs [ceil(P/dir_group),3] f32 -> sigma [P], rgbc [P,4] | None.  wimg: packed_weights() image of the parameters (half precision), or None."""
+    require_cuda(enc, xyz, p_net, p_den, wimg)
     P = xyz.shape[0]
     assert enc.is_contiguous() and enc.shape[1] >= P
     dt = F16 if enc.dtype == torch.float16 else F32
     sigma = torch.empty(P, dtype=torch.float32, device=xyz.device)
     rgbc = torch.empty(P, 4, dtype=torch.float32, device=xyz.device) if with_rgb else None
-    check(lib.cnerf_field_forward_strided(ptr(enc), ptr(xyz), ptr(dirs) if with_rgb else None, int(dir_group), P, int(enc_dim), int(n_hidden_geo),
-                                          int(n_rgb_out), ptr(p_net), ptr(p_den), ptr(p_rgb) if with_rgb else None, ptr(sigma), ptr(rgbc), dt,
-                                          int(enc.shape[1]), stream()), "field_forward")
+    check(lib.cnerf_field_forward_img(ptr(enc), ptr(xyz), ptr(dirs) if with_rgb else None, int(dir_group), P, int(enc_dim), int(n_hidden_geo),
+                                      int(n_rgb_out), ptr(p_net), ptr(p_den), ptr(p_rgb) if with_rgb else None, ptr(sigma), ptr(rgbc), dt,
+                                      int(enc.shape[1]), ptr(wimg), stream()), "field_forward")
     return sigma, rgbc
 
 
-def field_forward_rows(enc, row0, xyz_rows, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma_out, rgbc_out):
+def field_forward_rows(enc, row0, xyz_rows, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma_out, rgbc_out, wimg=None):
     """Full evaluation (sigma + rgb/confidence) of rows row0 .. row0 + len(xyz_rows) of the kernel-layout feature buffer enc [L, P, 2], written
     into sigma_out [n] / rgbc_out [n, 4] (views into buffers that cover the whole sample list).  renderer._run_fused evaluates the coarse block
     as soon as its features exist — its sigma feeds the importance sampling, so the separate density-only pass of the reference
     (renderer.py:326) costs nothing extra — and the fine block after its gather."""
-    require_cuda(enc, xyz_rows, dirs, p_net, p_den, p_rgb, sigma_out, rgbc_out)
+    require_cuda(enc, xyz_rows, dirs, p_net, p_den, p_rgb, sigma_out, rgbc_out, wimg)
     n = xyz_rows.shape[0]
     assert enc.is_contiguous() and row0 + n <= enc.shape[1] and xyz_rows.is_contiguous() and dirs.is_contiguous()
     assert sigma_out.is_contiguous() and rgbc_out.is_contiguous() and sigma_out.numel() == n and rgbc_out.numel() == 4 * n
     dt = F16 if enc.dtype == torch.float16 else F32
     src = enc.data_ptr() + row0 * enc.shape[2] * enc.element_size()
-    check(lib.cnerf_field_forward_strided(src, ptr(xyz_rows), ptr(dirs), int(dir_group), n, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
-                                          ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(sigma_out), ptr(rgbc_out), dt, int(enc.shape[1]), stream()),
+    check(lib.cnerf_field_forward_img(src, ptr(xyz_rows), ptr(dirs), int(dir_group), n, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
+                                      ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(sigma_out), ptr(rgbc_out), dt, int(enc.shape[1]), ptr(wimg), stream()),
           "field_forward")
 
 
@@ -58,11 +100,12 @@ class FieldFunction(Function):
     (positions / directions get no gradient on CustomNeRF's path).  Nothing is saved but the inputs: the backward recomputes."""
 
     @staticmethod
-    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False):
+    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False, wimg=None):
         ctx.params = (p_net, p_den, p_rgb) if grad_in_place else None          # the Parameter objects themselves (their .grad is the target)
+        ctx.wimg = wimg                                                        # (the backward recomputes from the same parameters: same image)
         xyz = xyz.contiguous().float()
         dirs = dirs.contiguous().float()
-        sigma, rgbc = field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, True)
+        sigma, rgbc = field_forward_raw(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, True, wimg)
         ctx.save_for_backward(enc, xyz, dirs, p_net, p_den, p_rgb)
         ctx.cfg = (dir_group, enc_dim, n_hidden_geo, n_rgb_out)
         return sigma, rgbc
@@ -101,13 +144,13 @@ class FieldFunction(Function):
         ws = _workspace(P, enc_dim, n_hidden_geo, n_rgb_out, dt, xyz.device)
         if in_place:
             grad_chain_wait(xyz.device)                                # the partial reduction adds into the shared .grad buffers
-        check(lib.cnerf_field_backward_ex(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
-                                          ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
-                                          ptr(ws), ws.numel(), dt, ptr(tile_live), stream()), "field_backward")
+        check(lib.cnerf_field_backward_img(ptr(enc), ptr(xyz), ptr(dirs), int(dir_group), P, int(enc_dim), int(n_hidden_geo), int(n_rgb_out),
+                                           ptr(p_net), ptr(p_den), ptr(p_rgb), ptr(g_sigma), ptr(g_rgbc), ptr(g_enc), ptr(g_net), ptr(g_den), ptr(g_rgb),
+                                           ptr(ws), ws.numel(), dt, ptr(tile_live), ptr(getattr(ctx, 'wimg', None)), stream()), "field_backward")
         if in_place:
             grad_chain_record(xyz.device)
-            return g_enc, None, None, None, None, None, None, None, None, None, None
-        return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb, None
+            return g_enc, None, None, None, None, None, None, None, None, None, None, None
+        return g_enc, None, None, None, None, None, None, g_net, g_den, g_rgb, None, None
 
 
 class FieldAttach(Function):
@@ -115,20 +158,21 @@ class FieldAttach(Function):
     FieldFunction's (it recomputes the forward from the saved inputs, so nothing else has to be kept)."""
 
     @staticmethod
-    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc):
+    def forward(ctx, enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc, wimg=None):
         ctx.params = (p_net, p_den, p_rgb) if grad_in_place else None
+        ctx.wimg = wimg
         ctx.save_for_backward(enc, xyz.contiguous().float(), dirs.contiguous().float(), p_net, p_den, p_rgb)
         ctx.cfg = (dir_group, enc_dim, n_hidden_geo, n_rgb_out)
         return sigma.detach(), rgbc.detach()
 
     @staticmethod
     def backward(ctx, g_sigma, g_rgbc):
-        return FieldFunction.backward(ctx, g_sigma, g_rgbc) + (None, None)
+        return FieldFunction.backward(ctx, g_sigma, g_rgbc)[:11] + (None, None, None)
 
 
-def field_attach(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma, rgbc, grad_in_place=False):
-    return FieldAttach.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc)
+def field_attach(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, sigma, rgbc, grad_in_place=False, wimg=None):
+    return FieldAttach.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, sigma, rgbc, wimg)
 
 
-def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False):
-    return FieldFunction.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place)
+def field(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place=False, wimg=None):
+    return FieldFunction.apply(enc, xyz, dirs, dir_group, enc_dim, n_hidden_geo, n_rgb_out, p_net, p_den, p_rgb, grad_in_place, wimg)

@@ -12,7 +12,7 @@ from .renderer import NeRFRenderer
 from .encoding import get_encoder, get_embedder
 from .provider_utils import trunc_exp
 from .. import tcnn
-from ..field import field, field_attach, field_forward_raw, field_forward_rows
+from ..field import field, field_attach, field_forward_raw, field_forward_rows, packed_weights
 from ..gridencoder import GridEncoder
 
 
@@ -99,6 +99,17 @@ class NeRFNetwork(NeRFRenderer):
         surface, keep the reference's autocast rule.)"""
         return self.network.compute_dtype == torch.float16
 
+    def _weight_image(self):
+        """The fp16 fragment image of the three MLPs for the fused kernels (field.packed_weights), or None = the kernels stage from the float32
+        parameters.  Off unless `packed_field_weights` is set: the image is keyed on the parameters' version counters, which a write through
+        `.data` does not move (torch_ema's copy_to / restore, a drop-in trainer's `param.data.copy_`) — the trainers of this package, whose
+        every parameter write goes through an optimiser, switch it on for the duration of a training step (trainer.packed_weights_window)."""
+        if not self.__dict__.get('packed_field_weights') or not self._half():
+            return None
+        enc_dim, n_geo, n_rgb = self._fused_cfg()
+        return packed_weights(self.__dict__.setdefault('_wimg_cache', {}), enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
+                              self.rgb_network.params)
+
     def _geo(self, x):
         x_en = self.pos_en(x, bound=self.opt.bound)
         fea = self.network(x_en)
@@ -115,7 +126,7 @@ class NeRFNetwork(NeRFRenderer):
             x = x.reshape(-1, 3)
             enc = self.pos_en.encode(x, bound=self.opt.bound, half=self._half())
             sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
-                                self.rgb_network.params)
+                                self.rgb_network.params, wimg=self._weight_image())
             return sigma, (rgbc if n_rgb == 4 else rgbc[:, :3]), None
         if dir_group != 1:
             d = d.reshape(-1, 3).repeat_interleave(dir_group, dim=0)[:x.reshape(-1, 3).shape[0]]
@@ -133,7 +144,7 @@ class NeRFNetwork(NeRFRenderer):
             x = x.reshape(-1, 3).contiguous().float()
             enc = self.pos_en.encode(x, bound=self.opt.bound, half=self._half())
             sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None,
-                                         with_rgb=False)
+                                         with_rgb=False, wimg=self._weight_image())
             return {'sigma': sigma}
         return {'sigma': self._geo(x)[1]}
 
@@ -172,7 +183,8 @@ class NeRFNetwork(NeRFRenderer):
     def split_density(self, enc, x):
         """sigma of the first len(x) rows of enc (network_grid.py:180-193)"""
         enc_dim, n_geo, n_rgb = self._fused_cfg()
-        sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None, with_rgb=False)
+        sigma, _ = field_forward_raw(enc, x, None, 1, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params, None, with_rgb=False,
+                                     wimg=self._weight_image())
         return sigma
 
     def _overlap_plan(self):
@@ -204,7 +216,7 @@ class NeRFNetwork(NeRFRenderer):
         if torch.is_grad_enabled() and self.pos_en.embeddings.requires_grad:
             enc = self.pos_en.attach_backward(enc, unit, overlap=self._overlap_plan(), plan=plan)
         sigma, rgbc = field(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
-                            self.rgb_network.params, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
+                            self.rgb_network.params, grad_in_place=bool(getattr(self, 'grad_in_place', False)), wimg=self._weight_image())
         return sigma, rgbc
 
     # ---- block-wise full evaluation (renderer._run_fused): the coarse block is evaluated in full as soon as its features exist (its sigma is
@@ -218,7 +230,8 @@ class NeRFNetwork(NeRFRenderer):
         enc_dim, n_geo, n_rgb = self._fused_cfg()
         n = x_rows.shape[0]
         field_forward_rows(enc, row0, x_rows, d.reshape(-1, 3).contiguous().float(), dir_group, enc_dim, n_geo, n_rgb, self.network.params,
-                           self.density_network.params, self.rgb_network.params, sigma_all[row0:row0 + n], rgbc_all[row0:row0 + n])
+                           self.density_network.params, self.rgb_network.params, sigma_all[row0:row0 + n], rgbc_all[row0:row0 + n],
+                           wimg=self._weight_image())
 
     def split_attach(self, enc, unit, x, d, dir_group, sigma_all, rgbc_all, plan=None):
         """(sigma [P], rgbc [P, 4]) computed by split_forward_rows -> the same values, differentiable in the table and the MLP parameters"""
@@ -228,7 +241,8 @@ class NeRFNetwork(NeRFRenderer):
         if self.pos_en.embeddings.requires_grad:
             enc = self.pos_en.attach_backward(enc, unit, overlap=self._overlap_plan(), plan=plan)
         return field_attach(enc, x, d.reshape(-1, 3), dir_group, enc_dim, n_geo, n_rgb, self.network.params, self.density_network.params,
-                            self.rgb_network.params, sigma_all, rgbc_all, grad_in_place=bool(getattr(self, 'grad_in_place', False)))
+                            self.rgb_network.params, sigma_all, rgbc_all, grad_in_place=bool(getattr(self, 'grad_in_place', False)),
+                            wimg=self._weight_image())
 
     def get_params(self, lr):
         """network_grid.py:196-206: grid lr x10."""

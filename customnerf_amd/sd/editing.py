@@ -202,17 +202,18 @@ class EditTrainer(CheckpointMixin, EvalMixin):
 
     def train_step(self, data, multi=False):
         """one optimiser step of the editing loop (train_one_epoch body, utils_init_nerf.py:599-629, with editing=True)"""
-        from ..trainer import inf_check_is_folded
+        from ..trainer import inf_check_is_folded, packed_weights_window
         self.model.train()
         self._inf_folded = inf_check_is_folded(self)                     # (round 6: the gradient producers raise found_inf themselves: trainer.inf_check_is_folded)
         if self.scaler is not None:
             self.scaler.watch(self._inf_folded)
         try:
-            pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing_multi(data) if multi else self.train_step_editing(data)
-            if self.scaler is not None:
-                self.scaler.backward(loss)
-            else:
-                (loss * self.loss_scale).backward()
+            with packed_weights_window(self.model, self.opt):
+                pred_rgb, pred_ws, loss, loss_dict = self.train_step_editing_multi(data) if multi else self.train_step_editing(data)
+                if self.scaler is not None:
+                    self.scaler.backward(loss)
+                else:
+                    (loss * self.loss_scale).backward()
             apply_optimizer_step(self)                                   # gradient exchange (world > 1) + scaler check + Adam + shadow hand-over
         finally:
             if self.scaler is not None:

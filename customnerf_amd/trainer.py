@@ -80,6 +80,27 @@ def refresh_half_shadow(optimizer, model):
         enc.set_half_table(optimizer.half_shadows[enc.embeddings])   # the step just rewrote it: mark it current
 
 
+class packed_weights_window:
+    """`with packed_weights_window(model):` — for the duration of a training step the fused field kernels read the packed fp16 image of the MLP
+    parameters (NeRFNetwork._weight_image / field.packed_weights: one pack launch per parameter version instead of 14 us of staging in each
+    of the step's three field launches).  Only inside the step: there every parameter write goes through the trainer's optimiser, which moves
+    the version counters the image is keyed on; outside (evaluation under torch_ema's `.data` swaps, user code) the kernels stage from the
+    float32 parameters.  `opt.packed_field_weights = False` switches it off."""
+
+    def __init__(self, model, opt=None):
+        self.d = getattr(model, '__dict__', None) if getattr(opt, 'packed_field_weights', True) else None
+
+    def __enter__(self):
+        if self.d is not None:
+            self.prev = self.d.get('packed_field_weights', False)
+            self.d['packed_field_weights'] = True
+
+    def __exit__(self, *exc):
+        if self.d is not None:
+            self.d['packed_field_weights'] = self.prev
+        return False
+
+
 def inf_check_is_folded(trainer):
     """Round 6: GradScaler's inf check is a pass over every gradient (9 us for the benchmark table, 30 us for the reference
     field's).  With the scaler WATCHED (DynamicLossScaler.watch) the two kernels that produce the gradients raise found_inf themselves — the field
@@ -321,7 +342,8 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
     def train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
         self._watch_scaler()
         try:
-            return self._train_step(rays_o, rays_d, rgbs, mask, select_inds, **render_kw)
+            with packed_weights_window(self.model, self.opt):
+                return self._train_step(rays_o, rays_d, rgbs, mask, select_inds, **render_kw)
         finally:
             if self.scaler is not None:
                 self.scaler.watch(False)                 # (the library holds a raw pointer into the scaler's state only for the duration of a step)
@@ -386,7 +408,7 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             graph = torch.cuda.CUDAGraph()
             self._watch_scaler()
             try:
-                with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')):
+                with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')), packed_weights_window(self.model, self.opt):
                     with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
                         outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
                         loss = self.loss(outputs, rgbs, mask)

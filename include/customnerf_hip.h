@@ -34,7 +34,7 @@ extern "C" {
  * 2: the GroupNorm / GEMM-epilogue statistics buffers of customnerf_sd.h are int64[B][G][2] fixed point (were float[B][G][2]).
  * 4: struct CnerfSdGemm grew the ln_* fields (LayerNorm of the output rows in the split-K tail); new entry points
  *    cnerf_grid_encode_forward_ordered, cnerf_sd_concat_gn, cnerf_sd_gemm_serves_ln, cnerf_profile_stage_events. */
-#define CNERF_ABI_VERSION 4
+#define CNERF_ABI_VERSION 5
 int cnerf_abi_version(void);
 /* name of the code object's target ("gfx950") */
 const char *cnerf_target_arch(void);
@@ -273,6 +273,27 @@ int cnerf_field_backward_ex(const void *enc, const float *xyz, const float *dirs
                             uint64_t workspace_bytes, int dtype, const uint8_t *tile_live, void *stream);
 int cnerf_field_backward_workspace_bytes(uint32_t P, uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, int dtype,
                                          uint64_t *bytes);
+/* Packed weights (ABI 5).  Every launch above re-derives its fp16 MFMA fragment image of the three MLPs from the float32 parameters (14 us per
+ * launch, three launches per training step).  cnerf_field_pack_weights writes that image once — `image`: 16-byte aligned device buffer of
+ * cnerf_field_weight_image_bytes() bytes; the caller repacks after every change of the parameters — and the _img variants copy it into LDS
+ * instead (CNERF_F16 only: with weight_image == NULL or CNERF_F32 they ARE cnerf_field_forward_strided / cnerf_field_backward_ex; the
+ * narrow-encoding backward — enc_dim <= 16 — accepts an image and ignores it).  Results are bit-identical: the image holds the very halves
+ * the kernels would have staged.  The reference has no counterpart (tcnn keeps fp16 parameters: network_grid.py:98-139). */
+/* *id = the capture sequence id of `stream` while it is capturing into a hipGraph, 0 otherwise (host-side query, no launch): what a cache of
+ * derived device data — e.g. the packed weights below — needs to know that a refresh it issues now is RECORDED, not executed. */
+int cnerf_stream_capture_id(void *stream, uint64_t *id);
+int cnerf_field_weight_image_bytes(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, uint64_t *bytes);
+int cnerf_field_pack_weights(uint32_t enc_dim, uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                             const float *params_rgb, void *image, uint64_t image_bytes, void *stream);
+int cnerf_field_forward_img(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                            uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                            const float *params_rgb, float *sigma, float *rgbc, int dtype, uint32_t enc_level_stride,
+                            const void *weight_image, void *stream);
+int cnerf_field_backward_img(const void *enc, const float *xyz, const float *dirs, uint32_t dir_group, uint32_t P, uint32_t enc_dim,
+                             uint32_t n_hidden_geo, uint32_t n_rgb_out, const float *params_net, const float *params_den,
+                             const float *params_rgb, const float *grad_sigma, const float *grad_rgbc, void *grad_enc,
+                             float *grad_params_net, float *grad_params_den, float *grad_params_rgb, void *workspace,
+                             uint64_t workspace_bytes, int dtype, const uint8_t *tile_live, const void *weight_image, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Generic fully fused MLP = tinycudann.Network(n_in, n_out, {FullyFusedMLP, ReLU, 64 neurons, 1|2 hidden layers})

@@ -156,3 +156,103 @@ def test_field_backward_is_reproducible():
         outs.append((pn.grad.clone(), pd.grad.clone(), pr.grad.clone(), e.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ---- packed weights (ABI 5: cnerf_field_pack_weights + the _img entry points) ----
+def _field_run(enc_t, x, d, dir_group, L, n_geo, params, gs, gc, wimg):
+    from customnerf_amd.field import field
+    pn, pd, pr = (t.detach().clone().requires_grad_(True) for t in params)
+    if wimg == "pack":
+        from customnerf_amd.field import packed_weights
+        wimg = packed_weights({}, 2 * L, n_geo, 4, pn, pd, pr)
+    e = enc_t.detach().clone().requires_grad_(True)
+    s, c = field(e, x, d, dir_group, 2 * L, n_geo, 4, pn, pd, pr, wimg=wimg)
+    torch.autograd.backward([s, c], [gs, gc])
+    return s.detach(), c.detach(), e.grad, pn.grad, pd.grad, pr.grad
+
+
+@pytest.mark.parametrize("L,n_geo,P,dir_group", [(16, 2, 40000, 1), (16, 1, 64 * 300, 64), (12, 2, 5003, 1), (4, 1, 3000, 1)])
+def test_packed_weights_are_bit_identical(L, n_geo, P, dir_group):
+    """forward and backward reading the packed fp16 image (k_field_pack) against the same launches staging from the float32 parameters:
+    the image holds the very halves the kernels stage, so every output is the same bits ((4, 1): the narrow-encoding backward accepts an
+    image and ignores it)"""
+    ref, enc, x, d = make_case(L, n_geo, P, seed=5)
+    params = [t.detach().clone().cuda() for t in (ref.network, ref.density_network, ref.rgb_network)]
+    n_dir = (P + dir_group - 1) // dir_group
+    g = torch.Generator().manual_seed(1)
+    gs, gc = torch.randn(P, generator=g).cuda() * 0.05, torch.randn(P, 4, generator=g).cuda()
+    with torch.no_grad():
+        e = enc.encode(cuda(x), bound=2.0, half=True)
+    a = _field_run(e, cuda(x), cuda(d[:n_dir]), dir_group, L, n_geo, params, gs, gc, None)
+    b = _field_run(e, cuda(x), cuda(d[:n_dir]), dir_group, L, n_geo, params, gs, gc, "pack")
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # density-only launch (the image's rgb layers are not copied)
+    from customnerf_amd.field import field_forward_raw, packed_weights
+    s0, _ = field_forward_raw(e, cuda(x), None, 1, 2 * L, n_geo, 4, params[0], params[1], None, with_rgb=False)
+    s1, _ = field_forward_raw(e, cuda(x), None, 1, 2 * L, n_geo, 4, params[0], params[1], None, with_rgb=False,
+                              wimg=packed_weights({}, 2 * L, n_geo, 4, *params))
+    assert torch.equal(s0, s1) and torch.equal(s0, a[0])
+
+
+def test_packed_weights_follow_the_parameters():
+    """the cache repacks when a parameter's version counter or fused-optimiser epoch moved, records a pack inside a stream capture (a replay
+    after a parameter update then evaluates the NEW parameters), and drops its eager freshness after a capture"""
+    from customnerf_amd.field import field_forward_raw, packed_weights
+    L, n_geo, P = 16, 2, 4096
+    ref, enc, x, d = make_case(L, n_geo, P, seed=9)
+    pn, pd, pr = (t.detach().clone().cuda() for t in (ref.network, ref.density_network, ref.rgb_network))
+    with torch.no_grad():
+        e = enc.encode(cuda(x), bound=2.0, half=True)
+    xs, ds = cuda(x), cuda(d)
+    run = lambda w: field_forward_raw(e, xs, ds, 1, 2 * L, n_geo, 4, pn, pd, pr, wimg=w)
+    cache = {}
+    w = packed_weights(cache, 2 * L, n_geo, 4, pn, pd, pr)
+    assert packed_weights(cache, 2 * L, n_geo, 4, pn, pd, pr).data_ptr() == w.data_ptr()
+    s0, c0 = run(w)
+    pn.mul_(1.25)                                                         # in-place op: the version counter moves
+    s1, c1 = run(packed_weights(cache, 2 * L, n_geo, 4, pn, pd, pr))
+    sr, cr = run(None)
+    assert torch.equal(s1, sr) and torch.equal(c1, cr) and not torch.equal(c1, c0)
+    pr.data.mul_(0.5)                                                     # a raw write + the fused optimiser's epoch (optim.FusedAdam.step)
+    pr._cnerf_epoch = getattr(pr, '_cnerf_epoch', 0) + 1
+    s2, c2 = run(packed_weights(cache, 2 * L, n_geo, 4, pn, pd, pr))
+    sr, cr = run(None)
+    assert torch.equal(s2, sr) and torch.equal(c2, cr)
+    # capture: forward through the image; the pack is part of the graph
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cache_s = {}
+        run(packed_weights(cache_s, 2 * L, n_geo, 4, pn, pd, pr))        # warm-up on the capture stream (allocations)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            sg, cg = run(packed_weights(cache_s, 2 * L, n_geo, 4, pn, pd, pr))
+            sg2, cg2 = run(packed_weights(cache_s, 2 * L, n_geo, 4, pn, pd, pr))      # second use inside the capture: no second pack needed
+        slot = next(iter(cache_s.values()))
+        assert slot['key'] is None                                       # eager freshness dropped: the replays rewrite the image
+        pd.mul_(0.75)
+        graph.replay()
+        torch.cuda.synchronize()
+        sr, cr = run(None)
+        assert torch.equal(sg, sr) and torch.equal(cg, cr) and torch.equal(sg2, sr) and torch.equal(cg2, cr)
+        pn.mul_(0.9)
+        s3, c3 = run(packed_weights(cache_s, 2 * L, n_geo, 4, pn, pd, pr))            # eager again: repacked
+        sr, cr = run(None)
+        assert torch.equal(s3, sr) and torch.equal(c3, cr)
+    torch.cuda.current_stream().wait_stream(side)
+
+
+def test_pack_weights_argument_validation():
+    import ctypes
+    from customnerf_amd._lib import lib, ptr
+    need = ctypes.c_uint64(0)
+    assert lib.cnerf_field_weight_image_bytes(32, 2, 4, ctypes.addressof(need)) == 0 and need.value == 2 * (64 * 32 + 3 * 4096 + 2048 + 64 * 96 + 2048)
+    assert lib.cnerf_field_weight_image_bytes(33, 2, 4, ctypes.addressof(need)) < 0
+    p = torch.zeros(8192, device='cuda')
+    img = torch.empty(need.value, dtype=torch.uint8, device='cuda')
+    assert lib.cnerf_field_pack_weights(32, 2, 4, ptr(p), ptr(p), ptr(p), ptr(img), need.value - 16, None) < 0         # image too small
+    assert lib.cnerf_field_pack_weights(32, 2, 4, ptr(p), ptr(p), None, ptr(img), need.value, None) < 0                # NULL parameter vector
+    assert lib.cnerf_field_pack_weights(32, 2, 4, ptr(p), ptr(p), ptr(p), img.data_ptr() + 8, need.value, None) < 0    # misaligned image

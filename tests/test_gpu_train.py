@@ -296,6 +296,43 @@ def test_training_is_bit_reproducible():
         assert torch.equal(pa, pb)
 
 
+def test_training_is_bit_identical_with_and_without_packed_weights():
+    """the trainers run their steps on the packed fp16 image of the MLP parameters (trainer.packed_weights_window: one pack per optimiser step
+    instead of staging in each of the three field launches); six steps — eager, then the graphed step, whose capture records its own pack —
+    end in the parameters of the same steps with the image off (`opt.packed_field_weights = False`), bit for bit"""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+
+    def train(packed):
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True)
+        opt.packed_field_weights = packed
+        model = NeRFNetwork(opt).cuda()
+        H = W = 64
+        o, d, rgb, mask = _target_scene(H, W, 1)
+        tr = ReconTrainer(model, opt, fp16=True)
+        kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+        for i in range(3):
+            torch.manual_seed(100 + i)
+            tr.train_step(o[0], d[0], rgb[0], mask[0], **kw)
+        used = bool(model.__dict__.get('_wimg_cache'))
+        assert not model.__dict__.get('packed_field_weights', False)        # the window closed with the step
+        for i in range(4):                                                  # (two eager warm-ups + capture + one replay inside)
+            torch.manual_seed(200 + i)
+            tr.train_step_graphed(o[0], d[0], rgb[0], mask[0], **kw)
+        return [p.detach().clone() for p in model.parameters()], used
+
+    try:
+        (a, used_a), (b, used_b) = train(True), train(False)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+    assert used_a and not used_b
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+
+
 def test_training_trajectory_is_bit_identical_with_and_without_early_termination():
     """Early termination (the compositing backward flushes gradients the half-precision consumers would round to zero; field backward and scatter skip the
     dead tiles / rows) is claimed to change no bit of any parameter gradient.  Compounded over a run: 400 optimiser steps on the analytic sphere scene from
