@@ -222,16 +222,17 @@ _GRAD_CHAIN = {}
 
 def grad_chain_wait(device):
     """Kernels that read-modify-write the trainers' shared persistent .grad buffers (grid scatter, field partial reduction) must not
-    overlap each other across streams: wait for the previous one ..."""
+    overlap each other across streams: wait for the previous one ...  On ONE stream the launch order already is that order, and nothing is
+    enqueued (round 6: an event record per producer was a 5.8 us bubble on the queue, two per step — scratch/recon_gaps.sh); a producer on
+    another stream waits for the tail of the previous producer's stream (a later point than the producer itself: conservative)."""
     import torch
-    ev = _GRAD_CHAIN.get(device)
-    if ev is not None:
-        torch.cuda.current_stream(device).wait_event(ev)
+    cur = torch.cuda.current_stream(device)
+    last = _GRAD_CHAIN.get(device)
+    if last is not None and last.cuda_stream != cur.cuda_stream:
+        cur.wait_stream(last)
 
 
 def grad_chain_record(device):
-    """... and leave an event behind for the next."""
+    """... and remember which stream the next one has to order itself after."""
     import torch
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    _GRAD_CHAIN[device] = ev
+    _GRAD_CHAIN[device] = torch.cuda.current_stream(device)

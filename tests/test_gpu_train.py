@@ -267,6 +267,53 @@ def test_in_place_gradient_accumulation_matches_autograd_accumulation():
         tcnn.set_default_dtype(torch.float32)
 
 
+def test_in_place_gradients_from_two_streams_are_ordered():
+    """_lib.grad_chain_wait / _record: the in-place gradient producers of one stream enqueue nothing (launch order is the order); a producer on a
+    second stream orders itself after the first stream's tail.  Two passes — the second on a side stream that does NOT wait for the main stream
+    by itself — accumulate the gradients of two passes on one stream."""
+    from customnerf_amd import scene as sc, tcnn, _lib
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import enable_grad_in_place, flat_grad_buffer
+    tcnn.set_default_dtype(torch.float16)
+    try:
+        H = W = 64
+        o, d, rgb, mask = _target_scene(H, W, 1)
+        g = torch.Generator().manual_seed(7)
+        draws = dict(light=torch.randn(3, generator=g), z=torch.rand(H * W, 32, generator=g), u=torch.rand(H * W, 32, generator=g))
+        grads = []
+        for two_streams in (False, True):
+            torch.manual_seed(0)
+            opt = sc.make_opt(fp16=True, num_levels=16, log2_hashmap_size=19, desired_resolution=2048)
+            model = NeRFNetwork(opt).cuda().train()
+            flat = flat_grad_buffer(model.parameters())
+            enable_grad_in_place(model)
+
+            def one_pass():
+                with torch.autocast('cuda', dtype=torch.float16):
+                    res = model.render(o[0], d[0], staged=False, perturb=True, force_all_rays=True, num_steps=32, upsample_steps=32, _draws=draws)
+                    loss = ((res['image'].reshape(-1, 3).float() - rgb[0]) ** 2).mean() + 0.1 * res['render_mask'].float().mean()
+                (loss * 1024.0).backward()
+
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):      # settle the per-model caches (fp16 shadow table) ...
+                model.render(o[0], d[0], staged=False, perturb=True, force_all_rays=True, num_steps=32, upsample_steps=32, _draws=draws)
+            torch.cuda.synchronize()                                                 # ... so that the side stream's forward reads nothing in flight
+            one_pass()
+            if two_streams:
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):                            # (no side.wait_stream(main): the producers have to order themselves)
+                    one_pass()
+                assert _lib._GRAD_CHAIN[o.device].cuda_stream == side.cuda_stream
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                one_pass()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in model.parameters()])
+        for a, b in zip(*grads):
+            assert float(a.abs().max()) > 0 and torch.equal(a, b)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+
+
 def test_training_is_bit_reproducible():
     """Two identical fp16 trainings (same seed, full-size 128x128 views so that the binned fixed-point scatter, the wave-specialised field
     backward and the split-bin reduction all run) end in bit-identical parameters: every reduction on the path has a fixed order or is
