@@ -374,6 +374,17 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
     for (int v = 0; v < 3; v++)
 #pragma unroll
         for (int k = 0; k < 6; k++) go[v][k] = g_out[((size_t)v * N + n) * 6 + k];
+    // A variant none of whose six outputs received a gradient adds exact zeros to every sample gradient of the ray: skip its transmittance scans and
+    // exponentials (wave-uniform: the wave owns the ray).  The reconstruction loss touches the first variant only (k_recon_loss writes zeros for the
+    // other two), the editing losses all three.  (`!(x == 0)`: a NaN gradient keeps its variant.)
+    bool use[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 6; k++) any = any || !(go[v][k] == 0.0f);
+        use[v] = __builtin_amdgcn_readfirstlane(any ? 1 : 0) != 0;
+    }
 
     // pass 1: totals sum_k G_k w_k per variant
     float tot[3] = {0, 0, 0};
@@ -393,6 +404,7 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
             const float e = rn_edit(c.w, soft, thr);
 #pragma unroll
             for (int v = 0; v < 3; v++) {
+                if (!use[v]) continue;
                 const float alpha = ok ? 1.0f - expf(-delta * (sigma * rn_variant_scale(v, e))) : 0.0f;
                 const float tr = rn_excl_prod_scan(ok ? (1.0f - alpha + 1e-15f) : 1.0f, carry[v], lane);
                 const float G = go[v][0] * c.x + go[v][1] * c.y + go[v][2] * c.z + go[v][3] * zn + go[v][4] + (detach_mask ? 0.0f : go[v][5] * c.w);
@@ -400,7 +412,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
             }
         }
 #pragma unroll
-        for (int v = 0; v < 3; v++) tot[v] = rn_wave_sum(tot[v]);
+        for (int v = 0; v < 3; v++)
+            if (use[v]) tot[v] = rn_wave_sum(tot[v]);
     }
     // pass 2: gradients
     float carry[3] = {1.0f, 1.0f, 1.0f}, pref[3] = {0, 0, 0};
@@ -421,6 +434,7 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
         float4 gc = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 3; v++) {
+            if (!use[v]) continue;
             const float m = rn_variant_scale(v, e);
             const float alpha = ok ? 1.0f - expf(-delta * (sigma * m)) : 0.0f;
             const float q = 1.0f - alpha + 1e-15f;
