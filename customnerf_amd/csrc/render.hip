@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
                                                                   uint32_t T, uint32_t t, float *__restrict__ z_all, float *__restrict__ xyz_all,
                                                                   float *__restrict__ xyz_fine, uint32_t *__restrict__ src_index, float *__restrict__ unit_fine,
                                                                   float bound) {
-    __shared__ float s_z[RN_WAVES][RN_MAXS], s_w[RN_WAVES][RN_MAXS], s_cdf[RN_WAVES][RN_MAXS], s_bin[RN_WAVES][RN_MAXS], s_nz[RN_WAVES][RN_MAXS];
+    __shared__ float s_z[RN_WAVES][RN_MAXS], s_w[RN_WAVES][RN_MAXS], s_cdf[RN_WAVES][RN_MAXS], s_bin[RN_WAVES][RN_MAXS];
+    __shared__ __attribute__((aligned(16))) float s_nz[RN_WAVES][RN_MAXS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
     if (n >= N) return;                                   // whole wave exits together; no workgroup barrier below
@@ -181,9 +182,15 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
         const float tt = (u - cb) / denom;
         nz[m] = bins[below] + tt * (bins[above] - bins[below]);
     }
+    // (the rank loops below read the fine samples four at a time: pad to a multiple of four with +inf, which no comparison counts)
+    for (uint32_t m = t + lane; m < ((t + 3u) & ~3u); m += 64) nz[m] = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
     // merge by rank: position of a coarse sample = its index + #fine < it; of a fine sample = its rank among the fine ones
     // (ties by index) + #coarse <= it.  Equal values give equal samples, so any tie order reproduces torch.sort's output.
+    // Round 6: 16-byte broadcast reads of the fine samples (a scalar LDS read per comparison was a 192-step latency chain per lane) and a
+    // binary search in the coarse samples, which are sorted (stratified draw; the rank rule above already relies on it).
+    const float4 *nz4 = reinterpret_cast<const float4 *>(nz);
+    const uint32_t t4 = (t + 3u) >> 2;
     const float *o = rays_o + (size_t)n * 3, *d = rays_d + (size_t)n * 3;
     // Two output forms.  Merged (xyz_all): positions in sorted order, what the reference evaluates.  Split (xyz_fine + src_index): the
     // new samples stay in their own block [N, t, 3] behind the coarse block [N, T, 3] (whose grid features are already computed),
@@ -193,7 +200,10 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
     for (uint32_t i = lane; i < T; i += 64) {
         const float v = zz[i];
         uint32_t pos = i;
-        for (uint32_t m = 0; m < t; m++) pos += (nz[m] < v) ? 1u : 0u;
+        for (uint32_t m = 0; m < t4; m++) {
+            const float4 w = nz4[m];
+            pos += ((w.x < v) ? 1u : 0u) + ((w.y < v) ? 1u : 0u) + ((w.z < v) ? 1u : 0u) + ((w.w < v) ? 1u : 0u);
+        }
         za[pos] = v;
         if (xa) {
             float p[3];
@@ -205,11 +215,19 @@ __global__ void __launch_bounds__(RN_THREADS) k_sample_fine_merge(const float *_
     for (uint32_t m = lane; m < t; m += 64) {
         const float v = nz[m];
         uint32_t pos = 0;
-        for (uint32_t k = 0; k < t; k++) {
-            const float w = nz[k];
-            pos += (w < v || (w == v && k < m)) ? 1u : 0u;
+        for (uint32_t k = 0; k < t4; k++) {
+            const float4 w = nz4[k];
+            pos += ((w.x < v || (w.x == v && 4 * k < m)) ? 1u : 0u) + ((w.y < v || (w.y == v && 4 * k + 1 < m)) ? 1u : 0u) +
+                   ((w.z < v || (w.z == v && 4 * k + 2 < m)) ? 1u : 0u) + ((w.w < v || (w.w == v && 4 * k + 3 < m)) ? 1u : 0u);
         }
-        for (uint32_t i = 0; i < T; i++) pos += (zz[i] <= v) ? 1u : 0u;
+        {
+            uint32_t lo = 0, hi = T;                          // #coarse <= v = first index with zz > v
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (zz[mid] <= v) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
+        }
         float p[3];
         rn_point(o, d, v, aabb, p);
         za[pos] = v;
