@@ -27,6 +27,9 @@
 // 8-byte pair records, block-local counting, fixed-capacity bin regions with spill) serves everything CustomNeRF runs — the benchmark table and the
 // reference field's own 2^21-entry table.  The second form (histogram-driven pair records, rounds 2-4) is gone; its record format lives on.
 #include "grid_common.h"
+#include <vector>
+#include <algorithm>
+#include <cstdio>
 
 #define BN_CHUNK_LOG2 12
 #define BN_CHUNK (1u << BN_CHUNK_LOG2)            // table entries per bin  (x 2 ch x 8 B fixed point = 64 KiB LDS)
@@ -167,15 +170,18 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin_scan_blocks(uint32_t *_
 // bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
 __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
                                                         uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records,
-                                                        uint32_t *__restrict__ seg_bin) {
+                                                        uint32_t *__restrict__ seg_bin, uint32_t *__restrict__ split_list = nullptr) {
     __shared__ uint32_t wt_r[16], wt_s[16];
-    __shared__ uint32_t carry_r, carry_s;
+    __shared__ uint32_t carry_r, carry_s, n_split;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry_r = 0; carry_s = 0; }
+    if (tid == 0) { carry_r = 0; carry_s = 0; n_split = 0; }
     __syncthreads();
     for (uint32_t start = 0; start < total_bins; start += 1024) {
         const uint32_t i = start + tid;
         const uint32_t r = i < total_bins ? bin_total[i] : 0;
+        // (segments rounded to nearest with the last one taking the remainder — no near-empty second segment for a bin a few records over the
+        // segment size — were measured: nothing at random initialisation, accumulate 181 -> 200 us on a fitted field, whose crowded bins then
+        // run 1.5 segments in one workgroup: profiles/r06_reduce_split_ab.txt)
         const uint32_t s = (r + seg_records - 1) / seg_records;
         const uint32_t ir = cn_wave_incl_scan(r), is = cn_wave_incl_scan(s);
         if (lane == 63) { wt_r[wave] = ir; wt_s[wave] = is; }
@@ -192,12 +198,16 @@ __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_tota
             seg_first[i] = cs + bs + is - s;
             if (seg_bin)                                            // segment -> bin map: the accumulate workgroups look their bin up in one load
                 for (uint32_t k = 0; k < s; k++) seg_bin[cs + bs + is - s + k] = i;
+            if (split_list && s > 1) split_list[1 + atomicAdd(&n_split, 1u)] = i;      // the bins k_bin3_reduce_split has to visit (any order)
         }
         __syncthreads();
         if (tid == 0) { carry_r = cr + tr; carry_s = cs + ts; }
         __syncthreads();
     }
-    if (tid == 0) { bin_base[total_bins] = carry_r; seg_first[total_bins] = carry_s; }
+    if (tid == 0) {
+        bin_base[total_bins] = carry_r; seg_first[total_bins] = carry_s;
+        if (split_list) split_list[0] = n_split;
+    }
 }
 
 // ---- sweep 1d: write the records
@@ -937,11 +947,21 @@ __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels 
 }
 
 // sum the fixed-point partial images of the split bins into the gradient table (contiguous chunks on dense levels, interleaved bins on hashed / wrapped ones)
+// The crowded bins of the dense levels split into dozens of segments (level 0 of the benchmark table: two bins of 4 M records, ~57 segments each): one
+// thread summing all of a group's partials was a serial chain of that many dependent load rounds on a handful of workgroups (35 us).  Round 6: a wave
+// takes every fourth segment of 64 groups (64-bit integer sums: any order gives the same bits), the four waves meet in LDS; the workgroups walk the
+// list of split bins that k_bin_scan_bins leaves behind (one workgroup per bin and slice of EVERY bin was 200 k empty workgroups on the bear table).
+#define B3_RS_GROUPS 64                             // groups of four values (two local entries x two channels) per workgroup
+#define B3_RS_BINS 256                              // grid.x: workgroups striding over the split-bin list
 __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
-                                                           const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots) {
-    const uint32_t bin = blockIdx.x;
+                                                           const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots,
+                                                           const uint32_t *__restrict__ split_list) {
+    __shared__ long long s_sum[3][B3_RS_GROUPS][4];
+    const uint32_t n_split = split_list ? split_list[0] : gridDim.x;                // (no list: one workgroup column per bin)
+    for (uint32_t b = blockIdx.x; b < n_split; b += gridDim.x) {                    // (workgroup-uniform trip count: the barrier below is safe)
+    const uint32_t bin = split_list ? split_list[1 + b] : b;
     const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
-    if (nseg <= 1) return;
+    if (nseg <= 1) continue;
     uint32_t slot = 0;
     while (slot + 1 < n_slots && plan.p.bin_first[slot + 1] <= bin) slot++;
     const uint32_t level = lv.order[slot];
@@ -949,22 +969,39 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     const uint32_t hb = plan.hbits[slot], cb = bin - plan.p.bin_first[slot];
     const uint32_t e0 = dense_lvl ? cb << BN_CHUNK_LOG2 : 0u;
     const uint32_t n_entries = dense_lvl ? min(BN_CHUNK, lv.size[level] - e0) : min(BN_CHUNK, lv.size[level] >> hb);
-    const uint32_t j = blockIdx.y * 256 + threadIdx.x;                             // group of four values (two local entries x two channels)
-    if (j >= n_entries / 2) return;
+    if (blockIdx.y * B3_RS_GROUPS >= n_entries / 2) continue;                      // (workgroup-uniform)
+    const uint32_t lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.y * B3_RS_GROUPS + lane;                           // group of four values (two local entries x two channels)
+    const bool ok = j < n_entries / 2;
     long long sum[4] = {0, 0, 0, 0};
-    const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
-#pragma unroll 4
-    for (uint32_t s = 0; s < nseg; s++) {
-        const longlong2 v0 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[0];
-        const longlong2 v1 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[1];
-        sum[0] += v0.x; sum[1] += v0.y; sum[2] += v1.x; sum[3] += v1.y;
+    if (ok) {
+        const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
+#pragma unroll 8
+        for (uint32_t s = sl; s < nseg; s += 4) {
+            const longlong2 v0 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[0];
+            const longlong2 v1 = reinterpret_cast<const longlong2 *>(src + (size_t)s * (BN_CHUNK * 2))[1];
+            sum[0] += v0.x; sum[1] += v0.y; sum[2] += v1.x; sum[3] += v1.y;
+        }
     }
-    const uint32_t e = dense_lvl ? e0 + 2 * j : b3_entry_of(2 * j, cb, hb);
-    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e) * 2);
-    float4 g = *dst;
-    g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
-    g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
-    *dst = g;
+    if (sl) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_sum[sl - 1][lane][k] = sum[k];
+    }
+    __syncthreads();
+    if (!sl && ok) {
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += s_sum[w][lane][k];
+        const uint32_t e = dense_lvl ? e0 + 2 * j : b3_entry_of(2 * j, cb, hb);
+        float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e) * 2);
+        float4 g = *dst;
+        g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
+        g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
+        *dst = g;
+    }
+    __syncthreads();                                                                 // (s_sum is reused by the next bin of this workgroup)
+    }
 }
 
 // The records of a bin segment that live in RUNS of the point blocks' private regions (a dense level's bins; the spill of a hashed bin): the
@@ -1211,7 +1248,7 @@ static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &pla
 
 // ---- third form, host side
 struct Bin3Ws {
-    uint32_t *runs, *pre, *cursor, *bin_base, *seg_first, *seg_bin;
+    uint32_t *runs, *pre, *cursor, *bin_base, *seg_first, *seg_bin, *split_list;
     uint2 *hslab, *dslab;
     long long *partial;
     uint64_t max_seg, cursor_bytes;
@@ -1275,6 +1312,7 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
     const uint64_t o_cur = off; off = bn_align(off + ((uint64_t)p2.total_bins + 2) * 4);       // (+ the partner word of a 64-bit pair reservation past the last bin)
     const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
+    const uint64_t o_split = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);    // count + the bins that were split (k_bin_scan_bins -> k_bin3_reduce_split)
     const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
     const uint64_t d_records = (uint64_t)nl * p2.nb * B3_REGION;                   // the point blocks' private regions: every record of a dense level, the spill of a hashed one
     (void)n_dense;
@@ -1291,6 +1329,7 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
         ws->cursor_bytes = (uint64_t)p2.total_bins * 4;
         ws->bin_base = (uint32_t *)(p + o_base);
         ws->seg_first = (uint32_t *)(p + o_seg);
+        ws->split_list = (uint32_t *)(p + o_split);
         ws->hslab = (uint2 *)(p + o_h);
         ws->dslab = (uint2 *)(p + o_d);
         ws->seg_bin = (uint32_t *)(p + o_segbin);
@@ -1331,14 +1370,36 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     cn_stage(1, st);
     hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
                        plan, nl);
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin);
+    static const int rs_list = cn_tune_env("CNERF_B3_RSLIST", 1);                 // tuning builds: 0 = one workgroup column per bin (profiles/r06_reduce_split_ab.txt)
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
                        (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
                        (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0));
     cn_stage(2, st);
-    hipLaunchKernelGGL(k_bin3_reduce_split, dim3(p2.total_bins, BN_CHUNK * 2 / 4 / 256), dim3(256), 0, st, (const long long *)ws.partial, ws.seg_first, lv, plan,
-                       gemb, nl);
+    hipLaunchKernelGGL(k_bin3_reduce_split, dim3(!rs_list || p2.total_bins < B3_RS_BINS ? p2.total_bins : B3_RS_BINS, BN_CHUNK * 2 / 4 / B3_RS_GROUPS), dim3(256), 0, st,
+                       (const long long *)ws.partial, ws.seg_first, lv, plan, gemb, nl, rs_list ? (const uint32_t *)ws.split_list : (const uint32_t *)nullptr);
     cn_stage(3, st);
+#ifdef CNERF_TUNING
+    static const int dbg = cn_tune_env("CNERF_B3_DEBUG", 0);                     // tuning builds: split statistics of every dbg-th call (synchronises)
+    static int dbg_calls = 0;
+    if (dbg && (++dbg_calls % dbg) == 0) {
+        uint32_t n_split = 0, n_seg = 0;
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(&n_split, ws.split_list, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&n_seg, ws.seg_first + p2.total_bins, 4, hipMemcpyDeviceToHost);
+        std::vector<uint32_t> sf(p2.total_bins + 1), bb(p2.total_bins + 1);
+        (void)hipMemcpy(sf.data(), ws.seg_first, sf.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(bb.data(), ws.bin_base, bb.size() * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[b3] call %d: bins %u segments %u split bins %u seg %u | per slot (bins, segments, records, max bin):", dbg_calls, p2.total_bins, n_seg, n_split, seg);
+        for (uint32_t sl = 0; sl < nl; sl++) {
+            uint32_t mx = 0;
+            for (uint32_t b_ = p2.bin_first[sl]; b_ < p2.bin_first[sl + 1]; b_++) mx = std::max(mx, bb[b_ + 1] - bb[b_]);
+            fprintf(stderr, " L%u(%u,%u,%u,%u)", lv.order[sl], p2.bin_first[sl + 1] - p2.bin_first[sl], sf[p2.bin_first[sl + 1]] - sf[p2.bin_first[sl]],
+                    bb[p2.bin_first[sl + 1]] - bb[p2.bin_first[sl]], mx);
+        }
+        fprintf(stderr, "\n");
+    }
+#endif
     return cn_launch_status();
 }
 
