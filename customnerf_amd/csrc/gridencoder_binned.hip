@@ -950,7 +950,8 @@ __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels 
 // The crowded bins of the dense levels split into dozens of segments (level 0 of the benchmark table: two bins of 4 M records, ~57 segments each): one
 // thread summing all of a group's partials was a serial chain of that many dependent load rounds on a handful of workgroups (35 us).  Round 6: a wave
 // takes every fourth segment of 64 groups (64-bit integer sums: any order gives the same bits), the four waves meet in LDS; the workgroups walk the
-// list of split bins that k_bin_scan_bins leaves behind (one workgroup per bin and slice of EVERY bin was 200 k empty workgroups on the bear table).
+// list of split bins that k_bin_scan_bins leaves behind (one workgroup per bin and slice of EVERY bin was 200 k empty workgroups on the bear table):
+// 27 us (profiles/r06_reduce_split_ab.txt).
 #define B3_RS_GROUPS 64                             // groups of four values (two local entries x two channels) per workgroup
 #define B3_RS_BINS 256                              // grid.x: workgroups striding over the split-bin list
 __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
