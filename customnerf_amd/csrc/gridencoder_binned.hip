@@ -953,7 +953,9 @@ __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels 
 // list of split bins that k_bin_scan_bins leaves behind (one workgroup per bin and slice of EVERY bin was 200 k empty workgroups on the bear table):
 // 27 us (profiles/r06_reduce_split_ab.txt).
 #define B3_RS_GROUPS 64                             // groups of four values (two local entries x two channels) per workgroup
+#ifndef B3_RS_BINS
 #define B3_RS_BINS 256                              // grid.x: workgroups striding over the split-bin list
+#endif
 __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
                                                            const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots,
                                                            const uint32_t *__restrict__ split_list) {
@@ -1226,7 +1228,13 @@ static uint32_t b2_seg(uint32_t B, uint32_t max_chunks = 128) {
     const uint64_t hashed_bin = (uint64_t)B * 4 / (max_chunks ? max_chunks : 1);
     const uint64_t s = hashed_bin + hashed_bin / 8;
     // small tables (few bins per level) would otherwise get a handful of million-record workgroups: cap, and let those bins split
-    return (uint32_t)(s < B2_SEG_MIN ? B2_SEG_MIN : (s > (1u << 17) ? (1u << 17) : s));
+    // ... and beyond 2^18 records a typical hashed bin is divided into EQUAL segments (round 6; the flat 2^17 cap gave every hashed bin of a 32768-ray
+    // batch a second segment of a few thousand records — two 64 KiB partial images and a reduction per bin for nothing: 3.91 -> 3.80 ms per step;
+    // one segment per bin at 65536 rays, on the other hand, costs the accumulate 13 %: profiles/r06_reduce_split_ab.txt)
+    static const uint64_t cap = (uint64_t)b2_env("CNERF_B3_SEG_CAP", 1 << 18);
+    if (s < B2_SEG_MIN) return B2_SEG_MIN;
+    const uint64_t k = (s + cap - 1) / cap;
+    return (uint32_t)((s + k - 1) / k);
 }
 
 static uint32_t b2_max_chunks(const Bin2Plan &plan, uint32_t nl) {
@@ -1371,13 +1379,14 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     cn_stage(1, st);
     hipLaunchKernelGGL(k_bin3_totals, dim3(p2.total_bins), dim3(BN_SCAN_THREADS), 0, st, (const uint32_t *)ws.runs, ws.pre, (const uint32_t *)ws.cursor, ws.bin_base,
                        plan, nl);
+    static const uint32_t rs_bins = (uint32_t)cn_tune_env("CNERF_B3_RS_BINS", B3_RS_BINS);
     static const int rs_list = cn_tune_env("CNERF_B3_RSLIST", 1);                 // tuning builds: 0 = one workgroup column per bin (profiles/r06_reduce_split_ab.txt)
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
                        (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
                        (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0));
     cn_stage(2, st);
-    hipLaunchKernelGGL(k_bin3_reduce_split, dim3(!rs_list || p2.total_bins < B3_RS_BINS ? p2.total_bins : B3_RS_BINS, BN_CHUNK * 2 / 4 / B3_RS_GROUPS), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_bin3_reduce_split, dim3(!rs_list || p2.total_bins < rs_bins ? p2.total_bins : rs_bins, BN_CHUNK * 2 / 4 / B3_RS_GROUPS), dim3(256), 0, st,
                        (const long long *)ws.partial, ws.seg_first, lv, plan, gemb, nl, rs_list ? (const uint32_t *)ws.split_list : (const uint32_t *)nullptr);
     cn_stage(3, st);
 #ifdef CNERF_TUNING
