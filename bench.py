@@ -310,6 +310,8 @@ def run_recon(args, world, rank, dev):
         opt.tune_gather_traversal = False
     if getattr(args, "no_packed_weights", False):
         opt.packed_field_weights = False
+    if getattr(args, "no_fused_table_adam", False):
+        opt.fuse_table_adam = False
     model = NeRFNetwork(opt).to(dev)
     H = W = args.res
     V = 8
@@ -610,6 +612,7 @@ def main():
     ap.add_argument("--sds-views", type=int, default=1, help="edit leg: camera views per step through one UNet batch of 2V")
     ap.add_argument("--rays", type=int, default=0,
                     help="recon leg: regroup the views' rays into steps of this many rays (default 0 = one whole view per step); must divide 8 * res * res")
+    ap.add_argument("--no-fused-table-adam", action="store_true", help="recon leg: the grid table's Adam update as its own launch after the backward pass (A/B of optim.FusedAdam.arm_in_backward)")
     ap.add_argument("--no-packed-weights", action="store_true", help="recon leg: the field kernels stage their weights from the float32 parameters in every launch (A/B of trainer.packed_weights_window)")
     ap.add_argument("--no-tune-traversal", action="store_true", help="recon leg: keep the importance-sample gather level-major (no in-place TraversalTuner trials)")
     ap.add_argument("--stage-events", action="store_true", help="recon leg: per-kernel event times of the last step's scatter and field backward (config.stage_ms)")

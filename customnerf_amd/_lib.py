@@ -82,6 +82,8 @@ SIGNATURES = {
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],
     "cnerf_scaler_check": [vp, u64, vp, vp],
     "cnerf_scaler_watch": [vp],
+    "cnerf_grid_backward_adam": [vp],
+    "cnerf_grid_backward_adam_consumed": [vp],
     "cnerf_adam_step_scaled": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, vp, f32, i32, vp],
     "cnerf_dp_pack": [vp, vp, u64, f32, vp],
     "cnerf_dp_reduce": [vp, u32, u64, vp, vp, vp],
@@ -141,6 +143,12 @@ class AdamJobs(C.Structure):
     """struct CnerfAdamJobs of include/customnerf_hip.h"""
     _fields_ = [("p", vp * ADAM_MAX_JOBS), ("g", vp * ADAM_MAX_JOBS), ("m", vp * ADAM_MAX_JOBS), ("v", vp * ADAM_MAX_JOBS), ("p_half", vp * ADAM_MAX_JOBS),
                 ("n", u64 * ADAM_MAX_JOBS), ("lr", f32 * ADAM_MAX_JOBS), ("n_jobs", u32)]
+
+
+class GridAdam(C.Structure):
+    """struct CnerfGridAdam of include/customnerf_hip.h"""
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_half", vp), ("n", u64), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
+                ("scaler_state", vp), ("extra_inv", f32), ("zero_grad", C.c_int)]
 
 
 F32, F16 = 0, 1

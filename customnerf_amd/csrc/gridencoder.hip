@@ -544,9 +544,29 @@ int bn_prepare_rows(const float *inputs, const GridLevels &lv, uint32_t B, uint3
 int bn_prepare_finish(const GridLevels &lv, uint32_t B, uint32_t nl, int dtype, void *workspace, hipStream_t st);
 uint32_t bn_hist_block_points(int dtype);
 bool bn_needs_plan(uint32_t B, uint32_t nl, const GridLevels &lv, int dtype, uint32_t gridtype);
+void bn_grid_adam_arm(const CnerfGridAdam *cfg);
+int bn_grid_adam_consumed();
 #define BN_MIN_UPDATES (1u << 20)        // below this many (point, level) pairs the plain atomic kernel is cheaper than five launches
 
 extern "C" {
+
+int cnerf_grid_backward_adam(const CnerfGridAdam *cfg) {
+    if (cfg) {
+        if (!cfg->p || !cfg->g || !cfg->m || !cfg->v || !cfg->scaler_state) return CNERF_ENULL;
+        if (cfg->n == 0 || (cfg->n & 3) || ((((uintptr_t)cfg->p) | ((uintptr_t)cfg->g) | ((uintptr_t)cfg->m) | ((uintptr_t)cfg->v)) & 15) ||
+            (((uintptr_t)cfg->p_half) & 7))
+            return CNERF_EINVAL;
+        if (!(cfg->beta1 >= 0.0f && cfg->beta1 < 1.0f) || !(cfg->beta2 >= 0.0f && cfg->beta2 < 1.0f) || !(cfg->eps >= 0.0f)) return CNERF_EINVAL;
+    }
+    bn_grid_adam_arm(cfg);
+    return CNERF_OK;
+}
+
+int cnerf_grid_backward_adam_consumed(int *yes) {
+    if (!yes) return CNERF_ENULL;
+    *yes = bn_grid_adam_consumed();
+    return CNERF_OK;
+}
 
 int cnerf_grid_encode_forward_ordered(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D,
                                       uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin_scan_blocks(uint32_t *_
 // bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
 __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
                                                         uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records,
-                                                        uint32_t *__restrict__ seg_bin, uint32_t *__restrict__ split_list = nullptr) {
+                                                        uint32_t *__restrict__ seg_bin, uint32_t *__restrict__ split_list = nullptr, int min_one = 0) {
     __shared__ uint32_t wt_r[16], wt_s[16];
     __shared__ uint32_t carry_r, carry_s, n_split;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_tota
         // (segments rounded to nearest with the last one taking the remainder — no near-empty second segment for a bin a few records over the
         // segment size — were measured: nothing at random initialisation, accumulate 181 -> 200 us on a fitted field, whose crowded bins then
         // run 1.5 segments in one workgroup: profiles/r06_reduce_split_ab.txt)
-        const uint32_t s = (r + seg_records - 1) / seg_records;
+        uint32_t s = (r + seg_records - 1) / seg_records;
+        if (min_one && i < total_bins && s == 0) s = 1;              // fused optimiser step: a bin without records still has to visit its entries
         const uint32_t ir = cn_wave_incl_scan(r), is = cn_wave_incl_scan(s);
         if (lane == 63) { wt_r[wave] = ir; wt_s[wave] = is; }
         __syncthreads();
@@ -922,23 +923,108 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin3_totals(const uint32_t 
     if (tid == 0) bin_total[bin] = hashed ? min(cursor[bin] & 0x7FFFFFFFu, plan.capb) + carry : carry;
 }
 
+// ---- the table's optimiser step inside the scatter (round 6, cnerf_grid_backward_adam): the flush below is where a table entry's gradient of this
+// backward pass becomes final — one owner per bin, or k_bin3_reduce_split for a split one — and k_adam_scaled would read it back 0.4 ms later, together
+// with p / m / v, at the HBM roofline (62 us for the benchmark table).  Applied here the update rides on kernels that are bound by LDS atomics, and the
+// gradient never makes the round trip.  Same arithmetic as k_adam_scaled (misc.hip), value for value: the parameters after a step are bit-identical.
+struct B3Adam {
+    float *p, *m, *v;
+    __half *ph;
+    const float *state;                              // the loss scaler's {scale, growth_tracker, found_inf, good_steps}
+    float lr, beta1, beta2, eps, extra_inv;
+    int zero_grad, on;
+};
+struct B3AdamConst { float gscale, step_size, rsqrt_bc2; int skip; };
+__device__ __forceinline__ B3AdamConst b3_adam_const(const B3Adam &ad) {           // (k_adam_scaled's prologue)
+    B3AdamConst c;
+    c.skip = ad.state[2] != 0.0f;
+    c.gscale = ad.extra_inv / ad.state[0];
+    const double step = (double)ad.state[3] + 1.0;
+    const double bc1 = 1.0 - pow((double)ad.beta1, step), bc2 = 1.0 - pow((double)ad.beta2, step);
+    c.step_size = (float)((double)ad.lr / bc1);
+    c.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    return c;
+}
+// gg = the final gradient of four consecutive floats at float index `idx` (a multiple of 4), pp / mm / vv = parameter and moments there;
+// d4 = their slot in the gradient table
+__device__ __forceinline__ void b3_adam_update(const B3Adam &ad, const B3AdamConst &c, size_t idx, float4 gg, float4 pp, float4 mm, float4 vv, float4 *d4) {
+    float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float gk = ga[k] * c.gscale;
+        ma[k] = ad.beta1 * ma[k] + (1.0f - ad.beta1) * gk;
+        va[k] = ad.beta2 * va[k] + (1.0f - ad.beta2) * gk * gk;
+        pa[k] -= c.step_size * ma[k] / (sqrtf(va[k]) * c.rsqrt_bc2 + ad.eps);
+    }
+    *reinterpret_cast<float4 *>(ad.p + idx) = pp;
+    *reinterpret_cast<float4 *>(ad.m + idx) = mm;
+    *reinterpret_cast<float4 *>(ad.v + idx) = vv;
+    *d4 = ad.zero_grad ? make_float4(0, 0, 0, 0) : gg;
+    if (ad.ph) {
+        union { __half2 h[2]; uint2 u; } o;
+        o.h[0] = __floats2half2_rn(pp.x, pp.y);
+        o.h[1] = __floats2half2_rn(pp.z, pp.w);
+        *reinterpret_cast<uint2 *>(ad.ph + idx) = o.u;
+    }
+}
+__device__ __forceinline__ void b3_adam_apply(const B3Adam &ad, const B3AdamConst &c, size_t idx, float4 gg, float4 *d4) {
+    if (c.skip) {                                    // non-finite gradients somewhere in this step: no update, the gradients are still cleared
+        *d4 = ad.zero_grad ? make_float4(0, 0, 0, 0) : gg;
+        return;
+    }
+    b3_adam_update(ad, c, idx, gg, *reinterpret_cast<const float4 *>(ad.p + idx), *reinterpret_cast<const float4 *>(ad.m + idx),
+                   *reinterpret_cast<const float4 *>(ad.v + idx), d4);
+}
+
 // flush of a finished LDS image: sole owner -> read-modify-write of the gradient table; a split bin parks its fixed-point image.
 // hbits = 0xFF: dense level (the bin is a contiguous chunk); else a hashed level's interleaved bin.
 __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels &lv, const Bin2Plan &plan, uint32_t slot, uint32_t bin, uint32_t nseg, uint32_t gseg,
-                                         float *__restrict__ grad_grid, long long *__restrict__ partial, uint32_t hbits) {
+                                         float *__restrict__ grad_grid, long long *__restrict__ partial, uint32_t hbits, const B3Adam &ad,
+                                         const B3AdamConst &adc) {
     const uint32_t level = lv.order[slot];
     const uint32_t cb = bin - plan.bin_first[slot];
     const uint32_t e0 = hbits == 0xFFu ? cb << BN_CHUNK_LOG2 : 0u;
     const uint32_t n_entries = hbits == 0xFFu ? min(BN_CHUNK, lv.size[level] - e0) : min(BN_CHUNK, lv.size[level] >> hbits);
     float *__restrict__ dst = grad_grid + (size_t)lv.offset[level] * 2;
-    if (nseg == 1) {
+    if (nseg == 1 && ad.on && !adc.skip) {
+        // the optimiser step rides on the flush: a full bin is two groups of four floats per thread — every load of both (gradient, parameter,
+        // two moments) is issued before the first use (one memory round trip per workgroup instead of two)
+        constexpr int NIT = BN_CHUNK / 2 / 1024;
+        float4 gg[NIT], pp[NIT], mm[NIT], vv[NIT];
+        auto index_of = [&](uint32_t j) {                                          // float index of the group (recomputed at the use: registers)
+            const uint32_t e = hbits == 0xFFu ? e0 + 2 * j : b3_entry_of(2 * j, cb, hbits);
+            return ((size_t)lv.offset[level] + e) * 2;
+        };
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t j = it * 1024 + threadIdx.x;
+            if (j < n_entries / 2) {
+                const size_t idx = index_of(j);
+                gg[it] = *reinterpret_cast<const float4 *>(grad_grid + idx);
+                pp[it] = *reinterpret_cast<const float4 *>(ad.p + idx);
+                mm[it] = *reinterpret_cast<const float4 *>(ad.m + idx);
+                vv[it] = *reinterpret_cast<const float4 *>(ad.v + idx);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t j = it * 1024 + threadIdx.x;
+            if (j >= n_entries / 2) continue;
+            const size_t idx = index_of(j);
+            float4 g = gg[it];
+            g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
+            g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
+            b3_adam_update(ad, adc, idx, g, pp[it], mm[it], vv[it], reinterpret_cast<float4 *>(grad_grid + idx));
+        }
+    } else if (nseg == 1) {
         for (uint32_t j = threadIdx.x; j < n_entries / 2; j += 1024) {             // two entries x two channels per thread
             const uint32_t e = hbits == 0xFFu ? e0 + 2 * j : b3_entry_of(2 * j, cb, hbits);
             float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)e * 2);
             float4 g = *d4;
             g.x += bn_acc_to_float<__half>(acc[j * 2]); g.y += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2]);
             g.z += bn_acc_to_float<__half>(acc[j * 2 + 1]); g.w += bn_acc_to_float<__half>(acc[BN_CHUNK + j * 2 + 1]);
-            *d4 = g;
+            if (ad.on) b3_adam_apply(ad, adc, ((size_t)lv.offset[level] + e) * 2, g, d4);      // (a skipped step: clears the gradient)
+            else *d4 = g;
         }
     } else {
         long long *__restrict__ img = partial + (size_t)gseg * (BN_CHUNK * 2);
@@ -958,9 +1044,20 @@ __device__ __forceinline__ void b3_flush(const long long *acc, const GridLevels 
 #endif
 __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__restrict__ partial, const uint32_t *__restrict__ seg_first,
                                                            const GridLevels lv, const Bin3Plan plan, float *__restrict__ grad_grid, uint32_t n_slots,
-                                                           const uint32_t *__restrict__ split_list) {
+                                                           const uint32_t *__restrict__ split_list, const B3Adam ad) {
     __shared__ long long s_sum[3][B3_RS_GROUPS][4];
     const uint32_t n_split = split_list ? split_list[0] : gridDim.x;                // (no list: one workgroup column per bin)
+    if (blockIdx.x >= n_split) return;
+    B3AdamConst adc = {0.0f, 0.0f, 0.0f, 0};
+    if (ad.on) {                                                                     // (one lane evaluates the double-precision powers)
+        __shared__ float s_adam[4];
+        if (threadIdx.x == 0) {
+            const B3AdamConst c = b3_adam_const(ad);
+            s_adam[0] = c.gscale; s_adam[1] = c.step_size; s_adam[2] = c.rsqrt_bc2; s_adam[3] = c.skip ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        adc.gscale = s_adam[0]; adc.step_size = s_adam[1]; adc.rsqrt_bc2 = s_adam[2]; adc.skip = s_adam[3] != 0.0f;
+    }
     for (uint32_t b = blockIdx.x; b < n_split; b += gridDim.x) {                    // (workgroup-uniform trip count: the barrier below is safe)
     const uint32_t bin = split_list ? split_list[1 + b] : b;
     const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
@@ -1001,7 +1098,8 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
         float4 g = *dst;
         g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
         g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
-        *dst = g;
+        if (ad.on) b3_adam_apply(ad, adc, ((size_t)lv.offset[level] + e) * 2, g, dst);
+        else *dst = g;
     }
     __syncthreads();                                                                 // (s_sum is reused by the next bin of this workgroup)
     }
@@ -1094,7 +1192,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
                                                      const uint32_t *__restrict__ pre, const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_base,
                                                      const uint32_t *__restrict__ seg_first, const GridLevels lv, const Bin3Plan plan,
                                                      float *__restrict__ grad_grid, long long *__restrict__ partial, const uint32_t *__restrict__ seg_bin,
-                                                     uint32_t n_slots, uint32_t seg_records, uint32_t only) {
+                                                     uint32_t n_slots, uint32_t seg_records, uint32_t only, const B3Adam ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];   // [2][BN_CHUNK] accumulators, scratch words, the tile list (one LDS object)
     long long *acc = reinterpret_cast<long long *>(bn_lds);
     uint32_t *s_w = reinterpret_cast<uint32_t *>(bn_lds + sizeof(long long) * BN_CHUNK * 2);
@@ -1111,6 +1209,11 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
     (void)only;
 #endif
     const uint32_t nb = plan.p.nb;
+    __shared__ float s_adam[4];
+    if (ad.on && threadIdx.x == 64) {                                                // (one lane of the second wave evaluates the double-precision powers,
+        const B3AdamConst c = b3_adam_const(ad);                                     //  behind the whole record stream: read after the barriers below)
+        s_adam[0] = c.gscale; s_adam[1] = c.step_size; s_adam[2] = c.rsqrt_bc2; s_adam[3] = c.skip ? 1.0f : 0.0f;
+    }
     if (threadIdx.x == 0) {
         const uint32_t bin = seg_bin[gseg];
         uint32_t slot = 0;
@@ -1177,7 +1280,9 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
         b3_walk_runs<B3_WALK>(acc, s_c, tiles, rt, pt, lvl_slab, nb, pb_first, begin, end);
     }
     __syncthreads();
-    b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot]);
+    B3AdamConst adc = {0.0f, 0.0f, 0.0f, 0};
+    if (ad.on) { adc.gscale = s_adam[0]; adc.step_size = s_adam[1]; adc.rsqrt_bc2 = s_adam[2]; adc.skip = s_adam[3] != 0.0f; }
+    b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot], ad, adc);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1353,6 +1458,30 @@ __global__ void __launch_bounds__(256) k_bin3_zero(uint32_t *__restrict__ p, uin
     if (i < n) p[i] = 0;
 }
 
+// cnerf_grid_backward_adam: the optimiser step armed for the next backward pass into `g` (one shot)
+static CnerfGridAdam g_grid_adam;
+static bool g_grid_adam_armed = false;
+static int g_grid_adam_consumed = 0;
+void bn_grid_adam_arm(const CnerfGridAdam *cfg) {
+    g_grid_adam_armed = cfg != nullptr;
+    if (cfg) { g_grid_adam = *cfg; g_grid_adam_consumed = 0; }
+}
+int bn_grid_adam_consumed() { const int c = g_grid_adam_consumed; g_grid_adam_consumed = 0; return c; }
+// any backward pass into the armed gradient table disarms; only one that covers the WHOLE table through the third form applies the step
+static B3Adam b3_take_adam(float *gemb, const GridLevels &lv, uint32_t nl, bool third_form) {
+    B3Adam ad = {};
+    if (!g_grid_adam_armed || g_grid_adam.g != gemb) return ad;
+    g_grid_adam_armed = false;
+    const uint64_t covered = ((uint64_t)lv.offset[nl - 1] + lv.size[nl - 1]) * 2;
+    if (!third_form || covered != g_grid_adam.n) return ad;
+    ad.p = g_grid_adam.p; ad.m = g_grid_adam.m; ad.v = g_grid_adam.v; ad.ph = reinterpret_cast<__half *>(g_grid_adam.p_half);
+    ad.state = g_grid_adam.scaler_state;
+    ad.lr = g_grid_adam.lr; ad.beta1 = g_grid_adam.beta1; ad.beta2 = g_grid_adam.beta2; ad.eps = g_grid_adam.eps; ad.extra_inv = g_grid_adam.extra_inv;
+    ad.zero_grad = g_grid_adam.zero_grad; ad.on = 1;
+    g_grid_adam_consumed = 1;
+    return ad;
+}
+
 static int b3_backward(const __half *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                        uint32_t interp, void *workspace, hipStream_t st) {
     if (nl == 0) return CNERF_OK;
@@ -1372,6 +1501,7 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     }
     const Bin2Plan &p2 = plan.p;
     const uint32_t seg = b2_seg(B, b2_max_chunks(p2, nl));
+    const B3Adam ad = b3_take_adam(gemb, lv, nl, true);
     hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
     cn_stage(0, st);
     hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B3_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
@@ -1381,13 +1511,13 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
                        plan, nl);
     static const uint32_t rs_bins = (uint32_t)cn_tune_env("CNERF_B3_RS_BINS", B3_RS_BINS);
     static const int rs_list = cn_tune_env("CNERF_B3_RSLIST", 1);                 // tuning builds: 0 = one workgroup column per bin (profiles/r06_reduce_split_ab.txt)
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list, ad.on);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
                        (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
-                       (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0));
+                       (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0), ad);
     cn_stage(2, st);
     hipLaunchKernelGGL(k_bin3_reduce_split, dim3(!rs_list || p2.total_bins < rs_bins ? p2.total_bins : rs_bins, BN_CHUNK * 2 / 4 / B3_RS_GROUPS), dim3(256), 0, st,
-                       (const long long *)ws.partial, ws.seg_first, lv, plan, gemb, nl, rs_list ? (const uint32_t *)ws.split_list : (const uint32_t *)nullptr);
+                       (const long long *)ws.partial, ws.seg_first, lv, plan, gemb, nl, rs_list ? (const uint32_t *)ws.split_list : (const uint32_t *)nullptr, ad);
     cn_stage(3, st);
 #ifdef CNERF_TUNING
     static const int dbg = cn_tune_env("CNERF_B3_DEBUG", 0);                     // tuning builds: split statistics of every dbg-th call (synchronises)
@@ -1498,6 +1628,7 @@ int bn_prepare(const float *inputs, const GridLevels &lv, uint32_t B, uint32_t n
 int bn_backward(const void *grad, const float *inputs, const GridLevels &lv, float *gemb, uint32_t B, uint32_t nl, uint32_t gridtype, int ac,
                 uint32_t interp, int dtype, void *workspace, hipStream_t st, bool prepared) {
     if (b3_enabled(lv, nl, B, dtype, gridtype, ac)) return b3_backward((const __half *)grad, inputs, lv, gemb, B, nl, gridtype, ac, interp, workspace, st);
+    if (nl) (void)b3_take_adam(gemb, lv, nl, false);                                 // (the first form does not carry the optimiser step: disarm)
     if (!prepared) {
         const int rc = bn_phase1(inputs, lv, B, nl, gridtype, ac, interp, dtype, workspace, st);
         if (rc) return rc;

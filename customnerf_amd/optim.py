@@ -5,7 +5,7 @@ import torch
 
 import ctypes
 
-from ._lib import lib, check, ptr, stream, require_cuda, AdamJobs, ADAM_MAX_JOBS
+from ._lib import lib, check, ptr, stream, require_cuda, AdamJobs, ADAM_MAX_JOBS, GridAdam
 
 SMALL_PARAM_MAX = 1 << 16          # tensors up to this size go through the single-workgroup multi-tensor launch (the three MLPs: 22.5 k floats)
 
@@ -85,16 +85,64 @@ class FusedAdam(torch.optim.Optimizer):
         self.skip_params = set()        # id(p) of parameters some other owner updates (dp.ShardedExchange: the sharded grid table)
         self.updates_scaler = False     # set by step(): the last launch of this step also ran GradScaler.update() (the caller must not run it again)
 
+    # ---- the grid table's step inside the backward scatter (cnerf_grid_backward_adam) -------------------------------------------------------
+    def arm_in_backward(self, p):
+        """Arm THIS step's update of parameter `p` (the grid table) for the backward pass that is about to run: the scatter's flush applies it where
+        the gradient becomes final, and step() then leaves `p` alone (bit-identical parameters; the table's own Adam launch — 62 us at the HBM roofline
+        for the benchmark table — disappears).  Needs the on-device loss scaler, a persistent contiguous float32 `p.grad` (the trainers'
+        flat_grad_buffer) and the current learning rate already in the parameter group.  The caller guarantees that the coming backward pass is the
+        only contribution to `p.grad` in this optimiser step (ReconTrainer: one render, one backward) and that nothing but the fused field's own
+        kernels can raise found_inf (trainer.inf_check_is_folded).  -> True if armed.  step() disarms whatever happened."""
+        self.disarm_in_backward()
+        if self.scaler is None or p.grad is None or not (p.is_cuda and p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32
+                                                           and p.grad.dtype == torch.float32 and p.numel() % 4 == 0):
+            return False
+        group = next((g for g in self.param_groups if any(q is p for q in g['params'])), None)
+        if group is None or id(p) in self.skip_params:
+            return False
+        st = self.state[p]
+        if not st:
+            st['step'] = 0
+            st['exp_avg'] = torch.zeros_like(p)
+            st['exp_avg_sq'] = torch.zeros_like(p)
+        sh = self.half_shadows.get(p)
+        require_cuda(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], sh, self.scaler.state)
+        cfg = GridAdam()
+        cfg.p, cfg.g, cfg.m, cfg.v = p.data.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+        cfg.p_half = sh.data_ptr() if sh is not None else None
+        cfg.n = p.numel()
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps'])
+        cfg.scaler_state = self.scaler.state.data_ptr()
+        cfg.extra_inv = float(self.grad_scale_inv)
+        cfg.zero_grad = int(self.zero_grad_in_step)
+        check(lib.cnerf_grid_backward_adam(ctypes.addressof(cfg)), "grid_backward_adam")
+        self._armed = p
+        return True
+
+    def disarm_in_backward(self):
+        """-> the parameter whose armed step a backward pass applied (step() must skip it), or None; nothing stays armed"""
+        p, self._armed = getattr(self, '_armed', None), None
+        if p is None:
+            return None
+        done = ctypes.c_int(0)
+        check(lib.cnerf_grid_backward_adam_consumed(ctypes.addressof(done)), "grid_backward_adam_consumed")
+        check(lib.cnerf_grid_backward_adam(None), "grid_backward_adam")
+        return p if done.value else None
+
     @torch.no_grad()
     def step(self, closure=None):
         self.updates_scaler = False
         if self.scaler is not None:
             self.scaler._update_consumed = False      # (a caller that skipped update() after the previous step, as the trainers used to)
+        stepped = self.disarm_in_backward()             # the table, when the backward scatter already applied its update (arm_in_backward)
+        if stepped is not None:
+            self.state[stepped]['step'] += 1
+            stepped._cnerf_epoch = getattr(stepped, '_cnerf_epoch', 0) + 1
         small = []                      # (p, state, group) of the small tensors: one multi-tensor launch at the end (with a scaler)
         betas0, eps0 = self.param_groups[0]['betas'], self.param_groups[0]['eps']
         for group in self.param_groups:
             for p in group['params']:
-                if p.grad is None or id(p) in self.skip_params:
+                if p.grad is None or id(p) in self.skip_params or p is stepped:
                     continue
                 st = self.state[p]
                 if not st:

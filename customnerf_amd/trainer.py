@@ -348,6 +348,20 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             if self.scaler is not None:
                 self.scaler.watch(False)                 # (the library holds a raw pointer into the scaler's state only for the duration of a step)
 
+    def _arm_table_step(self):
+        """The grid table's Adam update inside the backward scatter (optim.FusedAdam.arm_in_backward): only where this step's ONE backward pass is the
+        table gradient's only source and found_inf is final when the scatter runs — fused Adam with the on-device scaler, the inf check folded into
+        the field's gradient producers (inf_check_is_folded: every trainable parameter is the fused field's, persistent in-place gradients), one
+        GPU, eager (a captured backward would freeze the learning rate).  `opt.fuse_table_adam = False` switches it off."""
+        if not (self.fused_adam and getattr(self, '_inf_folded', False) and self.world_size == 1 and getattr(self, '_dp', None) is None
+                and getattr(self.opt, 'fuse_table_adam', True) and not torch.cuda.is_current_stream_capturing()):
+            return False
+        f = self.lr_factor()                                          # (apply_optimizer_step sets the same values again after the backward pass)
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g['lr'] = base * f
+        self.optimizer.grad_scale_inv = 1.0 / (self.loss_scale * self.world_size)
+        return self.optimizer.arm_in_backward(self.model.pos_en.embeddings)
+
     def _train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
         self.model.train()
         rays_o, rays_d, rgbs, mask = self.select_rays(rays_o, rays_d, rgbs, mask, select_inds)
@@ -355,7 +369,12 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
             loss = self.loss(outputs, rgbs, mask)
         if self.scaler is not None:
-            self.scaler.backward(loss)
+            self._arm_table_step()
+            try:
+                self.scaler.backward(loss)
+            except BaseException:
+                self.optimizer.disarm_in_backward()
+                raise
         else:
             (loss * self.loss_scale).backward()
         if self.fused_adam:

@@ -279,6 +279,27 @@ int cnerf_field_backward_workspace_bytes(uint32_t P, uint32_t enc_dim, uint32_t 
  * instead (CNERF_F16 only: with weight_image == NULL or CNERF_F32 they ARE cnerf_field_forward_strided / cnerf_field_backward_ex; the
  * narrow-encoding backward — enc_dim <= 16 — accepts an image and ignores it).  Results are bit-identical: the image holds the very halves
  * the kernels would have staged.  The reference has no counterpart (tcnn keeps fp16 parameters: network_grid.py:98-139). */
+/* The table's optimiser step inside the backward scatter (ABI 5).  cnerf_grid_encode_backward* is where a table entry's gradient becomes final, and
+ * cnerf_adam_step_scaled would read it back — with the parameter and both moments — a few launches later (62 us at the HBM roofline for the benchmark
+ * table).  cnerf_grid_backward_adam(cfg) ARMS that step for the NEXT backward pass whose grad_embeddings == cfg->g (one shot; NULL disarms): if that
+ * pass runs the histogram-free binned scatter (fp16, 3-D, C = 2) over ALL levels of the table (cfg->n floats), every entry leaves the pass updated
+ * as cnerf_adam_step_scaled(p, g, m, v, p_half, n, lr, beta1, beta2, eps, scaler_state, extra_inv, zero_grad) would have left it — bit for bit, the
+ * skip on found_inf included — and cnerf_grid_backward_adam_consumed() reports 1 (reads and clears); otherwise nothing is applied, it reports 0 and the
+ * caller steps the table as usual.  The caller guarantees that this backward pass is the ONLY contribution to g in this optimiser step and that the
+ * scaler's found_inf is final when the scatter runs (cnerf_scaler_watch covers the field's own producers).  Host-side switches, no launch.
+ * No counterpart in the reference (torch.optim.Adam after loss.backward(): main.py:182, utils_init_nerf.py:608-616). */
+typedef struct CnerfGridAdam {
+    float *p, *g, *m, *v;            /* parameter, its gradient table, Adam moments: n floats each */
+    void *p_half;                    /* fp16 shadow of p refreshed in the same pass, or NULL */
+    uint64_t n;
+    float lr, beta1, beta2, eps;
+    const float *scaler_state;       /* float32[4] {scale, growth_tracker, found_inf, good_steps} (cnerf_scaler_*) */
+    float extra_inv;                 /* extra factor on the un-scaling (1 / world_size) */
+    int zero_grad;                   /* clear g after the update */
+} CnerfGridAdam;
+int cnerf_grid_backward_adam(const CnerfGridAdam *cfg);
+int cnerf_grid_backward_adam_consumed(int *yes);
+
 /* *id = the capture sequence id of `stream` while it is capturing into a hipGraph, 0 otherwise (host-side query, no launch): what a cache of
  * derived device data — e.g. the packed weights below — needs to know that a refresh it issues now is RECORDED, not executed. */
 int cnerf_stream_capture_id(void *stream, uint64_t *id);

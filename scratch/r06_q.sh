@@ -3,9 +3,8 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=gpurun_out/r06q
 mkdir -p $out
-timeout 1500 python -m pytest tests/test_gpu_gridencoder.py tests/test_gpu_fullsize.py tests/test_gpu_train.py -q -x --timeout=600 > $out/pytest.log 2>&1; grep -E "passed|failed|error" $out/pytest.log | tail -3
-make -s -C customnerf_amd/csrc -B -j64 TUNING=1 > $out/make_tuning.log 2>&1; tail -1 $out/make_tuning.log
-for a in "--rays 16384" "--rays 32768" "--rays 65536" "--rays 8192"; do
-echo "=== $a"
-bash scratch/ab_recon.sh r06q/ab "$a" "-" "CNERF_B3_SEG_CAP=131072" "-" "CNERF_B3_SEG_CAP=131072"
-done 2>&1 | tee $out/ab_rs3.txt
+for a in "--grid bear" "--prefit 300" "--rays 2048" ""; do
+for rep in 1 2; do
+for v in "" "--no-fused-table-adam"; do
+timeout 200 python3 bench.py --task recon --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-roofline $a $v 2>/dev/null | python3 -c "import json,sys; print('[$a $v] step %.4f ms' % json.load(sys.stdin)['ms_per_step'])"
+done; done; done 2>&1 | tee $out/ab_fadam2.txt

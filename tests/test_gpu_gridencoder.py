@@ -382,3 +382,125 @@ def test_sample_major_traversal_is_bit_identical(name, kw, B, row0):
     torch.cuda.synchronize()
     tuner.plan()
     assert len(tuner.history) >= 1 and tuner.choice in (LEVEL_MAJOR, SAMPLE_MAJOR)
+
+
+# ---- the table's optimiser step inside the backward scatter (ABI 5: cnerf_grid_backward_adam) ----
+def _adam_reference_and_fused(enc, x, g_lbc, scaler_state, p_half, max_level=None, lr=1e-2, zero_grad=1, prefill=None):
+    """-> (reference: backward into g, then cnerf_adam_step_scaled), (fused: the same backward with the step armed), consumed"""
+    from customnerf_amd._lib import lib, ptr, stream, check, GridAdam
+    import ctypes
+    L, C = enc.num_levels, enc.level_dim
+    ml = L if max_level is None else max_level
+    S = float(np.log2(enc.per_level_scale))
+    B = x.shape[0]
+    need = ctypes.c_uint64(0)
+    lib.cnerf_grid_encode_backward_workspace_bytes(enc._offsets_host.ctypes.data, B, 3, C, L, ml, S, enc.base_resolution, 1, ctypes.addressof(need))
+    ws = torch.empty(int(need.value) + 256, dtype=torch.uint8, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    m0 = torch.rand(enc.embeddings.shape, device='cuda', generator=gen) * 1e-3
+    v0 = torch.rand(enc.embeddings.shape, device='cuda', generator=gen) * 1e-6
+    outs = []
+    consumed = None
+    for fused in (False, True):
+        p = enc.embeddings.detach().clone()
+        m, v = m0.clone(), v0.clone()
+        g = torch.zeros_like(p) if prefill is None else prefill.clone()
+        ph = torch.zeros(p.shape, dtype=torch.half, device='cuda') if p_half else None
+        st = scaler_state.clone()
+        if fused:
+            cfg = GridAdam()
+            cfg.p, cfg.g, cfg.m, cfg.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            cfg.p_half = ph.data_ptr() if ph is not None else None
+            cfg.n = p.numel()
+            cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = lr, 0.9, 0.99, 1e-15
+            cfg.scaler_state, cfg.extra_inv, cfg.zero_grad = st.data_ptr(), 1.0, zero_grad
+            check(lib.cnerf_grid_backward_adam(ctypes.addressof(cfg)))
+        check(lib.cnerf_grid_encode_backward(ptr(g_lbc), ptr(x), enc._offsets_host.ctypes.data, ptr(g), B, 3, C, L, ml, S, enc.base_resolution, None, None,
+                                             enc.gridtype_id, int(enc.align_corners), enc.interp_id, 1, ptr(ws), ws.numel(), stream()))
+        if fused:
+            done = ctypes.c_int(0)
+            check(lib.cnerf_grid_backward_adam_consumed(ctypes.addressof(done)))
+            check(lib.cnerf_grid_backward_adam(None))
+            consumed = bool(done.value)
+        if not fused or not consumed:
+            check(lib.cnerf_adam_step_scaled(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ph), p.numel(), lr, 0.9, 0.99, 1e-15, ptr(st), 1.0, zero_grad, stream()))
+        torch.cuda.synchronize()
+        outs.append((p, m, v, g, ph))
+    return outs[0], outs[1], consumed
+
+
+@pytest.mark.parametrize("case", ["uniform", "corner", "overflow_skip", "accumulated_grad", "no_shadow_keep_grad"])
+def test_table_adam_inside_the_scatter_is_bit_identical(case):
+    """cnerf_grid_backward_adam: the Adam update applied by the scatter's flush (sole-owner bins, the split bins' reduction, bins without a single record)
+    leaves parameter, moments, gradient table and fp16 shadow exactly as the backward pass followed by cnerf_adam_step_scaled does — uniform samples,
+    samples confined to a corner of the volume (most bins of the dense levels see no record; a few are crowded and split), a step the loss scaler
+    skips (found_inf set: no update, gradients cleared), a gradient table that already holds a contribution, and without shadow / without clearing"""
+    enc = build(CONFIGS[0][1], scale=0.5)
+    L, C = enc.num_levels, enc.level_dim
+    B = 150001
+    rng = np.random.default_rng(31)
+    x = make_inputs(B, 3, seed=32)
+    if case == "corner":
+        x = x * 0.07 + 0.01
+    x = cuda(x)
+    g = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32)).cuda().half().contiguous()
+    state = torch.tensor([128.0, 3.0, 1.0 if case == "overflow_skip" else 0.0, 17.0], device='cuda')
+    prefill = None
+    if case == "accumulated_grad":
+        prefill = torch.from_numpy(rng.standard_normal(tuple(enc.embeddings.shape)).astype(np.float32)).cuda()
+    ref, fus, consumed = _adam_reference_and_fused(enc, x, g, state, p_half=case != "no_shadow_keep_grad", zero_grad=0 if case == "no_shadow_keep_grad" else 1,
+                                                   prefill=prefill)
+    assert consumed
+    names = ("p", "m", "v", "g", "p_half")
+    for n, a, b in zip(names, ref, fus):
+        if a is None:
+            assert b is None
+            continue
+        assert torch.equal(a, b), n
+    p_ref = ref[0]
+    if case == "overflow_skip":
+        assert torch.equal(p_ref, enc.embeddings.detach()) and float(ref[3].abs().max()) == 0.0
+    else:
+        assert not torch.equal(p_ref, enc.embeddings.detach())
+        assert torch.equal(ref[4], p_ref.half()) if ref[4] is not None else float(ref[3].abs().max()) > 0.0
+
+
+def test_table_adam_is_not_applied_by_a_partial_or_foreign_backward():
+    """the armed step is one shot and all-or-nothing: a backward pass over fewer levels than the table has (max_level), or into another gradient
+    table, applies nothing and reports so — the caller's own optimiser launch then does the update"""
+    from customnerf_amd._lib import lib, ptr, stream, check, GridAdam
+    import ctypes
+    enc = build(CONFIGS[0][1], scale=0.5)
+    L, C = enc.num_levels, enc.level_dim
+    B = 100001
+    rng = np.random.default_rng(41)
+    x = cuda(make_inputs(B, 3, seed=42))
+    g = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32)).cuda().half().contiguous()
+    state = torch.tensor([64.0, 0.0, 0.0, 5.0], device='cuda')
+    ref, fus, consumed = _adam_reference_and_fused(enc, x, g, state, p_half=True, max_level=12)
+    assert consumed is False
+    for a, b in zip(ref, fus):
+        assert torch.equal(a, b)
+    # armed for another table: this backward leaves it armed and untouched, the explicit disarm clears it
+    other = torch.zeros_like(enc.embeddings)
+    cfg = GridAdam()
+    cfg.p, cfg.g, cfg.m, cfg.v, cfg.p_half, cfg.n = other.data_ptr(), other.data_ptr(), other.data_ptr(), other.data_ptr(), None, other.numel()
+    cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.scaler_state, cfg.extra_inv, cfg.zero_grad = 1e-2, 0.9, 0.99, 1e-15, state.data_ptr(), 1.0, 1
+    check(lib.cnerf_grid_backward_adam(ctypes.addressof(cfg)))
+    ref2, fus2, consumed2 = None, None, None
+    S = float(np.log2(enc.per_level_scale))
+    need = ctypes.c_uint64(0)
+    lib.cnerf_grid_encode_backward_workspace_bytes(enc._offsets_host.ctypes.data, B, 3, C, L, L, S, enc.base_resolution, 1, ctypes.addressof(need))
+    ws = torch.empty(int(need.value) + 256, dtype=torch.uint8, device='cuda')
+    out = torch.zeros_like(enc.embeddings)
+    check(lib.cnerf_grid_encode_backward(ptr(g), ptr(x), enc._offsets_host.ctypes.data, ptr(out), B, 3, C, L, L, S, enc.base_resolution, None, None,
+                                         enc.gridtype_id, int(enc.align_corners), enc.interp_id, 1, ptr(ws), ws.numel(), stream()))
+    done = ctypes.c_int(1)
+    check(lib.cnerf_grid_backward_adam_consumed(ctypes.addressof(done)))
+    check(lib.cnerf_grid_backward_adam(None))
+    assert done.value == 0 and float(other.abs().max()) == 0.0 and float(out.abs().max()) > 0.0
+    # argument validation
+    bad = GridAdam()
+    assert lib.cnerf_grid_backward_adam(ctypes.addressof(bad)) < 0                       # NULL pointers
+    cfg.n = other.numel() + 2
+    assert lib.cnerf_grid_backward_adam(ctypes.addressof(cfg)) < 0                       # n not a multiple of 4

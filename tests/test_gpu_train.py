@@ -380,6 +380,50 @@ def test_training_is_bit_identical_with_and_without_packed_weights():
         assert torch.equal(pa, pb)
 
 
+def test_training_is_bit_identical_with_the_table_step_inside_the_scatter():
+    """ReconTrainer arms the grid table's Adam update for its one backward pass (optim.FusedAdam.arm_in_backward -> cnerf_grid_backward_adam): eight
+    steps — among them one the loss scaler skips (its scale is raised until the half-precision gradients overflow) — end in the parameters, Adam
+    moments and scaler state of the same steps with `opt.fuse_table_adam = False`, bit for bit; and the fused run really took the fused path"""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+
+    def train(fuse):
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True)
+        opt.fuse_table_adam = fuse
+        model = NeRFNetwork(opt).cuda()
+        H = W = 64
+        o, d, rgb, mask = _target_scene(H, W, 1)
+        tr = ReconTrainer(model, opt, fp16=True)
+        kw = dict(num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+        applied = []
+        inner = tr.optimizer.disarm_in_backward
+        tr.optimizer.disarm_in_backward = lambda: (applied.append(inner()), applied[-1])[1]
+        for i in range(8):
+            torch.manual_seed(100 + i)
+            if i == 4:
+                tr.scaler.state[0] = 2.0 ** 40                              # this step overflows: skipped, the scale backs off
+            tr.train_step(o[0], d[0], rgb[0], mask[0], **kw)
+            if i == 4:
+                tr.scaler.state[0] = 65536.0
+        emb = model.pos_en.embeddings
+        st = tr.optimizer.state[emb]
+        n_applied = sum(a is not None for a in applied)
+        return ([p.detach().clone() for p in model.parameters()] + [st['exp_avg'].clone(), st['exp_avg_sq'].clone(), tr.scaler.state.clone(),
+                                                                    model.pos_en.half_table().clone()], n_applied, st['step'])
+
+    try:
+        (a, na, sa), (b, nb, sb) = train(True), train(False)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+    assert na == 8 and nb == 0 and sa == sb == 8
+    assert float(a[-2][3]) == 7.0                                           # seven counted steps: the overflowing one was skipped in both runs
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+
+
 def test_training_trajectory_is_bit_identical_with_and_without_early_termination():
     """Early termination (the compositing backward flushes gradients the half-precision consumers would round to zero; field backward and scatter skip the
     dead tiles / rows) is claimed to change no bit of any parameter gradient.  Compounded over a run: 400 optimiser steps on the analytic sphere scene from
