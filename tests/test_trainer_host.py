@@ -117,3 +117,39 @@ def test_inf_check_fold_conditions():
     assert not inf_check_is_folded(trainer(Model(), opt=argparse.Namespace(fold_inf_check=False)))
     m = Model(); m.grad_in_place = False
     assert not inf_check_is_folded(trainer(m))
+
+
+def test_table_step_is_armed_only_where_one_backward_pass_owns_the_gradient(monkeypatch):
+    """ReconTrainer._arm_table_step: the grid table's Adam update moves into the backward scatter only for a single-GPU fused-Adam step whose inf
+    check is folded into the gradient producers, outside stream capture, and not when switched off; when it arms, the learning rate of the step
+    is in the parameter groups and the un-scaling factor is set before the optimiser is asked"""
+    calls = []
+
+    class Opt:
+        param_groups = [{'lr': 0.0}, {'lr': 0.0}]
+        grad_scale_inv = None
+
+        def arm_in_backward(self, p):
+            calls.append((p, [g['lr'] for g in self.param_groups], self.grad_scale_inv))
+            return True
+
+    class PosEn:
+        embeddings = object()
+
+    class Model:
+        pos_en = PosEn()
+
+    def trainer(**kw):
+        d = dict(model=Model(), optimizer=Opt(), world_size=1, _dp=None, fused_adam=True, _inf_folded=True, opt=argparse.Namespace(), base_lrs=[1.0, 0.1],
+                 loss_scale=1.0, lr_factor=lambda: 0.5)
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    assert ReconTrainer._arm_table_step(trainer()) is True
+    assert calls == [(PosEn.embeddings, [0.5, 0.05], 1.0)]
+    for kw in (dict(fused_adam=False), dict(_inf_folded=False), dict(world_size=2), dict(_dp=object()), dict(opt=argparse.Namespace(fuse_table_adam=False))):
+        assert ReconTrainer._arm_table_step(trainer(**kw)) is False
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    assert ReconTrainer._arm_table_step(trainer()) is False
+    assert len(calls) == 1
