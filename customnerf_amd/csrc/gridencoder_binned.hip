@@ -578,8 +578,9 @@ __device__ __forceinline__ void b3_push_record(long long *acc, B3Pending &c, con
 #ifndef B3_THREADS
 #define B3_THREADS 1024                          // workgroup of k_bin3_emit (B3_PTS / B3_THREADS samples per thread)
 #endif
-// staging capacity in records: a hashed level emits 4.125 records per sample on average (one x-pair in 32 leaves as two singles: 8448 +- 31 per
-// block), a dense one 4; 8832 = + 12 sigma (what still does not fit spills), and two blocks (2 x 79.1 KiB) share a CU
+// staging capacity in records: a hashed level emits 4.03 records per sample on average (one x-pair in 2^B3_K = 128 leaves as two singles: 8256 per
+// block; 8448 +- 31 with the 32-entry granules of round 5), a dense one 4; 8832 leaves room for both (what still does not fit spills), and two
+// blocks (2 x 79.1 KiB) share a CU
 #define B3_CAP (B3_PTS * 4 + 640)
 #define B3_WIDE_CHUNKS BN_MAX_CHUNKS               // bins per level of a wide level (T = 2^21: 512 chunks of 4096 entries)
 #ifndef B3_WALK_BLOCKS
@@ -599,10 +600,17 @@ struct Bin3Plan {
 // row alone (x < 4096 never reaches the chunk bits), so on the coarser hashed levels — a few thousand rows — the bin loads follow the scene (bins
 // at twice the mean load on the benchmark's level 5).  A bin here owns the entries whose index bits [B3_K, B3_K + log2 bins) equal the bin id:
 // x spreads every row over the bins, the loads are uniform wherever the samples are spread, and a bin is still 4096 entries = one 64 KiB LDS
-// image, written back as 256-byte granules (2^B3_K entries x 2 channels x float32).  An x-pair stays one record while x ^ (x + 1) < 2^B3_K
-// (31 pairs in 32); the others travel as two single records: 4.125 records per sample and level, 8448 +- 31 per block (the four pairs of a sample
-// share x, so the unpaired ones come in fours) against a staging capacity of 8832.
-#define B3_K 5u
+// image, written back as granules of 2^B3_K entries (x 2 channels x float32).  An x-pair stays one record while x ^ (x + 1) < 2^B3_K; the others
+// travel as two single records (the four pairs of a sample share x, so the unpaired ones come in fours).
+// Granule size (round 6 sweep, profiles/r06_granule_sweep.txt; emit / accumulate us, benchmark table | bear table | fitted field):
+//   2^5 (round 5)  461 / 396 | 530 / 602 | 264 / 206        2^6  457 / 390 | 516 / 580 | 256 / 205
+//   2^7 (shipped)  449 / 378 | 498 / 567 | 248 / 204        2^8  448 / 384 | 493 / 559 | 246 / 200
+// — fewer unpaired records (1 pair in 128 instead of 1 in 32) and 1 KiB instead of 256-byte granules under the flush (which carries the table's
+// optimiser step since round 6); at 2^8 the x coordinate of a level coarser than 256 lines no longer reaches the bin bits at all (the imbalance the
+// interleave exists to remove), for no further gain.
+#ifndef B3_K
+#define B3_K 7u
+#endif
 __device__ __forceinline__ uint32_t b3_bin_of(uint32_t e, uint32_t hbits) { return (e >> B3_K) & ((1u << hbits) - 1u); }
 __device__ __forceinline__ uint32_t b3_local_of(uint32_t e, uint32_t hbits) { return ((e >> (B3_K + hbits)) << B3_K) | (e & ((1u << B3_K) - 1u)); }
 __device__ __forceinline__ uint32_t b3_entry_of(uint32_t local, uint32_t bin, uint32_t hbits) {
@@ -1393,7 +1401,7 @@ static bool b3_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin3Plan &pla
         uint32_t hb = 0;
         while ((1u << hb) < nch) hb++;
         plan.hbits[s] = (uint8_t)hb;
-        const uint64_t mean = (uint64_t)B * 17 / 4 / nch;                          // four pair records per sample (one in 16 travels as two singles), spread evenly by the interleave
+        const uint64_t mean = (uint64_t)B * 17 / 4 / nch;                          // four pair records per sample (+ the unpaired ones: at most one in 16 as two singles), spread evenly by the interleave
         const uint64_t c = mean + mean / 2 + 8192;
         cap = cap > c ? cap : c;
     }
