@@ -170,10 +170,22 @@ __global__ void __launch_bounds__(BN_SCAN_THREADS) k_bin_scan_blocks(uint32_t *_
 // bin_total and bin_base may alias (in-place): every thread reads its element before anyone overwrites it
 __global__ void __launch_bounds__(1024) k_bin_scan_bins(const uint32_t *bin_total, uint32_t *bin_base,
                                                         uint32_t *__restrict__ seg_first, uint32_t total_bins, uint32_t seg_records,
-                                                        uint32_t *__restrict__ seg_bin, uint32_t *__restrict__ split_list = nullptr, int min_one = 0) {
+                                                        uint32_t *__restrict__ seg_bin, uint32_t *__restrict__ split_list = nullptr, int min_one = 0,
+                                                        const float *__restrict__ adam_state = nullptr, float adam_lr = 0.0f, float adam_beta1 = 0.0f,
+                                                        float adam_beta2 = 0.0f, float adam_extra_inv = 0.0f, float *__restrict__ adam_const = nullptr) {
     __shared__ uint32_t wt_r[16], wt_s[16];
     __shared__ uint32_t carry_r, carry_s, n_split;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (adam_const && tid == 1023) {
+        // the optimiser step carried by the accumulate (B3Adam): k_adam_scaled's prologue, evaluated ONCE per backward pass here (two double-precision
+        // powers) — the scaler's found_inf is final: field backward and emit, its only producers on this path, precede this launch
+        const double step = (double)adam_state[3] + 1.0;
+        const double bc1 = 1.0 - pow((double)adam_beta1, step), bc2 = 1.0 - pow((double)adam_beta2, step);
+        adam_const[0] = adam_extra_inv / adam_state[0];
+        adam_const[1] = (float)((double)adam_lr / bc1);
+        adam_const[2] = (float)(1.0 / sqrt(bc2));
+        adam_const[3] = adam_state[2] != 0.0f ? 1.0f : 0.0f;
+    }
     if (tid == 0) { carry_r = 0; carry_s = 0; n_split = 0; }
     __syncthreads();
     for (uint32_t start = 0; start < total_bins; start += 1024) {
@@ -941,16 +953,12 @@ struct B3Adam {
     const float *state;                              // the loss scaler's {scale, growth_tracker, found_inf, good_steps}
     float lr, beta1, beta2, eps, extra_inv;
     int zero_grad, on;
+    const float *cst;                                // {gscale, step_size, rsqrt_bc2, skip}: written by k_bin_scan_bins of the same backward pass
 };
 struct B3AdamConst { float gscale, step_size, rsqrt_bc2; int skip; };
-__device__ __forceinline__ B3AdamConst b3_adam_const(const B3Adam &ad) {           // (k_adam_scaled's prologue)
+__device__ __forceinline__ B3AdamConst b3_adam_const(const B3Adam &ad) {           // (k_adam_scaled's prologue: see k_bin_scan_bins)
     B3AdamConst c;
-    c.skip = ad.state[2] != 0.0f;
-    c.gscale = ad.extra_inv / ad.state[0];
-    const double step = (double)ad.state[3] + 1.0;
-    const double bc1 = 1.0 - pow((double)ad.beta1, step), bc2 = 1.0 - pow((double)ad.beta2, step);
-    c.step_size = (float)((double)ad.lr / bc1);
-    c.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    c.gscale = ad.cst[0]; c.step_size = ad.cst[1]; c.rsqrt_bc2 = ad.cst[2]; c.skip = ad.cst[3] != 0.0f;
     return c;
 }
 // gg = the final gradient of four consecutive floats at float index `idx` (a multiple of 4), pp / mm / vv = parameter and moments there;
@@ -1057,15 +1065,7 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     const uint32_t n_split = split_list ? split_list[0] : gridDim.x;                // (no list: one workgroup column per bin)
     if (blockIdx.x >= n_split) return;
     B3AdamConst adc = {0.0f, 0.0f, 0.0f, 0};
-    if (ad.on) {                                                                     // (one lane evaluates the double-precision powers)
-        __shared__ float s_adam[4];
-        if (threadIdx.x == 0) {
-            const B3AdamConst c = b3_adam_const(ad);
-            s_adam[0] = c.gscale; s_adam[1] = c.step_size; s_adam[2] = c.rsqrt_bc2; s_adam[3] = c.skip ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        adc.gscale = s_adam[0]; adc.step_size = s_adam[1]; adc.rsqrt_bc2 = s_adam[2]; adc.skip = s_adam[3] != 0.0f;
-    }
+    if (ad.on) adc = b3_adam_const(ad);
     for (uint32_t b = blockIdx.x; b < n_split; b += gridDim.x) {                    // (workgroup-uniform trip count: the barrier below is safe)
     const uint32_t bin = split_list ? split_list[1 + b] : b;
     const uint32_t s0 = seg_first[bin], nseg = seg_first[bin + 1] - s0;
@@ -1082,6 +1082,17 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
     const uint32_t j = blockIdx.y * B3_RS_GROUPS + lane;                           // group of four values (two local entries x two channels)
     const bool ok = j < n_entries / 2;
     long long sum[4] = {0, 0, 0, 0};
+    // the finishing wave's read-modify-write operands (gradient; parameter and moments when the optimiser step rides along): issued in front of the sums
+    const uint32_t e_dst = dense_lvl ? e0 + 2 * j : b3_entry_of(2 * j, cb, hb);
+    const size_t idx = ((size_t)lv.offset[level] + e_dst) * 2;
+    const bool fin = !sl && ok, upd = fin && ad.on && !adc.skip;
+    float4 g_old = make_float4(0, 0, 0, 0), pp = g_old, mm = g_old, vv = g_old;
+    if (fin) g_old = *reinterpret_cast<const float4 *>(grad_grid + idx);
+    if (upd) {
+        pp = *reinterpret_cast<const float4 *>(ad.p + idx);
+        mm = *reinterpret_cast<const float4 *>(ad.m + idx);
+        vv = *reinterpret_cast<const float4 *>(ad.v + idx);
+    }
     if (ok) {
         const long long *__restrict__ src = partial + (size_t)s0 * (BN_CHUNK * 2) + (size_t)j * 4;
 #pragma unroll 8
@@ -1101,12 +1112,12 @@ __global__ void __launch_bounds__(256) k_bin3_reduce_split(const long long *__re
         for (int w = 0; w < 3; w++)
 #pragma unroll
             for (int k = 0; k < 4; k++) sum[k] += s_sum[w][lane][k];
-        const uint32_t e = dense_lvl ? e0 + 2 * j : b3_entry_of(2 * j, cb, hb);
-        float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)lv.offset[level] + e) * 2);
-        float4 g = *dst;
+        float4 *dst = reinterpret_cast<float4 *>(grad_grid + idx);
+        float4 g = g_old;
         g.x += bn_acc_to_float<__half>(sum[0]); g.y += bn_acc_to_float<__half>(sum[1]);
         g.z += bn_acc_to_float<__half>(sum[2]); g.w += bn_acc_to_float<__half>(sum[3]);
-        if (ad.on) b3_adam_apply(ad, adc, ((size_t)lv.offset[level] + e) * 2, g, dst);
+        if (upd) b3_adam_update(ad, adc, idx, g, pp, mm, vv, dst);
+        else if (ad.on) *dst = ad.zero_grad ? make_float4(0, 0, 0, 0) : g;              // (a skipped step: clears the gradient)
         else *dst = g;
     }
     __syncthreads();                                                                 // (s_sum is reused by the next bin of this workgroup)
@@ -1217,11 +1228,6 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
     (void)only;
 #endif
     const uint32_t nb = plan.p.nb;
-    __shared__ float s_adam[4];
-    if (ad.on && threadIdx.x == 64) {                                                // (one lane of the second wave evaluates the double-precision powers,
-        const B3AdamConst c = b3_adam_const(ad);                                     //  behind the whole record stream: read after the barriers below)
-        s_adam[0] = c.gscale; s_adam[1] = c.step_size; s_adam[2] = c.rsqrt_bc2; s_adam[3] = c.skip ? 1.0f : 0.0f;
-    }
     if (threadIdx.x == 0) {
         const uint32_t bin = seg_bin[gseg];
         uint32_t slot = 0;
@@ -1289,7 +1295,7 @@ __global__ void __launch_bounds__(1024, 8) k_bin3_accum(const uint2 *__restrict_
     }
     __syncthreads();
     B3AdamConst adc = {0.0f, 0.0f, 0.0f, 0};
-    if (ad.on) { adc.gscale = s_adam[0]; adc.step_size = s_adam[1]; adc.rsqrt_bc2 = s_adam[2]; adc.skip = s_adam[3] != 0.0f; }
+    if (ad.on) adc = b3_adam_const(ad);
     b3_flush(acc, lv, plan.p, slot, bin, nseg, gseg, grad_grid, partial, plan.dense_slot[slot] != 0xFFFFFFFFu ? 0xFFu : (uint32_t)plan.hbits[slot], ad, adc);
 }
 
@@ -1371,6 +1377,7 @@ static void b2_plan(const GridLevels &lv, uint32_t nl, uint32_t B, Bin2Plan &pla
 // ---- third form, host side
 struct Bin3Ws {
     uint32_t *runs, *pre, *cursor, *bin_base, *seg_first, *seg_bin, *split_list;
+    float *adam_const;
     uint2 *hslab, *dslab;
     long long *partial;
     uint64_t max_seg, cursor_bytes;
@@ -1434,7 +1441,8 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
     const uint64_t o_cur = off; off = bn_align(off + ((uint64_t)p2.total_bins + 2) * 4);       // (+ the partner word of a 64-bit pair reservation past the last bin)
     const uint64_t o_base = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
     const uint64_t o_seg = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
-    const uint64_t o_split = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);    // count + the bins that were split (k_bin_scan_bins -> k_bin3_reduce_split)
+    const uint64_t o_split = off; off = bn_align(off + (uint64_t)(p2.total_bins + 1) * 4);
+    const uint64_t o_adamc = off; off = bn_align(off + 16);                                   // B3AdamConst of this backward pass (k_bin_scan_bins)    // count + the bins that were split (k_bin_scan_bins -> k_bin3_reduce_split)
     const uint64_t h_records = (uint64_t)p2.total_bins * plan.capb;               // bin-major regions (the dense levels' bins leave theirs unused)
     const uint64_t d_records = (uint64_t)nl * p2.nb * B3_REGION;                   // the point blocks' private regions: every record of a dense level, the spill of a hashed one
     (void)n_dense;
@@ -1452,6 +1460,7 @@ static uint64_t b3_layout(const Bin3Plan &plan, uint32_t n_dense, uint32_t B, ui
         ws->bin_base = (uint32_t *)(p + o_base);
         ws->seg_first = (uint32_t *)(p + o_seg);
         ws->split_list = (uint32_t *)(p + o_split);
+        ws->adam_const = (float *)(p + o_adamc);
         ws->hslab = (uint2 *)(p + o_h);
         ws->dslab = (uint2 *)(p + o_d);
         ws->seg_bin = (uint32_t *)(p + o_segbin);
@@ -1509,7 +1518,8 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
     }
     const Bin2Plan &p2 = plan.p;
     const uint32_t seg = b2_seg(B, b2_max_chunks(p2, nl));
-    const B3Adam ad = b3_take_adam(gemb, lv, nl, true);
+    B3Adam ad = b3_take_adam(gemb, lv, nl, true);
+    ad.cst = ws.adam_const;
     hipLaunchKernelGGL(k_bin3_zero, dim3(cn_div_up(p2.total_bins, 256)), dim3(256), 0, st, ws.cursor, p2.total_bins);    // (a kernel, not a memset node: hipGraph capture)
     cn_stage(0, st);
     hipLaunchKernelGGL(k_bin3_emit, dim3(p2.nb * nl), dim3(B3_THREADS), emit_lds, st, grad, inputs, lv, plan, ws.runs, ws.cursor, ws.hslab, ws.dslab, B, gridtype, ac,
@@ -1519,7 +1529,8 @@ static int b3_backward(const __half *grad, const float *inputs, const GridLevels
                        plan, nl);
     static const uint32_t rs_bins = (uint32_t)cn_tune_env("CNERF_B3_RS_BINS", B3_RS_BINS);
     static const int rs_list = cn_tune_env("CNERF_B3_RSLIST", 1);                 // tuning builds: 0 = one workgroup column per bin (profiles/r06_reduce_split_ab.txt)
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list, ad.on);
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1024), 0, st, ws.bin_base, ws.bin_base, ws.seg_first, p2.total_bins, seg, ws.seg_bin, ws.split_list, ad.on,
+                       ad.state, ad.lr, ad.beta1, ad.beta2, ad.extra_inv, ad.on ? ws.adam_const : (float *)nullptr);
     hipLaunchKernelGGL(k_bin3_accum, dim3((uint32_t)ws.max_seg), dim3(1024), acc_lds, st, (const uint2 *)ws.hslab, (const uint2 *)ws.dslab, (const uint32_t *)ws.runs,
                        (const uint32_t *)ws.pre, (const uint32_t *)ws.cursor, (const uint32_t *)ws.bin_base, (const uint32_t *)ws.seg_first, lv, plan, gemb, ws.partial,
                        (const uint32_t *)ws.seg_bin, nl, seg, (uint32_t)b2_env("CNERF_B3_ONLY", 0), ad);
