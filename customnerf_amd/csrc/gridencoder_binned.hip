@@ -633,7 +633,7 @@ __device__ __forceinline__ bool b3_paired_h(uint32_t i0, uint32_t i1) {
     return m != 0 && m < (1u << B3_K) && (m & (m + 1)) == 0;
 }
 
-__global__ void __launch_bounds__(B3_THREADS, 8) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
+__global__ void __launch_bounds__(B3_THREADS, B3_THREADS >= 1024 ? 8 : 4) k_bin3_emit(const __half *__restrict__ grad, const float *__restrict__ inputs, const GridLevels lv,
                                                           const Bin3Plan plan, uint32_t *__restrict__ runs, uint32_t *__restrict__ cursor,
                                                           uint2 *__restrict__ hslab, uint2 *__restrict__ dslab, uint32_t B,
                                                           uint32_t gridtype, int align_corners, uint32_t interp, float *__restrict__ grad_grid, uint32_t n_slots,
