@@ -446,6 +446,39 @@ def test_composite_run_kernel_vs_oracle(soft, dbg, dmask):
     np.testing.assert_allclose(c.grad.cpu().numpy(), gc_ref, rtol=1e-3, atol=1e-5 * max(1.0, float(np.abs(gc_ref).max())))
 
 
+@pytest.mark.parametrize("used,S,T", [((1,), 128, 64), ((0, 2), 100, 50), ((2,), 40, 20), ((0, 1, 2), 200, 100), ((), 128, 64)])
+def test_composite_backward_with_unused_variants_and_chunk_counts(used, S, T):
+    """the compositing backward skips a variant none of whose outputs received a gradient (round 6) and keeps a ray's samples in registers for
+    1 .. 4 chunks of 64: gradients into any subset of the three variants, for 40 / 100 / 128 / 200 samples per ray, against autograd on the oracle"""
+    from customnerf_amd.nerf.render_ops import composite_run
+    N = 150
+    sig, rgbc, z, nears, fars = _rand_composite_inputs(N, S, seed=S)
+    s_ref, c_ref = sig.clone().requires_grad_(True), rgbc.clone().requires_grad_(True)
+    rgb, conf = c_ref[..., :3], c_ref[..., 3:4]
+    sd = ((fars - nears) / T)[:, None]
+    e = torch.sigmoid((conf - 0.5) * 100)
+    kw = dict(train_conf=True, detach_bg=False, detach_mask_from_field=False)
+    refs = [to.weights_sum_i(sd, s_ref[..., None], z, nears[:, None], fars[:, None], rgb, (1, N), conf, is_all=True, **kw),
+            to.weights_sum_i(sd, s_ref[..., None] * e, z, nears[:, None], fars[:, None], rgb, (1, N), conf, if_fg=True, **kw),
+            to.weights_sum_i(sd, s_ref[..., None] * (1 - e), z, nears[:, None], fars[:, None], rgb, (1, N), conf, **kw)]
+    s, c = sig.clone().cuda().requires_grad_(True), rgbc.clone().cuda().requires_grad_(True)
+    out_ray, _ = composite_run(s, c, z.cuda(), nears.cuda(), fars.cuda(), T, True, 0.5, False, False)
+    g = torch.Generator().manual_seed(5)
+    loss_ref, loss = (s_ref * 0).sum() + (c_ref * 0).sum(), (out_ray * 0).sum()
+    for v in used:
+        r = refs[v]
+        gi = torch.randn(N, 6, generator=g)
+        loss_ref = loss_ref + (r['image'].reshape(N, 3) * gi[:, :3]).sum() + (r['depth'].reshape(N) * gi[:, 3]).sum() + \
+            (r['weights_sum'] * gi[:, 4]).sum() + (r['render_mask'].reshape(N) * gi[:, 5]).sum()
+        loss = loss + (out_ray[v] * gi.cuda()).sum()
+    loss_ref.backward(); loss.backward()
+    gs_ref, gc_ref = s_ref.grad.numpy(), c_ref.grad.numpy()
+    np.testing.assert_allclose(s.grad.cpu().numpy(), gs_ref, rtol=1e-3, atol=1e-5 * max(1.0, float(np.abs(gs_ref).max())))
+    np.testing.assert_allclose(c.grad.cpu().numpy(), gc_ref, rtol=1e-3, atol=1e-5 * max(1.0, float(np.abs(gc_ref).max())))
+    if not used:
+        assert float(s.grad.abs().max()) == 0.0 and float(c.grad.abs().max()) == 0.0
+
+
 def test_sampling_kernels_vs_oracle():
     """cnerf_sample_coarse / cnerf_sample_fine_merge against the torch restatement of renderer.py:310-363 (train and det)."""
     from customnerf_amd.nerf import render_ops
