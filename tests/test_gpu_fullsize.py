@@ -77,6 +77,31 @@ def test_fp16_scatter_is_bit_deterministic_and_adjoint_full_size():
     assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs)) + 1.0, (lhs, rhs)
 
 
+def test_fp16_scatter_with_every_hashed_bin_split_is_deterministic_and_adjoint():
+    """Four views' worth of samples in one backward pass (65536 rays x 128 samples = 8.4 M points, the multi-view edit step's size): the scatter's
+    segment size is capped, EVERY hashed bin splits into two segments, and k_bin3_reduce_split's workgroups walk a split-bin list several times
+    longer than its grid (round 6) — same invariants as at the benchmark size: bit-reproducible, adjoint to the gather"""
+    enc = _encoder()
+    x = torch.cat([_ray_points(10 + k) for k in range(4)], 0).contiguous()
+    P = x.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(12)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    G = (torch.randn(16, P, 2, device="cuda", generator=g) * 0.05).half()
+    grads = []
+    for _ in range(2):
+        enc.embeddings.grad = None
+        out = enc.encode(x, bound=2.0, half=True)
+        out.backward(G)
+        grads.append(enc.embeddings.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    lhs = float((out.detach().double() * G.double()).sum())
+    rhs = float((enc.half_table().double() * grads[0].double()).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs)) + 4.0, (lhs, rhs)
+    del out, grads, G, x
+    torch.cuda.empty_cache()                                           # (the scatter workspace of this size is ~14 GB: give it back)
+
+
 def test_run_full_view_invariants():
     """one 128x128 view through run(): merged samples sorted per ray, weights in [0,1], sum <= 1, fg + bg weights partition by the
     soft mask, everything finite"""
