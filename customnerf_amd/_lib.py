@@ -77,6 +77,7 @@ SIGNATURES = {
     "cnerf_recon_loss_scaled": [vp, vp, vp, u32, f32, f32, vp, vp, vp, vp],
     "cnerf_sample_coarse_unit_aabb": [vp, vp, vp, f32, vp, u32, u32, vp, vp, vp, vp, vp, f32, vp],
     "cnerf_composite_run_indexed": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp, vp, vp, vp],
+    "cnerf_composite_run_indexed_variants": [vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, vp, vp, vp, vp, vp, u32, vp],
     "cnerf_composite_run_backward_indexed": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, vp],
     "cnerf_composite_run_backward_indexed_flush": [vp, vp, vp, vp, vp, vp, u32, u32, u32, i32, f32, i32, i32, vp, vp, vp, i32, vp, vp],
     "cnerf_adam_step": [vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, u32, f32, i32, vp],

@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *_
                                                                   const float *__restrict__ fars, uint32_t N, uint32_t S, uint32_t num_steps, int soft,
                                                                   float thr, float *__restrict__ out_ray, float *__restrict__ out_w,
                                                                   const uint32_t *__restrict__ src_index, float *__restrict__ sigma_m,
-                                                                  float *__restrict__ rgbc_m) {
+                                                                  float *__restrict__ rgbc_m, uint32_t vmask) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * RN_WAVES + wave;
     if (n >= N) return;
@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *_
     const float sd = (far - near) / (float)num_steps;
     const float *zr = z_vals + (size_t)n * S;
     const float4 *c4 = reinterpret_cast<const float4 *>(rgbc);
+    // vmask: bit v set = variant v wanted (cnerf_composite_run_indexed_variants); the others are written as zeros without their scans / exponentials
     float carry[3] = {1.0f, 1.0f, 1.0f};
     float acc[3][6];
 #pragma unroll
@@ -343,6 +344,10 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *_
         const float e = rn_edit(c.w, soft, thr);
 #pragma unroll
         for (int v = 0; v < 3; v++) {
+            if (!((vmask >> v) & 1u)) {
+                if (ok && out_w) out_w[((size_t)v * N + n) * S + i] = 0.0f;
+                continue;
+            }
             const float alpha = ok ? 1.0f - expf(-delta * (sigma * rn_variant_scale(v, e))) : 0.0f;
             const float tr = rn_excl_prod_scan(ok ? (1.0f - alpha + 1e-15f) : 1.0f, carry[v], lane);
             const float w = alpha * tr;
@@ -355,6 +360,10 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_fwd(const float *_
     }
 #pragma unroll
     for (int v = 0; v < 3; v++) {
+        if (!((vmask >> v) & 1u)) {
+            if (lane < 6) out_ray[((size_t)v * N + n) * 6 + lane] = 0.0f;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const float s = rn_wave_sum(acc[v][k]);
@@ -619,12 +628,19 @@ int cnerf_sample_fine_merge(const float *rays_o, const float *rays_d, const floa
 int cnerf_composite_run_indexed(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars, uint32_t N, uint32_t S,
                                 uint32_t num_steps, int soft_mask, float conf_thr, const uint32_t *src_index, float *out_ray, float *out_weights,
                                 float *sigma_sorted, float *rgbc_sorted, void *stream) {
-    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0) return CNERF_EINVAL;
+    return cnerf_composite_run_indexed_variants(sigmas, rgbc, z_vals, nears, fars, N, S, num_steps, soft_mask, conf_thr, src_index, out_ray, out_weights,
+                                                sigma_sorted, rgbc_sorted, 7u, stream);
+}
+
+int cnerf_composite_run_indexed_variants(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars, uint32_t N,
+                                         uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, const uint32_t *src_index, float *out_ray,
+                                         float *out_weights, float *sigma_sorted, float *rgbc_sorted, uint32_t variant_mask, void *stream) {
+    if (S == 0 || S > 64 * RN_MAXCH || num_steps == 0 || variant_mask == 0 || variant_mask > 7u) return CNERF_EINVAL;
     if (N == 0) return CNERF_OK;
     if (!sigmas || !rgbc || !z_vals || !nears || !fars || !out_ray) return CNERF_ENULL;
     if ((((uintptr_t)rgbc) | ((uintptr_t)rgbc_sorted)) & 15) return CNERF_EINVAL;
     hipLaunchKernelGGL(k_composite_run_fwd, dim3(cn_div_up(N, RN_WAVES)), dim3(RN_THREADS), 0, CN_STREAM(stream), sigmas, rgbc, z_vals, nears, fars, N, S,
-                       num_steps, soft_mask, conf_thr, out_ray, out_weights, src_index, sigma_sorted, rgbc_sorted);
+                       num_steps, soft_mask, conf_thr, out_ray, out_weights, src_index, sigma_sorted, rgbc_sorted, variant_mask);
     return cn_launch_status();
 }
 

@@ -78,14 +78,15 @@ class _CompositeRunIndexed(Function):
     what it needs from sigma / rgbc, and the result dict asks for them lazily (composite_run_indexed_aux)."""
 
     @staticmethod
-    def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero=False):
+    def forward(ctx, sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero=False, variants=7):
         sigmas = sigmas.contiguous().float()
         rgbc = rgbc.contiguous().float()
         N, S = z_vals.shape
         ctx.flush = bool(flush_half_zero)
         out_ray = torch.empty(3, N, 6, dtype=torch.float32, device=z_vals.device)
-        check(lib.cnerf_composite_run_indexed(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask), float(conf_thr),
-                                              ptr(src_index), ptr(out_ray), None, None, None, stream()), "composite_run_indexed")
+        check(lib.cnerf_composite_run_indexed_variants(ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, int(num_steps), int(soft_mask),
+                                                       float(conf_thr), ptr(src_index), ptr(out_ray), None, None, None, int(variants), stream()),
+              "composite_run_indexed")
         ctx.save_for_backward(sigmas, rgbc, z_vals, src_index, nears, fars)
         ctx.cfg = (int(num_steps), int(soft_mask), float(conf_thr), int(detach_bg), int(detach_mask))
         return out_ray
@@ -93,7 +94,7 @@ class _CompositeRunIndexed(Function):
     @staticmethod
     def backward(ctx, g_ray):
         if g_ray is None:
-            return (None,) * 12
+            return (None,) * 13
         sigmas, rgbc, z_vals, src_index, nears, fars = ctx.saved_tensors
         num_steps, soft, thr, dbg, dmask = ctx.cfg
         N, S = z_vals.shape
@@ -116,14 +117,16 @@ class _CompositeRunIndexed(Function):
         else:
             check(lib.cnerf_composite_run_backward_indexed(ptr(g_ray), ptr(sigmas), ptr(rgbc), ptr(z_vals), ptr(nears), ptr(fars), N, S, num_steps, soft, thr,
                                                            dbg, dmask, ptr(src_index), ptr(g_sigma), ptr(g_rgbc), stream()), "composite_run_backward_indexed")
-        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None, None, None
+        return g_sigma, g_rgbc, None, None, None, None, None, None, None, None, None, None, None
 
 
 def composite_run_indexed(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg=False, detach_mask=False,
-                          flush_half_zero=False):
+                          flush_half_zero=False, variants=7):
     """sigmas [P], rgbc [P,4] in sample-list order -> out_ray [3,N,6] (differentiable in sigmas / rgbc).
-    flush_half_zero: the producer of sigmas / rgbc is the half-precision fused field (cnerf_composite_run_backward_indexed_flush)."""
-    return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero)
+    flush_half_zero: the producer of sigmas / rgbc is the half-precision fused field (cnerf_composite_run_backward_indexed_flush).
+    variants: bit mask of the composites to compute (1 all, 2 edit region, 4 background); the rows of the others are zeros."""
+    return _CompositeRunIndexed.apply(sigmas, rgbc, z_vals, src_index, nears, fars, num_steps, soft_mask, conf_thr, detach_bg, detach_mask, flush_half_zero,
+                                      variants)
 
 
 @torch.no_grad()

@@ -128,7 +128,7 @@ class NeRFRenderer(nn.Module):
             # (upsample_steps == 0 fails in the reference as well: `weights` is bound only inside `if upsample_steps > 0`, renderer.py:333-384)
             raise ValueError(f"run(): the sampling kernels take 3..128 coarse and 2..128 importance samples per ray (got {num_steps} + {upsample_steps}; "
                              "the reference's recipe is 64 + 64)")
-        return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws)
+        return self._run_fused(rays_o, rays_d, num_steps, upsample_steps, perturb, _draws, fg_bg=bool(kwargs.get('fg_bg', True)))
 
     def _dirs_twice(self, rays_d):
         """[d | d] for the split sample list, cached per view: a dataset's ray directions are resident tensors that come back every epoch
@@ -157,9 +157,11 @@ class NeRFRenderer(nn.Module):
             raise ValueError("run() with opt.train_conf needs forward() to return rgb + 1 confidence channel (network_grid.py:126-129)")
         return sigmas.reshape(-1), rgbc.reshape(-1, 4)
 
-    def _run_fused(self, rays_o, rays_d, num_steps, upsample_steps, perturb, _draws=None):
+    def _run_fused(self, rays_o, rays_d, num_steps, upsample_steps, perturb, _draws=None, fg_bg=True):
         """run() on the fused kernels: 2 sampling launches + 2 field launches (+1 gather each) + 1 composite launch.
-        Same result dict as run(); RNG draws keep the reference's order (rand(N,T) then rand(N,t))."""
+        Same result dict as run(); RNG draws keep the reference's order (rand(N,T) then rand(N,t)).
+        fg_bg=False (the reconstruction trainer, whose loss reads the first composite only): the edit-region / background composites are not
+        computed and the result dict has no 'fg' / 'bg' entries."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -240,7 +242,8 @@ class NeRFRenderer(nn.Module):
             # early termination of the backward (north_star; the reference's own is `T < T_thresh` on its march path): only where the gradients
             # go into the half-precision fused field, whose backward rounds them to half anyway
             flush = bool(grad_on and getattr(self.opt, 'early_termination', True) and self._fused_cfg() and self._half())
-            out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask, flush_half_zero=flush)
+            out_ray = render_ops.composite_run_indexed(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr, dbg, dmask, flush_half_zero=flush,
+                                                       variants=7 if fg_bg else 1)
             # per-sample by-products (weights, sorted-order sigma / rgbc copies, detached): a second launch, only if somebody reads them
             aux = _Lazy(lambda: render_ops.composite_run_indexed_aux(sig_l, rgbc_l, z_all, src, nears, fars, num_steps, soft, thr))
             weights_of = lambda v: _Lazy(lambda: aux.get()[0][v])
@@ -269,8 +272,9 @@ class NeRFRenderer(nn.Module):
             results['edit_mask'] = _Lazy(lambda: conf_of().detach() > 0.5)
         results['z_vals'] = z_all
         results['_out_ray'] = out_ray                                        # [3, N, 6] raw composite output (trainer.ReconTrainer's fused loss)
-        results['fg'] = pack(1)
-        results['bg'] = pack(2)
+        if fg_bg or not split:                                               # (fg_bg=False: the two composites were not computed — no such keys)
+            results['fg'] = pack(1)
+            results['bg'] = pack(2)
         return results
 
     def weights_sum_i(self, sample_dist, sigmas, normals, dirs, weights, z_vals, nears, fars, rgbs, prefix, masks=None,

@@ -365,6 +365,7 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
     def _train_step(self, rays_o, rays_d, rgbs, mask, select_inds=None, **render_kw):
         self.model.train()
         rays_o, rays_d, rgbs, mask = self.select_rays(rays_o, rays_d, rgbs, mask, select_inds)
+        render_kw.setdefault('fg_bg', getattr(self, 'needs_fg_bg', False))       # the reconstruction loss reads the first composite only
         with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
             outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
             loss = self.loss(outputs, rgbs, mask)
@@ -429,7 +430,8 @@ class ReconTrainer(CheckpointMixin, EvalMixin):
             try:
                 with torch.cuda.graph(graph, pool=self.__dict__.get('_graph_pool')), packed_weights_window(self.model, self.opt):
                     with torch.autocast('cuda', dtype=torch.float16, enabled=self.fp16):
-                        outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True, **render_kw)
+                        outputs = self.model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=True,
+                                                    **dict(render_kw, fg_bg=render_kw.get('fg_bg', getattr(self, 'needs_fg_bg', False))))
                         loss = self.loss(outputs, rgbs, mask)
                     self.scaler.backward(loss)
                     loss = loss.detach()

@@ -414,6 +414,13 @@ int cnerf_composite_run_indexed(const float *sigmas, const float *rgbc, const fl
                                 uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr,
                                 const uint32_t *src_index, float *out_ray, float *out_weights, float *sigma_sorted,
                                 float *rgbc_sorted, void *stream);
+/* cnerf_composite_run_indexed computing only the variants whose bit is set in variant_mask (bit 0 all, 1 edit region, 2 background; 7 = all three):
+ * the rows of out_ray (and of out_weights, when given) that belong to the others are written as zeros.  The reconstruction stage reads the first
+ * composite only (utils_init_nerf.py:214-260 `train_step`); the editing stage all three. */
+int cnerf_composite_run_indexed_variants(const float *sigmas, const float *rgbc, const float *z_vals, const float *nears, const float *fars,
+                                         uint32_t N, uint32_t S, uint32_t num_steps, int soft_mask, float conf_thr, const uint32_t *src_index,
+                                         float *out_ray, float *out_weights, float *sigma_sorted, float *rgbc_sorted, uint32_t variant_mask,
+                                         void *stream);
 int cnerf_composite_run_backward_indexed(const float *grad_out_ray, const float *sigmas, const float *rgbc, const float *z_vals,
                                          const float *nears, const float *fars, uint32_t N, uint32_t S, uint32_t num_steps,
                                          int soft_mask, float conf_thr, int detach_bg, int detach_mask_from_field,

@@ -479,6 +479,28 @@ def test_composite_backward_with_unused_variants_and_chunk_counts(used, S, T):
         assert float(s.grad.abs().max()) == 0.0 and float(c.grad.abs().max()) == 0.0
 
 
+def test_composite_forward_computes_the_requested_variants_only():
+    """cnerf_composite_run_indexed_variants: with the mask of the reconstruction trainer (first composite only) the first composite and its
+    gradients are the bits of the three-composite launch, the other rows are zeros; run(fg_bg=False) drops the 'fg' / 'bg' entries"""
+    from customnerf_amd.nerf import render_ops
+    N, S, T = 300, 128, 64
+    sig, rgbc, z, nears, fars = _rand_composite_inputs(N, S, seed=9)
+    z, nears, fars = z.cuda(), nears.cuda(), fars.cuda()
+    ident = torch.arange(N * S, dtype=torch.int32, device='cuda').view(N, S)
+    g = torch.randn(N, 6, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = []
+    for variants in (7, 1, 5):
+        s_, c_ = sig.reshape(-1).clone().cuda().requires_grad_(True), rgbc.reshape(-1, 4).clone().cuda().requires_grad_(True)
+        o = render_ops.composite_run_indexed(s_, c_, z, ident, nears, fars, T, True, 0.5, variants=variants)
+        (o[0] * g).sum().backward()
+        outs.append((o.detach(), s_.grad, c_.grad))
+    full, first, first_bg = outs
+    assert torch.equal(full[0][0], first[0][0]) and torch.equal(full[1], first[1]) and torch.equal(full[2], first[2])
+    assert float(first[0][1:].abs().max()) == 0.0
+    assert torch.equal(full[0][0], first_bg[0][0]) and torch.equal(full[0][2], first_bg[0][2]) and float(first_bg[0][1].abs().max()) == 0.0
+    assert float(full[0][1].abs().max()) > 0.0
+
+
 def test_sampling_kernels_vs_oracle():
     """cnerf_sample_coarse / cnerf_sample_fine_merge against the torch restatement of renderer.py:310-363 (train and det)."""
     from customnerf_amd.nerf import render_ops

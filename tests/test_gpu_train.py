@@ -380,6 +380,35 @@ def test_training_is_bit_identical_with_and_without_packed_weights():
         assert torch.equal(pa, pb)
 
 
+def test_training_without_the_unused_composites_is_bit_identical():
+    """ReconTrainer renders with fg_bg=False (its loss reads the first composite; the edit-region / background composites are not computed): the
+    parameters after four steps are those of the same steps with all three composites (`needs_fg_bg = True`), and the outputs have no 'fg'"""
+    from customnerf_amd import scene as sc, tcnn
+    from customnerf_amd.nerf.network_grid import NeRFNetwork
+    from customnerf_amd.trainer import ReconTrainer
+    tcnn.set_default_dtype(torch.float16)
+
+    def train(need):
+        torch.manual_seed(0)
+        opt = sc.make_opt(fp16=True)
+        model = NeRFNetwork(opt).cuda()
+        o, d, rgb, mask = _target_scene(64, 64, 1)
+        tr = ReconTrainer(model, opt, fp16=True)
+        tr.needs_fg_bg = need
+        for i in range(4):
+            torch.manual_seed(100 + i)
+            _, outputs = tr.train_step(o[0], d[0], rgb[0], mask[0], num_steps=opt.num_steps, upsample_steps=opt.upsample_steps)
+        return [p.detach().clone() for p in model.parameters()], ('fg' in outputs)
+
+    try:
+        (a, fa), (b, fb) = train(False), train(True)
+    finally:
+        tcnn.set_default_dtype(torch.float32)
+    assert not fa and fb
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+
+
 def test_training_is_bit_identical_with_the_table_step_inside_the_scatter():
     """ReconTrainer arms the grid table's Adam update for its one backward pass (optim.FusedAdam.arm_in_backward -> cnerf_grid_backward_adam): eight
     steps — among them one the loss scaler skips (its scale is raised until the half-precision gradients overflow) — end in the parameters, Adam
