@@ -519,12 +519,14 @@ __global__ void __launch_bounds__(RN_THREADS) k_composite_run_bwd(const float *_
 // train_step_pretrain's loss (utils_init_nerf.py:220-234) and its gradient in one launch instead of ~35 elementwise / reduce launches:
 //   loss = w_rgb * mean((image - rgb_gt)^2) + w_conf * mean((render_mask - mask_gt)^2)      (image / render_mask of the `all` composite)
 // writes d(loss)/d(out_ray) [3][N][6] (zero outside the `all` variant's image and render_mask slots) and per-workgroup partial sums;
-// a one-wave second launch adds them in a fixed order into loss[0].
+// the workgroup that finishes last adds them in a fixed order into loss[0] (a second launch until round 6).
 #define RL_BLOCKS 64
+__device__ unsigned int g_recon_loss_ticket = 0;     // one k_recon_loss in flight per device (the last workgroup to finish adds the partials and clears it)
 __global__ void __launch_bounds__(256) k_recon_loss(const float *__restrict__ out_ray, const float *__restrict__ rgb_gt, const float *__restrict__ mask_gt,
                                                     uint32_t N, float k_rgb, float k_m, float *__restrict__ partial, float *__restrict__ g_out,
-                                                    const float *__restrict__ grad_scale) {
+                                                    const float *__restrict__ grad_scale, float *__restrict__ loss) {
     __shared__ float red[2][4];
+    __shared__ unsigned int s_last;
     float s_rgb = 0.0f, s_m = 0.0f;
     const float gsc = grad_scale ? grad_scale[0] : 1.0f;          // the backward pass's seed (the loss scale), folded into the stored gradient
     for (uint32_t n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
@@ -553,14 +555,21 @@ __global__ void __launch_bounds__(256) k_recon_loss(const float *__restrict__ ou
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[0][wave] = s_rgb; red[1][wave] = s_m; }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         partial[blockIdx.x] = k_rgb * (red[0][0] + red[0][1] + red[0][2] + red[0][3]) + k_m * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        // round 6: the sum of the partials by whichever workgroup finishes last (one launch less), in the fixed lane order of the former second launch (a wave sum over the partials) — same bits.
+        // Release the partial (agent scope: the other workgroups run on other XCDs), take a ticket; the last one acquires and adds.
+        __threadfence();
+        s_last = atomicAdd(&g_recon_loss_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __threadfence();
+        const float v = rn_wave_sum(threadIdx.x < gridDim.x ? __builtin_nontemporal_load(partial + threadIdx.x) : 0.0f);
+        if (threadIdx.x == 0) { loss[0] = v; g_recon_loss_ticket = 0; }
+    }
 }
 
-__global__ void __launch_bounds__(64) k_recon_loss_sum(const float *__restrict__ partial, uint32_t n, float *__restrict__ loss) {
-    const float v = rn_wave_sum(threadIdx.x < n ? partial[threadIdx.x] : 0.0f);           // fixed order: deterministic
-    if (threadIdx.x == 0) loss[0] = v;
-}
 
 extern "C" {
 
@@ -693,11 +702,10 @@ int cnerf_recon_loss_scaled(const float *out_ray, const float *rgb_gt, const flo
                             const float *grad_scale, float *loss, float *grad_out_ray, void *stream) {
     if (N == 0) return CNERF_EINVAL;
     if (!out_ray || !rgb_gt || !loss || !grad_out_ray) return CNERF_ENULL;
-    // the partial sums live in loss[1 .. RL_BLOCKS] (loss must hold 1 + 64 floats), added in a fixed order by the second launch
+    // the partial sums live in loss[1 .. RL_BLOCKS] (loss must hold 1 + 64 floats), added in a fixed order by the last workgroup to finish
     const uint32_t blocks = cn_div_up(N, 256) < RL_BLOCKS ? cn_div_up(N, 256) : RL_BLOCKS;
     hipLaunchKernelGGL(k_recon_loss, dim3(blocks), dim3(256), 0, CN_STREAM(stream), out_ray, rgb_gt, mask_gt, N, w_rgb / (3.0f * (float)N),
-                       mask_gt ? w_conf / (float)N : 0.0f, loss + 1, grad_out_ray, grad_scale);
-    hipLaunchKernelGGL(k_recon_loss_sum, dim3(1), dim3(64), 0, CN_STREAM(stream), loss + 1, blocks, loss);
+                       mask_gt ? w_conf / (float)N : 0.0f, loss + 1, grad_out_ray, grad_scale, loss);
     return cn_launch_status();
 }
 
